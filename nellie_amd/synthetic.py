@@ -1,0 +1,76 @@
+"""
+Deterministic synthetic volumes for parity tests and `bench.py`.
+
+The reference ships no benchmark inputs (its sample file is absent from the
+checkout), so the build defines its own generator: N(100, 5) float32 noise plus
+axis-aligned tubes with a Gaussian cross-section (amplitude 200, radius
+U(1.5, 4.0) voxels), one third of the tubes along each of X, Y and Z.  A tube's
+profile is evaluated inside a +-5r window (it is < 1e-3 of a noise sigma
+beyond).  `numpy.random.default_rng` (PCG64) streams are stable across numpy
+versions, so a (shape, seed) pair names the same bytes everywhere.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+SEEDS = {"C2": 1234, "C3": 2345, "C4": 3456, "C5": 4567}
+
+
+def n_tubes(shape) -> int:
+    n = int(np.prod(shape))
+    return max(6, int(n / 2 ** 20 * 0.75))
+
+
+def make_volume(shape, seed: int, tubes: int | None = None, dtype=np.float32,
+                z_offset: int = 0, global_nz: int | None = None) -> np.ndarray:
+    """
+    (Z, Y, X) volume.  With `z_offset`/`global_nz` a rank generates only its own
+    Z-slab `[z_offset, z_offset + shape[0])` of the global (global_nz, Y, X)
+    volume: tube geometry is drawn for the global shape, noise per global plane.
+    """
+    nz, ny, nx = (int(s) for s in shape)
+    gz = int(global_nz) if global_nz is not None else nz
+    gshape = (gz, ny, nx)
+    k = n_tubes(gshape) if tubes is None else int(tubes)
+    vol = np.empty((nz, ny, nx), dtype=np.float32)
+    # noise: one independent stream per global plane so slabs agree with the full volume
+    for z in range(nz):
+        prng = np.random.default_rng([int(seed), 1, z + z_offset])
+        vol[z] = prng.standard_normal((ny, nx), dtype=np.float32) * np.float32(5.0) + np.float32(100.0)
+    rng = np.random.default_rng([int(seed), 0])
+    axes = rng.integers(0, 3, size=k) if k % 3 else np.repeat(np.arange(3), k // 3)
+    radii = rng.uniform(1.5, 4.0, size=k)
+    cu = rng.uniform(0.0, 1.0, size=k)
+    cv = rng.uniform(0.0, 1.0, size=k)
+    dims = (gz, ny, nx)
+    for ax, r, u, v in zip(axes, radii, cu, cv):
+        other = [d for d in range(3) if d != ax]
+        c0 = u * (dims[other[0]] - 1)
+        c1 = v * (dims[other[1]] - 1)
+        w = int(np.ceil(5.0 * r))
+        lo0, hi0 = max(0, int(c0) - w), min(dims[other[0]], int(c0) + w + 1)
+        lo1, hi1 = max(0, int(c1) - w), min(dims[other[1]], int(c1) + w + 1)
+        g0 = np.arange(lo0, hi0, dtype=np.float64)
+        g1 = np.arange(lo1, hi1, dtype=np.float64)
+        prof = (200.0 * np.exp(-((g0[:, None] - c0) ** 2 + (g1[None, :] - c1) ** 2)
+                               / (2.0 * r * r))).astype(np.float32)
+        if ax == 0:      # along Z: profile over (Y, X), every plane of the slab
+            vol[:, lo0:hi0, lo1:hi1] += prof[None, :, :]
+        else:
+            # profile over (Z, other): clip the Z window to this slab
+            zlo, zhi = max(lo0, z_offset), min(hi0, z_offset + nz)
+            if zlo >= zhi:
+                continue
+            p = prof[zlo - lo0:zhi - lo0]
+            if ax == 1:  # along Y: profile over (Z, X)
+                vol[zlo - z_offset:zhi - z_offset, :, lo1:hi1] += p[:, None, :]
+            else:        # along X: profile over (Z, Y)
+                vol[zlo - z_offset:zhi - z_offset, lo1:hi1, :] += p[:, :, None]
+    if np.dtype(dtype) != np.float32:
+        info = np.iinfo(dtype)
+        vol = np.clip(np.rint(vol), info.min, info.max).astype(dtype)
+    return vol
+
+
+ISO_01 = {"X": 0.1, "Y": 0.1, "Z": 0.1, "T": 1.0}
+ANISO_03 = {"X": 0.1, "Y": 0.1, "Z": 0.3, "T": 1.0}

@@ -1,0 +1,707 @@
+"""
+CPU ORACLE for the Nellie `nellie/segmentation` hot path (Filter -> Label).
+
+THIS FILE IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may
+import it, and there only as the checker / timed CPU baseline -- never as the
+thing shipped.  The product (`nellie_amd/`) never imports this module and fails
+loudly when its HIP library is missing.
+
+What it is: a step-by-step numpy restatement (plus a small plain-C helper,
+`oracle/ccl_oracle.c`, for the integer connected-component / flood-fill work)
+of the reference algorithm, each function citing the reference `file:line`
+(paths relative to the reference checkout root) it follows.  Third-party
+arithmetic the reference reaches through `scipy.ndimage` (scipy==1.15.3) and
+`numpy` (numpy==2.2.6, both pinned in the reference's uv.lock) is restated from
+its published algorithm:
+
+  * scipy.ndimage.gaussian_filter / gaussian_filter1d / correlate1d
+      separable Gaussian, radius int(truncate*sd+0.5), float64 accumulation in
+      the symmetric-kernel order `c*w0 + sum_j (in[-j]+in[+j])*w[j]`, result
+      stored to float32 after each axis, 'reflect' = (d c b a | a b c d | d c b a).
+  * numpy.gradient            central differences, one-sided at the faces.
+  * numpy.histogram           uniform-bin fast path incl. the +-1 edge fix-up.
+  * numpy.linalg.eigvalsh     float32 in -> float64 LAPACK -> float32 out; restated as
+                              the float64 trigonometric closed form rounded to float32.
+  * numpy.percentile          method='linear'.
+  * scipy.ndimage.binary_opening / binary_fill_holes / label / uniform_filter.
+
+Pinning (parity is PINNED): the reference's own tests hold no vector for Filter
+and two toy cases for Label (tests/test_labelling.py:25-77).  The oracle is
+therefore pinned against golden vectors produced by importing the reference
+itself in the build container (tests/golden/make_golden.py, committed with the
+.npz files) and, where scipy/numpy are importable, against the library calls
+directly (tests/test_oracle_*.py).
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+import os
+import subprocess
+from types import SimpleNamespace
+
+import numpy as np
+
+F32 = np.float32
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+# =============================================================================
+# C helper (integer work: CCL, flood fill)
+# =============================================================================
+_LIB = None
+
+
+def build_c_helper(force: bool = False) -> str:
+    """Compile oracle/ccl_oracle.c -> oracle/libccl_oracle.so with gcc."""
+    src = os.path.join(_HERE, "ccl_oracle.c")
+    out = os.path.join(_HERE, "libccl_oracle.so")
+    if force or (not os.path.exists(out)) or os.path.getmtime(out) < os.path.getmtime(src):
+        subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-o", out, src])
+    return out
+
+
+def _lib():
+    global _LIB
+    if _LIB is None:
+        path = build_c_helper()
+        lib = ctypes.CDLL(path)
+        i64 = ctypes.c_int64
+        p = ctypes.c_void_p
+        lib.orc_label.restype = i64
+        lib.orc_label.argtypes = [p, p, i64, i64, i64, ctypes.c_int]
+        lib.orc_fill_holes.restype = None
+        lib.orc_fill_holes.argtypes = [p, p, i64, i64, i64]
+        _LIB = lib
+    return _LIB
+
+
+# =============================================================================
+# Filter: parameters
+# =============================================================================
+def z_ratio(dim_res) -> float:
+    """filtering.py:75-78."""
+    z_res = dim_res.get("Z") or dim_res.get("X") or 1.0
+    x_res = dim_res.get("X") or 1.0
+    return float(z_res) / float(x_res)
+
+
+def spacing3(dim_res):
+    """filtering.py:265-275 (3-D branch)."""
+    z = dim_res.get("Z") or dim_res.get("X") or 1.0
+    y = dim_res.get("Y") or 1.0
+    x = dim_res.get("X") or 1.0
+    return (float(z), float(y), float(x))
+
+
+def default_sigmas(dim_res, min_radius_um=0.25, max_radius_um=1.0):
+    """filtering.py:88-89, 288-316."""
+    min_radius_px = min_radius_um / dim_res["X"]
+    max_radius_px = max_radius_um / dim_res["X"]
+    min_sigma_step_size = 0.2
+    num_sigma = 5
+    sigma_1 = min_radius_px / 2.0
+    sigma_2 = max_radius_px / 3.0
+    sigma_min = min(sigma_1, sigma_2)
+    sigma_max = max(sigma_1, sigma_2)
+    if sigma_max <= sigma_min:
+        sigma_max = sigma_min + min_sigma_step_size
+    step_calc = (sigma_max - sigma_min) / float(num_sigma)
+    step = max(min_sigma_step_size, step_calc)
+    sigmas = list(np.arange(sigma_min, sigma_max, step, dtype=float))
+    sigmas.sort()
+    return sigmas
+
+
+def sigma_vec(sigma, zr):
+    """filtering.py:277-286 (3-D branch)."""
+    return (float(sigma) / zr, float(sigma), float(sigma))
+
+
+def cascade_deltas(sigmas, zr):
+    """filtering.py:814-825: per-scale incremental sigma per axis."""
+    out = []
+    prev = 0.0
+    for s in sigmas:
+        vp = sigma_vec(prev, zr)
+        vc = sigma_vec(s, zr)
+        d = []
+        for sp, sc in zip(vp, vc):
+            diff = max(0.0, float(sc) ** 2 - float(sp) ** 2)
+            d.append(float(np.sqrt(diff)))
+        out.append(tuple(d))
+        prev = s
+    return out
+
+
+# =============================================================================
+# scipy.ndimage.gaussian_filter restated
+# =============================================================================
+def gaussian_kernel1d(sigma: float, radius: int) -> np.ndarray:
+    """scipy/ndimage/_filters.py `_gaussian_kernel1d` (order 0)."""
+    sigma2 = sigma * sigma
+    x = np.arange(-radius, radius + 1)
+    phi_x = np.exp(-0.5 / sigma2 * x ** 2)
+    phi_x = phi_x / phi_x.sum()
+    return phi_x
+
+
+def gaussian_radius(sigma: float, truncate: float = 3.0) -> int:
+    """scipy `gaussian_filter1d`: lw = int(truncate * sd + 0.5)."""
+    return int(truncate * float(sigma) + 0.5)
+
+
+def _reflect_index(idx: np.ndarray, n: int) -> np.ndarray:
+    """scipy NI_EXTEND_REFLECT: (d c b a | a b c d | d c b a)."""
+    period = 2 * n
+    m = np.mod(idx, period)
+    return np.where(m >= n, period - 1 - m, m)
+
+
+def correlate1d_reflect_f32(a: np.ndarray, w: np.ndarray, axis: int) -> np.ndarray:
+    """
+    scipy ni_filters.c NI_Correlate1D, symmetric branch, mode=reflect, origin 0:
+        tmp = in[0]*w[0];  for j = -r..-1: tmp += (in[j] + in[-j]) * w[j]
+    in float64, one rounding per operation, result stored as float32.
+    """
+    assert a.dtype == np.float32
+    r = (len(w) - 1) // 2
+    n = a.shape[axis]
+    a64 = np.moveaxis(a, axis, 0).astype(np.float64)
+    idx = np.arange(n)
+    tmp = a64 * w[r]
+    for j in range(-r, 0):
+        lo = a64[_reflect_index(idx + j, n)]
+        hi = a64[_reflect_index(idx - j, n)]
+        tmp = tmp + (lo + hi) * w[r + j]
+    return np.ascontiguousarray(np.moveaxis(tmp.astype(np.float32), 0, axis))
+
+
+def gaussian_filter_f32(a: np.ndarray, sigmas, truncate: float = 3.0) -> np.ndarray:
+    """scipy gaussian_filter(mode='reflect'): axes in order, skipping sigma <= 1e-15."""
+    out = a
+    for axis, sd in enumerate(sigmas):
+        if sd > 1e-15:
+            r = gaussian_radius(sd, truncate)
+            w = gaussian_kernel1d(float(sd), r)
+            out = correlate1d_reflect_f32(out, w, axis)
+    return out
+
+
+# =============================================================================
+# threshold helpers
+# =============================================================================
+def sample_strides(shape, max_samples=int(1e6)):
+    """filtering.py:328-340."""
+    if max_samples is None or max_samples <= 0:
+        return (1,) * len(shape)
+    total = int(np.prod(shape))
+    if total <= max_samples:
+        return (1,) * len(shape)
+    ndim = len(shape)
+    stride = int(np.ceil((total / max_samples) ** (1.0 / ndim)))
+    strides = [max(1, stride) for _ in range(ndim)]
+    while int(np.prod([int(np.ceil(s / st)) for s, st in zip(shape, strides)])) > max_samples:
+        idx = int(np.argmax([s / st for s, st in zip(shape, strides)]))
+        strides[idx] += 1
+    return tuple(strides)
+
+
+def subsample_positive(arr, max_samples=int(1e6)):
+    """filtering.py:342-363."""
+    if arr.size == 0:
+        return arr
+    st = sample_strides(arr.shape, max_samples)
+    if not all(s == 1 for s in st):
+        arr = arr[tuple(slice(None, None, s) for s in st)]
+    arr = arr[arr > 0]
+    if arr.size == 0:
+        return arr
+    if arr.size > max_samples:
+        stride = max(1, arr.size // max_samples)
+        arr = arr[::stride]
+    return arr
+
+
+def linspace_f32(first: np.float32, last: np.float32, num: int) -> np.ndarray:
+    """numpy/_core/function_base.py `linspace` for float32 endpoints, endpoint=True."""
+    first = F32(first)
+    last = F32(last)
+    div = num - 1
+    delta = F32(last - first)
+    y = np.arange(0, num, dtype=np.float32)
+    step = F32(delta / F32(div))
+    if step == 0:
+        y = y / F32(div)
+        y = y * delta
+    else:
+        y = y * step
+    y = y + first
+    y[-1] = last
+    return y.astype(np.float32)
+
+
+def histogram_f32(flat: np.ndarray, nbins: int = 256):
+    """
+    numpy/lib/_histograms_impl.py `histogram(a, bins=n, range=(a.min(), a.max()))`
+    for float32 data: float32 bin edges from linspace, index = trunc((a-first)/(last-first)*n)
+    in float32, then the +-1 edge correction against the float32 edges.
+    """
+    flat = np.ascontiguousarray(flat, dtype=np.float32).reshape(-1)
+    first = flat.min()
+    last = flat.max()
+    if first == last:
+        first = F32(first - F32(0.5))
+        last = F32(last + F32(0.5))
+    edges = linspace_f32(first, last, nbins + 1)
+    if np.any(edges[:-1] >= edges[1:]):
+        raise ValueError(
+            f"Too many bins for data range. Cannot create {nbins} finite-sized bins.")
+    norm_denom = F32(last - first)
+    f_idx = ((flat - first) / norm_denom) * F32(nbins)
+    idx = f_idx.astype(np.intp)
+    idx[idx == nbins] -= 1
+    dec = flat < edges[idx]
+    idx[dec] -= 1
+    inc = (flat >= edges[idx + 1]) & (idx != nbins - 1)
+    idx[inc] += 1
+    counts = np.bincount(idx, minlength=nbins).astype(np.intp)
+    return counts, edges
+
+
+def otsu_from_hist(counts, edges):
+    """gpu_functions.py:36-50 (everything after the histogram call)."""
+    bin_centers = (edges[:-1] + edges[1:]) / 2.0
+    c = counts / np.sum(counts)
+    weight1 = np.cumsum(c)
+    mean1 = np.cumsum(c * bin_centers) / weight1
+    weight2 = np.cumsum(c[::-1])[::-1]
+    mean2 = (np.cumsum((c * bin_centers)[::-1]) / weight2[::-1])[::-1]
+    variance12 = weight1[:-1] * weight2[1:] * (mean1[:-1] - mean2[1:]) ** 2
+    idx = np.argmax(variance12)
+    return bin_centers[idx]
+
+
+def triangle_from_hist(counts, edges):
+    """gpu_functions.py:64-94 (everything after the histogram call)."""
+    nbins = len(counts)
+    bin_centers = (edges[:-1] + edges[1:]) / 2.0
+    hist = counts / np.sum(counts)
+    arg_peak_height = np.argmax(hist)
+    peak_height = hist[arg_peak_height]
+    arg_low_level, arg_high_level = np.flatnonzero(hist)[[0, -1]]
+    flip = arg_peak_height - arg_low_level < arg_high_level - arg_peak_height
+    if flip:
+        hist = np.flip(hist, axis=0)
+        arg_low_level = nbins - arg_high_level - 1
+        arg_peak_height = nbins - arg_peak_height - 1
+    width = arg_peak_height - arg_low_level
+    x1 = np.arange(width)
+    y1 = hist[x1 + arg_low_level]
+    norm = np.sqrt(peak_height ** 2 + width ** 2)
+    peak_height = peak_height / norm
+    width = width / norm
+    length = peak_height * x1 - width * y1
+    arg_level = np.argmax(length) + arg_low_level
+    if flip:
+        arg_level = nbins - arg_level - 1
+    return bin_centers[arg_level]
+
+
+def otsu_threshold(values, nbins=256):
+    """gpu_functions.py:23-50."""
+    counts, edges = histogram_f32(values, nbins)
+    return otsu_from_hist(counts, edges)
+
+
+def triangle_threshold(values, nbins=256):
+    """gpu_functions.py:53-94."""
+    counts, edges = histogram_f32(values, nbins)
+    return triangle_from_hist(counts, edges)
+
+
+def min_tri_otsu(values, nbins=256):
+    """The recurring `min(triangle, otsu)` on one sample set (one histogram serves both)."""
+    counts, edges = histogram_f32(values, nbins)
+    return min(triangle_from_hist(counts, edges), otsu_from_hist(counts, edges))
+
+
+def calculate_gamma(gauss, max_samples=int(1e6)) -> float:
+    """filtering.py:365-380."""
+    positive = subsample_positive(gauss, max_samples)
+    if positive.size == 0:
+        return float(np.finfo(np.float32).eps)
+    gamma = float(min_tri_otsu(positive))
+    if gamma <= 0:
+        gamma = float(np.finfo(np.float32).eps)
+    return gamma
+
+
+# =============================================================================
+# Hessian (numpy.gradient applied twice), Frobenius mask
+# =============================================================================
+def gradient_axis(f: np.ndarray, h: float, axis: int) -> np.ndarray:
+    """
+    numpy/lib/_function_base_impl.py `gradient`, uniform spacing, edge_order=1, float32:
+      interior (f[i+1]-f[i-1]) / (2.*h); faces (f[1]-f[0])/h and (f[-1]-f[-2])/h.
+    `h` is a python float => weak scalar => float32 arithmetic with divisor float32(2h)/float32(h).
+    """
+    assert f.dtype == np.float32
+    n = f.shape[axis]
+    if n < 2:
+        raise ValueError(
+            "Shape of array too small to calculate a numerical gradient, "
+            "at least (edge_order + 1) elements are required.")
+    fm = np.moveaxis(f, axis, 0)
+    out = np.empty_like(fm)
+    out[1:-1] = (fm[2:] - fm[:-2]) / F32(2.0 * h)
+    out[0] = (fm[1] - fm[0]) / F32(h)
+    out[-1] = (fm[-1] - fm[-2]) / F32(h)
+    return np.ascontiguousarray(np.moveaxis(out, 0, axis))
+
+
+def hessian_components(img: np.ndarray, spacing):
+    """filtering.py:518-536: (hxx,hxy,hxz,hyy,hyz,hzz) with 'x' = axis 0 (naming only)."""
+    g0 = gradient_axis(img, spacing[0], 0)
+    g1 = gradient_axis(img, spacing[1], 1)
+    g2 = gradient_axis(img, spacing[2], 2)
+    hxx = gradient_axis(g0, spacing[0], 0)
+    hxy = gradient_axis(g0, spacing[1], 1)
+    hxz = gradient_axis(g0, spacing[2], 2)
+    hyy = gradient_axis(g1, spacing[1], 1)
+    hyz = gradient_axis(g1, spacing[2], 2)
+    hzz = gradient_axis(g2, spacing[2], 2)
+    return hxx, hxy, hxz, hyy, hyz, hzz
+
+
+def frobenius(h6):
+    """filtering.py:538-562: frob_sq, max_abs, frob = sqrt(frob_sq)/max_abs."""
+    hxx, hxy, hxz, hyy, hyz, hzz = h6
+    frob_sq = hxx ** 2 + hyy ** 2 + hzz ** 2 + F32(2.0) * (hxy ** 2 + hxz ** 2 + hyz ** 2)
+    max_abs = 0.0
+    for comp in h6:
+        if comp.size > 0:
+            max_abs = max(max_abs, float(np.max(np.abs(comp))))
+    if max_abs <= 0:
+        max_abs = 1.0
+    with np.errstate(invalid="ignore"):
+        frob = np.sqrt(frob_sq) / F32(max_abs)
+    return frob_sq, max_abs, frob
+
+
+def frob_mask(frob, frob_thresh=None, frob_thresh_division=2, max_samples=int(1e6)):
+    """filtering.py:407-444.  Returns (mask, threshold_used_or_None)."""
+    inf_mask = np.isinf(frob)
+    if np.any(inf_mask):
+        finite_vals = frob[~inf_mask]
+        max_finite = float(np.max(finite_vals)) if finite_vals.size > 0 else 0.0
+        frob = frob.copy()
+        frob[inf_mask] = max_finite
+    if not frob_thresh_division:
+        return frob > 0, None
+    if frob_thresh is None:
+        positive = subsample_positive(frob, max_samples)
+        if positive.size == 0:
+            thr = 0.0
+        else:
+            thr = float(min_tri_otsu(positive))
+    else:
+        thr = float(frob_thresh)
+    with np.errstate(invalid="ignore"):
+        mask = frob > (thr / frob_thresh_division)
+    return mask, thr
+
+
+# =============================================================================
+# numpy.linalg.eigvalsh restated (3x3 symmetric, float32 in/out, float64 inside)
+# =============================================================================
+def eigvalsh3_f32(hxx, hxy, hxz, hyy, hyz, hzz):
+    """
+    numpy.linalg.eigvalsh on float32 (M,3,3): numpy/linalg/_linalg.py computes in
+    float64 (LAPACK dsyevd) and casts the ascending eigenvalues back to float32.
+    Restated as the float64 trigonometric closed form (Smith 1961):
+        q = tr/3, B = A - qI, p = sqrt(||B||_F^2 / 6), r = det(B)/(2 p^3) clipped to [-1,1],
+        phi = acos(r)/3, lambda_k = q + 2 p cos(phi + 2 pi k / 3)
+    rounded to float32.  Returns (M,3) ascending.
+    """
+    a00 = hxx.astype(np.float64); a01 = hxy.astype(np.float64); a02 = hxz.astype(np.float64)
+    a11 = hyy.astype(np.float64); a12 = hyz.astype(np.float64); a22 = hzz.astype(np.float64)
+    q = (a00 + a11 + a22) / 3.0
+    b00 = a00 - q; b11 = a11 - q; b22 = a22 - q
+    p2 = (b00 * b00 + b11 * b11 + b22 * b22 + 2.0 * (a01 * a01 + a02 * a02 + a12 * a12)) / 6.0
+    p = np.sqrt(p2)
+    det = (b00 * (b11 * b22 - a12 * a12)
+           - a01 * (a01 * b22 - a12 * a02)
+           + a02 * (a01 * a12 - b11 * a02))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        r = det / (2.0 * p2 * p)
+    r = np.where(p2 > 0, r, 0.0)
+    r = np.clip(r, -1.0, 1.0)
+    phi = np.arccos(r) / 3.0
+    e_max = q + 2.0 * p * np.cos(phi)
+    e_min = q + 2.0 * p * np.cos(phi + (2.0 * np.pi / 3.0))
+    e_mid = 3.0 * q - e_max - e_min
+    ev = np.stack([e_min, e_mid, e_max], axis=1)
+    return ev.astype(np.float32)
+
+
+def sort_by_abs(ev):
+    """filtering.py:583-584: argsort(|ev|) (stable for the 3-element insertion sort) + take."""
+    order = np.argsort(np.abs(ev), axis=1, kind="stable")
+    return np.take_along_axis(ev, order, axis=1)
+
+
+def frangi_response(ev, alpha_sq, beta_sq, gamma_sq):
+    """filtering.py:744-766 (3-D branch).  float32 throughout; python floats are weak scalars."""
+    l1 = ev[:, 0]
+    l2 = ev[:, 1]
+    l3 = ev[:, 2]
+    with np.errstate(all="ignore"):
+        ra_sq = (np.abs(l2) / (np.abs(l3) + 1e-12)) ** 2
+        rb_sq = (np.abs(l2) / (np.sqrt(np.abs(l2 * l3)) + 1e-12)) ** 2
+        s_sq = l1 ** 2 + l2 ** 2 + l3 ** 2
+        v = ((1.0 - np.exp(-(ra_sq / alpha_sq)))
+             * np.exp(-(rb_sq / beta_sq))
+             * (1.0 - np.exp(-(s_sq / gamma_sq))))
+    v[l3 > 0] = 0.0
+    v[l2 > 0] = 0.0
+    v = np.nan_to_num(v, nan=0.0, posinf=0.0, neginf=0.0)
+    return v
+
+
+# =============================================================================
+# Filter frame
+# =============================================================================
+def compute_vesselness(frame, dim_res, sigmas=None, alpha_sq=0.5, beta_sq=0.5,
+                       frob_thresh=None, frob_thresh_division=2,
+                       max_samples=int(1e6), mask=True, trace=None):
+    """
+    filtering.py:806-853 (+ 651-715 for the masked evaluation).
+    `trace`, if a list, receives one dict per scale with the intermediates the
+    golden vectors pin.
+    """
+    frame = np.asarray(frame, dtype=np.float32)
+    zr = z_ratio(dim_res)
+    spacing = spacing3(dim_res)
+    if sigmas is None:
+        sigmas = default_sigmas(dim_res)
+    vesselness = np.zeros_like(frame, dtype=np.float32)
+    masks = np.ones_like(frame, dtype=bool)
+    gauss = frame.copy()  # the reference blurs in place (hazard B.1); results are identical
+    for sigma, delta in zip(sigmas, cascade_deltas(sigmas, zr)):
+        if any(s > 0 for s in delta):
+            gauss = gaussian_filter_f32(gauss, delta, 3.0)
+        gamma = calculate_gamma(gauss, max_samples)
+        gamma_sq = 2.0 * (float(gamma) ** 2)
+        h6 = hessian_components(gauss, spacing)
+        if mask:
+            _, max_abs, frob = frobenius(h6)
+            h_mask, thr = frob_mask(frob, frob_thresh, frob_thresh_division, max_samples)
+        else:
+            max_abs, thr = None, None
+            h_mask = np.ones_like(frame, dtype=bool)
+        rec = dict(sigma=float(sigma), delta=delta, gamma=gamma, gamma_sq=gamma_sq,
+                   max_abs=max_abs, frob_thr=thr, mask_count=int(h_mask.sum()))
+        if trace is not None:
+            rec["gauss"] = gauss.copy()
+            trace.append(rec)
+        if not np.any(h_mask):
+            continue
+        coords = np.where(h_mask)
+        ev = eigvalsh3_f32(*[c[coords] for c in h6])
+        ev = sort_by_abs(ev)
+        v = frangi_response(ev, alpha_sq, beta_sq, gamma_sq).astype(np.float32, copy=False)
+        vessel_scale = np.zeros_like(frame, dtype=np.float32)
+        vessel_scale[coords] = v
+        if trace is not None:
+            rec["vessel_scale"] = vessel_scale
+        vesselness = np.maximum(vesselness, vessel_scale)
+        masks &= h_mask
+    return vesselness, masks
+
+
+def run_frame(frame, dim_res, **kw):
+    """filtering.py:910-933 (3-D, remove_edges=False): vesselness * masks."""
+    vesselness, masks = compute_vesselness(frame, dim_res, **kw)
+    return vesselness * masks
+
+
+def percentile_linear_f32(values: np.ndarray, q: float):
+    """numpy.percentile(values, q) (method='linear') for a float32 1-D array -> float32."""
+    a = np.sort(np.asarray(values, dtype=np.float32).reshape(-1))
+    n = a.size
+    qq = np.true_divide(np.asanyarray(q), 100)       # float64 0-d
+    virtual = (n - 1) * qq
+    lo = int(np.floor(virtual))
+    hi = min(lo + 1, n - 1)
+    g = np.asanyarray(virtual - lo)                  # float64 0-d
+    # numpy `_lerp`: a + (b-a)*t ; where t >= 0.5: b - (b-a)*(1-t)
+    av = a[lo]
+    bv = a[hi]
+    diff = bv - av                                   # float32 scalar
+    res = np.add(av, diff * g)
+    if g >= 0.5:
+        res = np.subtract(bv, diff * (1 - g))
+    if diff == 0:
+        res = av
+    return np.float32(res) if a.dtype == np.float32 else res
+
+
+def binary_erosion6(m: np.ndarray) -> np.ndarray:
+    """scipy.ndimage.binary_erosion, default 6-connected cross, border_value=0."""
+    p = np.pad(m, 1, mode="constant", constant_values=False)
+    c = p[1:-1, 1:-1, 1:-1]
+    return (c & p[:-2, 1:-1, 1:-1] & p[2:, 1:-1, 1:-1]
+            & p[1:-1, :-2, 1:-1] & p[1:-1, 2:, 1:-1]
+            & p[1:-1, 1:-1, :-2] & p[1:-1, 1:-1, 2:])
+
+
+def binary_dilation6(m: np.ndarray) -> np.ndarray:
+    """scipy.ndimage.binary_dilation, default 6-connected cross, border_value=0."""
+    p = np.pad(m, 1, mode="constant", constant_values=False)
+    c = p[1:-1, 1:-1, 1:-1]
+    return (c | p[:-2, 1:-1, 1:-1] | p[2:, 1:-1, 1:-1]
+            | p[1:-1, :-2, 1:-1] | p[1:-1, 2:, 1:-1]
+            | p[1:-1, 1:-1, :-2] | p[1:-1, 1:-1, 2:])
+
+
+def mask_volume(frangi_frame, max_samples=int(1e6), return_thr=False):
+    """filtering.py:952-967."""
+    positive = subsample_positive(frangi_frame, max_samples)
+    if positive.size == 0:
+        return (frangi_frame, None) if return_thr else frangi_frame
+    thr = percentile_linear_f32(positive, 1)
+    m = frangi_frame > thr
+    m = binary_dilation6(binary_erosion6(m))      # binary_opening, 1 iteration
+    out = frangi_frame * m
+    return (out, thr) if return_thr else out
+
+
+def filter_frame(frame, dim_res, **kw):
+    """filtering.py:1012-1020: _run_frame then _mask_volume when the frame has signal."""
+    fr = run_frame(frame, dim_res, **kw)
+    if float(np.sum(fr)) > 0.0:
+        fr = mask_volume(fr, kw.get("max_samples", int(1e6)))
+    return fr
+
+
+# =============================================================================
+# Label
+# =============================================================================
+def min_area_pixels(dim_res, min_radius_um=0.25):
+    """labelling.py:95-97, 209-219 (3-D branch)."""
+    x_res = dim_res.get("X") or 1.0
+    y_res = dim_res.get("Y") or x_res
+    z_res = dim_res.get("Z") or x_res
+    r = max(float(min_radius_um), float(x_res))
+    volume_um3 = (4.0 / 3.0) * np.pi * (r ** 3)
+    volume_px = volume_um3 / (float(x_res) * float(y_res) * float(z_res))
+    return max(1, int(np.ceil(volume_px)))
+
+
+def sample_nonzero(frame, max_samples=1_000_000):
+    """labelling.py:385-438 (no mask arguments: the default path)."""
+    flat = frame.reshape(-1)
+    if flat.size == 0:
+        return flat
+    max_samples = max(1, int(max_samples))
+    step = max(int(flat.size) // max_samples, 1)
+    offsets = (0, step // 2) if step > 1 and step // 2 > 0 else (0,)
+    values = flat[:0]
+    for offset in offsets:
+        sample = flat[offset::step]
+        values = sample[sample > 0]
+        if values.size > 0 or step == 1:
+            return values
+    if float(flat.max()) <= 0:
+        return values
+    return flat[flat > 0]
+
+
+def frangi_threshold(frangi, max_samples=1_000_000, nbins=256):
+    """labelling.py:440-455: log10-domain min(triangle, otsu); None when no positive sample."""
+    values = sample_nonzero(frangi, max_samples)
+    if values.size == 0:
+        return None
+    log_values = np.log10(values)
+    counts, edges = histogram_f32(log_values, nbins)
+    triangle = 10 ** triangle_from_hist(counts, edges)
+    otsu = 10 ** otsu_from_hist(counts, edges)
+    return min(triangle, otsu)
+
+
+def label26(mask: np.ndarray) -> np.ndarray:
+    """scipy.ndimage.label(structure=ones(3,3,3)): int32 ids in raster order of first voxel."""
+    return _label(mask, 26)
+
+
+def _label(mask, conn):
+    m = np.ascontiguousarray(mask, dtype=np.uint8)
+    out = np.zeros(m.shape, dtype=np.int32)
+    nz, ny, nx = m.shape
+    _lib().orc_label(m.ctypes.data, out.ctypes.data, nz, ny, nx, conn)
+    return out
+
+
+def fill_holes6(mask: np.ndarray) -> np.ndarray:
+    """scipy.ndimage.binary_fill_holes (default 6-connected structure)."""
+    m = np.ascontiguousarray(mask, dtype=np.uint8)
+    out = np.empty(m.shape, dtype=np.uint8)
+    nz, ny, nx = m.shape
+    _lib().orc_fill_holes(m.ctypes.data, out.ctypes.data, nz, ny, nx)
+    return out.astype(bool)
+
+
+def majority3(mask: np.ndarray) -> np.ndarray:
+    """
+    labelling.py:503-505: uniform_filter(float32 mask, size=3, mode='reflect') > 0.5
+    == at least 14 of the 27 reflect-padded neighbours set (13/27 < 0.5 < 14/27).
+    """
+    p = np.pad(mask.astype(np.int32), 1, mode="symmetric")
+    s = p[:-2] + p[1:-1] + p[2:]
+    s = s[:, :-2] + s[:, 1:-1] + s[:, 2:]
+    s = s[:, :, :-2] + s[:, :, 1:-1] + s[:, :, 2:]
+    return s >= 14
+
+
+def get_labels(frangi, frangi_thresh, min_area):
+    """labelling.py:467-509 (3-D)."""
+    if frangi_thresh is None:
+        mask = np.zeros_like(frangi, dtype=bool)
+    else:
+        mask = frangi > frangi_thresh
+    mask = fill_holes6(mask)
+    labels = label26(mask)
+    if labels.size == 0:
+        return mask, labels
+    areas = np.bincount(labels.ravel())
+    if areas.size <= 1:
+        return mask, labels
+    areas[0] = 0
+    keep = areas >= min_area
+    mask = keep[labels]
+    mask = majority3(mask)
+    labels = label26(mask)
+    return mask, labels
+
+
+def label_frame(frangi, dim_res, min_radius_um=0.25, max_samples=1_000_000, nbins=256,
+                return_thr=False):
+    """labelling.py:511-532 (defaults: no intensity threshold) + 538-556."""
+    thr = frangi_threshold(frangi, max_samples, nbins)
+    _, labels = get_labels(frangi, thr, min_area_pixels(dim_res, min_radius_um))
+    return (labels, thr) if return_thr else labels
+
+
+def segment_frame(frame, dim_res):
+    """Filter then Label on one 3-D frame: (im_preprocessed float32, im_instance_label int32)."""
+    fr = filter_frame(frame, dim_res)
+    return fr, label_frame(fr, dim_res)
+
+
+def fake_im_info(shape_zyx, dim_res):
+    """The duck-typed ImInfo the reference's own tests use (tests/test_labelling.py:7-22)."""
+    z, y, x = shape_zyx
+    return SimpleNamespace(no_t=True, no_z=False, shape=(1, z, y, x), axes="TZYX",
+                           dim_res=dict(dim_res))
