@@ -528,24 +528,36 @@ def run_frame(frame, dim_res, **kw):
 
 
 def percentile_linear_f32(values: np.ndarray, q: float):
-    """numpy.percentile(values, q) (method='linear') for a float32 1-D array -> float32."""
+    """
+    numpy.percentile(values, q) (method='linear') for a float32 1-D array, numpy 2.2.6
+    (numpy/lib/_function_base_impl.py:4257 `percentile`, `_quantile`, `_get_indexes`,
+    `_get_gamma`, `_lerp`): for float input the quantile is q / float32(100), so the
+    virtual index (n-1)*q, its fractional part and the interpolation are ALL float32.
+    """
     a = np.sort(np.asarray(values, dtype=np.float32).reshape(-1))
     n = a.size
-    qq = np.true_divide(np.asanyarray(q), 100)       # float64 0-d
-    virtual = (n - 1) * qq
-    lo = int(np.floor(virtual))
-    hi = min(lo + 1, n - 1)
-    g = np.asanyarray(virtual - lo)                  # float64 0-d
-    # numpy `_lerp`: a + (b-a)*t ; where t >= 0.5: b - (b-a)*(1-t)
+    q32 = np.true_divide(q, F32(100))                # float32
+    virtual = F32((n - 1) * q32)                     # python int * float32 -> float32
+    if virtual >= n - 1:
+        lo = hi = n - 1
+        prev_f = F32(-1)
+    elif virtual < 0:
+        lo = hi = 0
+        prev_f = F32(0)
+    else:
+        prev_f = np.floor(virtual)
+        lo = int(prev_f)
+        hi = lo + 1
+    # `_get_gamma` subtracts the intp index (after the -1 / 0 clamps) from the f32 virtual index
+    prev_idx = np.intp(lo if lo != n - 1 or virtual < n - 1 else -1)
+    gamma = F32(np.asanyarray(virtual - prev_idx, dtype=np.float32))
     av = a[lo]
     bv = a[hi]
-    diff = bv - av                                   # float32 scalar
-    res = np.add(av, diff * g)
-    if g >= 0.5:
-        res = np.subtract(bv, diff * (1 - g))
-    if diff == 0:
-        res = av
-    return np.float32(res) if a.dtype == np.float32 else res
+    diff = np.subtract(bv, av)
+    res = np.add(av, diff * gamma)
+    if gamma >= 0.5:
+        res = np.subtract(bv, diff * (1 - gamma))
+    return F32(res)
 
 
 def binary_erosion6(m: np.ndarray) -> np.ndarray:

@@ -1,0 +1,56 @@
+import glob
+import os
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+GOLDEN_DIR = os.path.join(REPO, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def golden_names(prefix=""):
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, prefix + "*.npz")))
+
+
+def load_golden(name):
+    g = dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False))
+    if "input" not in g and "input_shape" in g:
+        import zlib
+        from nellie_amd.synthetic import make_volume
+        vol = make_volume(tuple(int(s) for s in g["input_shape"]), int(g["input_seed"]))
+        assert np.uint32(zlib.crc32(vol.tobytes())) == g["input_crc"], "synthetic generator drifted"
+        g["input"] = vol
+    if "dim_res" in g:
+        z, y, x = (float(v) for v in g["dim_res"])
+        g["dim_res_dict"] = {"X": x, "Y": y, "Z": z, "T": 1.0}
+    g["kwargs"] = {}
+    for k in list(g):
+        if k.startswith("kw_"):
+            v = float(g[k])
+            name_ = k[3:]
+            if np.isnan(v):
+                g["kwargs"][name_] = None
+            elif name_ == "frob_thresh_division":
+                g["kwargs"][name_] = int(v)
+            else:
+                g["kwargs"][name_] = v
+    return g
+
+
+FILTER_CASES = [n for n in golden_names() if not n.startswith("labelonly")]
+LABEL_ONLY_CASES = golden_names("labelonly")
+
+
+@pytest.fixture(scope="session")
+def hip():
+    """The product's HIP library handle; GPU tests fail loudly when it is missing."""
+    from nellie_amd import hipnative
+    return hipnative.load()

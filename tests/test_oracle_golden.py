@@ -1,0 +1,87 @@
+"""
+CPU tests: the oracle (oracle/nellie_oracle.py + oracle/ccl_oracle.c) against the
+golden vectors captured from the imported reference (tests/golden/make_golden.py).
+This is what pins the oracle; everything up to the final Frangi product must be
+bit-equal, and on these fixtures the final product is bit-equal too (same numpy exp).
+"""
+import zlib
+
+import numpy as np
+import pytest
+
+from conftest import FILTER_CASES, LABEL_ONLY_CASES, load_golden
+from oracle import nellie_oracle as orc
+
+
+def _filter_kwargs(g):
+    kw = dict(g["kwargs"])
+    sig_kw = {k: kw.pop(k) for k in ("min_radius_um", "max_radius_um") if k in kw}
+    return kw, sig_kw
+
+
+@pytest.mark.parametrize("name", FILTER_CASES)
+def test_filter_matches_reference(name):
+    g = load_golden(name)
+    dr = g["dim_res_dict"]
+    kw, sig_kw = _filter_kwargs(g)
+    vol = g["input"]
+    if "error_type" in g:
+        with pytest.raises(ValueError, match=str(g["error_msg"])[:30]):
+            orc.filter_frame(vol, dr, **kw)
+        return
+    sigmas = orc.default_sigmas(dr, **sig_kw)
+    assert np.array_equal(np.array(sigmas), g["sigmas"])
+    trace = []
+    vess, masks = orc.compute_vesselness(vol, dr, sigmas=sigmas, trace=trace, **kw)
+    assert len(trace) == len(g["gamma"])
+    for s, rec in enumerate(trace):
+        assert rec["gamma"] == g["gamma"][s]
+        assert np.uint32(zlib.crc32(rec["gauss"].tobytes())) == g["gauss_crc"][s], f"gauss scale {s}"
+        assert np.array_equal(rec["gauss"][vol.shape[0] // 2], g["gauss_mid_planes"][s])
+        assert rec["max_abs"] == g["max_abs"][s]
+        if not np.isnan(g["frob_thr"][s]):
+            assert rec["frob_thr"] == g["frob_thr"][s]
+        assert rec["mask_count"] == g["mask_count"][s]
+    fr = vess * masks
+    assert np.array_equal(fr, g["run_frame"])
+    if float(fr.sum()) > 0:
+        out, thr = orc.mask_volume(fr, return_thr=True)
+        assert float(thr) == float(g["percentile_thr"])
+    else:
+        out = fr
+    assert out.dtype == np.float32
+    assert np.array_equal(out, g["frangi"])
+
+
+@pytest.mark.parametrize("name", [n for n in FILTER_CASES])
+def test_label_matches_reference_given_reference_frangi(name):
+    g = load_golden(name)
+    if "error_type" in g:
+        pytest.skip("reference raises on this input")
+    labels, thr = orc.label_frame(g["frangi"], g["dim_res_dict"], return_thr=True)
+    if np.isnan(g["label_thr"]):
+        assert thr is None
+    else:
+        assert float(thr) == float(g["label_thr"])
+    assert orc.min_area_pixels(g["dim_res_dict"]) == int(g["min_area_pixels"])
+    assert labels.dtype == np.int32
+    assert np.array_equal(labels, g["labels"])
+
+
+@pytest.mark.parametrize("name", LABEL_ONLY_CASES)
+def test_label_only_cases(name):
+    g = load_golden(name)
+    labels, thr = orc.label_frame(g["frangi"], g["dim_res_dict"], return_thr=True)
+    assert float(thr) == float(g["label_thr"])
+    assert np.array_equal(labels, g["labels"])
+    assert labels.max() >= 4
+
+
+def test_reference_toy_label_semantics():
+    """tests/test_labelling.py:25-53 restated for 3-D: ids restart at 1 per call, subset of {0,1}."""
+    fr = np.zeros((5, 7, 7), np.float32)
+    fr[1:4, 1:6, 1:6] = 1.0
+    dr = {"X": 1.0, "Y": 1.0, "Z": 1.0, "T": 1.0}
+    for _ in range(2):
+        _, labels = orc.get_labels(fr, 0.5, orc.min_area_pixels(dr))
+        assert labels.max() == 1 and set(np.unique(labels)) <= {0, 1}
