@@ -1,0 +1,197 @@
+/*
+ * nellie_amd.h -- C-ABI of libnellie_hip.so, the MI355X (gfx950) native engine for
+ * Nellie's `nellie/segmentation` hot path: Filter (multiscale Frangi) -> Label.
+ *
+ * The reference (aelefebv/nellie v1.0.3) is pure Python: its "FFI" for this path is the
+ * `xp`/`ndi` module handle that swaps numpy/scipy.ndimage for cupy/cupyx
+ * (nellie/segmentation/filtering.py:117-159, labelling.py:115-154).  This library is what
+ * a third backend binds instead: every entry point below replaces one group of xp/ndi calls
+ * of the reference, cited as `file:line` relative to the reference checkout.  The host side
+ * stays Python (the nellie_amd.segmentation modules) and talks to this ABI through ctypes:
+ * numpy in, numpy out, plain pointers and sizes, no torch / cupy types.
+ *
+ * Conventions
+ *  - Every function returns an int status (NL_OK == 0) and, on failure, writes a
+ *    NUL-terminated message into the caller's `err` buffer (`errlen` bytes, may be NULL/0).
+ *    No exceptions cross the boundary.  The Python layer maps NL_ENODEV to
+ *    RuntimeError("GPU backend requested but ...") and NL_ENOMEM to MemoryError so the
+ *    reference's retry ladder (nellie/utils/adaptive_run.py:116-141) keeps working.
+ *  - Volumes are C-contiguous (Z, Y, X), X fastest.  All host buffers are owned by the
+ *    caller; all device buffers are owned by the context.  Inputs are never written.
+ *  - A context is bound to one device and one local volume shape.  It may hold a Z-slab of
+ *    a larger global volume (multi-GPU): `gz0` is the global index of local plane 0, `gnz`
+ *    the global plane count, `[own_lo, own_hi)` the planes this rank owns (the rest are
+ *    ghost planes).  Boundary rules (reflect padding, one-sided differences, zero border)
+ *    apply only at true faces of the GLOBAL volume.  Single GPU: gz0 = 0, gnz = nz,
+ *    own = [0, nz).
+ *  - Entry points call hipSetDevice themselves and are synchronous on return unless noted
+ *    (nl_* _async variants enqueue on the context stream; nl_sync waits).  One context must
+ *    not be used from two threads at once; different contexts may be.
+ */
+#ifndef NELLIE_AMD_H
+#define NELLIE_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* status codes */
+#define NL_OK      0
+#define NL_EINVAL  1   /* bad argument */
+#define NL_ENODEV  2   /* no usable HIP device */
+#define NL_ENOMEM  3   /* device or host allocation failed (out of memory) */
+#define NL_EHIP    4   /* any other HIP runtime error */
+#define NL_ESTATE  5   /* call order violated */
+#define NL_ECOMM   6   /* RCCL error */
+
+/* numpy dtype codes accepted by the upload entry points */
+#define NL_U8 0
+#define NL_I8 1
+#define NL_U16 2
+#define NL_I16 3
+#define NL_U32 4
+#define NL_I32 5
+#define NL_F32 6
+#define NL_F64 7
+#define NL_U64 8
+#define NL_I64 9
+
+/* fields a sampling call can read */
+#define NL_FIELD_GAUSS  0  /* current Gaussian scale-space volume */
+#define NL_FIELD_FROB   1  /* sqrt(frob_sq)/max_abs of the current scale, inf -> max finite (filtering.py:421-426, 562) */
+#define NL_FIELD_FRANGI 2  /* the Filter output (after nl_filter_finish / nl_mask_volume) or the uploaded Frangi image */
+
+typedef struct nl_ctx nl_ctx;
+
+const char *nl_version(void);
+
+/* Replaces cupy.cuda.runtime.getDeviceCount / memGetInfo (adaptive_run.py:23-43). */
+int nl_device_count(int *count, char *err, size_t errlen);
+int nl_device_mem_info(int device, int64_t *free_bytes, int64_t *total_bytes, char *err, size_t errlen);
+int nl_device_name(int device, char *name, size_t namelen, char *err, size_t errlen);
+
+int nl_ctx_create(nl_ctx **out, int device,
+                  int64_t nz_local, int64_t ny, int64_t nx,
+                  int64_t gz0, int64_t gnz, int64_t own_lo, int64_t own_hi,
+                  char *err, size_t errlen);
+int nl_ctx_destroy(nl_ctx *ctx);
+int nl_sync(nl_ctx *ctx, char *err, size_t errlen);
+/* bytes of device memory a context of this shape allocates (for the low-memory decision,
+   adaptive_run.py:88-100) */
+int64_t nl_ctx_bytes(int64_t nz_local, int64_t ny, int64_t nx);
+
+/* ------------------------------------------------------------------ Filter ------------ */
+
+/* frame = xp.asarray(memmap[t], dtype=float32)  (filtering.py:917-924).
+   Uploads local planes [z0, z1) from `host` (shape (z1-z0, ny, nx), dtype code) and
+   converts to float32.  Also resets the per-frame state (vesselness = 0, masks = 1;
+   filtering.py:807-808). */
+int nl_filter_load(nl_ctx *ctx, const void *host, int dtype, int64_t z0, int64_t z1,
+                   char *err, size_t errlen);
+
+/* One cascade step: ndi.gaussian_filter(gauss, sigma=delta, output=gauss, mode="reflect",
+   truncate=3.0) (filtering.py:827-835) = up to three correlate1d passes, axis order Z, Y, X,
+   float64 accumulation in scipy's symmetric order, float32 store after each pass.
+   w* are the 2r+1 float64 kernel weights the host computed exactly like scipy
+   (`_gaussian_kernel1d`); a NULL pointer skips that axis (sigma <= 1e-15).
+   Output planes [z0, z1) are produced; the input must be valid on [z0-rz, z1+rz) clipped to
+   the local slab (true global faces reflect). */
+int nl_gauss_step(nl_ctx *ctx,
+                  const double *wz, int rz, const double *wy, int ry, const double *wx, int rx,
+                  int64_t z0, int64_t z1, char *err, size_t errlen);
+
+/* arr[::sz, ::sy, ::sx] of a field on the owned planes (strides are those of the GLOBAL
+   lattice; filtering.py:342-346, 355-356).  `out` receives the samples in C order, `*n`
+   their number; `cap` is the capacity of `out` in elements. */
+int nl_sample_gather(nl_ctx *ctx, int field, int64_t sz, int64_t sy, int64_t sx,
+                     float *out, int64_t cap, int64_t *n, char *err, size_t errlen);
+
+/* min / max / count of the POSITIVE lattice samples (arr[arr > 0]; filtering.py:357 and the
+   range=(min,max) of gpu_functions.py:31-35, 60-64).  npos == 0 leaves mn/mx untouched. */
+int nl_sample_minmax(nl_ctx *ctx, int field, int64_t sz, int64_t sy, int64_t sx,
+                     float *mn, float *mx, int64_t *npos, char *err, size_t errlen);
+
+/* numpy.histogram(positive, bins=nbins, range=(first,last)) counts (gpu_functions.py:31, 60):
+   float32 index computation + the +-1 correction against the float32 `edges` (nbins+1
+   values from numpy.linspace, computed by the host).  counts[nbins] int64. */
+int nl_sample_hist(nl_ctx *ctx, int field, int64_t sz, int64_t sy, int64_t sx,
+                   const float *edges, int nbins, int64_t *counts, char *err, size_t errlen);
+
+/* Hessian by double finite differences of the current Gaussian volume (xp.gradient twice,
+   filtering.py:518-536) on the owned planes; returns
+     max_abs          = max over the six components of max|h|         (filtering.py:556-561; NOT yet mapped 0 -> 1)
+     max_frob_sq      = largest finite frob_sq                         (filtering.py:538-543)
+     any_inf          = 1 if some frob_sq is +inf                      (filtering.py:421-426)
+   `spacing` = (dz, dy, dx) as the reference's python floats. */
+int nl_hessian_stats(nl_ctx *ctx, const double spacing[3],
+                     float *max_abs, float *max_frob_sq, int *any_inf, char *err, size_t errlen);
+
+/* Fixes the normalisation NL_FIELD_FROB and nl_vesselness_step use: frob = sqrt(frob_sq)/max_abs,
+   +inf replaced by max_finite (the host passes max_abs already mapped <=0 -> 1.0). */
+int nl_set_frob_norm(nl_ctx *ctx, float max_abs, float max_finite, char *err, size_t errlen);
+
+/* One scale of filtering.py:842-851 on the owned planes:
+     h_mask     = use_thr ? frob > thr : frob > 0            (filtering.py:428-444)
+     v          = Frangi(eigvalsh(H) sorted by |.|) on h_mask, 0 elsewhere (filtering.py:574-585, 744-766)
+     vesselness = maximum(vesselness, v); masks &= h_mask    (filtering.py:850-851)
+   The host calls it only when the mask is non-empty (filtering.py:843-844).
+   `mask_count` (may be NULL) receives the number of owned voxels in h_mask. */
+int nl_vesselness_step(nl_ctx *ctx, float gamma_sq, float alpha_sq, float beta_sq,
+                       int use_thr, float thr, int64_t *mask_count, char *err, size_t errlen);
+
+/* vesselness * masks (filtering.py:926) -> NL_FIELD_FRANGI.  n_positive = number of owned
+   voxels > 0 (the `sum > 0` test of filtering.py:1016-1017). */
+int nl_filter_finish(nl_ctx *ctx, int64_t *n_positive, char *err, size_t errlen);
+
+/* filtering.py:964-966: mask = frangi > thr; binary_opening (6-connected cross, one
+   iteration, border 0); frangi *= mask. */
+int nl_mask_volume(nl_ctx *ctx, float thr, char *err, size_t errlen);
+
+/* D2H of NL_FIELD_FRANGI local planes [z0, z1) (filtering.py:1023-1031). */
+int nl_filter_store(nl_ctx *ctx, float *host, int64_t z0, int64_t z1, char *err, size_t errlen);
+
+/* Debug / test access: D2H of the current Gaussian volume, local planes [z0, z1). */
+int nl_gauss_store(nl_ctx *ctx, float *host, int64_t z0, int64_t z1, char *err, size_t errlen);
+
+/* ------------------------------------------------------------------ Label ------------- */
+
+/* frangi_in_mem = xp.asarray(frangi_view) (labelling.py:547): host float32 -> NL_FIELD_FRANGI. */
+int nl_label_load_frangi(nl_ctx *ctx, const float *host, int64_t z0, int64_t z1,
+                         char *err, size_t errlen);
+
+/* frangi *= (original > thresh) (labelling.py:550-552); the comparison is done in float64 on
+   the exactly converted original, `thresh` already rounded by the host as numpy would. */
+int nl_label_intensity_mask(nl_ctx *ctx, const void *host_original, int dtype, double thresh,
+                            char *err, size_t errlen);
+
+/* flat[offset::step] of a field (labelling.py:393, 412). */
+int nl_flat_sample_gather(nl_ctx *ctx, int field, int64_t offset, int64_t step,
+                          float *out, int64_t cap, int64_t *n, char *err, size_t errlen);
+
+/* labelling.py:467-509 on the device:
+     mask = has_thr ? frangi > thr : 0; binary_fill_holes (6-conn) if fill_holes;
+     label (26-conn); remove components with < min_area voxels; uniform_filter(3) > 0.5;
+     label again.  Ids are int32, 1..K in raster order of each component's first voxel. */
+int nl_label_run(nl_ctx *ctx, int has_thr, float thr, int64_t min_area, int fill_holes,
+                 int64_t *n_labels, char *err, size_t errlen);
+
+/* D2H of the int32 label volume, local planes [z0, z1) (labelling.py:727-729). */
+int nl_label_store(nl_ctx *ctx, int32_t *host, int64_t z0, int64_t z1, char *err, size_t errlen);
+
+/* ------------------------------------------------------------------ timing ------------ */
+/* HIP-event timing on the context stream (bench.py's roofline figures). */
+int nl_timer_begin(nl_ctx *ctx, char *err, size_t errlen);
+int nl_timer_end_ms(nl_ctx *ctx, float *ms, char *err, size_t errlen);
+/* accumulated HIP-event time and launch count of one named kernel group since the last
+   reset; names: "gauss", "hessian_stats", "vesselness", "sample", "finish", "mask_volume", "label" */
+int nl_prof_enable(nl_ctx *ctx, int on);
+int nl_prof_get(nl_ctx *ctx, const char *name, double *ms, int64_t *launches);
+int nl_prof_reset(nl_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NELLIE_AMD_H */

@@ -1,0 +1,1327 @@
+// libnellie_hip.so -- hand-written HIP for gfx950 (MI355X): Nellie's Filter -> Label hot path.
+// C-ABI in include/nellie_amd.h.  Compile with -ffp-contract=off: every float operation
+// below is meant to round exactly where numpy/scipy round.
+#include <stdarg.h>
+#include "nl_common.h"
+
+#define NL_VERSION "nellie_amd-hip 0.1.0 (gfx950)"
+
+// =================================================================================================
+// device helpers
+// =================================================================================================
+struct VolGeom {
+    i64 nzl, ny, nx;   // local shape
+    i64 gz0, gnz;      // global placement of local plane 0, global plane count
+};
+
+struct HessP {
+    float hz, hy, hx;      // float32(h)      : one-sided divisor at a face
+    float hz2, hy2, hx2;   // float32(2.0*h)  : central divisor
+};
+
+// scipy NI_EXTEND_REFLECT (d c b a | a b c d | d c b a)
+__device__ __forceinline__ i64 reflect_idx(i64 i, i64 n) {
+    if (i >= 0 && i < n) return i;
+    i64 p = 2 * n;
+    i %= p;
+    if (i < 0) i += p;
+    return i >= n ? p - 1 - i : i;
+}
+
+// wave64 reductions (CDNA wavefront = 64 lanes)
+__device__ __forceinline__ float wave_max_f(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_min_f(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ int wave_or_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o, 64);
+    return v;
+}
+
+// -------------------------------------------------------------------------------------------------
+// np.gradient applied twice (filtering.py:518-536), fused: every first derivative is rounded to
+// float32 (true IEEE division by float32(2h) / float32(h)) before it is differenced again.
+// Faces use clamped indices + the one-sided divisor, independently at both stages.
+// Component order = the reference's (hxx,hxy,hxz,hyy,hyz,hzz) with "x" = axis 0 (Z).
+// -------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void hessian_at(const float *__restrict__ g, const VolGeom &v, const HessP &hp,
+                                           i64 z, i64 y, i64 x, float h[6]) {
+    const i64 sy = v.nx, sz = v.ny * v.nx;
+    const i64 gz = v.gz0 + z;
+    // outer-difference sites and divisors
+    const bool z_lo = (gz == 0), z_hi = (gz == v.gnz - 1);
+    const bool y_lo = (y == 0), y_hi = (y == v.ny - 1);
+    const bool x_lo = (x == 0), x_hi = (x == v.nx - 1);
+    const i64 zl = z_lo ? z : z - 1, zh = z_hi ? z : z + 1;
+    const i64 yl = y_lo ? y : y - 1, yh = y_hi ? y : y + 1;
+    const i64 xl = x_lo ? x : x - 1, xh = x_hi ? x : x + 1;
+    const float dz = (z_lo || z_hi) ? hp.hz : hp.hz2;
+    const float dy = (y_lo || y_hi) ? hp.hy : hp.hy2;
+    const float dx = (x_lo || x_hi) ? hp.hx : hp.hx2;
+
+    auto F = [&](i64 zz, i64 yy, i64 xx) -> float { return g[zz * sz + yy * sy + xx]; };
+    auto GZ = [&](i64 zz, i64 yy, i64 xx) -> float {
+        const i64 gg = v.gz0 + zz;
+        const bool lo = (gg == 0), hi = (gg == v.gnz - 1);
+        const float a = F(lo ? zz : zz - 1, yy, xx), b = F(hi ? zz : zz + 1, yy, xx);
+        return (b - a) / ((lo || hi) ? hp.hz : hp.hz2);
+    };
+    auto GY = [&](i64 zz, i64 yy, i64 xx) -> float {
+        const bool lo = (yy == 0), hi = (yy == v.ny - 1);
+        const float a = F(zz, lo ? yy : yy - 1, xx), b = F(zz, hi ? yy : yy + 1, xx);
+        return (b - a) / ((lo || hi) ? hp.hy : hp.hy2);
+    };
+    auto GX = [&](i64 zz, i64 yy, i64 xx) -> float {
+        const bool lo = (xx == 0), hi = (xx == v.nx - 1);
+        const float a = F(zz, yy, lo ? xx : xx - 1), b = F(zz, yy, hi ? xx : xx + 1);
+        return (b - a) / ((lo || hi) ? hp.hx : hp.hx2);
+    };
+    h[0] = (GZ(zh, y, x) - GZ(zl, y, x)) / dz;   // hxx = d0 g0
+    h[1] = (GZ(z, yh, x) - GZ(z, yl, x)) / dy;   // hxy = d1 g0
+    h[2] = (GZ(z, y, xh) - GZ(z, y, xl)) / dx;   // hxz = d2 g0
+    h[3] = (GY(z, yh, x) - GY(z, yl, x)) / dy;   // hyy = d1 g1
+    h[4] = (GY(z, y, xh) - GY(z, y, xl)) / dx;   // hyz = d2 g1
+    h[5] = (GX(z, y, xh) - GX(z, y, xl)) / dx;   // hzz = d2 g2
+}
+
+// filtering.py:538-543, float32, numpy's left-to-right association
+__device__ __forceinline__ float frob_sq_of(const float h[6]) {
+    const float a = h[0] * h[0] + h[3] * h[3] + h[5] * h[5];
+    const float b = 2.0f * (h[1] * h[1] + h[2] * h[2] + h[4] * h[4]);
+    return a + b;
+}
+
+// frob = sqrt(frob_sq)/max_abs with +inf -> max finite (filtering.py:421-426, 562)
+__device__ __forceinline__ float frob_norm(float fsq, float max_abs, float max_finite) {
+    float fr = sqrtf(fsq) / max_abs;
+    if (isinf(fr)) fr = max_finite;
+    return fr;
+}
+
+// -------------------------------------------------------------------------------------------------
+// numpy.linalg.eigvalsh on a float32 3x3 symmetric matrix = float64 LAPACK result cast to
+// float32 (numpy/linalg/_linalg.py computes in double).  Closed form in float64 (Smith 1961),
+// then the |lambda| ordering of filtering.py:583-584 and the Frangi response of
+// filtering.py:744-766 in float32.
+// -------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void eig3_sorted_abs(const float h[6], float &l1, float &l2, float &l3) {
+    const double a00 = h[0], a01 = h[1], a02 = h[2], a11 = h[3], a12 = h[4], a22 = h[5];
+    const double q = (a00 + a11 + a22) / 3.0;
+    const double b00 = a00 - q, b11 = a11 - q, b22 = a22 - q;
+    const double p2 = (b00 * b00 + b11 * b11 + b22 * b22 + 2.0 * (a01 * a01 + a02 * a02 + a12 * a12)) / 6.0;
+    const double p = sqrt(p2);
+    const double det = b00 * (b11 * b22 - a12 * a12) - a01 * (a01 * b22 - a12 * a02) + a02 * (a01 * a12 - b11 * a02);
+    double r = (p2 > 0.0) ? det / (2.0 * p2 * p) : 0.0;
+    r = r < -1.0 ? -1.0 : (r > 1.0 ? 1.0 : r);
+    const double phi = acos(r) / 3.0;
+    const double e_max = q + 2.0 * p * cos(phi);
+    const double e_min = q + 2.0 * p * cos(phi + 2.0943951023931953 /* 2*pi/3 */);
+    const double e_mid = 3.0 * q - e_max - e_min;
+    float a = (float)e_min, b = (float)e_mid, c = (float)e_max;   // ascending, as eigvalsh returns
+    // stable insertion sort by |.| (numpy argsort of 3 elements)
+    float ka = fabsf(a), kb = fabsf(b), kc = fabsf(c);
+    if (kb < ka) { float t = a; a = b; b = t; t = ka; ka = kb; kb = t; }
+    if (kc < kb) {
+        float t = b; b = c; c = t; t = kb; kb = kc; kc = t;
+        if (kb < ka) { t = a; a = b; b = t; t = ka; ka = kb; kb = t; }
+    }
+    l1 = a; l2 = b; l3 = c;
+}
+
+__device__ __forceinline__ float frangi3(float l1, float l2, float l3, float alpha_sq, float beta_sq, float gamma_sq) {
+    const float al2 = fabsf(l2), al3 = fabsf(l3);
+    const float ra = al2 / (al3 + 1e-12f);
+    const float ra_sq = ra * ra;
+    const float rb = al2 / (sqrtf(fabsf(l2 * l3)) + 1e-12f);
+    const float rb_sq = rb * rb;
+    const float s_sq = l1 * l1 + l2 * l2 + l3 * l3;
+    const float A = 1.0f - expf(-(ra_sq / alpha_sq));
+    const float B = expf(-(rb_sq / beta_sq));
+    const float C = 1.0f - expf(-(s_sq / gamma_sq));
+    float v = A * B * C;
+    if (l3 > 0.0f) v = 0.0f;
+    if (l2 > 0.0f) v = 0.0f;
+    if (!(fabsf(v) <= 3.402823466e38f)) v = 0.0f;   // nan_to_num(nan=0, posinf=0, neginf=0)
+    return v;
+}
+
+// =================================================================================================
+// kernels: dtype conversion
+// =================================================================================================
+template <typename T>
+__global__ void convert_kernel(const T *__restrict__ src, float *__restrict__ dst, i64 n) {
+    i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) dst[i] = (float)src[i];
+}
+
+template <typename T>
+__global__ void intensity_mask_kernel(const T *__restrict__ orig, float *__restrict__ frangi, double thresh, i64 n) {
+    i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        // frangi * mask with mask bool: False -> +0.0 * x (keeps numpy's signed zero / nan semantics simple: x finite >= 0)
+        if (!((double)orig[i] > thresh)) frangi[i] = frangi[i] * 0.0f;
+    }
+}
+
+__global__ void fill_f32_kernel(float *p, float v, i64 n) {
+    i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) p[i] = v;
+}
+
+// =================================================================================================
+// kernels: separable Gaussian (scipy correlate1d, symmetric branch, float64 accumulate)
+//   tmp = in[0]*w[r];  for j = r..1: tmp += (in[-j] + in[+j]) * w[r-j];  out = (float)tmp
+// One thread per output voxel; lanes run along X so every tap is a coalesced row read.
+// =================================================================================================
+#define NL_MAX_RADIUS 63
+struct GaussW { double w[NL_MAX_RADIUS + 1]; int r; };   // w[k] = weight at distance k from the centre
+
+template <int AXIS>
+__global__ void __launch_bounds__(256)
+gauss_axis_kernel(const float *__restrict__ in, float *__restrict__ out, VolGeom v, i64 z0, i64 z1, GaussW gw) {
+    const i64 x = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const i64 y = blockIdx.y;
+    const i64 z = z0 + blockIdx.z;
+    if (x >= v.nx) return;
+    const i64 sy = v.nx, sz = v.ny * v.nx;
+    const i64 c = z * sz + y * sy + x;
+    double tmp = (double)in[c] * gw.w[0];
+    for (int j = gw.r; j >= 1; --j) {
+        i64 il, ih;
+        if (AXIS == 0) {
+            il = (reflect_idx(v.gz0 + z - j, v.gnz) - v.gz0) * sz + y * sy + x;
+            ih = (reflect_idx(v.gz0 + z + j, v.gnz) - v.gz0) * sz + y * sy + x;
+        } else if (AXIS == 1) {
+            il = z * sz + reflect_idx(y - j, v.ny) * sy + x;
+            ih = z * sz + reflect_idx(y + j, v.ny) * sy + x;
+        } else {
+            il = z * sz + y * sy + reflect_idx(x - j, v.nx);
+            ih = z * sz + y * sy + reflect_idx(x + j, v.nx);
+        }
+        const double s = (double)in[il] + (double)in[ih];
+        tmp = tmp + s * gw.w[j];
+    }
+    out[c] = (float)tmp;
+}
+
+// =================================================================================================
+// kernels: lattice sampling (strided subsample for the thresholds)
+// =================================================================================================
+struct Lattice {
+    i64 sz, sy, sx;      // strides (global lattice)
+    i64 cz, cy, cx;      // lattice extent on the owned planes
+    i64 zfirst;          // local z of the first owned lattice plane
+};
+
+struct FieldSrc {
+    const float *p;      // gauss (GAUSS/FROB) or frangi
+    int field;
+    HessP hp;
+    float max_abs, max_finite;
+};
+
+__device__ __forceinline__ float field_value(const FieldSrc &fs, const VolGeom &v, i64 z, i64 y, i64 x) {
+    if (fs.field == NL_FIELD_FROB) {
+        float h[6];
+        hessian_at(fs.p, v, fs.hp, z, y, x, h);
+        return frob_norm(frob_sq_of(h), fs.max_abs, fs.max_finite);
+    }
+    return fs.p[(z * v.ny + y) * v.nx + x];
+}
+
+__global__ void __launch_bounds__(256)
+sample_gather_kernel(FieldSrc fs, VolGeom v, Lattice L, float *__restrict__ out) {
+    const i64 total = L.cz * L.cy * L.cx;
+    i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const i64 ix = i % L.cx, iy = (i / L.cx) % L.cy, iz = i / (L.cx * L.cy);
+    out[i] = field_value(fs, v, L.zfirst + iz * L.sz, iy * L.sy, ix * L.sx);
+}
+
+// results: [0] = min bits (uint), [1] = max bits (uint), [2..3] = count (u64)
+__global__ void __launch_bounds__(256)
+sample_minmax_kernel(FieldSrc fs, VolGeom v, Lattice L, unsigned int *__restrict__ res) {
+    const i64 total = L.cz * L.cy * L.cx;
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    float mn = __int_as_float(0x7f800000), mx = 0.0f;
+    unsigned long long cnt = 0;
+    if (i < total) {
+        const i64 ix = i % L.cx, iy = (i / L.cx) % L.cy, iz = i / (L.cx * L.cy);
+        const float val = field_value(fs, v, L.zfirst + iz * L.sz, iy * L.sy, ix * L.sx);
+        if (val > 0.0f) { mn = val; mx = val; cnt = 1; }
+    }
+    mn = wave_min_f(mn); mx = wave_max_f(mx); cnt = wave_sum_u64(cnt);
+    if ((threadIdx.x & 63) == 0 && cnt) {
+        // positive floats order like their bit patterns
+        atomicMin(&res[0], __float_as_uint(mn));
+        atomicMax(&res[1], __float_as_uint(mx));
+        atomicAdd((unsigned long long *)(res + 2), cnt);
+    }
+}
+
+// numpy histogram fast path, float32 (numpy/lib/_histograms_impl.py): see include/nellie_amd.h
+__global__ void __launch_bounds__(256)
+sample_hist_kernel(FieldSrc fs, VolGeom v, Lattice L, const float *__restrict__ edges, int nbins,
+                   unsigned long long *__restrict__ counts) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *s_edges = (float *)smem;                          // nbins+1
+    unsigned int *s_cnt = (unsigned int *)(s_edges + nbins + 1 + ((nbins + 1) & 1));   // nbins
+    for (int k = threadIdx.x; k <= nbins; k += blockDim.x) s_edges[k] = edges[k];
+    for (int k = threadIdx.x; k < nbins; k += blockDim.x) s_cnt[k] = 0;
+    __syncthreads();
+    const float first = s_edges[0], last = s_edges[nbins];
+    const float denom = last - first;
+    const i64 total = L.cz * L.cy * L.cx;
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const i64 ix = i % L.cx, iy = (i / L.cx) % L.cy, iz = i / (L.cx * L.cy);
+        const float a = field_value(fs, v, L.zfirst + iz * L.sz, iy * L.sy, ix * L.sx);
+        if (a > 0.0f && a >= first && a <= last) {
+            const float fi = ((a - first) / denom) * (float)nbins;
+            int idx = (int)fi;
+            if (idx == nbins) idx -= 1;
+            if (a < s_edges[idx]) idx -= 1;
+            if (a >= s_edges[idx + 1] && idx != nbins - 1) idx += 1;
+            atomicAdd(&s_cnt[idx], 1u);
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < nbins; k += blockDim.x)
+        if (s_cnt[k]) atomicAdd(&counts[k], (unsigned long long)s_cnt[k]);
+}
+
+__global__ void __launch_bounds__(256)
+flat_gather_kernel(const float *__restrict__ p, i64 base, i64 offset, i64 step, i64 count, float *__restrict__ out) {
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) out[i] = p[base + offset + i * step];
+}
+
+// =================================================================================================
+// kernels: Hessian statistics and the per-scale vesselness update
+// =================================================================================================
+// res: [0] max|h| bits, [1] max finite frob_sq bits, [2] any_inf
+__global__ void __launch_bounds__(256)
+hessian_stats_kernel(const float *__restrict__ g, VolGeom v, HessP hp, i64 z0, i64 z1, unsigned int *__restrict__ res) {
+    const i64 x = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const i64 y = blockIdx.y;
+    const i64 z = z0 + blockIdx.z;
+    float mabs = 0.0f, mfrob = 0.0f;
+    int inf = 0;
+    if (x < v.nx) {
+        float h[6];
+        hessian_at(g, v, hp, z, y, x, h);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) mabs = fmaxf(mabs, fabsf(h[k]));
+        const float fsq = frob_sq_of(h);
+        if (isinf(fsq)) inf = 1; else mfrob = fmaxf(mfrob, fsq);   // fmaxf drops NaN
+    }
+    mabs = wave_max_f(mabs); mfrob = wave_max_f(mfrob); inf = wave_or_i(inf);
+    if ((threadIdx.x & 63) == 0) {
+        if (mabs > 0.0f) atomicMax(&res[0], __float_as_uint(mabs));
+        if (mfrob > 0.0f) atomicMax(&res[1], __float_as_uint(mfrob));
+        if (inf) atomicOr(&res[2], 1u);
+    }
+}
+
+struct VessP {
+    float gamma_sq, alpha_sq, beta_sq;
+    int use_thr;
+    float thr;
+    float max_abs, max_finite;
+};
+
+__global__ void __launch_bounds__(256)
+vesselness_kernel(const float *__restrict__ g, float *__restrict__ vmax, uint8_t *__restrict__ cmask,
+                  VolGeom v, HessP hp, VessP vp, i64 z0, i64 z1, unsigned long long *__restrict__ mask_count) {
+    const i64 x = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const i64 y = blockIdx.y;
+    const i64 z = z0 + blockIdx.z;
+    unsigned long long cnt = 0;
+    if (x < v.nx) {
+        const i64 c = (z * v.ny + y) * v.nx + x;
+        float h[6];
+        hessian_at(g, v, hp, z, y, x, h);
+        const float fr = frob_norm(frob_sq_of(h), vp.max_abs, vp.max_finite);
+        const bool m = vp.use_thr ? (fr > vp.thr) : (fr > 0.0f);
+        if (m) {
+            float l1, l2, l3;
+            eig3_sorted_abs(h, l1, l2, l3);
+            const float val = frangi3(l1, l2, l3, vp.alpha_sq, vp.beta_sq, vp.gamma_sq);
+            const float old = vmax[c];
+            if (val > old) vmax[c] = val;      // np.maximum(vesselness, vessel_scale); both finite, >= 0
+            cnt = 1;
+        } else {
+            cmask[c] = 0;                      // masks &= h_mask
+        }
+    }
+    cnt = wave_sum_u64(cnt);
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(mask_count, cnt);
+}
+
+// vesselness * masks (filtering.py:926); counts voxels > 0 on the owned planes
+__global__ void __launch_bounds__(256)
+finish_kernel(float *__restrict__ vmax, const uint8_t *__restrict__ cmask, i64 begin, i64 end,
+              unsigned long long *__restrict__ npos) {
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    unsigned long long cnt = 0;
+    for (i64 i = begin + (i64)blockIdx.x * blockDim.x + threadIdx.x; i < end; i += stride) {
+        float val = vmax[i];
+        if (!cmask[i]) { val = 0.0f; vmax[i] = 0.0f; }
+        if (val > 0.0f) cnt++;
+    }
+    cnt = wave_sum_u64(cnt);
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(npos, cnt);
+}
+
+// filtering.py:964-966: mask = f > thr; binary_opening (6-conn cross, border_value 0); f * mask.
+// Global-face aware along Z (ghost planes are real neighbours); requires 2 valid planes around.
+__global__ void __launch_bounds__(256)
+mask_volume_kernel(const float *__restrict__ f, float *__restrict__ out, VolGeom v, float thr, i64 z0, i64 z1) {
+    const i64 x = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const i64 y = blockIdx.y;
+    const i64 z = z0 + blockIdx.z;
+    if (x >= v.nx) return;
+    const i64 sy = v.nx, sz = v.ny * v.nx;
+    const i64 c = z * sz + y * sy + x;
+    const float val = f[c];
+    if (!(val != 0.0f)) { out[c] = val * 0.0f; return; }   // 0 * mask == 0 whatever the mask
+    auto in_vol = [&](i64 zz, i64 yy, i64 xx) -> bool {
+        const i64 gg = v.gz0 + zz;
+        return gg >= 0 && gg < v.gnz && yy >= 0 && yy < v.ny && xx >= 0 && xx < v.nx;
+    };
+    auto M = [&](i64 zz, i64 yy, i64 xx) -> bool { return in_vol(zz, yy, xx) && (f[zz * sz + yy * sy + xx] > thr); };
+    auto E = [&](i64 zz, i64 yy, i64 xx) -> bool {      // erosion at (zz,yy,xx); outside the volume = false
+        if (!in_vol(zz, yy, xx)) return false;
+        return M(zz, yy, xx) && M(zz - 1, yy, xx) && M(zz + 1, yy, xx) && M(zz, yy - 1, xx) && M(zz, yy + 1, xx) &&
+               M(zz, yy, xx - 1) && M(zz, yy, xx + 1);
+    };
+    const bool opened = E(z, y, x) || E(z - 1, y, x) || E(z + 1, y, x) || E(z, y - 1, x) || E(z, y + 1, x) ||
+                        E(z, y, x - 1) || E(z, y, x + 1);
+    out[c] = opened ? val : val * 0.0f;
+}
+
+// =================================================================================================
+// kernels: Label (labelling.py:467-509)
+// =================================================================================================
+__global__ void __launch_bounds__(256)
+threshold_kernel(const float *__restrict__ f, uint8_t *__restrict__ m, int has_thr, float thr, i64 n) {
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        m[i] = (has_thr && f[i] > thr) ? 1 : 0;
+}
+
+// ---- lock-free union-find on int32 parent array; root = minimum raster index of the set ----------
+__device__ __forceinline__ int uf_load(const int *L, int i) {
+    return __hip_atomic_load(L + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int uf_find(const int *L, int i) {
+    int p = uf_load(L, i);
+    while (p != i) { i = p; p = uf_load(L, i); }
+    return i;
+}
+__device__ __forceinline__ void uf_union(int *L, int a, int b) {
+    while (true) {
+        a = uf_find(L, a);
+        b = uf_find(L, b);
+        if (a == b) return;
+        if (a < b) { int t = a; a = b; b = t; }          // a > b : hang a under b
+        const int old = atomicMin(&L[a], b);
+        if (old == a) return;
+        a = old;                                          // someone re-rooted a meanwhile: retry from there
+    }
+}
+
+// FG = 1: components of m != 0; FG = 0: components of m == 0 (background, for fill-holes)
+template <int FG>
+__device__ __forceinline__ bool is_set(const uint8_t *m, i64 i) { return FG ? (m[i] != 0) : (m[i] == 0); }
+
+// init: every voxel of the set points at the start of its X-run within its 64-lane segment.
+template <int FG>
+__global__ void __launch_bounds__(256)
+ccl_init_kernel(const uint8_t *__restrict__ m, int *__restrict__ L, i64 nx, i64 nrows) {
+    // one wave per 64-voxel row segment
+    const i64 segs_per_row = (nx + 63) / 64;
+    const i64 wave = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (wave >= nrows * segs_per_row) return;
+    const i64 row = wave / segs_per_row, seg = wave % segs_per_row;
+    const i64 x = seg * 64 + lane;
+    const bool inb = x < nx;
+    const i64 i = row * nx + x;
+    const bool s = inb && is_set<FG>(m, i);
+    const unsigned long long bal = __ballot(s);
+    if (!inb) return;
+    if (!s) { L[i] = -1; return; }
+    // highest zero bit below `lane` -> run start
+    const unsigned long long below = (~bal) & ((lane == 0) ? 0ull : ((~0ull) >> (64 - lane)));
+    const int start = below ? (64 - __builtin_clzll(below)) : 0;
+    L[i] = (int)(row * nx + seg * 64 + start);
+}
+
+// merge: unions with the raster-preceding rows, skipping connections the X-neighbour already made.
+//   CONN = 26: rows (dz,dy) in {(-1,-1),(-1,0),(-1,+1),(0,-1)}, columns x-1..x+1
+//   CONN = 6 : rows (-1,0) and (0,-1), column x
+template <int FG, int CONN>
+__global__ void __launch_bounds__(256)
+ccl_merge_kernel(const uint8_t *__restrict__ m, int *__restrict__ L, i64 nz, i64 ny, i64 nx) {
+    const i64 x = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const i64 y = blockIdx.y, z = blockIdx.z;
+    if (x >= nx) return;
+    const i64 i = (z * ny + y) * nx + x;
+    if (!is_set<FG>(m, i)) return;
+    const bool left = (x > 0) && is_set<FG>(m, i - 1);
+    if (left && (x & 63) == 0) uf_union(L, (int)i, (int)(i - 1));   // stitch 64-lane segments of a run
+    auto row = [&](i64 zz, i64 yy) {
+        if (zz < 0 || yy < 0 || yy >= ny) return;
+        const i64 b = (zz * ny + yy) * nx;
+        const bool c0 = is_set<FG>(m, b + x);
+        if (CONN == 6) {
+            if (!c0) return;
+            if (left && is_set<FG>(m, b + x - 1)) return;          // same two runs already joined at x-1
+            uf_union(L, (int)i, (int)(b + x));
+        } else {
+            const bool cm = (x > 0) && is_set<FG>(m, b + x - 1);
+            const bool cp = (x + 1 < nx) && is_set<FG>(m, b + x + 1);
+            if (left) {
+                // x-1 (same run as us) already reached every set voxel in columns <= x of that row,
+                // and column x+1 hangs off column x when that one is set
+                if (cp && !c0) uf_union(L, (int)i, (int)(b + x + 1));
+            } else {
+                if (c0) uf_union(L, (int)i, (int)(b + x));
+                else {
+                    if (cm) uf_union(L, (int)i, (int)(b + x - 1));
+                    if (cp) uf_union(L, (int)i, (int)(b + x + 1));
+                }
+            }
+        }
+    };
+    if (CONN == 6) {
+        row(z - 1, y);
+        row(z, y - 1);
+    } else {
+        row(z - 1, y - 1);
+        row(z - 1, y);
+        row(z - 1, y + 1);
+        row(z, y - 1);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+ccl_flatten_kernel(int *__restrict__ L, i64 n) {
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int p = L[i];
+        if (p >= 0 && p != (int)i) {
+            const int r = uf_find(L, p);
+            if (r != p) L[i] = r;
+        }
+    }
+}
+
+// fill holes: background components touching the GLOBAL volume border stay background
+__global__ void __launch_bounds__(256)
+border_mark_kernel(const int *__restrict__ L, uint8_t *__restrict__ flag, VolGeom v) {
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    const i64 n = v.nzl * v.ny * v.nx;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int r = L[i];
+        if (r < 0) continue;
+        const i64 x = i % v.nx, y = (i / v.nx) % v.ny, z = i / (v.nx * v.ny);
+        const i64 gz = v.gz0 + z;
+        if (gz == 0 || gz == v.gnz - 1 || y == 0 || y == v.ny - 1 || x == 0 || x == v.nx - 1) flag[r] = 1;
+    }
+}
+__global__ void __launch_bounds__(256)
+clear_root_flags_kernel(const int *__restrict__ L, uint8_t *__restrict__ flag, i64 n) {
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        if (L[i] == (int)i) flag[i] = 0;
+}
+__global__ void __launch_bounds__(256)
+fill_holes_apply_kernel(const int *__restrict__ L, const uint8_t *__restrict__ flag, uint8_t *__restrict__ m, i64 n) {
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int r = L[i];
+        if (r >= 0 && !flag[r]) m[i] = 1;       // enclosed background -> foreground
+    }
+}
+
+// areas: zero at roots, then one atomicAdd per X-run segment (bincount, labelling.py:495)
+__global__ void __launch_bounds__(256)
+zero_at_roots_kernel(const int *__restrict__ L, int *__restrict__ area, i64 n) {
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        if (L[i] == (int)i) area[i] = 0;
+}
+__global__ void __launch_bounds__(256)
+area_count_kernel(const int *__restrict__ L, int *__restrict__ area, i64 nx, i64 nrows) {
+    const i64 segs_per_row = (nx + 63) / 64;
+    const i64 wave = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (wave >= nrows * segs_per_row) return;
+    const i64 row = wave / segs_per_row, seg = wave % segs_per_row;
+    const i64 x = seg * 64 + lane;
+    const bool inb = x < nx;
+    const int r = inb ? L[row * nx + x] : -1;
+    const bool s = r >= 0;
+    const unsigned long long bal = __ballot(s);
+    if (!s) return;
+    // run leader = lane whose left neighbour is not set; it adds the run length
+    const bool leader = (lane == 0) || !((bal >> (lane - 1)) & 1ull);
+    if (leader) {
+        const unsigned long long rest = ~(bal >> lane);            // first zero above lane ends the run
+        const int len = rest ? __builtin_ctzll(rest) : (64 - lane);
+        atomicAdd(&area[r], len);
+    }
+}
+__global__ void __launch_bounds__(256)
+keep_large_kernel(const int *__restrict__ L, const int *__restrict__ area, uint8_t *__restrict__ m, int min_area, i64 n) {
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int r = L[i];
+        m[i] = (r >= 0 && area[r] >= min_area) ? 1 : 0;
+    }
+}
+
+// uniform_filter(float32 mask, size=3, mode='reflect') > 0.5  ==  >= 14 of the 27 clamped neighbours
+__global__ void __launch_bounds__(256)
+majority_kernel(const uint8_t *__restrict__ m, uint8_t *__restrict__ out, VolGeom v) {
+    const i64 x = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const i64 y = blockIdx.y, z = blockIdx.z;
+    if (x >= v.nx) return;
+    int cnt = 0;
+#pragma unroll
+    for (int dz = -1; dz <= 1; ++dz) {
+        i64 zz = z + dz;
+        const i64 gg = v.gz0 + zz;
+        if (gg < 0) zz = z; else if (gg >= v.gnz) zz = z;          // reflect == clamp for a 3-window
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) {
+            i64 yy = y + dy;
+            yy = yy < 0 ? 0 : (yy >= v.ny ? v.ny - 1 : yy);
+            const i64 b = (zz * v.ny + yy) * v.nx;
+            const i64 xm = x > 0 ? x - 1 : 0, xp = x + 1 < v.nx ? x + 1 : v.nx - 1;
+            cnt += (int)m[b + xm] + (int)m[b + x] + (int)m[b + xp];
+        }
+    }
+    out[(z * v.ny + y) * v.nx + x] = cnt >= 14 ? 1 : 0;
+}
+
+// raster renumbering of roots: ids 1..K in order of the root (= first voxel) index
+#define SCAN_CHUNK 4096
+__global__ void __launch_bounds__(256)
+root_count_kernel(const int *__restrict__ L, i64 n, unsigned int *__restrict__ blk) {
+    const i64 base = (i64)blockIdx.x * SCAN_CHUNK;
+    unsigned long long cnt = 0;
+    for (int k = threadIdx.x; k < SCAN_CHUNK; k += 256) {
+        const i64 i = base + k;
+        if (i < n && L[i] == (int)i) cnt++;
+    }
+    __shared__ unsigned int s[4];
+    cnt = wave_sum_u64(cnt);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = (unsigned int)cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) blk[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+// single block exclusive scan of the per-chunk counts (nblk <= a few 1e5)
+__global__ void __launch_bounds__(1024)
+blk_scan_kernel(unsigned int *__restrict__ blk, i64 nblk, unsigned long long *__restrict__ total) {
+    __shared__ unsigned int s_w[16];
+    __shared__ unsigned int s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (i64 base = 0; base < nblk; base += 1024) {
+        const i64 i = base + threadIdx.x;
+        const unsigned int val = (i < nblk) ? blk[i] : 0u;
+        unsigned int inc = val;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned int t = __shfl_up(inc, o, 64);
+            if ((threadIdx.x & 63) >= o) inc += t;
+        }
+        if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        unsigned int woff = 0;
+        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) woff += s_w[w];
+        const unsigned int carry = s_carry;
+        if (i < nblk) blk[i] = carry + woff + inc - val;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = carry + woff + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = s_carry;
+}
+// newid[root] = rank + 1 (ordered within a chunk by a serial-in-wave ballot scan)
+__global__ void __launch_bounds__(256)
+root_assign_kernel(const int *__restrict__ L, i64 n, const unsigned int *__restrict__ blk, int *__restrict__ newid) {
+    const i64 base = (i64)blockIdx.x * SCAN_CHUNK;
+    __shared__ unsigned int s_w[4];
+    __shared__ unsigned int s_run;
+    if (threadIdx.x == 0) s_run = blk[blockIdx.x];
+    __syncthreads();
+    for (int k0 = 0; k0 < SCAN_CHUNK; k0 += 256) {
+        const i64 i = base + k0 + threadIdx.x;
+        const bool isroot = (i < n) && (L[i] == (int)i);
+        const unsigned long long bal = __ballot(isroot);
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        const unsigned int before = (unsigned int)__builtin_popcountll(bal & ((lane == 0) ? 0ull : ((~0ull) >> (64 - lane))));
+        if (lane == 0) s_w[w] = (unsigned int)__builtin_popcountll(bal);
+        __syncthreads();
+        unsigned int woff = 0;
+        for (int q = 0; q < w; ++q) woff += s_w[q];
+        const unsigned int run = s_run;
+        if (isroot) newid[i] = (int)(run + woff + before + 1);
+        __syncthreads();
+        if (threadIdx.x == 0) s_run = run + s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        __syncthreads();
+    }
+}
+__global__ void __launch_bounds__(256)
+relabel_kernel(const int *__restrict__ L, const int *__restrict__ newid, int *__restrict__ out, i64 n) {
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int r = L[i];
+        out[i] = r >= 0 ? newid[r] : 0;
+    }
+}
+
+// =================================================================================================
+// host side: context, launch helpers, C-ABI
+// =================================================================================================
+static inline unsigned int grid1d(i64 n, int block = 256, i64 cap = 256 * 32) {
+    i64 g = (n + block - 1) / block;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (unsigned int)g;
+}
+
+static VolGeom geom(const nl_ctx *c) { return VolGeom{c->nzl, c->ny, c->nx, c->gz0, c->gnz}; }
+static HessP hessp(const nl_ctx *c) { return HessP{c->hz, c->hy, c->hx, c->hz2, c->hy2, c->hx2}; }
+
+static size_t dtype_size(int dt) {
+    switch (dt) {
+        case NL_U8: case NL_I8: return 1;
+        case NL_U16: case NL_I16: return 2;
+        case NL_U32: case NL_I32: case NL_F32: return 4;
+        case NL_F64: case NL_U64: case NL_I64: return 8;
+    }
+    return 0;
+}
+
+extern "C" const char *nl_version(void) { return NL_VERSION; }
+
+extern "C" int nl_device_count(int *count, char *err, size_t errlen) {
+    if (!count) return nl_fail(err, errlen, NL_EINVAL, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return nl_fail(err, errlen, NL_ENODEV, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *count = n;
+    return NL_OK;
+}
+
+extern "C" int nl_device_mem_info(int device, int64_t *free_bytes, int64_t *total_bytes, char *err, size_t errlen) {
+    NL_HIP(hipSetDevice(device));
+    size_t f = 0, t = 0;
+    NL_HIP(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = (int64_t)f;
+    if (total_bytes) *total_bytes = (int64_t)t;
+    return NL_OK;
+}
+
+extern "C" int nl_device_name(int device, char *name, size_t namelen, char *err, size_t errlen) {
+    hipDeviceProp_t p;
+    NL_HIP(hipGetDeviceProperties(&p, device));
+    if (name && namelen) snprintf(name, namelen, "%s (%s, %d CUs)", p.name, p.gcnArchName, p.multiProcessorCount);
+    return NL_OK;
+}
+
+extern "C" int64_t nl_ctx_bytes(int64_t nz_local, int64_t ny, int64_t nx) {
+    const int64_t n = nz_local * ny * nx;
+    return n * (4 * 4 + 3) + (1 << 16) + ((n + SCAN_CHUNK - 1) / SCAN_CHUNK + 1) * 4;
+}
+
+extern "C" int nl_ctx_destroy(nl_ctx *c) {
+    if (!c) return NL_OK;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    for (auto &kv : c->prof) for (auto &r : kv.second) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+    for (int k = 0; k < 4; ++k) if (c->f[k]) hipFree(c->f[k]);
+    for (int k = 0; k < 3; ++k) if (c->m[k]) hipFree(c->m[k]);
+    if (c->d_small) hipFree(c->d_small);
+    if (c->d_blk) hipFree(c->d_blk);
+    if (c->h_small) hipHostFree(c->h_small);
+    if (c->t0) hipEventDestroy(c->t0);
+    if (c->t1) hipEventDestroy(c->t1);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+    return NL_OK;
+}
+
+extern "C" int nl_ctx_create(nl_ctx **out, int device, int64_t nzl, int64_t ny, int64_t nx,
+                             int64_t gz0, int64_t gnz, int64_t own_lo, int64_t own_hi, char *err, size_t errlen) {
+    if (!out) return nl_fail(err, errlen, NL_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (nzl < 1 || ny < 1 || nx < 1) return nl_fail(err, errlen, NL_EINVAL, "empty volume (%lld,%lld,%lld)", (i64)nzl, (i64)ny, (i64)nx);
+    if (gz0 < 0 || gz0 + nzl > gnz) return nl_fail(err, errlen, NL_EINVAL, "slab [%lld,%lld) outside the global volume of %lld planes", (i64)gz0, (i64)(gz0 + nzl), (i64)gnz);
+    if (own_lo < 0 || own_hi > nzl || own_lo >= own_hi) return nl_fail(err, errlen, NL_EINVAL, "bad owned range [%lld,%lld)", (i64)own_lo, (i64)own_hi);
+    const i64 n = (i64)nzl * ny * nx;
+    if (n >= ((i64)1 << 31)) return nl_fail(err, errlen, NL_EINVAL, "local slab of %lld voxels exceeds the int32 label index range; shard over Z", n);
+    if (ny > 65535 || nzl > 65535) return nl_fail(err, errlen, NL_EINVAL, "Y and local Z extents must be <= 65535");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return nl_fail(err, errlen, NL_ENODEV, "GPU backend requested but no HIP device is available (%s)", e == hipSuccess ? "0 devices" : hipGetErrorString(e));
+    if (device < 0 || device >= ndev) return nl_fail(err, errlen, NL_ENODEV, "GPU backend requested but device %d does not exist (%d devices)", device, ndev);
+    NL_HIP(hipSetDevice(device));
+    nl_ctx *c = new nl_ctx();
+    c->device = device; c->nzl = nzl; c->ny = ny; c->nx = nx; c->gz0 = gz0; c->gnz = gnz;
+    c->own_lo = own_lo; c->own_hi = own_hi; c->n = n;
+    int rc = NL_OK;
+    auto alloc = [&](void **p, size_t bytes) -> bool {
+        hipError_t ee = hipMalloc(p, bytes);
+        if (ee != hipSuccess) {
+            rc = nl_fail(err, errlen, ee == hipErrorOutOfMemory ? NL_ENOMEM : NL_EHIP,
+                         "hipMalloc(%zu bytes): %s%s", bytes, hipGetErrorString(ee), ee == hipErrorOutOfMemory ? " [out of memory]" : "");
+            return false;
+        }
+        return true;
+    };
+    bool ok = true;
+    for (int k = 0; k < 4 && ok; ++k) ok = alloc((void **)&c->f[k], (size_t)n * 4);
+    for (int k = 0; k < 3 && ok; ++k) ok = alloc((void **)&c->m[k], (size_t)n);
+    if (ok) ok = alloc(&c->d_small, 1 << 16);
+    c->blk_cap = (n + SCAN_CHUNK - 1) / SCAN_CHUNK + 1;
+    if (ok) ok = alloc(&c->d_blk, (size_t)c->blk_cap * 4);
+    if (ok && hipHostMalloc(&c->h_small, 1 << 16, hipHostMallocDefault) != hipSuccess) {
+        rc = nl_fail(err, errlen, NL_ENOMEM, "hipHostMalloc failed [out of memory]"); ok = false;
+    }
+    if (ok && (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+               hipEventCreate(&c->t0) != hipSuccess || hipEventCreate(&c->t1) != hipSuccess)) {
+        rc = nl_fail(err, errlen, NL_EHIP, "stream/event creation failed"); ok = false;
+    }
+    if (!ok) { nl_ctx_destroy(c); return rc; }
+    *out = c;
+    return NL_OK;
+}
+
+extern "C" int nl_sync(nl_ctx *c, char *err, size_t errlen) {
+    if (!c) return nl_fail(err, errlen, NL_EINVAL, "ctx is NULL");
+    NL_HIP(hipSetDevice(c->device));
+    NL_HIP(hipStreamSynchronize(c->stream));
+    return NL_OK;
+}
+
+#define NL_ENTER(c)                                                    \
+    if (!(c)) return nl_fail(err, errlen, NL_EINVAL, "ctx is NULL");   \
+    NL_HIP(hipSetDevice((c)->device));
+
+static int upload_convert(nl_ctx *c, const void *host, int dtype, float *dst, i64 count, char *err, size_t errlen) {
+    const size_t es = dtype_size(dtype);
+    if (!es) return nl_fail(err, errlen, NL_EINVAL, "unsupported dtype code %d", dtype);
+    if (dtype == NL_F32) {
+        NL_HIP(hipMemcpyAsync(dst, host, (size_t)count * 4, hipMemcpyHostToDevice, c->stream));
+        NL_HIP(hipStreamSynchronize(c->stream));
+        return NL_OK;
+    }
+    // stage raw bytes in free float volumes (2 consecutive volumes cover 8-byte types)
+    void *raw = nullptr;
+    bool own = false;
+    // find a free f[] buffer that is not dst's buffer
+    for (int k = 0; k < 4 && !raw; ++k) {
+        const bool contains = (dst >= c->f[k] && dst < c->f[k] + c->n);
+        if (!contains && k != c->i_vmax && es <= 4) raw = c->f[k];
+    }
+    if (!raw) { NL_HIP(hipMalloc(&raw, (size_t)count * es)); own = true; }
+    NL_HIP(hipMemcpyAsync(raw, host, (size_t)count * es, hipMemcpyHostToDevice, c->stream));
+    const unsigned int g = grid1d(count);
+    switch (dtype) {
+        case NL_U8: convert_kernel<uint8_t><<<g, 256, 0, c->stream>>>((const uint8_t *)raw, dst, count); break;
+        case NL_I8: convert_kernel<int8_t><<<g, 256, 0, c->stream>>>((const int8_t *)raw, dst, count); break;
+        case NL_U16: convert_kernel<uint16_t><<<g, 256, 0, c->stream>>>((const uint16_t *)raw, dst, count); break;
+        case NL_I16: convert_kernel<int16_t><<<g, 256, 0, c->stream>>>((const int16_t *)raw, dst, count); break;
+        case NL_U32: convert_kernel<uint32_t><<<g, 256, 0, c->stream>>>((const uint32_t *)raw, dst, count); break;
+        case NL_I32: convert_kernel<int32_t><<<g, 256, 0, c->stream>>>((const int32_t *)raw, dst, count); break;
+        case NL_F64: convert_kernel<double><<<g, 256, 0, c->stream>>>((const double *)raw, dst, count); break;
+        case NL_U64: convert_kernel<uint64_t><<<g, 256, 0, c->stream>>>((const uint64_t *)raw, dst, count); break;
+        case NL_I64: convert_kernel<int64_t><<<g, 256, 0, c->stream>>>((const int64_t *)raw, dst, count); break;
+    }
+    NL_CHECK_LAUNCH();
+    NL_HIP(hipStreamSynchronize(c->stream));
+    if (own) hipFree(raw);
+    return NL_OK;
+}
+
+extern "C" int nl_filter_load(nl_ctx *c, const void *host, int dtype, int64_t z0, int64_t z1, char *err, size_t errlen) {
+    NL_ENTER(c);
+    if (!host || z0 < 0 || z1 > c->nzl || z0 >= z1) return nl_fail(err, errlen, NL_EINVAL, "bad plane range [%lld,%lld)", (i64)z0, (i64)z1);
+    c->i_gauss = 0; c->i_vmax = 3; c->i_labels = -1; c->frangi_ready = 0;
+    const i64 plane = c->ny * c->nx;
+    int rc = upload_convert(c, host, dtype, c->f[0] + z0 * plane, (z1 - z0) * plane, err, errlen);
+    if (rc) return rc;
+    // vesselness = zeros, masks = ones (filtering.py:807-808)
+    NL_HIP(hipMemsetAsync(c->f[c->i_vmax], 0, (size_t)c->n * 4, c->stream));
+    NL_HIP(hipMemsetAsync(c->m[0], 1, (size_t)c->n, c->stream));
+    NL_HIP(hipStreamSynchronize(c->stream));
+    return NL_OK;
+}
+
+static int fill_gw(GaussW &gw, const double *w, int r, char *err, size_t errlen) {
+    if (r < 0 || r > NL_MAX_RADIUS) return nl_fail(err, errlen, NL_EINVAL, "Gaussian radius %d outside [0,%d]", r, NL_MAX_RADIUS);
+    gw.r = r;
+    for (int k = 0; k <= r; ++k) gw.w[k] = w[r + k];   // w[] has 2r+1 entries centred at r (symmetric)
+    return NL_OK;
+}
+
+extern "C" int nl_gauss_step(nl_ctx *c, const double *wz, int rz, const double *wy, int ry, const double *wx, int rx,
+                             int64_t z0, int64_t z1, char *err, size_t errlen) {
+    NL_ENTER(c);
+    if (z0 < 0 || z1 > c->nzl || z0 >= z1) return nl_fail(err, errlen, NL_EINVAL, "bad plane range [%lld,%lld)", (i64)z0, (i64)z1);
+    const VolGeom v = geom(c);
+    // three ping-pong volumes f[0..2]: the source of a pass is dead once the pass has run,
+    // so "the next one" is always a legal destination
+    const dim3 blk(256, 1, 1);
+    const dim3 grid((unsigned)((c->nx + 255) / 256), (unsigned)c->ny, (unsigned)(z1 - z0));
+    ProfScope ps(c, "gauss");
+    int src = c->i_gauss;
+    GaussW gw;
+    int rc;
+    if (wz) {
+        if ((rc = fill_gw(gw, wz, rz, err, errlen))) return rc;
+        // every tap must land inside the local slab unless it reflects at a true face
+        if ((z0 - rz < 0 && c->gz0 > 0) || (z1 - 1 + rz >= c->nzl && c->gz0 + c->nzl < c->gnz))
+            return nl_fail(err, errlen, NL_EINVAL, "Z pass of radius %d on planes [%lld,%lld) reaches outside the local slab", rz, (i64)z0, (i64)z1);
+        const int dst = (src + 1) % 3;
+        gauss_axis_kernel<0><<<grid, blk, 0, c->stream>>>(c->f[src], c->f[dst], v, z0, z1, gw);
+        NL_CHECK_LAUNCH();
+        src = dst;
+    }
+    if (wy) {
+        if ((rc = fill_gw(gw, wy, ry, err, errlen))) return rc;
+        const int dst = (src + 1) % 3;
+        gauss_axis_kernel<1><<<grid, blk, 0, c->stream>>>(c->f[src], c->f[dst], v, z0, z1, gw);
+        NL_CHECK_LAUNCH();
+        src = dst;
+    }
+    if (wx) {
+        if ((rc = fill_gw(gw, wx, rx, err, errlen))) return rc;
+        const int dst = (src + 1) % 3;
+        gauss_axis_kernel<2><<<grid, blk, 0, c->stream>>>(c->f[src], c->f[dst], v, z0, z1, gw);
+        NL_CHECK_LAUNCH();
+        src = dst;
+    }
+    c->i_gauss = src;
+    return NL_OK;
+}
+
+static int make_lattice(const nl_ctx *c, i64 sz, i64 sy, i64 sx, Lattice &L, char *err, size_t errlen) {
+    if (sz < 1 || sy < 1 || sx < 1) return nl_fail(err, errlen, NL_EINVAL, "strides must be >= 1");
+    L.sz = sz; L.sy = sy; L.sx = sx;
+    // owned global planes [g_lo, g_hi): lattice planes are global z = k*sz
+    const i64 g_lo = c->gz0 + c->own_lo, g_hi = c->gz0 + c->own_hi;
+    const i64 k_lo = (g_lo + sz - 1) / sz, k_hi = (g_hi + sz - 1) / sz;   // k in [k_lo, k_hi)
+    L.cz = k_hi > k_lo ? k_hi - k_lo : 0;
+    L.zfirst = k_lo * sz - c->gz0;
+    L.cy = (c->ny + sy - 1) / sy;
+    L.cx = (c->nx + sx - 1) / sx;
+    return NL_OK;
+}
+
+static int make_field(nl_ctx *c, int field, FieldSrc &fs, char *err, size_t errlen) {
+    fs.field = field; fs.hp = hessp(c); fs.max_abs = c->frob_max_abs; fs.max_finite = c->frob_max_finite;
+    if (field == NL_FIELD_GAUSS) fs.p = c->f[c->i_gauss];
+    else if (field == NL_FIELD_FROB) {
+        if (!c->have_spacing) return nl_fail(err, errlen, NL_ESTATE, "NL_FIELD_FROB before nl_hessian_stats");
+        fs.p = c->f[c->i_gauss];
+    } else if (field == NL_FIELD_FRANGI) fs.p = c->f[c->i_vmax];
+    else return nl_fail(err, errlen, NL_EINVAL, "unknown field %d", field);
+    return NL_OK;
+}
+
+extern "C" int nl_sample_gather(nl_ctx *c, int field, int64_t sz, int64_t sy, int64_t sx, float *out, int64_t cap,
+                                int64_t *n, char *err, size_t errlen) {
+    NL_ENTER(c);
+    Lattice L; FieldSrc fs; int rc;
+    if ((rc = make_lattice(c, sz, sy, sx, L, err, errlen))) return rc;
+    if ((rc = make_field(c, field, fs, err, errlen))) return rc;
+    const i64 total = L.cz * L.cy * L.cx;
+    if (n) *n = total;
+    if (total == 0 || (!out && cap == 0)) return NL_OK;   // size query
+    if (!out || cap < total) return nl_fail(err, errlen, NL_EINVAL, "output capacity %lld < %lld samples", (i64)cap, total);
+    // a free float volume as staging: whichever of f[0..2] is not the current gauss
+    float *stage = c->f[(c->i_gauss + 1) % 3];
+    if (total > c->n) return nl_fail(err, errlen, NL_EINVAL, "lattice larger than the volume");
+    {
+        ProfScope ps(c, "sample");
+        sample_gather_kernel<<<(unsigned)((total + 255) / 256), 256, 0, c->stream>>>(fs, geom(c), L, stage);
+        NL_CHECK_LAUNCH();
+    }
+    NL_HIP(hipMemcpyAsync(out, stage, (size_t)total * 4, hipMemcpyDeviceToHost, c->stream));
+    NL_HIP(hipStreamSynchronize(c->stream));
+    return NL_OK;
+}
+
+extern "C" int nl_sample_minmax(nl_ctx *c, int field, int64_t sz, int64_t sy, int64_t sx, float *mn, float *mx,
+                                int64_t *npos, char *err, size_t errlen) {
+    NL_ENTER(c);
+    Lattice L; FieldSrc fs; int rc;
+    if ((rc = make_lattice(c, sz, sy, sx, L, err, errlen))) return rc;
+    if ((rc = make_field(c, field, fs, err, errlen))) return rc;
+    const i64 total = L.cz * L.cy * L.cx;
+    unsigned int *res = (unsigned int *)c->d_small;
+    unsigned int *h = (unsigned int *)c->h_small;
+    h[0] = 0xffffffffu; h[1] = 0; h[2] = 0; h[3] = 0;
+    NL_HIP(hipMemcpyAsync(res, h, 16, hipMemcpyHostToDevice, c->stream));
+    if (total > 0) {
+        ProfScope ps(c, "sample");
+        sample_minmax_kernel<<<(unsigned)((total + 255) / 256), 256, 0, c->stream>>>(fs, geom(c), L, res);
+        NL_CHECK_LAUNCH();
+    }
+    NL_HIP(hipMemcpyAsync(h, res, 16, hipMemcpyDeviceToHost, c->stream));
+    NL_HIP(hipStreamSynchronize(c->stream));
+    const unsigned long long cnt = *(unsigned long long *)(h + 2);
+    if (npos) *npos = (int64_t)cnt;
+    if (cnt) {
+        if (mn) memcpy(mn, &h[0], 4);
+        if (mx) memcpy(mx, &h[1], 4);
+    }
+    return NL_OK;
+}
+
+extern "C" int nl_sample_hist(nl_ctx *c, int field, int64_t sz, int64_t sy, int64_t sx, const float *edges, int nbins,
+                              int64_t *counts, char *err, size_t errlen) {
+    NL_ENTER(c);
+    if (!edges || !counts || nbins < 1 || nbins > 4096) return nl_fail(err, errlen, NL_EINVAL, "bad histogram arguments (nbins=%d)", nbins);
+    Lattice L; FieldSrc fs; int rc;
+    if ((rc = make_lattice(c, sz, sy, sx, L, err, errlen))) return rc;
+    if ((rc = make_field(c, field, fs, err, errlen))) return rc;
+    const i64 total = L.cz * L.cy * L.cx;
+    // d_small layout: [0, 32K) counts (u64 x nbins), [32K, 64K) edges (f32 x nbins+1)
+    unsigned long long *d_counts = (unsigned long long *)c->d_small;
+    float *d_edges = (float *)((char *)c->d_small + (1 << 15));
+    NL_HIP(hipMemsetAsync(d_counts, 0, (size_t)nbins * 8, c->stream));
+    memcpy((char *)c->h_small + (1 << 15), edges, (size_t)(nbins + 1) * 4);
+    NL_HIP(hipMemcpyAsync(d_edges, (char *)c->h_small + (1 << 15), (size_t)(nbins + 1) * 4, hipMemcpyHostToDevice, c->stream));
+    if (total > 0) {
+        ProfScope ps(c, "sample");
+        const size_t sh = (size_t)(nbins + 2) * 4 + (size_t)nbins * 4;
+        sample_hist_kernel<<<grid1d(total, 256, 1024), 256, sh, c->stream>>>(fs, geom(c), L, d_edges, nbins, d_counts);
+        NL_CHECK_LAUNCH();
+    }
+    NL_HIP(hipMemcpyAsync(c->h_small, d_counts, (size_t)nbins * 8, hipMemcpyDeviceToHost, c->stream));
+    NL_HIP(hipStreamSynchronize(c->stream));
+    memcpy(counts, c->h_small, (size_t)nbins * 8);
+    return NL_OK;
+}
+
+extern "C" int nl_hessian_stats(nl_ctx *c, const double spacing[3], float *max_abs, float *max_frob_sq, int *any_inf,
+                                char *err, size_t errlen) {
+    NL_ENTER(c);
+    if (!spacing) return nl_fail(err, errlen, NL_EINVAL, "spacing is NULL");
+    if (c->gnz < 2 || c->ny < 2 || c->nx < 2)
+        return nl_fail(err, errlen, NL_EINVAL, "Shape of array too small to calculate a numerical gradient, at least (edge_order + 1) elements are required.");
+    c->hz = (float)spacing[0]; c->hy = (float)spacing[1]; c->hx = (float)spacing[2];
+    c->hz2 = (float)(2.0 * spacing[0]); c->hy2 = (float)(2.0 * spacing[1]); c->hx2 = (float)(2.0 * spacing[2]);
+    c->have_spacing = 1;
+    unsigned int *res = (unsigned int *)c->d_small;
+    NL_HIP(hipMemsetAsync(res, 0, 16, c->stream));
+    {
+        ProfScope ps(c, "hessian_stats");
+        const dim3 grid((unsigned)((c->nx + 255) / 256), (unsigned)c->ny, (unsigned)(c->own_hi - c->own_lo));
+        hessian_stats_kernel<<<grid, 256, 0, c->stream>>>(c->f[c->i_gauss], geom(c), hessp(c), c->own_lo, c->own_hi, res);
+        NL_CHECK_LAUNCH();
+    }
+    unsigned int *h = (unsigned int *)c->h_small;
+    NL_HIP(hipMemcpyAsync(h, res, 16, hipMemcpyDeviceToHost, c->stream));
+    NL_HIP(hipStreamSynchronize(c->stream));
+    if (max_abs) memcpy(max_abs, &h[0], 4);
+    if (max_frob_sq) memcpy(max_frob_sq, &h[1], 4);
+    if (any_inf) *any_inf = (int)h[2];
+    return NL_OK;
+}
+
+extern "C" int nl_set_frob_norm(nl_ctx *c, float max_abs, float max_finite, char *err, size_t errlen) {
+    if (!c) return nl_fail(err, errlen, NL_EINVAL, "ctx is NULL");
+    c->frob_max_abs = max_abs; c->frob_max_finite = max_finite;
+    return NL_OK;
+}
+
+extern "C" int nl_vesselness_step(nl_ctx *c, float gamma_sq, float alpha_sq, float beta_sq, int use_thr, float thr,
+                                  int64_t *mask_count, char *err, size_t errlen) {
+    NL_ENTER(c);
+    if (!c->have_spacing) return nl_fail(err, errlen, NL_ESTATE, "nl_vesselness_step before nl_hessian_stats");
+    unsigned long long *d_cnt = (unsigned long long *)c->d_small;
+    NL_HIP(hipMemsetAsync(d_cnt, 0, 8, c->stream));
+    VessP vp{gamma_sq, alpha_sq, beta_sq, use_thr, thr, c->frob_max_abs, c->frob_max_finite};
+    {
+        ProfScope ps(c, "vesselness");
+        const dim3 grid((unsigned)((c->nx + 255) / 256), (unsigned)c->ny, (unsigned)(c->own_hi - c->own_lo));
+        vesselness_kernel<<<grid, 256, 0, c->stream>>>(c->f[c->i_gauss], c->f[c->i_vmax], c->m[0], geom(c), hessp(c), vp,
+                                                       c->own_lo, c->own_hi, d_cnt);
+        NL_CHECK_LAUNCH();
+    }
+    if (mask_count) {
+        NL_HIP(hipMemcpyAsync(c->h_small, d_cnt, 8, hipMemcpyDeviceToHost, c->stream));
+        NL_HIP(hipStreamSynchronize(c->stream));
+        *mask_count = (int64_t)(*(unsigned long long *)c->h_small);
+    }
+    return NL_OK;
+}
+
+extern "C" int nl_filter_finish(nl_ctx *c, int64_t *n_positive, char *err, size_t errlen) {
+    NL_ENTER(c);
+    unsigned long long *d_cnt = (unsigned long long *)c->d_small;
+    NL_HIP(hipMemsetAsync(d_cnt, 0, 8, c->stream));
+    const i64 plane = c->ny * c->nx;
+    {
+        ProfScope ps(c, "finish");
+        finish_kernel<<<grid1d((c->own_hi - c->own_lo) * plane), 256, 0, c->stream>>>(c->f[c->i_vmax], c->m[0], c->own_lo * plane,
+                                                                                         c->own_hi * plane, d_cnt);
+        NL_CHECK_LAUNCH();
+    }
+    NL_HIP(hipMemcpyAsync(c->h_small, d_cnt, 8, hipMemcpyDeviceToHost, c->stream));
+    NL_HIP(hipStreamSynchronize(c->stream));
+    if (n_positive) *n_positive = (int64_t)(*(unsigned long long *)c->h_small);
+    c->frangi_ready = 1;
+    return NL_OK;
+}
+
+extern "C" int nl_mask_volume(nl_ctx *c, float thr, char *err, size_t errlen) {
+    NL_ENTER(c);
+    // result goes to a free gauss volume, which then becomes the Frangi volume
+    int dst = -1;
+    for (int k = 0; k < 3; ++k) if (k != c->i_gauss) { dst = k; break; }
+    {
+        ProfScope ps(c, "mask_volume");
+        const dim3 grid((unsigned)((c->nx + 255) / 256), (unsigned)c->ny, (unsigned)(c->own_hi - c->own_lo));
+        mask_volume_kernel<<<grid, 256, 0, c->stream>>>(c->f[c->i_vmax], c->f[dst], geom(c), thr, c->own_lo, c->own_hi);
+        NL_CHECK_LAUNCH();
+    }
+    // swap roles: old vmax volume joins the gauss ping-pong set
+    float *tmp = c->f[c->i_vmax];
+    c->f[c->i_vmax] = c->f[dst];
+    c->f[dst] = tmp;
+    return NL_OK;
+}
+
+static int store_planes(nl_ctx *c, const void *dev_base, void *host, size_t elem, int64_t z0, int64_t z1, char *err, size_t errlen) {
+    if (!host || z0 < 0 || z1 > c->nzl || z0 >= z1) return nl_fail(err, errlen, NL_EINVAL, "bad plane range [%lld,%lld)", (i64)z0, (i64)z1);
+    const i64 plane = c->ny * c->nx;
+    NL_HIP(hipMemcpyAsync(host, (const char *)dev_base + (size_t)z0 * plane * elem, (size_t)(z1 - z0) * plane * elem,
+                          hipMemcpyDeviceToHost, c->stream));
+    NL_HIP(hipStreamSynchronize(c->stream));
+    return NL_OK;
+}
+
+extern "C" int nl_filter_store(nl_ctx *c, float *host, int64_t z0, int64_t z1, char *err, size_t errlen) {
+    NL_ENTER(c);
+    return store_planes(c, c->f[c->i_vmax], host, 4, z0, z1, err, errlen);
+}
+extern "C" int nl_gauss_store(nl_ctx *c, float *host, int64_t z0, int64_t z1, char *err, size_t errlen) {
+    NL_ENTER(c);
+    return store_planes(c, c->f[c->i_gauss], host, 4, z0, z1, err, errlen);
+}
+
+// ---------------------------------------------------------------------------------- Label -------
+extern "C" int nl_label_load_frangi(nl_ctx *c, const float *host, int64_t z0, int64_t z1, char *err, size_t errlen) {
+    NL_ENTER(c);
+    if (!host || z0 < 0 || z1 > c->nzl || z0 >= z1) return nl_fail(err, errlen, NL_EINVAL, "bad plane range [%lld,%lld)", (i64)z0, (i64)z1);
+    const i64 plane = c->ny * c->nx;
+    c->i_vmax = 3; c->i_gauss = 0; c->i_labels = -1;
+    NL_HIP(hipMemcpyAsync(c->f[c->i_vmax] + z0 * plane, host, (size_t)(z1 - z0) * plane * 4, hipMemcpyHostToDevice, c->stream));
+    NL_HIP(hipStreamSynchronize(c->stream));
+    c->frangi_ready = 1;
+    return NL_OK;
+}
+
+extern "C" int nl_label_intensity_mask(nl_ctx *c, const void *host_original, int dtype, double thresh, char *err, size_t errlen) {
+    NL_ENTER(c);
+    const size_t es = dtype_size(dtype);
+    if (!es || !host_original) return nl_fail(err, errlen, NL_EINVAL, "bad original image (dtype code %d)", dtype);
+    void *raw = nullptr;
+    NL_HIP(hipMalloc(&raw, (size_t)c->n * es));
+    hipError_t e = hipMemcpyAsync(raw, host_original, (size_t)c->n * es, hipMemcpyHostToDevice, c->stream);
+    if (e != hipSuccess) { hipFree(raw); return nl_fail(err, errlen, NL_EHIP, "upload of the original image failed: %s", hipGetErrorString(e)); }
+    float *fr = c->f[c->i_vmax];
+    const unsigned int g = grid1d(c->n);
+    switch (dtype) {
+        case NL_U8: intensity_mask_kernel<uint8_t><<<g, 256, 0, c->stream>>>((const uint8_t *)raw, fr, thresh, c->n); break;
+        case NL_I8: intensity_mask_kernel<int8_t><<<g, 256, 0, c->stream>>>((const int8_t *)raw, fr, thresh, c->n); break;
+        case NL_U16: intensity_mask_kernel<uint16_t><<<g, 256, 0, c->stream>>>((const uint16_t *)raw, fr, thresh, c->n); break;
+        case NL_I16: intensity_mask_kernel<int16_t><<<g, 256, 0, c->stream>>>((const int16_t *)raw, fr, thresh, c->n); break;
+        case NL_U32: intensity_mask_kernel<uint32_t><<<g, 256, 0, c->stream>>>((const uint32_t *)raw, fr, thresh, c->n); break;
+        case NL_I32: intensity_mask_kernel<int32_t><<<g, 256, 0, c->stream>>>((const int32_t *)raw, fr, thresh, c->n); break;
+        case NL_F32: intensity_mask_kernel<float><<<g, 256, 0, c->stream>>>((const float *)raw, fr, thresh, c->n); break;
+        case NL_F64: intensity_mask_kernel<double><<<g, 256, 0, c->stream>>>((const double *)raw, fr, thresh, c->n); break;
+        case NL_U64: intensity_mask_kernel<uint64_t><<<g, 256, 0, c->stream>>>((const uint64_t *)raw, fr, thresh, c->n); break;
+        case NL_I64: intensity_mask_kernel<int64_t><<<g, 256, 0, c->stream>>>((const int64_t *)raw, fr, thresh, c->n); break;
+    }
+    e = hipGetLastError();
+    hipStreamSynchronize(c->stream);
+    hipFree(raw);
+    if (e != hipSuccess) return nl_fail(err, errlen, NL_EHIP, "intensity mask kernel: %s", hipGetErrorString(e));
+    return NL_OK;
+}
+
+extern "C" int nl_flat_sample_gather(nl_ctx *c, int field, int64_t offset, int64_t step, float *out, int64_t cap, int64_t *n,
+                                     char *err, size_t errlen) {
+    NL_ENTER(c);
+    if (step < 1 || offset < 0) return nl_fail(err, errlen, NL_EINVAL, "bad offset/step");
+    if (field != NL_FIELD_FRANGI && field != NL_FIELD_GAUSS) return nl_fail(err, errlen, NL_EINVAL, "flat sampling supports GAUSS/FRANGI");
+    // flat index runs over the GLOBAL volume; this rank contributes indices inside its owned planes
+    const i64 plane = c->ny * c->nx;
+    const i64 g_begin = (c->gz0 + c->own_lo) * plane, g_end = (c->gz0 + c->own_hi) * plane;
+    i64 k0 = 0;
+    if (g_begin > offset) k0 = (g_begin - offset + step - 1) / step;
+    i64 k1 = (g_end > offset) ? (g_end - offset + step - 1) / step : 0;    // k in [k0,k1)
+    const i64 count = k1 > k0 ? k1 - k0 : 0;
+    if (n) *n = count;
+    if (count == 0 || (!out && cap == 0)) return NL_OK;   // size query
+    if (!out || cap < count) return nl_fail(err, errlen, NL_EINVAL, "output capacity %lld < %lld samples", (i64)cap, count);
+    const float *src = (field == NL_FIELD_FRANGI) ? c->f[c->i_vmax] : c->f[c->i_gauss];
+    float *stage = nullptr;
+    for (int k = 0; k < 3; ++k) if (k != c->i_gauss && c->f[k] != src) { stage = c->f[k]; break; }
+    {
+        ProfScope ps(c, "sample");
+        // local flat index = global - gz0*plane
+        flat_gather_kernel<<<(unsigned)((count + 255) / 256), 256, 0, c->stream>>>(src, -c->gz0 * plane, offset + k0 * step, step, count, stage);
+        NL_CHECK_LAUNCH();
+    }
+    NL_HIP(hipMemcpyAsync(out, stage, (size_t)count * 4, hipMemcpyDeviceToHost, c->stream));
+    NL_HIP(hipStreamSynchronize(c->stream));
+    return NL_OK;
+}
+
+template <int FG, int CONN>
+static int run_ccl(nl_ctx *c, const uint8_t *mask, int *L, char *err, size_t errlen) {
+    const i64 nrows = c->nzl * c->ny;
+    const i64 waves = nrows * ((c->nx + 63) / 64);
+    ccl_init_kernel<FG><<<(unsigned)((waves * 64 + 255) / 256), 256, 0, c->stream>>>(mask, L, c->nx, nrows);
+    NL_CHECK_LAUNCH();
+    const dim3 grid((unsigned)((c->nx + 255) / 256), (unsigned)c->ny, (unsigned)c->nzl);
+    ccl_merge_kernel<FG, CONN><<<grid, 256, 0, c->stream>>>(mask, L, c->nzl, c->ny, c->nx);
+    NL_CHECK_LAUNCH();
+    ccl_flatten_kernel<<<grid1d(c->n), 256, 0, c->stream>>>(L, c->n);
+    NL_CHECK_LAUNCH();
+    return NL_OK;
+}
+
+extern "C" int nl_label_run(nl_ctx *c, int has_thr, float thr, int64_t min_area, int fill_holes, int64_t *n_labels,
+                            char *err, size_t errlen) {
+    NL_ENTER(c);
+    if (!c->frangi_ready) return nl_fail(err, errlen, NL_ESTATE, "nl_label_run before a Frangi volume exists");
+    if (c->nzl != c->gnz) return nl_fail(err, errlen, NL_EINVAL, "nl_label_run works on a whole volume (use the sharded entry points for slabs)");
+    // buffers: frangi = f[i_vmax]; the other three float volumes serve as int32 scratch
+    int free_idx[3], nf = 0;
+    for (int k = 0; k < 4; ++k) if (k != c->i_vmax) free_idx[nf++] = k;
+    int *L = (int *)c->f[free_idx[0]];
+    int *aux = (int *)c->f[free_idx[1]];
+    int *out = (int *)c->f[free_idx[2]];
+    uint8_t *mA = c->m[1], *mB = c->m[2], *flag = c->m[0];
+    const i64 n = c->n;
+    const i64 nrows = c->nzl * c->ny;
+    const i64 waves = nrows * ((c->nx + 63) / 64);
+    int rc;
+    ProfScope ps(c, "label");
+    threshold_kernel<<<grid1d(n), 256, 0, c->stream>>>(c->f[c->i_vmax], mA, has_thr, thr, n);
+    NL_CHECK_LAUNCH();
+    if (fill_holes) {
+        if ((rc = run_ccl<0, 6>(c, mA, L, err, errlen))) return rc;
+        clear_root_flags_kernel<<<grid1d(n), 256, 0, c->stream>>>(L, flag, n);
+        NL_CHECK_LAUNCH();
+        border_mark_kernel<<<grid1d(n), 256, 0, c->stream>>>(L, flag, geom(c));
+        NL_CHECK_LAUNCH();
+        fill_holes_apply_kernel<<<grid1d(n), 256, 0, c->stream>>>(L, flag, mA, n);
+        NL_CHECK_LAUNCH();
+    }
+    if ((rc = run_ccl<1, 26>(c, mA, L, err, errlen))) return rc;
+    zero_at_roots_kernel<<<grid1d(n), 256, 0, c->stream>>>(L, aux, n);
+    NL_CHECK_LAUNCH();
+    area_count_kernel<<<(unsigned)((waves * 64 + 255) / 256), 256, 0, c->stream>>>(L, aux, c->nx, nrows);
+    NL_CHECK_LAUNCH();
+    const int ma = (int)(min_area > 0x7fffffff ? 0x7fffffff : min_area);
+    keep_large_kernel<<<grid1d(n), 256, 0, c->stream>>>(L, aux, mB, ma, n);
+    NL_CHECK_LAUNCH();
+    {
+        const dim3 grid((unsigned)((c->nx + 255) / 256), (unsigned)c->ny, (unsigned)c->nzl);
+        majority_kernel<<<grid, 256, 0, c->stream>>>(mB, mA, geom(c));
+        NL_CHECK_LAUNCH();
+    }
+    if ((rc = run_ccl<1, 26>(c, mA, L, err, errlen))) return rc;
+    const i64 nblk = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    unsigned int *blk = (unsigned int *)c->d_blk;
+    unsigned long long *d_total = (unsigned long long *)c->d_small;
+    root_count_kernel<<<(unsigned)nblk, 256, 0, c->stream>>>(L, n, blk);
+    NL_CHECK_LAUNCH();
+    blk_scan_kernel<<<1, 1024, 0, c->stream>>>(blk, nblk, d_total);
+    NL_CHECK_LAUNCH();
+    root_assign_kernel<<<(unsigned)nblk, 256, 0, c->stream>>>(L, n, blk, aux);
+    NL_CHECK_LAUNCH();
+    relabel_kernel<<<grid1d(n), 256, 0, c->stream>>>(L, aux, out, n);
+    NL_CHECK_LAUNCH();
+    NL_HIP(hipMemcpyAsync(c->h_small, d_total, 8, hipMemcpyDeviceToHost, c->stream));
+    NL_HIP(hipStreamSynchronize(c->stream));
+    if (n_labels) *n_labels = (int64_t)(*(unsigned long long *)c->h_small);
+    c->i_labels = free_idx[2];
+    return NL_OK;
+}
+
+extern "C" int nl_label_store(nl_ctx *c, int32_t *host, int64_t z0, int64_t z1, char *err, size_t errlen) {
+    NL_ENTER(c);
+    if (c->i_labels < 0) return nl_fail(err, errlen, NL_ESTATE, "nl_label_store before nl_label_run");
+    return store_planes(c, c->f[c->i_labels], host, 4, z0, z1, err, errlen);
+}
+
+// --------------------------------------------------------------------------------- timing -------
+extern "C" int nl_timer_begin(nl_ctx *c, char *err, size_t errlen) {
+    NL_ENTER(c);
+    NL_HIP(hipEventRecord(c->t0, c->stream));
+    return NL_OK;
+}
+extern "C" int nl_timer_end_ms(nl_ctx *c, float *ms, char *err, size_t errlen) {
+    NL_ENTER(c);
+    NL_HIP(hipEventRecord(c->t1, c->stream));
+    NL_HIP(hipEventSynchronize(c->t1));
+    float t = 0;
+    NL_HIP(hipEventElapsedTime(&t, c->t0, c->t1));
+    if (ms) *ms = t;
+    return NL_OK;
+}
+extern "C" int nl_prof_enable(nl_ctx *c, int on) { if (c) c->prof_on = on; return NL_OK; }
+extern "C" int nl_prof_reset(nl_ctx *c) {
+    if (!c) return NL_OK;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    for (auto &kv : c->prof) for (auto &r : kv.second) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+    c->prof.clear();
+    return NL_OK;
+}
+extern "C" int nl_prof_get(nl_ctx *c, const char *name, double *ms, int64_t *launches) {
+    if (!c || !name) return NL_EINVAL;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    double tot = 0; int64_t k = 0;
+    auto it = c->prof.find(name);
+    if (it != c->prof.end())
+        for (auto &r : it->second) { float t = 0; if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) { tot += t; ++k; } }
+    if (ms) *ms = tot;
+    if (launches) *launches = k;
+    return NL_OK;
+}

@@ -1,0 +1,87 @@
+// Internal declarations shared by the translation units of libnellie_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include <map>
+
+#include "../../include/nellie_amd.h"
+
+typedef long long i64;
+
+struct ProfRec { hipEvent_t a, b; };
+
+struct nl_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    i64 nzl = 0, ny = 0, nx = 0;      // local slab shape
+    i64 gz0 = 0, gnz = 0;             // global placement
+    i64 own_lo = 0, own_hi = 0;       // owned planes (local coordinates)
+    i64 n = 0;                        // nzl*ny*nx
+
+    float *f[4] = {nullptr, nullptr, nullptr, nullptr};   // four float32 volumes
+    uint8_t *m[3] = {nullptr, nullptr, nullptr};          // three byte volumes
+    int i_gauss = 0;        // f[] index holding the current Gaussian volume
+    int i_vmax = 3;         // f[] index holding vesselness / the Filter output
+    int i_labels = -1;      // f[] index holding the int32 labels after nl_label_run
+    // m[0] = cumulative mask during Filter
+
+    void *d_small = nullptr;   // scratch for reductions / histograms / weights (64 KiB)
+    void *h_small = nullptr;   // pinned mirror
+    void *d_blk = nullptr;     // per-block partials for scans
+    i64 blk_cap = 0;
+
+    float hz = 1, hy = 1, hx = 1;            // float32(h)
+    float hz2 = 2, hy2 = 2, hx2 = 2;         // float32(2.0*h)
+    int have_spacing = 0;
+    float frob_max_abs = 1.0f, frob_max_finite = 0.0f;
+    int frangi_ready = 0;
+
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    int prof_on = 0;
+    std::map<std::string, std::vector<ProfRec>> prof;
+    std::vector<hipEvent_t> ev_pool;
+};
+
+static inline int nl_fail(char *err, size_t errlen, int code, const char *fmt, ...) {
+    if (err && errlen) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(err, errlen, fmt, ap);
+        va_end(ap);
+    }
+    return code;
+}
+
+#define NL_HIP(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            int code_ = (e_ == hipErrorOutOfMemory) ? NL_ENOMEM                               \
+                        : (e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice) ? NL_ENODEV \
+                                                                                  : NL_EHIP;  \
+            return nl_fail(err, errlen, code_, "%s: %s (%s:%d)%s", #expr, hipGetErrorString(e_), \
+                           __FILE__, __LINE__, code_ == NL_ENOMEM ? " [out of memory]" : ""); \
+        }                                                                                     \
+    } while (0)
+
+#define NL_CHECK_LAUNCH() NL_HIP(hipGetLastError())
+
+// RAII profiling scope: records a HIP-event pair on the context stream around a kernel group.
+struct ProfScope {
+    nl_ctx *c; ProfRec r; bool on;
+    ProfScope(nl_ctx *ctx, const char *name) : c(ctx), on(ctx->prof_on != 0) {
+        if (!on) return;
+        hipEventCreate(&r.a); hipEventCreate(&r.b);
+        hipEventRecord(r.a, c->stream);
+        c->prof[name].push_back(r);
+        idx = c->prof[name].size() - 1; key = name;
+    }
+    ~ProfScope() { if (on) hipEventRecord(c->prof[key][idx].b, c->stream); }
+    size_t idx = 0; std::string key;
+};
+

@@ -1,0 +1,332 @@
+"""
+ctypes binding of libnellie_hip.so (C-ABI: include/nellie_amd.h).
+
+There is no CPU fallback: if the library is missing or no MI355X is present, every
+entry point raises.  Status codes map to the exception classes the reference's retry
+ladder recognises (nellie/utils/adaptive_run.py:116-141):
+    NL_ENODEV -> RuntimeError("GPU backend requested but ...")
+    NL_ENOMEM -> MemoryError("... out of memory ...")
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnellie_hip.so")
+
+NL_OK, NL_EINVAL, NL_ENODEV, NL_ENOMEM, NL_EHIP, NL_ESTATE, NL_ECOMM = range(7)
+FIELD_GAUSS, FIELD_FROB, FIELD_FRANGI = 0, 1, 2
+
+DTYPE_CODES = {
+    np.dtype(np.uint8): 0, np.dtype(np.int8): 1, np.dtype(np.uint16): 2, np.dtype(np.int16): 3,
+    np.dtype(np.uint32): 4, np.dtype(np.int32): 5, np.dtype(np.float32): 6, np.dtype(np.float64): 7,
+    np.dtype(np.uint64): 8, np.dtype(np.int64): 9,
+}
+
+_ERRLEN = 512
+_i64, _int, _f32, _f64 = C.c_int64, C.c_int, C.c_float, C.c_double
+_p = C.c_void_p
+_ERR = (C.c_char_p, C.c_size_t)
+
+# name -> argtypes WITHOUT the trailing (err, errlen) pair; every listed function returns int
+_PROTOS = {
+    "nl_device_count": [C.POINTER(_int)],
+    "nl_device_mem_info": [_int, C.POINTER(_i64), C.POINTER(_i64)],
+    "nl_device_name": [_int, C.c_char_p, C.c_size_t],
+    "nl_ctx_create": [C.POINTER(_p), _int, _i64, _i64, _i64, _i64, _i64, _i64, _i64],
+    "nl_sync": [_p],
+    "nl_filter_load": [_p, _p, _int, _i64, _i64],
+    "nl_gauss_step": [_p, _p, _int, _p, _int, _p, _int, _i64, _i64],
+    "nl_sample_gather": [_p, _int, _i64, _i64, _i64, _p, _i64, C.POINTER(_i64)],
+    "nl_sample_minmax": [_p, _int, _i64, _i64, _i64, C.POINTER(_f32), C.POINTER(_f32), C.POINTER(_i64)],
+    "nl_sample_hist": [_p, _int, _i64, _i64, _i64, _p, _int, _p],
+    "nl_hessian_stats": [_p, C.POINTER(_f64), C.POINTER(_f32), C.POINTER(_f32), C.POINTER(_int)],
+    "nl_set_frob_norm": [_p, _f32, _f32],
+    "nl_vesselness_step": [_p, _f32, _f32, _f32, _int, _f32, C.POINTER(_i64)],
+    "nl_filter_finish": [_p, C.POINTER(_i64)],
+    "nl_mask_volume": [_p, _f32],
+    "nl_filter_store": [_p, _p, _i64, _i64],
+    "nl_gauss_store": [_p, _p, _i64, _i64],
+    "nl_label_load_frangi": [_p, _p, _i64, _i64],
+    "nl_label_intensity_mask": [_p, _p, _int, _f64],
+    "nl_flat_sample_gather": [_p, _int, _i64, _i64, _p, _i64, C.POINTER(_i64)],
+    "nl_label_run": [_p, _int, _f32, _i64, _int, C.POINTER(_i64)],
+    "nl_label_store": [_p, _p, _i64, _i64],
+    "nl_timer_begin": [_p],
+    "nl_timer_end_ms": [_p, C.POINTER(_f32)],
+}
+# functions without the (err, errlen) tail
+_PLAIN = {
+    "nl_version": (C.c_char_p, []),
+    "nl_ctx_destroy": (_int, [_p]),
+    "nl_ctx_bytes": (_i64, [_i64, _i64, _i64]),
+    "nl_prof_enable": (_int, [_p, _int]),
+    "nl_prof_get": (_int, [_p, C.c_char_p, C.POINTER(_f64), C.POINTER(_i64)]),
+    "nl_prof_reset": (_int, [_p]),
+}
+ALL_SYMBOLS = sorted(list(_PROTOS) + list(_PLAIN))
+
+
+class NellieHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(msg)
+        self.code = code
+
+
+def _raise(code: int, msg: str):
+    if code == NL_ENODEV:
+        if "GPU backend requested" not in msg:
+            msg = "GPU backend requested but " + msg
+        raise RuntimeError(msg)
+    if code == NL_ENOMEM:
+        raise MemoryError(f"HIP out of memory: {msg}")
+    if code == NL_EINVAL:
+        raise ValueError(msg)
+    raise NellieHipError(code, f"libnellie_hip error {code}: {msg}")
+
+
+class _Lib:
+    def __init__(self, path: str):
+        self.path = path
+        self.cdll = C.CDLL(path)
+        for name, argtypes in _PROTOS.items():
+            fn = getattr(self.cdll, name)
+            fn.restype = _int
+            fn.argtypes = list(argtypes) + list(_ERR)
+        for name, (res, argtypes) in _PLAIN.items():
+            fn = getattr(self.cdll, name)
+            fn.restype = res
+            fn.argtypes = argtypes
+
+    def call(self, name: str, *args):
+        buf = C.create_string_buffer(_ERRLEN)
+        rc = getattr(self.cdll, name)(*args, buf, _ERRLEN)
+        if rc != NL_OK:
+            _raise(rc, buf.value.decode("utf-8", "replace"))
+
+    def version(self) -> str:
+        return self.cdll.nl_version().decode()
+
+    def device_count(self) -> int:
+        n = _int(0)
+        buf = C.create_string_buffer(_ERRLEN)
+        rc = self.cdll.nl_device_count(C.byref(n), buf, _ERRLEN)
+        return int(n.value) if rc == NL_OK else 0
+
+    def device_mem_info(self, device=0):
+        f, t = _i64(0), _i64(0)
+        self.call("nl_device_mem_info", device, C.byref(f), C.byref(t))
+        return int(f.value), int(t.value)
+
+    def device_name(self, device=0) -> str:
+        b = C.create_string_buffer(256)
+        self.call("nl_device_name", device, b, 256)
+        return b.value.decode()
+
+
+_LIB = None
+
+
+def load() -> _Lib:
+    """Load libnellie_hip.so or raise.  Never falls back to a CPU implementation."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"GPU backend requested but {LIB_PATH} is not built "
+                "(run `python -m nellie_amd.build`); nellie_amd has no CPU fallback")
+        _LIB = _Lib(LIB_PATH)
+    return _LIB
+
+
+def gpu_available() -> bool:
+    """adaptive_run.gpu_available (nellie/utils/adaptive_run.py:23-31) for the HIP backend."""
+    try:
+        return load().device_count() > 0
+    except Exception:
+        return False
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(_p)
+
+
+class Context:
+    """One device context = one (device, local slab shape) pair (include/nellie_amd.h nl_ctx)."""
+
+    def __init__(self, shape, device=0, gz0=0, gnz=None, own=None):
+        self.lib = load()
+        nz, ny, nx = (int(s) for s in shape)
+        self.shape = (nz, ny, nx)
+        self.gz0 = int(gz0)
+        self.gnz = int(gnz) if gnz is not None else nz
+        self.own = (0, nz) if own is None else (int(own[0]), int(own[1]))
+        self.device = int(device)
+        h = _p()
+        self.lib.call("nl_ctx_create", C.byref(h), self.device, nz, ny, nx, self.gz0, self.gnz,
+                      self.own[0], self.own[1])
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.cdll.nl_ctx_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _call(self, name, *args):
+        if not self._h:
+            raise NellieHipError(NL_ESTATE, "context is closed")
+        self.lib.call(name, self._h, *args)
+
+    def sync(self):
+        self._call("nl_sync")
+
+    # ---------------------------------------------------------------- Filter
+    def filter_load(self, frame: np.ndarray, z0=0, z1=None):
+        z1 = self.shape[0] if z1 is None else z1
+        a = np.ascontiguousarray(frame)
+        if a.dtype not in DTYPE_CODES:
+            a = a.astype(np.float32)
+        assert a.shape == (z1 - z0, self.shape[1], self.shape[2]), (a.shape, self.shape, z0, z1)
+        self._call("nl_filter_load", _ptr(a), DTYPE_CODES[a.dtype], z0, z1)
+
+    def gauss_step(self, wz, wy, wx, z0=0, z1=None):
+        z1 = self.shape[0] if z1 is None else z1
+        args = []
+        keep = []
+        for w in (wz, wy, wx):
+            if w is None:
+                args += [None, 0]
+            else:
+                w = np.ascontiguousarray(w, dtype=np.float64)
+                keep.append(w)
+                args += [_ptr(w), (len(w) - 1) // 2]
+        self._call("nl_gauss_step", *args, z0, z1)
+
+    def sample_gather(self, field, strides):
+        sz, sy, sx = (int(s) for s in strides)
+        n = _i64(0)
+        self._call("nl_sample_gather", field, sz, sy, sx, None, 0, C.byref(n))
+        out = np.empty(int(n.value), dtype=np.float32)
+        if out.size:
+            self._call("nl_sample_gather", field, sz, sy, sx, _ptr(out), out.size, C.byref(n))
+        return out
+
+    def sample_minmax(self, field, strides):
+        sz, sy, sx = (int(s) for s in strides)
+        mn, mx, n = _f32(0), _f32(0), _i64(0)
+        self._call("nl_sample_minmax", field, sz, sy, sx, C.byref(mn), C.byref(mx), C.byref(n))
+        return np.float32(mn.value), np.float32(mx.value), int(n.value)
+
+    def sample_hist(self, field, strides, edges: np.ndarray):
+        sz, sy, sx = (int(s) for s in strides)
+        e = np.ascontiguousarray(edges, dtype=np.float32)
+        counts = np.zeros(e.size - 1, dtype=np.int64)
+        self._call("nl_sample_hist", field, sz, sy, sx, _ptr(e), e.size - 1, _ptr(counts))
+        return counts
+
+    def hessian_stats(self, spacing):
+        sp = (_f64 * 3)(*[float(s) for s in spacing])
+        ma, mf, inf = _f32(0), _f32(0), _int(0)
+        self._call("nl_hessian_stats", sp, C.byref(ma), C.byref(mf), C.byref(inf))
+        return np.float32(ma.value), np.float32(mf.value), bool(inf.value)
+
+    def set_frob_norm(self, max_abs, max_finite):
+        self._call("nl_set_frob_norm", float(max_abs), float(max_finite))
+
+    def vesselness_step(self, gamma_sq, alpha_sq, beta_sq, thr, want_count=True):
+        n = _i64(0)
+        use = 0 if thr is None else 1
+        self._call("nl_vesselness_step", float(np.float32(gamma_sq)), float(np.float32(alpha_sq)),
+                   float(np.float32(beta_sq)), use, float(np.float32(0.0 if thr is None else thr)),
+                   C.byref(n) if want_count else None)
+        return int(n.value)
+
+    def filter_finish(self) -> int:
+        n = _i64(0)
+        self._call("nl_filter_finish", C.byref(n))
+        return int(n.value)
+
+    def mask_volume(self, thr):
+        self._call("nl_mask_volume", float(np.float32(thr)))
+
+    def filter_store(self, z0=0, z1=None, out=None):
+        z1 = self.shape[0] if z1 is None else z1
+        if out is None:
+            out = np.empty((z1 - z0, self.shape[1], self.shape[2]), dtype=np.float32)
+        assert out.dtype == np.float32 and out.flags.c_contiguous
+        self._call("nl_filter_store", _ptr(out), z0, z1)
+        return out
+
+    def gauss_store(self, z0=0, z1=None):
+        z1 = self.shape[0] if z1 is None else z1
+        out = np.empty((z1 - z0, self.shape[1], self.shape[2]), dtype=np.float32)
+        self._call("nl_gauss_store", _ptr(out), z0, z1)
+        return out
+
+    # ---------------------------------------------------------------- Label
+    def label_load_frangi(self, frangi: np.ndarray, z0=0, z1=None):
+        z1 = self.shape[0] if z1 is None else z1
+        a = np.ascontiguousarray(frangi, dtype=np.float32)
+        assert a.shape == (z1 - z0, self.shape[1], self.shape[2])
+        self._call("nl_label_load_frangi", _ptr(a), z0, z1)
+
+    def label_intensity_mask(self, original: np.ndarray, thresh: float):
+        a = np.ascontiguousarray(original)
+        if a.dtype not in DTYPE_CODES:
+            a = a.astype(np.float64)
+        assert a.shape == self.shape
+        self._call("nl_label_intensity_mask", _ptr(a), DTYPE_CODES[a.dtype], float(thresh))
+
+    def flat_sample_gather(self, field, offset, step):
+        n = _i64(0)
+        self._call("nl_flat_sample_gather", field, int(offset), int(step), None, 0, C.byref(n))
+        out = np.empty(int(n.value), dtype=np.float32)
+        if out.size:
+            self._call("nl_flat_sample_gather", field, int(offset), int(step), _ptr(out), out.size, C.byref(n))
+        return out
+
+    def label_run(self, thr, min_area, fill_holes=True) -> int:
+        n = _i64(0)
+        has = 0 if thr is None else 1
+        self._call("nl_label_run", has, float(np.float32(0.0 if thr is None else thr)), int(min_area),
+                   1 if fill_holes else 0, C.byref(n))
+        return int(n.value)
+
+    def label_store(self, z0=0, z1=None, out=None):
+        z1 = self.shape[0] if z1 is None else z1
+        if out is None:
+            out = np.empty((z1 - z0, self.shape[1], self.shape[2]), dtype=np.int32)
+        assert out.dtype == np.int32 and out.flags.c_contiguous
+        self._call("nl_label_store", _ptr(out), z0, z1)
+        return out
+
+    # ---------------------------------------------------------------- timing
+    def timer_begin(self):
+        self._call("nl_timer_begin")
+
+    def timer_end_ms(self) -> float:
+        ms = _f32(0)
+        self._call("nl_timer_end_ms", C.byref(ms))
+        return float(ms.value)
+
+    def prof_enable(self, on=True):
+        self.lib.cdll.nl_prof_enable(self._h, 1 if on else 0)
+
+    def prof_reset(self):
+        self.lib.cdll.nl_prof_reset(self._h)
+
+    def prof_get(self, name: str):
+        ms, k = _f64(0), _i64(0)
+        self.lib.cdll.nl_prof_get(self._h, name.encode(), C.byref(ms), C.byref(k))
+        return float(ms.value), int(k.value)

@@ -1,0 +1,311 @@
+"""
+Per-frame orchestration of the HIP engine: the host half of Nellie's Filter -> Label hot path.
+
+The device does every full-volume pass (libnellie_hip.so, include/nellie_amd.h); the host
+decides the data-dependent thresholds between passes exactly where the reference does
+(nellie/segmentation/filtering.py:806-853, 952-967; labelling.py:385-455), from 256-bin
+histograms / <= 1e6 samples the device hands back.  No array math on full volumes happens
+here, and there is no CPU fallback: without the HIP library this module cannot run.
+
+`FramePipeline` keeps one frame resident in HBM from upload to label download; the
+`Filter` / `Label` stage classes (nellie_amd/segmentation) wrap it behind the reference's
+stage API and on-disk layout.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Optional
+
+import numpy as np
+
+from nellie_amd import hipnative
+from nellie_amd.hipnative import FIELD_FRANGI, FIELD_FROB, FIELD_GAUSS
+from nellie_amd.utils.gpu_functions import (histogram_edges, min_triangle_otsu, otsu_threshold,
+                                            triangle_threshold)
+
+_EPS32 = float(np.finfo(np.float32).eps)
+_TRUNCATE = 3.0
+
+
+# ----------------------------------------------------------------------------- parameters
+def z_ratio_of(dim_res) -> float:
+    """filtering.py:75-78."""
+    z_res = dim_res.get("Z") or dim_res.get("X") or 1.0
+    x_res = dim_res.get("X") or 1.0
+    return float(z_res) / float(x_res)
+
+
+def spacing_of(dim_res):
+    """filtering.py:265-275."""
+    z = dim_res.get("Z") or dim_res.get("X") or 1.0
+    y = dim_res.get("Y") or 1.0
+    x = dim_res.get("X") or 1.0
+    return (float(z), float(y), float(x))
+
+
+def default_sigmas(dim_res, min_radius_um=0.25, max_radius_um=1.0):
+    """filtering.py:88-89, 288-316."""
+    min_radius_px = min_radius_um / dim_res["X"]
+    max_radius_px = max_radius_um / dim_res["X"]
+    min_sigma_step_size = 0.2
+    num_sigma = 5
+    sigma_1 = min_radius_px / 2.0
+    sigma_2 = max_radius_px / 3.0
+    sigma_min = min(sigma_1, sigma_2)
+    sigma_max = max(sigma_1, sigma_2)
+    if sigma_max <= sigma_min:
+        sigma_max = sigma_min + min_sigma_step_size
+    sigma_step_size_calculated = (sigma_max - sigma_min) / float(num_sigma)
+    sigma_step_size = max(min_sigma_step_size, sigma_step_size_calculated)
+    sigmas = list(np.arange(sigma_min, sigma_max, sigma_step_size, dtype=float))
+    sigmas.sort()
+    return sigmas
+
+
+def sample_strides(shape, max_samples):
+    """filtering.py:328-340."""
+    if max_samples is None or max_samples <= 0:
+        return (1,) * len(shape)
+    total = int(np.prod(shape))
+    if total <= max_samples:
+        return (1,) * len(shape)
+    ndim = len(shape)
+    stride = int(np.ceil((total / max_samples) ** (1.0 / ndim)))
+    strides = [max(1, stride) for _ in range(ndim)]
+    while int(np.prod([int(np.ceil(s / st)) for s, st in zip(shape, strides)])) > max_samples:
+        idx = int(np.argmax([s / st for s, st in zip(shape, strides)]))
+        strides[idx] += 1
+    return tuple(strides)
+
+
+def gaussian_weights(sigma: float):
+    """
+    scipy.ndimage `gaussian_filter1d` + `_gaussian_kernel1d` (order 0, truncate 3.0):
+    lw = int(truncate*sd + 0.5); w = exp(-0.5/sd^2 * x^2) / sum.  None when the axis is
+    skipped (scipy `gaussian_filter` skips sigma <= 1e-15).  Computed with numpy exactly as
+    scipy does, so the float64 weights carry scipy's bits.
+    """
+    sd = float(sigma)
+    if not sd > 1e-15:
+        return None
+    lw = int(_TRUNCATE * sd + 0.5)
+    sigma2 = sd * sd
+    x = np.arange(-lw, lw + 1)
+    phi_x = np.exp(-0.5 / sigma2 * x ** 2)
+    phi_x = phi_x / phi_x.sum()
+    return np.ascontiguousarray(phi_x[::-1])
+
+
+def cascade_deltas(sigmas, z_ratio):
+    """filtering.py:814-825."""
+    out = []
+    prev = 0.0
+    for sigma in sigmas:
+        vp = (float(prev) / z_ratio, float(prev), float(prev))
+        vc = (float(sigma) / z_ratio, float(sigma), float(sigma))
+        delta = []
+        for sp, sc in zip(vp, vc):
+            diff = max(0.0, float(sc) ** 2 - float(sp) ** 2)
+            delta.append(np.sqrt(diff))
+        out.append(tuple(delta))
+        prev = sigma
+    return out
+
+
+def min_area_pixels_of(dim_res, min_radius_um=0.25, no_z=False):
+    """labelling.py:95-97, 209-219."""
+    x_res = dim_res.get("X") or 1.0
+    y_res = dim_res.get("Y") or x_res
+    r = max(float(min_radius_um), float(x_res))
+    if no_z:
+        area_px = (np.pi * (r ** 2)) / (float(x_res) * float(y_res))
+        return max(1, int(np.ceil(area_px)))
+    z_res = dim_res.get("Z") or x_res
+    volume_um3 = (4.0 / 3.0) * np.pi * (r ** 3)
+    volume_px = volume_um3 / (float(x_res) * float(y_res) * float(z_res))
+    return max(1, int(np.ceil(volume_px)))
+
+
+@dataclass
+class FilterParams:
+    dim_res: dict
+    min_radius_um: float = 0.25
+    max_radius_um: float = 1.0
+    alpha_sq: float = 0.5
+    beta_sq: float = 0.5
+    frob_thresh: Optional[float] = None
+    frob_thresh_division: object = 2
+    max_threshold_samples: int = int(1e6)
+    sigmas: Optional[list] = None
+
+    def resolved_sigmas(self):
+        if self.sigmas is not None:
+            return list(self.sigmas)
+        return default_sigmas(self.dim_res, self.min_radius_um, self.max_radius_um)
+
+
+@dataclass
+class ScaleTrace:
+    sigma: float
+    gamma: float
+    max_abs: float
+    frob_thr: Optional[float]
+    mask_count: int
+    skipped: bool
+
+
+@dataclass
+class FrameTrace:
+    scales: list = field(default_factory=list)
+    n_positive: int = 0
+    percentile_thr: Optional[float] = None
+    label_thr: Optional[float] = None
+    n_labels: int = 0
+
+
+# ----------------------------------------------------------------------------- the pipeline
+class FramePipeline:
+    """One (Z, Y, X) frame on one GPU, resident in HBM across Filter and Label."""
+
+    def __init__(self, shape, device: int = 0):
+        self.shape = tuple(int(s) for s in shape)
+        if len(self.shape) != 3:
+            raise ValueError("FramePipeline takes a (Z, Y, X) shape")
+        self.ctx = hipnative.Context(self.shape, device=device)
+        self.trace = FrameTrace()
+
+    def close(self):
+        self.ctx.close()
+
+    # ------------------------------------------------------------------ Filter
+    def _threshold_from_field(self, fld, strides):
+        """min(triangle, otsu) over the positive lattice samples of a device field, or None if none."""
+        mn, mx, npos = self.ctx.sample_minmax(fld, strides)
+        if npos == 0:
+            return None
+        edges = histogram_edges(mn, mx, 256)
+        counts = self.ctx.sample_hist(fld, strides, edges)
+        return float(min_triangle_otsu(counts, edges))
+
+    def compute_vesselness(self, frame, p: FilterParams, mask: bool = True):
+        """filtering.py:806-853 + 926: leaves `vesselness * masks` on the device; returns #voxels > 0."""
+        ctx = self.ctx
+        max_samples = int(p.max_threshold_samples) if p.max_threshold_samples is not None else 0
+        if max_samples <= 0:
+            raise ValueError("max_threshold_samples must be a positive integer")
+        self.trace = FrameTrace()
+        ctx.filter_load(np.asarray(frame))
+        zr = z_ratio_of(p.dim_res)
+        spacing = spacing_of(p.dim_res)
+        sigmas = p.resolved_sigmas()
+        strides = sample_strides(self.shape, max_samples)
+        alpha_sq = float(p.alpha_sq)
+        beta_sq = float(p.beta_sq)
+        for sigma, delta in zip(sigmas, cascade_deltas(sigmas, zr)):
+            if any(s > 0 for s in delta):
+                ctx.gauss_step(*[gaussian_weights(d) for d in delta])
+            # gamma (filtering.py:365-380, 839-840)
+            gamma = self._threshold_from_field(FIELD_GAUSS, strides)
+            if gamma is None or gamma <= 0:
+                gamma = _EPS32
+            gamma_sq = 2.0 * (float(gamma) ** 2)
+            # Hessian statistics (filtering.py:555-562)
+            max_abs32, max_fsq32, any_inf = ctx.hessian_stats(spacing)
+            max_abs = float(max_abs32)
+            if max_abs <= 0:
+                max_abs = 1.0
+            with np.errstate(over="ignore", invalid="ignore", divide="ignore"):
+                max_frob = np.sqrt(np.float32(max_fsq32)) / np.float32(max_abs)   # float32, as the volume op
+            ctx.set_frob_norm(max_abs, float(max_frob) if any_inf else 0.0)
+            thr = None
+            if not mask:
+                # h_mask = ones_like(image) (filtering.py:566-567)
+                thr_cmp, nonempty = np.float32(-np.inf), True
+            elif not p.frob_thresh_division:
+                thr_cmp = None                                   # mask = frob > 0 (filtering.py:428-430)
+                nonempty = bool(max_frob > 0)
+            else:
+                if p.frob_thresh is None:
+                    t = self._threshold_from_field(FIELD_FROB, strides)
+                    thr = 0.0 if t is None else t                # filtering.py:433-439
+                else:
+                    thr = float(p.frob_thresh)
+                thr_cmp = np.float32(thr / p.frob_thresh_division)   # weak python scalar vs float32 array
+                nonempty = bool(max_frob > thr_cmp)
+            count = 0
+            if nonempty:                                         # filtering.py:843-844
+                count = ctx.vesselness_step(gamma_sq, alpha_sq, beta_sq, thr_cmp)
+            self.trace.scales.append(ScaleTrace(float(sigma), float(gamma), max_abs, thr, count, not nonempty))
+        self.trace.n_positive = ctx.filter_finish()
+        return self.trace.n_positive
+
+    def mask_volume(self, p: FilterParams):
+        """filtering.py:952-967 on the device-resident frame."""
+        strides = sample_strides(self.shape, int(p.max_threshold_samples))
+        sample = self.ctx.sample_gather(FIELD_FRANGI, strides)
+        positive = sample[sample > 0]
+        if positive.size == 0:
+            return None
+        thr = np.percentile(positive, 1)
+        self.ctx.mask_volume(thr)
+        self.trace.percentile_thr = float(thr)
+        return thr
+
+    def filter(self, frame, p: FilterParams, mask: bool = True):
+        """filtering.py:1012-1018: _run_frame, then _mask_volume when the frame has signal."""
+        npos = self.compute_vesselness(frame, p, mask=mask)
+        if npos > 0:      # float(sum(frame)) > 0 for a non-negative frame
+            self.mask_volume(p)
+        return npos
+
+    def download_frangi(self, out=None):
+        return self.ctx.filter_store(out=out)
+
+    # ------------------------------------------------------------------ Label
+    def upload_frangi(self, frangi):
+        self.ctx.label_load_frangi(np.asarray(frangi, dtype=np.float32))
+
+    def frangi_threshold(self, max_samples=1_000_000, nbins=256):
+        """labelling.py:385-455 on the device-resident Frangi frame (no mask arguments)."""
+        n = int(np.prod(self.shape))
+        if n == 0:
+            return None
+        max_samples = max(1, int(max_samples))
+        step = max(n // max_samples, 1)
+        offsets = (0, step // 2) if step > 1 and step // 2 > 0 else (0,)
+        values = np.zeros(0, np.float32)
+        found = False
+        for offset in offsets:
+            sample = self.ctx.flat_sample_gather(FIELD_FRANGI, offset, step)
+            values = sample[sample > 0]
+            if values.size > 0 or step == 1:
+                found = True
+                break
+        if not found:
+            full = self.ctx.flat_sample_gather(FIELD_FRANGI, 0, 1)     # rare: every strided sample empty
+            if full.size == 0 or float(full.max()) <= 0:
+                values = values[:0]
+            else:
+                values = full[full > 0]
+        if values.size == 0:
+            return None
+        return log10_min_triangle_otsu(values, nbins)
+
+    def label(self, frangi_thresh, min_area, fill_holes=True):
+        """labelling.py:467-509; returns the number of labels.  Labels stay on the device."""
+        self.trace.label_thr = None if frangi_thresh is None else float(frangi_thresh)
+        self.trace.n_labels = self.ctx.label_run(frangi_thresh, int(min_area), fill_holes)
+        return self.trace.n_labels
+
+    def download_labels(self, out=None):
+        return self.ctx.label_store(out=out)
+
+
+def log10_min_triangle_otsu(values, nbins=256):
+    """labelling.py:448-455: thresholds in the log10 domain, mapped back, minimum of the two."""
+    log_values = np.log10(values)
+    triangle = triangle_threshold(log_values, nbins=nbins)
+    triangle = 10 ** triangle
+    otsu, _ = otsu_threshold(log_values, nbins=nbins)
+    otsu = 10 ** otsu
+    return min(triangle, otsu)

@@ -1,0 +1,253 @@
+"""
+`Label`: drop-in for nellie.segmentation.labelling.Label (reference labelling.py:17-778)
+on the MI355X HIP engine.
+
+Same constructor keywords, same `.run()`, same product
+(`im_info.pipeline_paths['im_instance_label']`, int32, ids 1..K per frame in raster order of
+each object's first voxel, exactly scipy.ndimage.label's numbering).
+
+The per-frame thresholds are computed on the host from the memmap views, exactly as the
+reference does even on its GPU path (labelling.py:359-365, 511-532); thresholding, hole
+filling, both labelling passes, the small-object filter and the majority smoothing run on the
+device (nl_label_run).  `chunk_z` / `low_memory` are accepted and ignored: the reference's
+Z-chunked mode is not equivalent to its full-volume mode (per-chunk hole filling and area
+filter); this backend always produces the full-volume result.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from nellie_amd.pipeline import FramePipeline, log10_min_triangle_otsu, min_area_pixels_of
+from nellie_amd.utils import adaptive_run
+from nellie_amd.utils.base_logger import logger
+from nellie_amd.utils.gpu_functions import otsu_threshold
+
+_UNSET = object()
+
+
+class Label:
+    def __init__(self, im_info,
+                 num_t=None,
+                 threshold=None,
+                 otsu_thresh_intensity=False,
+                 viewer=None,
+                 chunk_z=None,
+                 flush_interval=1,
+                 min_radius_um=0.25,
+                 threshold_sampling_pixels=1_000_000,
+                 histogram_nbins=256,
+                 device="auto",
+                 low_memory: bool = False,
+                 max_chunk_voxels: int = int(1e6),
+                 device_index: int = 0):
+        self.im_info = im_info
+        self.device = device
+        self.device_type = self._resolve_backend(device)
+        self.device_index = int(device_index)
+        self.num_t = num_t
+        if num_t is None and not self.im_info.no_t:
+            self.num_t = im_info.shape[im_info.axes.index('T')]
+        self.threshold = threshold
+        self.otsu_thresh_intensity = otsu_thresh_intensity
+        self.im_memmap = None
+        self.frangi_memmap = None
+        self.semantic_mask_memmap = None
+        self.instance_label_memmap = None
+        self.shape = ()
+        self.debug = {}
+        self.viewer = viewer
+        self.chunk_z = None           # accepted, ignored (see module docstring)
+        self._user_chunk_z = chunk_z
+        self.flush_interval = max(1, int(flush_interval))
+        min_radius_um = float(min_radius_um)
+        x_res = self.im_info.dim_res.get("X") or 1.0
+        self.min_radius_um = max(min_radius_um, float(x_res))
+        self.threshold_sampling_pixels = int(threshold_sampling_pixels)
+        self.histogram_nbins = int(histogram_nbins)
+        self.eps = 1e-8
+        self.low_memory = bool(low_memory)
+        self.max_chunk_voxels = int(max_chunk_voxels)
+        self.ndim = 2 if self.im_info.no_z else 3
+        self.min_area_pixels = self._compute_min_area_pixels()
+        self._pipeline = None
+
+    def _resolve_backend(self, device):
+        """labelling.py:115-154 with HIP in the role of CuPy."""
+        device = (device or "auto").lower()
+        if device not in ("auto", "cpu", "gpu", "cuda"):
+            raise ValueError(f"Unsupported device '{device}'. Use 'auto', 'cpu', or 'gpu'.")
+        if device == "cpu":
+            raise RuntimeError(
+                "nellie_amd provides the MI355X HIP backend only: device='cpu' is not available "
+                "(no CPU fallback exists in this package; use the reference implementation on CPU)")
+        if not adaptive_run.gpu_available():
+            raise RuntimeError("GPU backend requested but no HIP device / libnellie_hip.so is available.")
+        return "hip"
+
+    def _compute_min_area_pixels(self):
+        """labelling.py:209-219 (min_radius_um already clamped to >= X resolution, :95-97)."""
+        return min_area_pixels_of(self.im_info.dim_res, self.min_radius_um, no_z=self.im_info.no_z)
+
+    def _get_pipeline(self, shape3) -> FramePipeline:
+        if self._pipeline is None or self._pipeline.shape != tuple(shape3):
+            if self._pipeline is not None:
+                self._pipeline.close()
+            self._pipeline = FramePipeline(shape3, device=self.device_index)
+        return self._pipeline
+
+    def close(self):
+        if self._pipeline is not None:
+            self._pipeline.close()
+            self._pipeline = None
+
+    def _get_t(self):
+        if self.num_t is None:
+            if self.im_info.no_t:
+                self.num_t = 1
+            else:
+                self.num_t = self.im_info.shape[self.im_info.axes.index('T')]
+
+    def _allocate_memory(self):
+        """labelling.py:337-353."""
+        logger.debug('Allocating memory for semantic segmentation.')
+        self.im_memmap = self.im_info.get_memmap(self.im_info.im_path)
+        self.frangi_memmap = self.im_info.get_memmap(self.im_info.pipeline_paths['im_preprocessed'])
+        self.shape = self.frangi_memmap.shape
+        self.instance_label_memmap = self.im_info.allocate_memory(
+            self.im_info.pipeline_paths['im_instance_label'], dtype='int32',
+            description='instance segmentation', return_memmap=True)
+
+    def _get_frame_views(self, t):
+        return self.im_memmap[t, ...], self.frangi_memmap[t, ...]
+
+    def _write_labels_for_frame(self, t, labels):
+        self.instance_label_memmap[t, ...] = labels
+
+    # ------------------------------------------------------------------ thresholds (host views)
+    def _sample_nonzero(self, frame, mask=None, mask_frame=None, mask_thresh=None):
+        """labelling.py:385-438, verbatim semantics on host (memmap) views."""
+        flat = frame.reshape(-1)
+        if flat.size == 0:
+            return flat
+        mask_flat = None
+        mask_mode = None
+        if mask is not None:
+            mask_flat = mask.reshape(-1)
+            mask_mode = "bool"
+        elif mask_frame is not None and mask_thresh is not None:
+            mask_flat = mask_frame.reshape(-1)
+            mask_mode = "thresh"
+        max_samples = max(1, int(self.threshold_sampling_pixels))
+        step = max(int(flat.size) // max_samples, 1)
+        offsets = (0, step // 2) if step > 1 and step // 2 > 0 else (0,)
+        values = flat[:0]
+        for offset in offsets:
+            sample = flat[offset::step]
+            if mask_mode == "bool":
+                values = sample[(sample > 0) & mask_flat[offset::step]]
+            elif mask_mode == "thresh":
+                values = sample[(sample > 0) & (mask_flat[offset::step] > mask_thresh)]
+            else:
+                values = sample[sample > 0]
+            if values.size > 0 or step == 1:
+                return values
+        max_val = float(flat.max())
+        if max_val <= 0:
+            return values
+        if mask_mode == "bool":
+            return flat[(flat > 0) & mask_flat]
+        if mask_mode == "thresh":
+            return flat[(flat > 0) & (mask_flat > mask_thresh)]
+        return flat[flat > 0]
+
+    def _compute_frangi_threshold(self, frame, mask_frame=None, mask_thresh=None):
+        """labelling.py:440-455."""
+        values = self._sample_nonzero(frame, mask_frame=mask_frame, mask_thresh=mask_thresh)
+        if values.size == 0:
+            return None
+        return log10_min_triangle_otsu(np.asarray(values), self.histogram_nbins)
+
+    def _compute_intensity_otsu_threshold(self, frame):
+        """labelling.py:457-465."""
+        values = self._sample_nonzero(frame)
+        if values.size == 0:
+            return None
+        thresh, _ = otsu_threshold(np.asarray(values), nbins=self.histogram_nbins)
+        return thresh
+
+    def _compute_frame_thresholds(self, original_view, frangi_view):
+        """labelling.py:511-532."""
+        intensity_thresh = None
+        if self.otsu_thresh_intensity:
+            intensity_thresh = self._compute_intensity_otsu_threshold(original_view)
+            if intensity_thresh is None:
+                intensity_thresh = 0
+        elif self.threshold is not None:
+            intensity_thresh = self.threshold
+        if intensity_thresh is not None:
+            frangi_thresh = self._compute_frangi_threshold(
+                frangi_view, mask_frame=original_view, mask_thresh=intensity_thresh)
+        else:
+            frangi_thresh = self._compute_frangi_threshold(frangi_view)
+        return intensity_thresh, frangi_thresh
+
+    # ------------------------------------------------------------------ frames
+    @staticmethod
+    def _as3d(a):
+        a = np.asarray(a)
+        return a[None, ...] if a.ndim == 2 else a
+
+    @staticmethod
+    def _effective_threshold(original: np.ndarray, thresh) -> float:
+        """The value `original > thresh` really compares against under numpy's promotion rules:
+        python scalars are weak (cast to the array's float dtype); numpy scalars promote with the array."""
+        if isinstance(thresh, (np.generic, np.ndarray)):
+            common = np.result_type(original.dtype, np.asarray(thresh).dtype)
+            return float(np.asarray(thresh).astype(common))
+        if original.dtype.kind == "f":
+            return float(original.dtype.type(thresh))
+        return float(thresh)
+
+    def _run_frame_full_volume(self, t, original_view, frangi_view, intensity_thresh, frangi_thresh):
+        """labelling.py:538-556: int32 labels of frame t (inputs are never modified)."""
+        logger.info(f'Running semantic segmentation, volume {t}/{(self.num_t or 1) - 1}')
+        frangi3 = self._as3d(frangi_view)
+        pipe = self._get_pipeline(frangi3.shape)
+        pipe.upload_frangi(frangi3)
+        if intensity_thresh is not None:
+            orig3 = self._as3d(original_view)
+            pipe.ctx.label_intensity_mask(orig3, self._effective_threshold(orig3, intensity_thresh))
+        pipe.label(frangi_thresh, self.min_area_pixels, fill_holes=not self.im_info.no_z)
+        labels = pipe.download_labels()
+        return labels[0] if np.asarray(frangi_view).ndim == 2 else labels
+
+    def _get_labels(self, frame, frangi_thresh=_UNSET):
+        """labelling.py:467-509: (mask, labels) for a host Frangi frame."""
+        if frangi_thresh is _UNSET:
+            frangi_thresh = self._compute_frangi_threshold(frame)
+        labels = self._run_frame_full_volume(0, None, frame, None, frangi_thresh)
+        return labels > 0, labels
+
+    def _run_segmentation(self):
+        """labelling.py:697-734."""
+        for t in range(self.num_t):
+            if self.viewer is not None:
+                self.viewer.status = f'Extracting organelles. Frame: {t + 1} of {self.num_t}.'
+            original_view, frangi_view = self._get_frame_views(t)
+            intensity_thresh, frangi_thresh = self._compute_frame_thresholds(original_view, frangi_view)
+            labels = self._run_frame_full_volume(t, original_view, frangi_view, intensity_thresh, frangi_thresh)
+            self._write_labels_for_frame(t, labels)
+            if (t + 1) % self.flush_interval == 0:
+                self.instance_label_memmap.flush()
+        self.instance_label_memmap.flush()
+
+    def run(self):
+        """labelling.py:736-778."""
+        logger.info('Running semantic segmentation.')
+        adaptive_run.normalize_device(self.device)
+        try:
+            self._get_t()
+            self._allocate_memory()
+            self._run_segmentation()
+        finally:
+            self.close()
