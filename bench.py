@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""
+bench.py -- Mvoxel/s of Nellie's segmentation hot path (5-scale Frangi Filter + Label) on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--shape Z Y X] [--no-cpu-baseline]
+
+One "step" = one pass of the whole hot path (float32 conversion, 5-scale Gaussian cascade,
+Hessian, eigenvalues, Frangi, scale-max, masks, percentile mask + opening, Label thresholds,
+hole filling, two 26-connected labellings, area filter, majority filter, raster renumbering)
+over one synthetic float32 frame that is ALREADY RESIDENT IN HBM when the timed region starts;
+outputs stay in HBM (the PCIe-inclusive rate is a separate, untimed-by-default figure, see
+DESIGN.md).  N = 1: BASELINE.json configs[2], 1024 x 1024 x 1024 float32 (headline).
+N > 1: the volume is (N*1024, 1024, 1024), sharded over Z, one rank per GPU (weak scaling).
+
+Prints ONE JSON line (rank 0) with the driver's contract plus `roofline` and `cpu_baseline`.
+The oracle is used here only for the `cpu_baseline` leg and the small accuracy check.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); 6290 GB/s measured copy
+B_ALG_TOTAL = 301.0            # Filter 257 + Label 44 bytes/voxel
+# algorithmic bytes per voxel of one launch of each kernel group (DESIGN.md "Kernels")
+B_ALG_KERNEL = {
+    "load": 8.0,               # 4 r + 4 w
+    "gauss": 24.0,             # three axis passes x (4 r + 4 w)
+    "hessian_stats": 4.0,      # 4 r
+    "vesselness": 14.0,        # gauss 4 r + vesselness 4 r + 4 w + mask 1 r + 1 w
+    "finish": 9.0,             # 4 r + 1 r + 4 w
+    "mask_volume": 8.0,        # 4 r + 4 w (fused threshold + opening + multiply)
+    "label": 44.0,             # SURVEY.md 8(d) Label row
+}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--shape", type=int, nargs=3, default=None, help="per-GPU slab Z Y X (default 1024^3)")
+    ap.add_argument("--seed", type=int, default=2345)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-shape", type=int, nargs=3, default=[64, 256, 256])
+    ap.add_argument("--with-io", action="store_true", help="also report the PCIe-inclusive rate (untimed otherwise)")
+    return ap.parse_args()
+
+
+def cpu_baseline(shape, seed):
+    """The oracle (CPU restatement of the reference, kind 'port') timed on the host cores."""
+    from nellie_amd.synthetic import ISO_01, make_volume
+    from oracle import nellie_oracle as orc
+    orc.build_c_helper()
+    vol = make_volume(shape, seed)
+    t0 = time.perf_counter()
+    fr = orc.filter_frame(vol, ISO_01)
+    t1 = time.perf_counter()
+    lab = orc.label_frame(fr, ISO_01)
+    t2 = time.perf_counter()
+    n = float(np.prod(shape))
+    return {
+        "value": round(n / (t2 - t0) / 1e6, 4), "unit": "Mvoxel/s", "cores": 1, "kind": "port",
+        "sample": f"oracle Filter+Label on a synthetic {shape[0]}x{shape[1]}x{shape[2]} float32 volume "
+                  f"(same generator, seed {seed}); Filter {n / (t1 - t0) / 1e6:.3f} Mvoxel/s, "
+                  f"Label {n / (t2 - t1) / 1e6:.2f} Mvoxel/s, {float(np.mean(fr > 0)) * 100:.2f}% voxels survive, "
+                  f"{int(lab.max())} labels; numpy/scipy-free single thread of {os.cpu_count()} host cores",
+    }, (vol, fr, lab)
+
+
+def accuracy_check(pl, vol, ref_fr, ref_lab):
+    """Every timing run also runs the parity check on the CPU-baseline volume."""
+    from nellie_amd.synthetic import ISO_01
+    pipe = pl.FramePipeline(vol.shape)
+    pipe.filter(vol, pl.FilterParams(dim_res=ISO_01))
+    fr = pipe.download_frangi()
+    scale = float(ref_fr.max()) if ref_fr.size else 1.0
+    err = np.abs(fr.astype(np.float64) - ref_fr)
+    ok = bool(np.all(err <= 1e-4 * np.abs(ref_fr) + 1e-6 * scale))
+    pipe.upload_frangi(ref_fr)
+    pipe.label(pipe.frangi_threshold(), pl.min_area_pixels_of(ISO_01))
+    lab_ok = bool(np.array_equal(pipe.download_labels(), ref_lab))
+    pipe.close()
+    return {"frangi_within_tol": ok, "frangi_max_norm_err": float(err.max() / scale) if scale else 0.0,
+            "labels_bit_exact_given_same_frangi": lab_ok}
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    n_gpus = args.gpus
+    if world != n_gpus and world > 1:
+        n_gpus = world
+    dist = None
+    if world > 1:
+        import torch.distributed as dist   # rendezvous + barrier + max-over-ranks only (control plane)
+        dist.init_process_group(backend="gloo", init_method="env://")
+
+    from nellie_amd import hipnative
+    from nellie_amd import pipeline as pl
+    from nellie_amd.synthetic import ISO_01, make_volume
+
+    lib = hipnative.load()
+    if lib.device_count() <= local_rank:
+        raise RuntimeError(f"GPU backend requested but device {local_rank} is not visible")
+
+    shape = tuple(args.shape) if args.shape else (1024, 1024, 1024)
+    gshape = (shape[0] * n_gpus, shape[1], shape[2])
+    p = pl.FilterParams(dim_res=ISO_01)
+    min_area = pl.min_area_pixels_of(ISO_01)
+
+    t_gen = time.perf_counter()
+    vol = make_volume(shape, args.seed, z_offset=rank * shape[0], global_nz=gshape[0])
+    t_gen = time.perf_counter() - t_gen
+
+    if world > 1:
+        from nellie_amd.sharded import ShardedFramePipeline
+        pipe = ShardedFramePipeline(gshape, rank=rank, world=world, device=local_rank)
+    else:
+        pipe = pl.FramePipeline(shape, device=local_rank)
+    t_up = time.perf_counter()
+    pipe.load_input(vol)
+    t_up = time.perf_counter() - t_up
+
+    def step():
+        pipe.filter(None, p)
+        thr = pipe.frangi_threshold()
+        return pipe.label(thr, min_area)
+
+    def barrier():
+        pipe.ctx.sync()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    pipe.ctx.prof_reset()
+    pipe.ctx.prof_enable(True)
+    barrier()
+    t0 = time.perf_counter()
+    n_labels = 0
+    for _ in range(args.steps):
+        n_labels = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    pipe.ctx.prof_enable(False)
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-kernel-group HIP-event times over the timed region (this rank)
+    groups = {}
+    for name in ("load", "gauss", "sample", "hessian_stats", "vesselness", "finish", "mask_volume", "label"):
+        ms, k = pipe.ctx.prof_get(name)
+        if k:
+            groups[name] = {"ms_total": ms, "launches": k, "ms_avg": ms / k}
+    n_local = float(np.prod(shape))
+    n_global = float(np.prod(gshape))
+    kernel_ms_per_step = sum(g["ms_total"] for g in groups.values()) / max(1, args.steps)
+    dom = max((g for g in groups if g in B_ALG_KERNEL), key=lambda g: groups[g]["ms_total"])
+    dom_bytes = B_ALG_KERNEL[dom] * n_local
+    dom_gbs = dom_bytes / (groups[dom]["ms_avg"] * 1e-3) / 1e9
+    roofline = {
+        "bound": "hbm", "kernel": dom, "achieved": round(dom_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(dom_gbs / HBM_PEAK_GBS, 4), "traffic": None,
+        "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": round(groups[dom]["ms_avg"], 4),
+        "pipeline": {
+            "algorithmic_bytes_per_voxel": B_ALG_TOTAL,
+            "kernel_ms_per_step": round(kernel_ms_per_step, 3),
+            "achieved": round(B_ALG_TOTAL * n_local / (kernel_ms_per_step * 1e-3) / 1e9, 1) if kernel_ms_per_step else None,
+            "frac": round(B_ALG_TOTAL * n_local / (kernel_ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if kernel_ms_per_step else None,
+        },
+        "groups_ms_per_step": {k: round(v["ms_total"] / max(1, args.steps), 3) for k, v in groups.items()},
+    }
+
+    io = None
+    if args.with_io and world == 1:
+        pipe.ctx.sync()
+        t0 = time.perf_counter()
+        pipe.load_input(vol)
+        step()
+        fr = pipe.download_frangi()
+        lab = pipe.download_labels()
+        io = {"pcie_inclusive_mvoxel_s": round(n_local / (time.perf_counter() - t0) / 1e6, 1)}
+        del fr, lab
+
+    tr = pipe.trace
+    pipe.close()
+
+    cpu = None
+    acc = None
+    if rank == 0 and not args.no_cpu_baseline:
+        cpu, (cvol, cfr, clab) = cpu_baseline(tuple(args.cpu_shape), 1234)
+        acc = accuracy_check(pl, cvol, cfr, clab)
+
+    if rank == 0:
+        value = n_global * args.steps / elapsed / 1e6
+        out = {
+            "metric": "Mvoxel/s multiscale Frangi (5 sigma) + Label, float32", "value": round(value, 1),
+            "unit": "Mvoxel/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": f"synthetic {gshape[0]}x{gshape[1]}x{gshape[2]} float32 volume "
+                            f"(N(100,5) noise + Gaussian tubes, seed {args.seed}), 0.1 um isotropic, "
+                            f"{len(p.resolved_sigmas())}-scale Frangi + Label, full hot path per step"
+                            + ("" if n_gpus == 1 else f", Z-slab shard {shape[0]} planes/GPU"),
+                "voxels": int(n_global), "per_gpu_shape": list(shape),
+                "survival_fraction": round(tr.n_positive / n_local, 5), "labels": int(n_labels),
+                "host_gen_s": round(t_gen, 1), "h2d_s": round(t_up, 2),
+            },
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        if acc is not None:
+            out["accuracy"] = acc
+        if io is not None:
+            out["io"] = io
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

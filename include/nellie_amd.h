@@ -92,6 +92,14 @@ int64_t nl_ctx_bytes(int64_t nz_local, int64_t ny, int64_t nx);
 int nl_filter_load(nl_ctx *ctx, const void *host, int dtype, int64_t z0, int64_t z1,
                    char *err, size_t errlen);
 
+/* The same in two halves, so a caller can keep the raw frame resident in HBM and restart from
+   it without touching the host again (what the reference's cupy path gets from keeping `frame`
+   alive): nl_input_load = H2D of the raw planes (any dtype, extra device allocation of the
+   frame's own size); nl_filter_begin = float32 conversion + per-frame reset, asynchronous. */
+int nl_input_load(nl_ctx *ctx, const void *host, int dtype, int64_t z0, int64_t z1,
+                  char *err, size_t errlen);
+int nl_filter_begin(nl_ctx *ctx, char *err, size_t errlen);
+
 /* One cascade step: ndi.gaussian_filter(gauss, sigma=delta, output=gauss, mode="reflect",
    truncate=3.0) (filtering.py:827-835) = up to three correlate1d passes, axis order Z, Y, X,
    float64 accumulation in scipy's symmetric order, float32 store after each pass.

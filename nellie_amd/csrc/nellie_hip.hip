@@ -373,6 +373,187 @@ vesselness_kernel(const float *__restrict__ g, float *__restrict__ vmax, uint8_t
     if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(mask_count, cnt);
 }
 
+// -------------------------------------------------------------------------------------------------
+// v2: Z-marching, LDS-tiled Hessian kernel (MODE 0 = statistics, MODE 1 = vesselness update).
+// A 1024-thread workgroup owns a 16(y) x 64(x) column tile and walks a chunk of Z planes.  Each
+// plane tile (+-2 halo, indices clamped at the volume faces so the padding replicates the edge
+// voxels) is read from HBM once into a 6-slot LDS ring; the next plane is fetched into registers
+// while the current one is computed (one barrier per plane).  All 24 stencil taps come from LDS.
+// Edge rules: with replicated padding f(clamp(q-1)) is simply tile[q-1]; only the divisor
+// (float32(h) at a face, float32(2h) inside) and the outer difference sites need selects.
+// -------------------------------------------------------------------------------------------------
+#define HM_TX 64
+#define HM_TY 16
+#define HM_PW (HM_TX + 4)
+#define HM_PH (HM_TY + 4)
+#define HM_PLANE (HM_PW * HM_PH)
+#define HM_SLOTS 6
+#define HM_ZCHUNK 64
+
+template <int MODE>
+__global__ void __launch_bounds__(1024)
+hessian_march_kernel(const float *__restrict__ g, float *__restrict__ vmax, uint8_t *__restrict__ cmask,
+                     VolGeom v, HessP hp, VessP vp, i64 z0, i64 z1, int ntx, int nty,
+                     unsigned int *__restrict__ res, unsigned long long *__restrict__ mask_count) {
+    __shared__ float sp[HM_SLOTS][HM_PLANE];
+    __shared__ float s_red[3][16];
+    __shared__ unsigned long long s_cnt[16];
+    const int tid = threadIdx.x;
+    const int lx = tid & 63, ly = tid >> 6;
+    // XCD-aware remap: workgroup b runs on XCD b % 8; give each XCD a contiguous run of tiles so that
+    // neighbouring tiles (shared halos) meet in the same L2.  Speed only, never correctness.
+    const unsigned nblk = gridDim.x;
+    unsigned bid = blockIdx.x;
+    if ((nblk & 7u) == 0u) bid = (bid & 7u) * (nblk >> 3) + (bid >> 3);
+    const int tx = bid % ntx;
+    const int ty = (bid / ntx) % nty;
+    const int zc = bid / (ntx * nty);
+    const i64 zc0 = z0 + (i64)zc * HM_ZCHUNK;
+    const i64 zc1 = (zc0 + HM_ZCHUNK < z1) ? zc0 + HM_ZCHUNK : z1;
+    const i64 sz = v.ny * v.nx;
+    const i64 xbase = (i64)tx * HM_TX - 2, ybase = (i64)ty * HM_TY - 2;
+    const i64 x = xbase + 2 + lx, y = ybase + 2 + ly;
+    const bool valid = (x < v.nx) && (y < v.ny);
+
+    // the (up to) two tile elements this thread stages per plane
+    i64 off0, off1 = -1;
+    {
+        const int e0 = tid;
+        i64 yy = ybase + e0 / HM_PW, xx = xbase + e0 % HM_PW;
+        yy = yy < 0 ? 0 : (yy > v.ny - 1 ? v.ny - 1 : yy);
+        xx = xx < 0 ? 0 : (xx > v.nx - 1 ? v.nx - 1 : xx);
+        off0 = yy * v.nx + xx;
+        const int e1 = tid + 1024;
+        if (e1 < HM_PLANE) {
+            i64 y1 = ybase + e1 / HM_PW, x1 = xbase + e1 % HM_PW;
+            y1 = y1 < 0 ? 0 : (y1 > v.ny - 1 ? v.ny - 1 : y1);
+            x1 = x1 < 0 ? 0 : (x1 > v.nx - 1 ? v.nx - 1 : x1);
+            off1 = y1 * v.nx + x1;
+        }
+    }
+    // clamp a local plane index to the GLOBAL volume
+    auto zclamp = [&](i64 zz) -> i64 {
+        const i64 gg = v.gz0 + zz;
+        return gg < 0 ? -v.gz0 : (gg > v.gnz - 1 ? v.gnz - 1 - v.gz0 : zz);
+    };
+    auto slot_of = [&](i64 zq) -> int { return (int)(zq % HM_SLOTS); };
+
+    // prologue: planes clamp(zc0-2 .. zc0+2)
+    {
+        i64 last = -1;
+        for (int k = -2; k <= 2; ++k) {
+            const i64 zq = zclamp(zc0 + k);
+            if (zq == last) continue;
+            last = zq;
+            float *dst = sp[slot_of(zq)];
+            dst[tid] = g[zq * sz + off0];
+            if (off1 >= 0) dst[tid + 1024] = g[zq * sz + off1];
+        }
+    }
+    __syncthreads();
+
+    // per-lane in-plane geometry (constant along Z)
+    const bool y_lo = (y == 0), y_hi = (y == v.ny - 1), x_lo = (x == 0), x_hi = (x == v.nx - 1);
+    const int jc = ly + 2, ic = lx + 2;
+    const int jl = jc - (y_lo ? 0 : 1), jh = jc + (y_hi ? 0 : 1);
+    const int il = ic - (x_lo ? 0 : 1), ih = ic + (x_hi ? 0 : 1);
+    const float dy = (y_lo || y_hi) ? hp.hy : hp.hy2;
+    const float dx = (x_lo || x_hi) ? hp.hx : hp.hx2;
+    // divisor of the first derivative taken AT row j / column i of the tile
+    auto divy_at = [&](int j) -> float { const i64 yy = ybase + j; return (yy == 0 || yy == v.ny - 1) ? hp.hy : hp.hy2; };
+    auto divx_at = [&](int i) -> float { const i64 xx = xbase + i; return (xx == 0 || xx == v.nx - 1) ? hp.hx : hp.hx2; };
+    const float dy_jl = divy_at(jl), dy_jh = divy_at(jh), dy_jc = divy_at(jc);
+    const float dx_il = divx_at(il), dx_ih = divx_at(ih);
+
+    float mabs = 0.0f, mfrob = 0.0f;
+    int anyinf = 0;
+    unsigned long long cnt = 0;
+
+    for (i64 z = zc0; z < zc1; ++z) {
+        // fetch plane z+3 for the next step while this one computes
+        const i64 zn = zclamp(z + 3);
+        const bool fetch = (z + 1 < zc1) && (zn != zclamp(z + 2));
+        float r0 = 0.0f, r1 = 0.0f;
+        if (fetch) {
+            r0 = g[zn * sz + off0];
+            if (off1 >= 0) r1 = g[zn * sz + off1];
+        }
+        if (valid) {
+            const i64 gz = v.gz0 + z;
+            const bool z_lo = (gz == 0), z_hi = (gz == v.gnz - 1);
+            const float *PP[5];
+#pragma unroll
+            for (int k = -2; k <= 2; ++k) PP[k + 2] = sp[slot_of(zclamp(z + k))];
+            const float dz = (z_lo || z_hi) ? hp.hz : hp.hz2;
+            auto divz_at = [&](int k) -> float { const i64 gg = gz + k; return (gg == 0 || gg == v.gnz - 1) ? hp.hz : hp.hz2; };
+            // first derivative along Z at plane z+k (k in -1..1), tile position (j,i)
+            auto GZ = [&](int k, int j, int i) -> float {
+                return (PP[k + 3][j * HM_PW + i] - PP[k + 1][j * HM_PW + i]) / divz_at(k);
+            };
+            const float *P0 = PP[2];
+            auto GYd = [&](int j, int i, float d) -> float { return (P0[(j + 1) * HM_PW + i] - P0[(j - 1) * HM_PW + i]) / d; };
+            auto GXd = [&](int j, int i, float d) -> float { return (P0[j * HM_PW + i + 1] - P0[j * HM_PW + i - 1]) / d; };
+            const int kh = z_hi ? 0 : 1, kl = z_lo ? 0 : -1;
+            float h[6];
+            h[0] = (GZ(kh, jc, ic) - GZ(kl, jc, ic)) / dz;
+            h[1] = (GZ(0, jh, ic) - GZ(0, jl, ic)) / dy;
+            h[2] = (GZ(0, jc, ih) - GZ(0, jc, il)) / dx;
+            h[3] = (GYd(jh, ic, dy_jh) - GYd(jl, ic, dy_jl)) / dy;
+            h[4] = (GYd(jc, ih, dy_jc) - GYd(jc, il, dy_jc)) / dx;
+            h[5] = (GXd(jc, ih, dx_ih) - GXd(jc, il, dx_il)) / dx;
+            const float fsq = frob_sq_of(h);
+            if (MODE == 0) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) mabs = fmaxf(mabs, fabsf(h[k]));
+                if (isinf(fsq)) anyinf = 1; else mfrob = fmaxf(mfrob, fsq);
+            } else {
+                const i64 c = z * sz + y * v.nx + x;
+                const float fr = frob_norm(fsq, vp.max_abs, vp.max_finite);
+                const bool m = vp.use_thr ? (fr > vp.thr) : (fr > 0.0f);
+                if (m) {
+                    float l1, l2, l3;
+                    eig3_sorted_abs(h, l1, l2, l3);
+                    const float val = frangi3(l1, l2, l3, vp.alpha_sq, vp.beta_sq, vp.gamma_sq);
+                    if (val > vmax[c]) vmax[c] = val;
+                    cnt++;
+                } else {
+                    cmask[c] = 0;
+                }
+            }
+        }
+        if (fetch) {
+            float *dst = sp[slot_of(zn)];
+            dst[tid] = r0;
+            if (off1 >= 0) dst[tid + 1024] = r1;
+        }
+        __syncthreads();
+    }
+
+    // one set of atomics per workgroup
+    const int w = tid >> 6;
+    if (MODE == 0) {
+        mabs = wave_max_f(mabs); mfrob = wave_max_f(mfrob); anyinf = wave_or_i(anyinf);
+        if ((tid & 63) == 0) { s_red[0][w] = mabs; s_red[1][w] = mfrob; s_red[2][w] = anyinf ? 1.0f : 0.0f; }
+        __syncthreads();
+        if (tid == 0) {
+            float a = 0.0f, b = 0.0f, c = 0.0f;
+            for (int k = 0; k < 16; ++k) { a = fmaxf(a, s_red[0][k]); b = fmaxf(b, s_red[1][k]); c = fmaxf(c, s_red[2][k]); }
+            if (a > 0.0f && __float_as_uint(a) > __hip_atomic_load(&res[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&res[0], __float_as_uint(a));
+            if (b > 0.0f && __float_as_uint(b) > __hip_atomic_load(&res[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&res[1], __float_as_uint(b));
+            if (c > 0.0f) atomicOr(&res[2], 1u);
+        }
+    } else {
+        cnt = wave_sum_u64(cnt);
+        if ((tid & 63) == 0) s_cnt[w] = cnt;
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long t = 0;
+            for (int k = 0; k < 16; ++k) t += s_cnt[k];
+            if (t) atomicAdd(mask_count, t);
+        }
+    }
+}
+
 // vesselness * masks (filtering.py:926); counts voxels > 0 on the owned planes
 __global__ void __launch_bounds__(256)
 finish_kernel(float *__restrict__ vmax, const uint8_t *__restrict__ cmask, i64 begin, i64 end,
@@ -766,6 +947,7 @@ extern "C" int nl_ctx_destroy(nl_ctx *c) {
     for (int k = 0; k < 4; ++k) if (c->f[k]) hipFree(c->f[k]);
     for (int k = 0; k < 3; ++k) if (c->m[k]) hipFree(c->m[k]);
     if (c->d_small) hipFree(c->d_small);
+    if (c->d_input) hipFree(c->d_input);
     if (c->d_blk) hipFree(c->d_blk);
     if (c->h_small) hipHostFree(c->h_small);
     if (c->t0) hipEventDestroy(c->t0);
@@ -880,6 +1062,46 @@ extern "C" int nl_filter_load(nl_ctx *c, const void *host, int dtype, int64_t z0
     NL_HIP(hipMemsetAsync(c->f[c->i_vmax], 0, (size_t)c->n * 4, c->stream));
     NL_HIP(hipMemsetAsync(c->m[0], 1, (size_t)c->n, c->stream));
     NL_HIP(hipStreamSynchronize(c->stream));
+    return NL_OK;
+}
+
+// Keep the raw frame resident in HBM (any dtype) so that a timed region can start from device memory.
+extern "C" int nl_input_load(nl_ctx *c, const void *host, int dtype, int64_t z0, int64_t z1, char *err, size_t errlen) {
+    NL_ENTER(c);
+    const size_t es = dtype_size(dtype);
+    if (!es) return nl_fail(err, errlen, NL_EINVAL, "unsupported dtype code %d", dtype);
+    if (!host || z0 < 0 || z1 > c->nzl || z0 >= z1) return nl_fail(err, errlen, NL_EINVAL, "bad plane range [%lld,%lld)", (i64)z0, (i64)z1);
+    if (c->d_input && c->input_dtype != dtype) { hipFree(c->d_input); c->d_input = nullptr; }
+    if (!c->d_input) NL_HIP(hipMalloc(&c->d_input, (size_t)c->n * es));
+    c->input_dtype = dtype;
+    const i64 plane = c->ny * c->nx;
+    NL_HIP(hipMemcpyAsync((char *)c->d_input + (size_t)z0 * plane * es, host, (size_t)(z1 - z0) * plane * es, hipMemcpyHostToDevice, c->stream));
+    NL_HIP(hipStreamSynchronize(c->stream));
+    return NL_OK;
+}
+
+// frame = xp.asarray(resident input, dtype=float32); vesselness = 0; masks = 1.  Asynchronous.
+extern "C" int nl_filter_begin(nl_ctx *c, char *err, size_t errlen) {
+    NL_ENTER(c);
+    if (!c->d_input) return nl_fail(err, errlen, NL_ESTATE, "nl_filter_begin before nl_input_load");
+    c->i_gauss = 0; c->i_vmax = 3; c->i_labels = -1; c->frangi_ready = 0;
+    ProfScope ps(c, "load");
+    const unsigned int g = grid1d(c->n);
+    switch (c->input_dtype) {
+        case NL_U8: convert_kernel<uint8_t><<<g, 256, 0, c->stream>>>((const uint8_t *)c->d_input, c->f[0], c->n); break;
+        case NL_I8: convert_kernel<int8_t><<<g, 256, 0, c->stream>>>((const int8_t *)c->d_input, c->f[0], c->n); break;
+        case NL_U16: convert_kernel<uint16_t><<<g, 256, 0, c->stream>>>((const uint16_t *)c->d_input, c->f[0], c->n); break;
+        case NL_I16: convert_kernel<int16_t><<<g, 256, 0, c->stream>>>((const int16_t *)c->d_input, c->f[0], c->n); break;
+        case NL_U32: convert_kernel<uint32_t><<<g, 256, 0, c->stream>>>((const uint32_t *)c->d_input, c->f[0], c->n); break;
+        case NL_I32: convert_kernel<int32_t><<<g, 256, 0, c->stream>>>((const int32_t *)c->d_input, c->f[0], c->n); break;
+        case NL_F32: convert_kernel<float><<<g, 256, 0, c->stream>>>((const float *)c->d_input, c->f[0], c->n); break;
+        case NL_F64: convert_kernel<double><<<g, 256, 0, c->stream>>>((const double *)c->d_input, c->f[0], c->n); break;
+        case NL_U64: convert_kernel<uint64_t><<<g, 256, 0, c->stream>>>((const uint64_t *)c->d_input, c->f[0], c->n); break;
+        case NL_I64: convert_kernel<int64_t><<<g, 256, 0, c->stream>>>((const int64_t *)c->d_input, c->f[0], c->n); break;
+    }
+    NL_CHECK_LAUNCH();
+    NL_HIP(hipMemsetAsync(c->f[c->i_vmax], 0, (size_t)c->n * 4, c->stream));
+    NL_HIP(hipMemsetAsync(c->m[0], 1, (size_t)c->n, c->stream));
     return NL_OK;
 }
 
@@ -1044,8 +1266,11 @@ extern "C" int nl_hessian_stats(nl_ctx *c, const double spacing[3], float *max_a
     NL_HIP(hipMemsetAsync(res, 0, 16, c->stream));
     {
         ProfScope ps(c, "hessian_stats");
-        const dim3 grid((unsigned)((c->nx + 255) / 256), (unsigned)c->ny, (unsigned)(c->own_hi - c->own_lo));
-        hessian_stats_kernel<<<grid, 256, 0, c->stream>>>(c->f[c->i_gauss], geom(c), hessp(c), c->own_lo, c->own_hi, res);
+        const int ntx = (int)((c->nx + HM_TX - 1) / HM_TX), nty = (int)((c->ny + HM_TY - 1) / HM_TY);
+        const int nzc = (int)((c->own_hi - c->own_lo + HM_ZCHUNK - 1) / HM_ZCHUNK);
+        VessP vp{};
+        hessian_march_kernel<0><<<(unsigned)(ntx * nty * nzc), 1024, 0, c->stream>>>(
+            c->f[c->i_gauss], nullptr, nullptr, geom(c), hessp(c), vp, c->own_lo, c->own_hi, ntx, nty, res, nullptr);
         NL_CHECK_LAUNCH();
     }
     unsigned int *h = (unsigned int *)c->h_small;
@@ -1072,9 +1297,10 @@ extern "C" int nl_vesselness_step(nl_ctx *c, float gamma_sq, float alpha_sq, flo
     VessP vp{gamma_sq, alpha_sq, beta_sq, use_thr, thr, c->frob_max_abs, c->frob_max_finite};
     {
         ProfScope ps(c, "vesselness");
-        const dim3 grid((unsigned)((c->nx + 255) / 256), (unsigned)c->ny, (unsigned)(c->own_hi - c->own_lo));
-        vesselness_kernel<<<grid, 256, 0, c->stream>>>(c->f[c->i_gauss], c->f[c->i_vmax], c->m[0], geom(c), hessp(c), vp,
-                                                       c->own_lo, c->own_hi, d_cnt);
+        const int ntx = (int)((c->nx + HM_TX - 1) / HM_TX), nty = (int)((c->ny + HM_TY - 1) / HM_TY);
+        const int nzc = (int)((c->own_hi - c->own_lo + HM_ZCHUNK - 1) / HM_ZCHUNK);
+        hessian_march_kernel<1><<<(unsigned)(ntx * nty * nzc), 1024, 0, c->stream>>>(
+            c->f[c->i_gauss], c->f[c->i_vmax], c->m[0], geom(c), hessp(c), vp, c->own_lo, c->own_hi, ntx, nty, nullptr, d_cnt);
         NL_CHECK_LAUNCH();
     }
     if (mask_count) {

@@ -30,6 +30,8 @@ struct nl_ctx {
     int i_labels = -1;      // f[] index holding the int32 labels after nl_label_run
     // m[0] = cumulative mask during Filter
 
+    void *d_input = nullptr;   // optional resident raw frame (nl_input_load)
+    int input_dtype = -1;
     void *d_small = nullptr;   // scratch for reductions / histograms / weights (64 KiB)
     void *h_small = nullptr;   // pinned mirror
     void *d_blk = nullptr;     // per-block partials for scans

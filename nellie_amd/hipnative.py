@@ -39,6 +39,8 @@ _PROTOS = {
     "nl_ctx_create": [C.POINTER(_p), _int, _i64, _i64, _i64, _i64, _i64, _i64, _i64],
     "nl_sync": [_p],
     "nl_filter_load": [_p, _p, _int, _i64, _i64],
+    "nl_input_load": [_p, _p, _int, _i64, _i64],
+    "nl_filter_begin": [_p],
     "nl_gauss_step": [_p, _p, _int, _p, _int, _p, _int, _i64, _i64],
     "nl_sample_gather": [_p, _int, _i64, _i64, _i64, _p, _i64, C.POINTER(_i64)],
     "nl_sample_minmax": [_p, _int, _i64, _i64, _i64, C.POINTER(_f32), C.POINTER(_f32), C.POINTER(_i64)],
@@ -199,6 +201,17 @@ class Context:
             a = a.astype(np.float32)
         assert a.shape == (z1 - z0, self.shape[1], self.shape[2]), (a.shape, self.shape, z0, z1)
         self._call("nl_filter_load", _ptr(a), DTYPE_CODES[a.dtype], z0, z1)
+
+    def input_load(self, frame: np.ndarray, z0=0, z1=None):
+        z1 = self.shape[0] if z1 is None else z1
+        a = np.ascontiguousarray(frame)
+        if a.dtype not in DTYPE_CODES:
+            a = a.astype(np.float32)
+        assert a.shape == (z1 - z0, self.shape[1], self.shape[2]), (a.shape, self.shape, z0, z1)
+        self._call("nl_input_load", _ptr(a), DTYPE_CODES[a.dtype], z0, z1)
+
+    def filter_begin(self):
+        self._call("nl_filter_begin")
 
     def gauss_step(self, wz, wy, wx, z0=0, z1=None):
         z1 = self.shape[0] if z1 is None else z1

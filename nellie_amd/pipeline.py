@@ -178,6 +178,10 @@ class FramePipeline:
         self.ctx.close()
 
     # ------------------------------------------------------------------ Filter
+    def load_input(self, frame):
+        """Keep the raw frame resident in HBM; `filter(None, ...)` then starts from device memory."""
+        self.ctx.input_load(np.asarray(frame))
+
     def _threshold_from_field(self, fld, strides):
         """min(triangle, otsu) over the positive lattice samples of a device field, or None if none."""
         mn, mx, npos = self.ctx.sample_minmax(fld, strides)
@@ -194,7 +198,10 @@ class FramePipeline:
         if max_samples <= 0:
             raise ValueError("max_threshold_samples must be a positive integer")
         self.trace = FrameTrace()
-        ctx.filter_load(np.asarray(frame))
+        if frame is None:
+            ctx.filter_begin()          # restart from the frame kept resident by load_input()
+        else:
+            ctx.filter_load(np.asarray(frame))
         zr = z_ratio_of(p.dim_res)
         spacing = spacing_of(p.dim_res)
         sigmas = p.resolved_sigmas()

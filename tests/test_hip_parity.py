@@ -29,6 +29,30 @@ def assert_frangi_close(got, ref, what=""):
     assert np.array_equal(got > 0, ref > 0), f"{what}: support differs"
 
 
+def assert_masked_close(got, ref, run_frame_ref, thr_ref, what="frangi"):
+    """
+    After _mask_volume (filtering.py:964-966) the frame went through `> percentile` and a binary
+    opening.  A voxel whose value sits within the Frangi tolerance of the threshold may legitimately
+    fall on either side, and the opening carries that decision to voxels within L1 distance 2.
+    Everywhere else the usual bar applies (tolerance on values, identical support).
+    """
+    thr = np.float32(thr_ref)
+    border = np.abs(run_frame_ref - thr) <= (2 * RTOL * abs(float(thr)) + ATOL_REL * float(run_frame_ref.max()))
+    zone = border.copy()
+    for _ in range(2):
+        zone = orc.binary_dilation6(zone)
+    if not border.any():
+        assert_frangi_close(got, ref, what)
+        return
+    keep = ~zone
+    g2, r2 = np.where(keep, got, 0).astype(np.float32), np.where(keep, ref, 0).astype(np.float32)
+    assert_frangi_close(g2, r2, what + " (outside the threshold-tie zone)")
+    # inside the zone a voxel is either the reference value, or zero, or the unmasked value
+    inside = zone & (got != ref)
+    ok = (got[inside] == 0) | (np.abs(got[inside] - run_frame_ref[inside]) <= RTOL * np.abs(run_frame_ref[inside]) + ATOL_REL * run_frame_ref.max())
+    assert ok.all(), f"{what}: unexplained values inside the threshold-tie zone"
+
+
 def _params(g):
     from nellie_amd.pipeline import FilterParams
     kw = dict(g["kwargs"])
@@ -77,7 +101,9 @@ def test_filter_golden(name, pipes):
         thr = pipe.mask_volume(p)
         # the percentile interpolates two order statistics of the (tolerance-equal) Frangi samples
         assert abs(float(thr) - float(g["percentile_thr"])) <= 2e-4 * float(g["percentile_thr"]) + 1e-12
-    assert_frangi_close(pipe.download_frangi(), g["frangi"], "frangi")
+        assert_masked_close(pipe.download_frangi(), g["frangi"], g["run_frame"], g["percentile_thr"])
+    else:
+        assert_frangi_close(pipe.download_frangi(), g["frangi"], "frangi")
 
 
 @pytest.mark.parametrize("name", [n for n in FILTER_CASES if n.startswith(("iso", "aniso", "odd", "u16"))])
