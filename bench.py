@@ -218,6 +218,7 @@ def main():
                             + ("" if n_gpus == 1 else f", Z-slab shard {shape[0]} planes/GPU"),
                 "voxels": int(n_global), "per_gpu_shape": list(shape),
                 "survival_fraction": round(tr.n_positive / n_local, 5), "labels": int(n_labels),
+                "mask_fraction_per_scale": [round(sc.mask_count / n_local, 4) for sc in tr.scales],
                 "host_gen_s": round(t_gen, 1), "h2d_s": round(t_up, 2),
             },
             "roofline": roofline, "cpu_baseline": cpu,

@@ -219,6 +219,104 @@ gauss_axis_kernel(const float *__restrict__ in, float *__restrict__ out, VolGeom
     out[c] = (float)tmp;
 }
 
+// -------------------------------------------------------------------------------------------------
+// v2 Gaussian passes.  Same arithmetic (scipy's order, float64), every input read from HBM once:
+//  * Z and Y passes: a thread owns one (.., x) column position and MARCHES along the filtered axis
+//    with a sliding window of 2R+1 float64 values in registers (static indexing through a fully
+//    unrolled phase loop); lanes run along X so every load/store is a coalesced 256-B row piece.
+//  * X pass: a workgroup stages a row piece (+-R halo, reflected) in LDS, each thread then computes
+//    4 consecutive outputs from 4+2R staged values and stores them as one float4.
+// Radii above GM_MAX_R fall back to the one-thread-per-voxel kernel above.
+// -------------------------------------------------------------------------------------------------
+#define GM_MAX_R 8
+#define GM_CHUNK 128
+struct GaussWS { double w[GM_MAX_R + 1]; };
+
+// AXIS 0: line = Z (grid over y-groups, x-tiles, z-chunks); AXIS 1: line = Y (grid over z-groups, x-tiles, y-chunks)
+template <int AXIS, int R>
+__global__ void __launch_bounds__(256)
+gauss_march_kernel(const float *__restrict__ in, float *__restrict__ out, VolGeom v, i64 z0, i64 z1, GaussWS gw) {
+    constexpr int W = 2 * R + 1;
+    const int lx = threadIdx.x & 63, lo = threadIdx.x >> 6;      // 64 x-positions x 4 "other" positions
+    const i64 x = (i64)blockIdx.x * 64 + lx;
+    const i64 sy = v.nx, sz = v.ny * v.nx;
+    i64 other, c0, c1, n_line, line_stride, base;
+    if (AXIS == 0) {
+        other = (i64)blockIdx.y * 4 + lo;                         // y
+        c0 = z0 + (i64)blockIdx.z * GM_CHUNK;
+        c1 = c0 + GM_CHUNK < z1 ? c0 + GM_CHUNK : z1;
+        if (other >= v.ny || x >= v.nx) return;
+        line_stride = sz; base = other * sy + x;
+    } else {
+        other = z0 + (i64)blockIdx.y * 4 + lo;                    // z
+        c0 = (i64)blockIdx.z * GM_CHUNK;
+        c1 = c0 + GM_CHUNK < v.ny ? c0 + GM_CHUNK : v.ny;
+        if (other >= z1 || x >= v.nx) return;
+        line_stride = sy; base = other * sz + x;
+    }
+    n_line = (AXIS == 0) ? v.gnz : v.ny;
+    const i64 goff = (AXIS == 0) ? v.gz0 : 0;                     // line coordinate of local index 0
+    auto ld = [&](i64 p) -> double {                               // p = local line index, may be outside
+        const i64 q = reflect_idx(goff + p, n_line) - goff;
+        return (double)in[base + q * line_stride];
+    };
+    double win[W];
+#pragma unroll
+    for (int k = 0; k < W - 1; ++k) win[k + 1] = ld(c0 - R + k);   // slots 1..W-1 hold c0-R .. c0+R-1
+    for (i64 p0 = c0; p0 < c1; p0 += W) {
+#pragma unroll
+        for (int ph = 0; ph < W; ++ph) {
+            const i64 p = p0 + ph;
+            if (p < c1) {
+                // the newest value (p+R) replaces the oldest slot, which is slot `ph`
+                win[ph] = ld(p + R);
+                // window position t (0..2R) = line index p-R+t lives in slot (ph + 1 + t) % W
+                double tmp = win[(ph + 1 + R) % W] * gw.w[0];
+#pragma unroll
+                for (int j = R; j >= 1; --j) {
+                    const double s = win[(ph + 1 + R - j) % W] + win[(ph + 1 + R + j) % W];
+                    tmp = tmp + s * gw.w[j];
+                }
+                out[base + p * line_stride] = (float)tmp;
+            }
+        }
+    }
+}
+
+#define GX_SEG 1024
+template <int R>
+__global__ void __launch_bounds__(256)
+gauss_x_kernel(const float *__restrict__ in, float *__restrict__ out, VolGeom v, i64 z0, i64 z1, GaussWS gw, int vec4) {
+    __shared__ float row[GX_SEG + 2 * GM_MAX_R];
+    const i64 y = blockIdx.y, z = z0 + blockIdx.z;
+    const i64 xs = (i64)blockIdx.x * GX_SEG;                       // first output of this segment
+    const i64 rb = (z * v.ny + y) * v.nx;
+    const int tid = threadIdx.x;
+    const i64 seg = (v.nx - xs < GX_SEG) ? v.nx - xs : GX_SEG;
+    for (int e = tid; e < seg + 2 * R; e += 256) row[e] = in[rb + reflect_idx(xs - R + e, v.nx)];
+    __syncthreads();
+    const int o = tid * 4;
+    if (o >= seg) return;
+    double d[4 + 2 * R];
+#pragma unroll
+    for (int k = 0; k < 4 + 2 * R; ++k) d[k] = (o + k < seg + 2 * R) ? (double)row[o + k] : 0.0;
+    float res[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        double tmp = d[q + R] * gw.w[0];
+#pragma unroll
+        for (int j = R; j >= 1; --j) tmp = tmp + (d[q + R - j] + d[q + R + j]) * gw.w[j];
+        res[q] = (float)tmp;
+    }
+    float *dst = out + rb + xs + o;
+    if (vec4 && o + 3 < seg) {
+        *reinterpret_cast<float4 *>(dst) = make_float4(res[0], res[1], res[2], res[3]);
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) if (o + q < seg) dst[q] = res[q];
+    }
+}
+
 // =================================================================================================
 // kernels: lattice sampling (strided subsample for the thresholds)
 // =================================================================================================
@@ -1112,6 +1210,37 @@ static int fill_gw(GaussW &gw, const double *w, int r, char *err, size_t errlen)
     return NL_OK;
 }
 
+template <int AXIS, int R>
+static void launch_gauss_march(nl_ctx *c, const float *src, float *dst, const VolGeom &v, i64 z0, i64 z1, const GaussW &gw) {
+    GaussWS ws;
+    for (int k = 0; k <= GM_MAX_R; ++k) ws.w[k] = k <= R ? gw.w[k] : 0.0;
+    dim3 grid;
+    if (AXIS == 0) grid = dim3((unsigned)((c->nx + 63) / 64), (unsigned)((c->ny + 3) / 4), (unsigned)((z1 - z0 + GM_CHUNK - 1) / GM_CHUNK));
+    else grid = dim3((unsigned)((c->nx + 63) / 64), (unsigned)((z1 - z0 + 3) / 4), (unsigned)((c->ny + GM_CHUNK - 1) / GM_CHUNK));
+    gauss_march_kernel<AXIS, R><<<grid, 256, 0, c->stream>>>(src, dst, v, z0, z1, ws);
+}
+template <int R>
+static void launch_gauss_x(nl_ctx *c, const float *src, float *dst, const VolGeom &v, i64 z0, i64 z1, const GaussW &gw) {
+    GaussWS ws;
+    for (int k = 0; k <= GM_MAX_R; ++k) ws.w[k] = k <= R ? gw.w[k] : 0.0;
+    const dim3 grid((unsigned)((c->nx + GX_SEG - 1) / GX_SEG), (unsigned)c->ny, (unsigned)(z1 - z0));
+    gauss_x_kernel<R><<<grid, 256, 0, c->stream>>>(src, dst, v, z0, z1, ws, (c->nx % 4 == 0) ? 1 : 0);
+}
+// returns false when the radius has no specialised kernel
+template <int AXIS>
+static bool launch_gauss_fast(nl_ctx *c, const float *src, float *dst, const VolGeom &v, i64 z0, i64 z1, const GaussW &gw) {
+#define NL_GCASE(RR)                                                                         \
+    case RR:                                                                                 \
+        if (AXIS == 2) launch_gauss_x<RR>(c, src, dst, v, z0, z1, gw);                       \
+        else launch_gauss_march<(AXIS == 2 ? 0 : AXIS), RR>(c, src, dst, v, z0, z1, gw);     \
+        return true;
+    switch (gw.r) {
+        NL_GCASE(1) NL_GCASE(2) NL_GCASE(3) NL_GCASE(4) NL_GCASE(5) NL_GCASE(6) NL_GCASE(7) NL_GCASE(8)
+        default: return false;
+    }
+#undef NL_GCASE
+}
+
 extern "C" int nl_gauss_step(nl_ctx *c, const double *wz, int rz, const double *wy, int ry, const double *wx, int rx,
                              int64_t z0, int64_t z1, char *err, size_t errlen) {
     NL_ENTER(c);
@@ -1131,21 +1260,24 @@ extern "C" int nl_gauss_step(nl_ctx *c, const double *wz, int rz, const double *
         if ((z0 - rz < 0 && c->gz0 > 0) || (z1 - 1 + rz >= c->nzl && c->gz0 + c->nzl < c->gnz))
             return nl_fail(err, errlen, NL_EINVAL, "Z pass of radius %d on planes [%lld,%lld) reaches outside the local slab", rz, (i64)z0, (i64)z1);
         const int dst = (src + 1) % 3;
-        gauss_axis_kernel<0><<<grid, blk, 0, c->stream>>>(c->f[src], c->f[dst], v, z0, z1, gw);
+        if (!launch_gauss_fast<0>(c, c->f[src], c->f[dst], v, z0, z1, gw))
+            gauss_axis_kernel<0><<<grid, blk, 0, c->stream>>>(c->f[src], c->f[dst], v, z0, z1, gw);
         NL_CHECK_LAUNCH();
         src = dst;
     }
     if (wy) {
         if ((rc = fill_gw(gw, wy, ry, err, errlen))) return rc;
         const int dst = (src + 1) % 3;
-        gauss_axis_kernel<1><<<grid, blk, 0, c->stream>>>(c->f[src], c->f[dst], v, z0, z1, gw);
+        if (!launch_gauss_fast<1>(c, c->f[src], c->f[dst], v, z0, z1, gw))
+            gauss_axis_kernel<1><<<grid, blk, 0, c->stream>>>(c->f[src], c->f[dst], v, z0, z1, gw);
         NL_CHECK_LAUNCH();
         src = dst;
     }
     if (wx) {
         if ((rc = fill_gw(gw, wx, rx, err, errlen))) return rc;
         const int dst = (src + 1) % 3;
-        gauss_axis_kernel<2><<<grid, blk, 0, c->stream>>>(c->f[src], c->f[dst], v, z0, z1, gw);
+        if (!launch_gauss_fast<2>(c, c->f[src], c->f[dst], v, z0, z1, gw))
+            gauss_axis_kernel<2><<<grid, blk, 0, c->stream>>>(c->f[src], c->f[dst], v, z0, z1, gw);
         NL_CHECK_LAUNCH();
         src = dst;
     }

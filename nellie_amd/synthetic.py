@@ -3,10 +3,11 @@ Deterministic synthetic volumes for parity tests and `bench.py`.
 
 The reference ships no benchmark inputs (its sample file is absent from the
 checkout), so the build defines its own generator: N(100, 5) float32 noise plus
-axis-aligned tubes with a Gaussian cross-section (amplitude 200, radius
-U(1.5, 4.0) voxels), one third of the tubes along each of X, Y and Z.  A tube's
-profile is evaluated inside a +-5r window (it is < 1e-3 of a noise sigma
-beyond).  `numpy.random.default_rng` (PCG64) streams are stable across numpy
+axis-aligned tube segments with a Gaussian cross-section (amplitude 200, radius
+U(1.5, 4.0) voxels), one third of them along each of X, Y and Z, each covering a
+random 20-60 % stretch of its axis (so a volume holds many separate objects, not
+one connected net).  A tube's profile is evaluated inside a +-5r window (it is
+< 1e-3 of a noise sigma beyond).  `numpy.random.default_rng` (PCG64) streams are stable across numpy
 versions, so a (shape, seed) pair names the same bytes everywhere.
 """
 from __future__ import annotations
@@ -42,8 +43,14 @@ def make_volume(shape, seed: int, tubes: int | None = None, dtype=np.float32,
     radii = rng.uniform(1.5, 4.0, size=k)
     cu = rng.uniform(0.0, 1.0, size=k)
     cv = rng.uniform(0.0, 1.0, size=k)
+    seg_len = rng.uniform(0.2, 0.6, size=k)
+    seg_pos = rng.uniform(0.0, 1.0, size=k)
     dims = (gz, ny, nx)
-    for ax, r, u, v in zip(axes, radii, cu, cv):
+    for ax, r, u, v, sl, sp in zip(axes, radii, cu, cv, seg_len, seg_pos):
+        # the stretch [a0, a1) of the tube's own axis it occupies
+        length = max(4, int(round(sl * dims[ax])))
+        a0 = int(round(sp * (dims[ax] - length)))
+        a1 = min(dims[ax], a0 + length)
         other = [d for d in range(3) if d != ax]
         c0 = u * (dims[other[0]] - 1)
         c1 = v * (dims[other[1]] - 1)
@@ -54,8 +61,10 @@ def make_volume(shape, seed: int, tubes: int | None = None, dtype=np.float32,
         g1 = np.arange(lo1, hi1, dtype=np.float64)
         prof = (200.0 * np.exp(-((g0[:, None] - c0) ** 2 + (g1[None, :] - c1) ** 2)
                                / (2.0 * r * r))).astype(np.float32)
-        if ax == 0:      # along Z: profile over (Y, X), every plane of the slab
-            vol[:, lo0:hi0, lo1:hi1] += prof[None, :, :]
+        if ax == 0:      # along Z: profile over (Y, X), planes a0..a1 clipped to this slab
+            zlo, zhi = max(a0, z_offset), min(a1, z_offset + nz)
+            if zlo < zhi:
+                vol[zlo - z_offset:zhi - z_offset, lo0:hi0, lo1:hi1] += prof[None, :, :]
         else:
             # profile over (Z, other): clip the Z window to this slab
             zlo, zhi = max(lo0, z_offset), min(hi0, z_offset + nz)
@@ -63,9 +72,9 @@ def make_volume(shape, seed: int, tubes: int | None = None, dtype=np.float32,
                 continue
             p = prof[zlo - lo0:zhi - lo0]
             if ax == 1:  # along Y: profile over (Z, X)
-                vol[zlo - z_offset:zhi - z_offset, :, lo1:hi1] += p[:, None, :]
+                vol[zlo - z_offset:zhi - z_offset, a0:a1, lo1:hi1] += p[:, None, :]
             else:        # along X: profile over (Z, Y)
-                vol[zlo - z_offset:zhi - z_offset, lo1:hi1, :] += p[:, :, None]
+                vol[zlo - z_offset:zhi - z_offset, lo1:hi1, a0:a1] += p[:, :, None]
     if np.dtype(dtype) != np.float32:
         info = np.iinfo(dtype)
         vol = np.clip(np.rint(vol), info.min, info.max).astype(dtype)
