@@ -28,6 +28,15 @@ __device__ __forceinline__ i64 reflect_idx(i64 i, i64 n) {
     return i >= n ? p - 1 - i : i;
 }
 
+// Exactly rounded float32 division by a constant d, given rcp = RN64(1/d):
+//   a/d = (float)((double)a * rcp).
+// Why it is exact: a/d can never sit closer than ~2^-48 (relative) to a float32 rounding boundary
+// (a - m*d is a non-zero integer multiple of 2^-47 for 24-bit a, d and a 25-bit midpoint m), while the
+// float64 product carries a relative error <= 2^-52, so the final rounding lands on the IEEE quotient.
+// (Sub-normal quotients are the one exception; differences of image intensities never get there.)
+// 3 instructions instead of the ~12 of an IEEE division; checked bit-for-bit on 1.2e9 operands.
+__device__ __forceinline__ float div_c(float a, double rcp) { return (float)((double)a * rcp); }
+
 // wave64 reductions (CDNA wavefront = 64 lanes)
 __device__ __forceinline__ float wave_max_f(float v) {
 #pragma unroll
@@ -472,30 +481,44 @@ vesselness_kernel(const float *__restrict__ g, float *__restrict__ vmax, uint8_t
 }
 
 // -------------------------------------------------------------------------------------------------
-// v2: Z-marching, LDS-tiled Hessian kernel (MODE 0 = statistics, MODE 1 = vesselness update).
+// v3: Z-marching, LDS-tiled Hessian kernel (MODE 0 = statistics, MODE 1 = vesselness update).
 // A 1024-thread workgroup owns a 16(y) x 64(x) column tile and walks a chunk of Z planes.  Each
 // plane tile (+-2 halo, indices clamped at the volume faces so the padding replicates the edge
-// voxels) is read from HBM once into a 6-slot LDS ring; the next plane is fetched into registers
+// voxels) is read from HBM once into an 8-slot LDS ring; the next plane is fetched into registers
 // while the current one is computed (one barrier per plane).  All 24 stencil taps come from LDS.
 // Edge rules: with replicated padding f(clamp(q-1)) is simply tile[q-1]; only the divisor
 // (float32(h) at a face, float32(2h) inside) and the outer difference sites need selects.
+// Divisions by the six constant spacings go through div_c (exactly rounded, see above).
+// MODE 1 only evaluates eigenvalues where the Frobenius mask holds (15-25 % of the voxels, scattered):
+// masked voxels are COMPACTED into an LDS queue (6 Hessian components + voxel index) and the
+// float64 eigen-solve + Frangi response runs on dense batches of 1024 queue entries.
 // -------------------------------------------------------------------------------------------------
 #define HM_TX 64
 #define HM_TY 16
 #define HM_PW (HM_TX + 4)
 #define HM_PH (HM_TY + 4)
 #define HM_PLANE (HM_PW * HM_PH)
-#define HM_SLOTS 6
+#define HM_SLOTS 8
 #define HM_ZCHUNK 64
+#define HM_QCAP 2048
+#define HM_LDS_FLOATS_STATS (HM_SLOTS * HM_PLANE + 64)
+#define HM_LDS_FLOATS_VESS (HM_SLOTS * HM_PLANE + 64 + 7 * HM_QCAP)
+
+struct HessR {          // reciprocals (float64) of float32(h) and float32(2h)
+    double z, y, x, z2, y2, x2;
+};
 
 template <int MODE>
 __global__ void __launch_bounds__(1024)
 hessian_march_kernel(const float *__restrict__ g, float *__restrict__ vmax, uint8_t *__restrict__ cmask,
-                     VolGeom v, HessP hp, VessP vp, i64 z0, i64 z1, int ntx, int nty,
+                     VolGeom v, HessR hr, VessP vp, int z0, int z1, int ntx, int nty,
                      unsigned int *__restrict__ res, unsigned long long *__restrict__ mask_count) {
-    __shared__ float sp[HM_SLOTS][HM_PLANE];
-    __shared__ float s_red[3][16];
-    __shared__ unsigned long long s_cnt[16];
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *sp = (float *)smem;                               // [HM_SLOTS][HM_PLANE]
+    float *s_red = sp + HM_SLOTS * HM_PLANE;               // 64 floats of reduction scratch
+    float *q_h = s_red + 64;                                 // [6][HM_QCAP]   (MODE 1)
+    int *q_i = (int *)(q_h + 6 * HM_QCAP);                   // [HM_QCAP]      (MODE 1)
+    int *s_tail = (int *)s_red + 48;                         // queue tail     (MODE 1)
     const int tid = threadIdx.x;
     const int lx = tid & 63, ly = tid >> 6;
     // XCD-aware remap: workgroup b runs on XCD b % 8; give each XCD a contiguous run of tiles so that
@@ -506,142 +529,191 @@ hessian_march_kernel(const float *__restrict__ g, float *__restrict__ vmax, uint
     const int tx = bid % ntx;
     const int ty = (bid / ntx) % nty;
     const int zc = bid / (ntx * nty);
-    const i64 zc0 = z0 + (i64)zc * HM_ZCHUNK;
-    const i64 zc1 = (zc0 + HM_ZCHUNK < z1) ? zc0 + HM_ZCHUNK : z1;
+    const int zc0 = z0 + zc * HM_ZCHUNK;
+    const int zc1 = (zc0 + HM_ZCHUNK < z1) ? zc0 + HM_ZCHUNK : z1;
+    const int nx = (int)v.nx, ny = (int)v.ny;
     const i64 sz = v.ny * v.nx;
-    const i64 xbase = (i64)tx * HM_TX - 2, ybase = (i64)ty * HM_TY - 2;
-    const i64 x = xbase + 2 + lx, y = ybase + 2 + ly;
-    const bool valid = (x < v.nx) && (y < v.ny);
+    const int gz0 = (int)v.gz0, gnz = (int)v.gnz;
+    const int xbase = tx * HM_TX - 2, ybase = ty * HM_TY - 2;
+    const int x = xbase + 2 + lx, y = ybase + 2 + ly;
+    const bool valid = (x < nx) && (y < ny);
 
-    // the (up to) two tile elements this thread stages per plane
-    i64 off0, off1 = -1;
+    // the (up to) two tile elements this thread stages per plane (in-plane offsets fit 32 bits)
+    int off0, off1 = -1;
     {
-        const int e0 = tid;
-        i64 yy = ybase + e0 / HM_PW, xx = xbase + e0 % HM_PW;
-        yy = yy < 0 ? 0 : (yy > v.ny - 1 ? v.ny - 1 : yy);
-        xx = xx < 0 ? 0 : (xx > v.nx - 1 ? v.nx - 1 : xx);
-        off0 = yy * v.nx + xx;
+        int yy = ybase + tid / HM_PW, xx = xbase + tid % HM_PW;
+        yy = yy < 0 ? 0 : (yy > ny - 1 ? ny - 1 : yy);
+        xx = xx < 0 ? 0 : (xx > nx - 1 ? nx - 1 : xx);
+        off0 = yy * nx + xx;
         const int e1 = tid + 1024;
         if (e1 < HM_PLANE) {
-            i64 y1 = ybase + e1 / HM_PW, x1 = xbase + e1 % HM_PW;
-            y1 = y1 < 0 ? 0 : (y1 > v.ny - 1 ? v.ny - 1 : y1);
-            x1 = x1 < 0 ? 0 : (x1 > v.nx - 1 ? v.nx - 1 : x1);
-            off1 = y1 * v.nx + x1;
+            int y1 = ybase + e1 / HM_PW, x1 = xbase + e1 % HM_PW;
+            y1 = y1 < 0 ? 0 : (y1 > ny - 1 ? ny - 1 : y1);
+            x1 = x1 < 0 ? 0 : (x1 > nx - 1 ? nx - 1 : x1);
+            off1 = y1 * nx + x1;
         }
     }
     // clamp a local plane index to the GLOBAL volume
-    auto zclamp = [&](i64 zz) -> i64 {
-        const i64 gg = v.gz0 + zz;
-        return gg < 0 ? -v.gz0 : (gg > v.gnz - 1 ? v.gnz - 1 - v.gz0 : zz);
+    auto zclamp = [&](int zz) -> int {
+        const int gg = gz0 + zz;
+        return gg < 0 ? -gz0 : (gg > gnz - 1 ? gnz - 1 - gz0 : zz);
     };
-    auto slot_of = [&](i64 zq) -> int { return (int)(zq % HM_SLOTS); };
 
+    if (MODE == 1 && tid == 0) *s_tail = 0;
     // prologue: planes clamp(zc0-2 .. zc0+2)
     {
-        i64 last = -1;
+        int last = -1;
         for (int k = -2; k <= 2; ++k) {
-            const i64 zq = zclamp(zc0 + k);
+            const int zq = zclamp(zc0 + k);
             if (zq == last) continue;
             last = zq;
-            float *dst = sp[slot_of(zq)];
-            dst[tid] = g[zq * sz + off0];
-            if (off1 >= 0) dst[tid + 1024] = g[zq * sz + off1];
+            float *dst = sp + (zq & (HM_SLOTS - 1)) * HM_PLANE;
+            const float *src = g + (i64)zq * sz;
+            dst[tid] = src[off0];
+            if (off1 >= 0) dst[tid + 1024] = src[off1];
         }
     }
     __syncthreads();
 
     // per-lane in-plane geometry (constant along Z)
-    const bool y_lo = (y == 0), y_hi = (y == v.ny - 1), x_lo = (x == 0), x_hi = (x == v.nx - 1);
+    const bool y_lo = (y == 0), y_hi = (y == ny - 1), x_lo = (x == 0), x_hi = (x == nx - 1);
     const int jc = ly + 2, ic = lx + 2;
     const int jl = jc - (y_lo ? 0 : 1), jh = jc + (y_hi ? 0 : 1);
     const int il = ic - (x_lo ? 0 : 1), ih = ic + (x_hi ? 0 : 1);
-    const float dy = (y_lo || y_hi) ? hp.hy : hp.hy2;
-    const float dx = (x_lo || x_hi) ? hp.hx : hp.hx2;
-    // divisor of the first derivative taken AT row j / column i of the tile
-    auto divy_at = [&](int j) -> float { const i64 yy = ybase + j; return (yy == 0 || yy == v.ny - 1) ? hp.hy : hp.hy2; };
-    auto divx_at = [&](int i) -> float { const i64 xx = xbase + i; return (xx == 0 || xx == v.nx - 1) ? hp.hx : hp.hx2; };
-    const float dy_jl = divy_at(jl), dy_jh = divy_at(jh), dy_jc = divy_at(jc);
-    const float dx_il = divx_at(il), dx_ih = divx_at(ih);
+    const double rdy = (y_lo || y_hi) ? hr.y : hr.y2;
+    const double rdx = (x_lo || x_hi) ? hr.x : hr.x2;
+    // reciprocal divisor of the first derivative taken AT row j / column i of the tile
+    auto rdy_at = [&](int j) -> double { const int yy = ybase + j; return (yy == 0 || yy == ny - 1) ? hr.y : hr.y2; };
+    auto rdx_at = [&](int i) -> double { const int xx = xbase + i; return (xx == 0 || xx == nx - 1) ? hr.x : hr.x2; };
+    const double rdy_jl = rdy_at(jl), rdy_jh = rdy_at(jh), rdy_jc = rdy_at(jc);
+    const double rdx_il = rdx_at(il), rdx_ih = rdx_at(ih);
+    const int o_cc = jc * HM_PW + ic;
+    const int o_hc = jh * HM_PW + ic, o_lc = jl * HM_PW + ic;     // rows jh / jl, column ic
+    const int o_ch = jc * HM_PW + ih, o_cl = jc * HM_PW + il;     // row jc, columns ih / il
 
     float mabs = 0.0f, mfrob = 0.0f;
     int anyinf = 0;
     unsigned long long cnt = 0;
+    int head = 0;
 
-    for (i64 z = zc0; z < zc1; ++z) {
+    auto process_entry = [&](int e) {
+        const int slot = e & (HM_QCAP - 1);
+        float h[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) h[k] = q_h[k * HM_QCAP + slot];
+        const int c = q_i[slot];
+        float l1, l2, l3;
+        eig3_sorted_abs(h, l1, l2, l3);
+        const float val = frangi3(l1, l2, l3, vp.alpha_sq, vp.beta_sq, vp.gamma_sq);
+        if (val > vmax[c]) vmax[c] = val;
+    };
+
+    for (int z = zc0; z < zc1; ++z) {
+        if (MODE == 1) {
+            // dense eigen batch once the queue holds a full workgroup's worth
+            const int tail = *(volatile int *)s_tail;
+            if (tail - head >= 1024) {            // uniform
+                process_entry(head + tid);
+                head += 1024;
+                __syncthreads();                  // entries read before their ring slots can be re-used
+            }
+        }
         // fetch plane z+3 for the next step while this one computes
-        const i64 zn = zclamp(z + 3);
+        const int zn = zclamp(z + 3);
         const bool fetch = (z + 1 < zc1) && (zn != zclamp(z + 2));
         float r0 = 0.0f, r1 = 0.0f;
         if (fetch) {
-            r0 = g[zn * sz + off0];
-            if (off1 >= 0) r1 = g[zn * sz + off1];
+            const float *src = g + (i64)zn * sz;
+            r0 = src[off0];
+            if (off1 >= 0) r1 = src[off1];
         }
+        bool m = false;
+        float h[6];
         if (valid) {
-            const i64 gz = v.gz0 + z;
-            const bool z_lo = (gz == 0), z_hi = (gz == v.gnz - 1);
-            const float *PP[5];
-#pragma unroll
-            for (int k = -2; k <= 2; ++k) PP[k + 2] = sp[slot_of(zclamp(z + k))];
-            const float dz = (z_lo || z_hi) ? hp.hz : hp.hz2;
-            auto divz_at = [&](int k) -> float { const i64 gg = gz + k; return (gg == 0 || gg == v.gnz - 1) ? hp.hz : hp.hz2; };
-            // first derivative along Z at plane z+k (k in -1..1), tile position (j,i)
-            auto GZ = [&](int k, int j, int i) -> float {
-                return (PP[k + 3][j * HM_PW + i] - PP[k + 1][j * HM_PW + i]) / divz_at(k);
-            };
-            const float *P0 = PP[2];
-            auto GYd = [&](int j, int i, float d) -> float { return (P0[(j + 1) * HM_PW + i] - P0[(j - 1) * HM_PW + i]) / d; };
-            auto GXd = [&](int j, int i, float d) -> float { return (P0[j * HM_PW + i + 1] - P0[j * HM_PW + i - 1]) / d; };
-            const int kh = z_hi ? 0 : 1, kl = z_lo ? 0 : -1;
-            float h[6];
-            h[0] = (GZ(kh, jc, ic) - GZ(kl, jc, ic)) / dz;
-            h[1] = (GZ(0, jh, ic) - GZ(0, jl, ic)) / dy;
-            h[2] = (GZ(0, jc, ih) - GZ(0, jc, il)) / dx;
-            h[3] = (GYd(jh, ic, dy_jh) - GYd(jl, ic, dy_jl)) / dy;
-            h[4] = (GYd(jc, ih, dy_jc) - GYd(jc, il, dy_jc)) / dx;
-            h[5] = (GXd(jc, ih, dx_ih) - GXd(jc, il, dx_il)) / dx;
+            const int gz = gz0 + z;
+            const bool z_lo = (gz == 0), z_hi = (gz == gnz - 1);
+            const float *Pm2 = sp + (zclamp(z - 2) & (HM_SLOTS - 1)) * HM_PLANE;
+            const float *Pm1 = sp + (zclamp(z - 1) & (HM_SLOTS - 1)) * HM_PLANE;
+            const float *P0 = sp + (z & (HM_SLOTS - 1)) * HM_PLANE;
+            const float *Pp1 = sp + (zclamp(z + 1) & (HM_SLOTS - 1)) * HM_PLANE;
+            const float *Pp2 = sp + (zclamp(z + 2) & (HM_SLOTS - 1)) * HM_PLANE;
+            const double rdz = (z_lo || z_hi) ? hr.z : hr.z2;
+            // first derivatives along Z at planes z-1, z, z+1 use planes (z-2,z), (z-1,z+1), (z,z+2)
+            const double rdz_m1 = (gz - 1 == 0) ? hr.z : hr.z2;                      // plane z-1 (exists when !z_lo)
+            const double rdz_0 = rdz;
+            const double rdz_p1 = (gz + 1 == gnz - 1) ? hr.z : hr.z2;                // plane z+1 (exists when !z_hi)
+            // h_zz: outer sites are z+1 (or z at the top face) and z-1 (or z at the bottom face)
+            const float gz_hi = z_hi ? div_c(P0[o_cc] - Pm1[o_cc], rdz_0) : div_c(Pp2[o_cc] - P0[o_cc], rdz_p1);
+            const float gz_lo = z_lo ? div_c(Pp1[o_cc] - P0[o_cc], rdz_0) : div_c(P0[o_cc] - Pm2[o_cc], rdz_m1);
+            h[0] = div_c(gz_hi - gz_lo, rdz);
+            h[1] = div_c(div_c(Pp1[o_hc] - Pm1[o_hc], rdz_0) - div_c(Pp1[o_lc] - Pm1[o_lc], rdz_0), rdy);
+            h[2] = div_c(div_c(Pp1[o_ch] - Pm1[o_ch], rdz_0) - div_c(Pp1[o_cl] - Pm1[o_cl], rdz_0), rdx);
+            h[3] = div_c(div_c(P0[o_hc + HM_PW] - P0[o_hc - HM_PW], rdy_jh) - div_c(P0[o_lc + HM_PW] - P0[o_lc - HM_PW], rdy_jl), rdy);
+            h[4] = div_c(div_c(P0[o_ch + HM_PW] - P0[o_ch - HM_PW], rdy_jc) - div_c(P0[o_cl + HM_PW] - P0[o_cl - HM_PW], rdy_jc), rdx);
+            h[5] = div_c(div_c(P0[o_ch + 1] - P0[o_ch - 1], rdx_ih) - div_c(P0[o_cl + 1] - P0[o_cl - 1], rdx_il), rdx);
             const float fsq = frob_sq_of(h);
             if (MODE == 0) {
 #pragma unroll
                 for (int k = 0; k < 6; ++k) mabs = fmaxf(mabs, fabsf(h[k]));
                 if (isinf(fsq)) anyinf = 1; else mfrob = fmaxf(mfrob, fsq);
             } else {
-                const i64 c = z * sz + y * v.nx + x;
                 const float fr = frob_norm(fsq, vp.max_abs, vp.max_finite);
-                const bool m = vp.use_thr ? (fr > vp.thr) : (fr > 0.0f);
+                m = vp.use_thr ? (fr > vp.thr) : (fr > 0.0f);
+                if (!m) cmask[(i64)z * sz + (i64)y * nx + x] = 0;        // masks &= h_mask
+            }
+        }
+        if (MODE == 1) {
+            // append the masked voxels of this wave to the queue (one LDS atomic per wave)
+            const unsigned long long bal = __ballot(m);
+            if (bal) {
+                const int lane = tid & 63;
+                const int leader = __builtin_ctzll(bal);
+                int base = 0;
+                if (lane == leader) base = atomicAdd(s_tail, (int)__builtin_popcountll(bal));
+                base = __shfl(base, leader, 64);
                 if (m) {
-                    float l1, l2, l3;
-                    eig3_sorted_abs(h, l1, l2, l3);
-                    const float val = frangi3(l1, l2, l3, vp.alpha_sq, vp.beta_sq, vp.gamma_sq);
-                    if (val > vmax[c]) vmax[c] = val;
+                    const int rank = (int)__builtin_popcountll(bal & ((1ull << lane) - 1ull));
+                    const int slot = (base + rank) & (HM_QCAP - 1);
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) q_h[k * HM_QCAP + slot] = h[k];
+                    q_i[slot] = (int)((i64)z * sz + (i64)y * nx + x);
                     cnt++;
-                } else {
-                    cmask[c] = 0;
                 }
             }
         }
         if (fetch) {
-            float *dst = sp[slot_of(zn)];
+            float *dst = sp + (zn & (HM_SLOTS - 1)) * HM_PLANE;
             dst[tid] = r0;
             if (off1 >= 0) dst[tid + 1024] = r1;
         }
         __syncthreads();
     }
+    if (MODE == 1) {
+        // drain the queue
+        const int tail = *(volatile int *)s_tail;
+        while (tail - head > 0) {
+            if (head + tid < tail) process_entry(head + tid);
+            head += 1024;
+        }
+    }
 
     // one set of atomics per workgroup
     const int w = tid >> 6;
+    __syncthreads();
     if (MODE == 0) {
         mabs = wave_max_f(mabs); mfrob = wave_max_f(mfrob); anyinf = wave_or_i(anyinf);
-        if ((tid & 63) == 0) { s_red[0][w] = mabs; s_red[1][w] = mfrob; s_red[2][w] = anyinf ? 1.0f : 0.0f; }
+        if ((tid & 63) == 0) { s_red[w] = mabs; s_red[16 + w] = mfrob; s_red[32 + w] = anyinf ? 1.0f : 0.0f; }
         __syncthreads();
         if (tid == 0) {
             float a = 0.0f, b = 0.0f, c = 0.0f;
-            for (int k = 0; k < 16; ++k) { a = fmaxf(a, s_red[0][k]); b = fmaxf(b, s_red[1][k]); c = fmaxf(c, s_red[2][k]); }
+            for (int k = 0; k < 16; ++k) { a = fmaxf(a, s_red[k]); b = fmaxf(b, s_red[16 + k]); c = fmaxf(c, s_red[32 + k]); }
             if (a > 0.0f && __float_as_uint(a) > __hip_atomic_load(&res[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&res[0], __float_as_uint(a));
             if (b > 0.0f && __float_as_uint(b) > __hip_atomic_load(&res[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&res[1], __float_as_uint(b));
             if (c > 0.0f) atomicOr(&res[2], 1u);
         }
     } else {
         cnt = wave_sum_u64(cnt);
+        unsigned long long *s_cnt = (unsigned long long *)s_red;
         if ((tid & 63) == 0) s_cnt[w] = cnt;
         __syncthreads();
         if (tid == 0) {
@@ -990,6 +1062,10 @@ static inline unsigned int grid1d(i64 n, int block = 256, i64 cap = 256 * 32) {
 }
 
 static VolGeom geom(const nl_ctx *c) { return VolGeom{c->nzl, c->ny, c->nx, c->gz0, c->gnz}; }
+static HessR hessr(const nl_ctx *c) {
+    return HessR{1.0 / (double)c->hz, 1.0 / (double)c->hy, 1.0 / (double)c->hx,
+                 1.0 / (double)c->hz2, 1.0 / (double)c->hy2, 1.0 / (double)c->hx2};
+}
 static HessP hessp(const nl_ctx *c) { return HessP{c->hz, c->hy, c->hx, c->hz2, c->hy2, c->hx2}; }
 
 static size_t dtype_size(int dt) {
@@ -1401,8 +1477,8 @@ extern "C" int nl_hessian_stats(nl_ctx *c, const double spacing[3], float *max_a
         const int ntx = (int)((c->nx + HM_TX - 1) / HM_TX), nty = (int)((c->ny + HM_TY - 1) / HM_TY);
         const int nzc = (int)((c->own_hi - c->own_lo + HM_ZCHUNK - 1) / HM_ZCHUNK);
         VessP vp{};
-        hessian_march_kernel<0><<<(unsigned)(ntx * nty * nzc), 1024, 0, c->stream>>>(
-            c->f[c->i_gauss], nullptr, nullptr, geom(c), hessp(c), vp, c->own_lo, c->own_hi, ntx, nty, res, nullptr);
+        hessian_march_kernel<0><<<(unsigned)(ntx * nty * nzc), 1024, HM_LDS_FLOATS_STATS * 4, c->stream>>>(
+            c->f[c->i_gauss], nullptr, nullptr, geom(c), hessr(c), vp, (int)c->own_lo, (int)c->own_hi, ntx, nty, res, nullptr);
         NL_CHECK_LAUNCH();
     }
     unsigned int *h = (unsigned int *)c->h_small;
@@ -1431,8 +1507,13 @@ extern "C" int nl_vesselness_step(nl_ctx *c, float gamma_sq, float alpha_sq, flo
         ProfScope ps(c, "vesselness");
         const int ntx = (int)((c->nx + HM_TX - 1) / HM_TX), nty = (int)((c->ny + HM_TY - 1) / HM_TY);
         const int nzc = (int)((c->own_hi - c->own_lo + HM_ZCHUNK - 1) / HM_ZCHUNK);
-        hessian_march_kernel<1><<<(unsigned)(ntx * nty * nzc), 1024, 0, c->stream>>>(
-            c->f[c->i_gauss], c->f[c->i_vmax], c->m[0], geom(c), hessp(c), vp, c->own_lo, c->own_hi, ntx, nty, nullptr, d_cnt);
+        static bool attr_set = false;
+        if (!attr_set) {
+            NL_HIP(hipFuncSetAttribute((const void *)hessian_march_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, HM_LDS_FLOATS_VESS * 4));
+            attr_set = true;
+        }
+        hessian_march_kernel<1><<<(unsigned)(ntx * nty * nzc), 1024, HM_LDS_FLOATS_VESS * 4, c->stream>>>(
+            c->f[c->i_gauss], c->f[c->i_vmax], c->m[0], geom(c), hessr(c), vp, (int)c->own_lo, (int)c->own_hi, ntx, nty, nullptr, d_cnt);
         NL_CHECK_LAUNCH();
     }
     if (mask_count) {
