@@ -189,6 +189,13 @@ int nl_label_run(nl_ctx *ctx, int has_thr, float thr, int64_t min_area, int fill
 /* D2H of the int32 label volume, local planes [z0, z1) (labelling.py:727-729). */
 int nl_label_store(nl_ctx *ctx, int32_t *host, int64_t z0, int64_t z1, char *err, size_t errlen);
 
+/* ------------------------------------------------------------------ test hooks -------- */
+/* Known-answer hook for the fused device routine (filtering.py:581-585 + 744-766): for n explicit
+   Hessians h6[n][6] = (hxx,hxy,hxz,hyy,hyz,hzz) writes out4[n][4] = (l1,l2,l3 sorted by |.|, Frangi
+   response).  impl 0 = production eigen-solve, 1 = libm acos/cos form. */
+int nl_debug_eig_frangi(nl_ctx *ctx, const float *h6, int64_t n, int impl, float alpha_sq, float beta_sq,
+                        float gamma_sq, float *out4, char *err, size_t errlen);
+
 /* ------------------------------------------------------------------ timing ------------ */
 /* HIP-event timing on the context stream (bench.py's roofline figures). */
 int nl_timer_begin(nl_ctx *ctx, char *err, size_t errlen);

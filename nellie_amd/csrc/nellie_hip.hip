@@ -125,7 +125,7 @@ __device__ __forceinline__ float frob_norm(float fsq, float max_abs, float max_f
 // then the |lambda| ordering of filtering.py:583-584 and the Frangi response of
 // filtering.py:744-766 in float32.
 // -------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void eig3_sorted_abs(const float h[6], float &l1, float &l2, float &l3) {
+__device__ __forceinline__ void eig3_sorted_abs_libm(const float h[6], float &l1, float &l2, float &l3) {
     const double a00 = h[0], a01 = h[1], a02 = h[2], a11 = h[3], a12 = h[4], a22 = h[5];
     const double q = (a00 + a11 + a22) / 3.0;
     const double b00 = a00 - q, b11 = a11 - q, b22 = a22 - q;
@@ -149,6 +149,78 @@ __device__ __forceinline__ void eig3_sorted_abs(const float h[6], float &l1, flo
     l1 = a; l2 = b; l3 = c;
 }
 
+// 1/sqrt(x) in float64 from the hardware estimate + two Newton steps (x > 0, normal range)
+__device__ __forceinline__ double rsqrt_f64(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const double t = x * y;
+        const double e = fma(-t, y, 1.0);
+        y = fma(0.5 * y, e, y);
+    }
+    return y;
+}
+
+// Stable |lambda| ordering of three ascending values (numpy argsort on 3 elements = insertion sort)
+__device__ __forceinline__ void sort3_abs(float a, float b, float c, float &l1, float &l2, float &l3) {
+    float ka = fabsf(a), kb = fabsf(b), kc = fabsf(c);
+    if (kb < ka) { float t = a; a = b; b = t; t = ka; ka = kb; kb = t; }
+    if (kc < kb) {
+        float t = b; b = c; c = t; t = kb; kb = kc; kc = t;
+        if (kb < ka) { t = a; a = b; b = t; t = ka; ka = kb; kb = t; }
+    }
+    l1 = a; l2 = b; l3 = c;
+}
+
+// Production eigen-solve: the same closed form, no libm.  With r = det(B)/(2 p^3) in [-1,1] and
+// phi = acos(|r|)/3 in [0, pi/6], c = cos(phi) is the largest root of 4c^3 - 3c = |r| (c in [0.866,1],
+// derivative 12c^2-3 in [6,9]: well conditioned): degree-4 starting polynomial (4.5e-6) + two Newton
+// steps with a float32 reciprocal of the derivative -> 1e-16.  s = sin(phi) = sqrt(1-c^2).
+//   r >= 0: e_max = q + 2pc, e_min = q - p(c + sqrt3 s);   r < 0: e_min = q - 2pc, e_max = q + p(c + sqrt3 s)
+// Accuracy ~1e-16 * ||A|| (near-degenerate pairs ~1e-8 * ||A||, exactly like the acos form), so the
+// float32-rounded eigenvalues equal LAPACK's except with probability ~1e-9 per value.
+__device__ __forceinline__ void eig3_sorted_abs(const float h[6], float &l1, float &l2, float &l3) {
+    const double a00 = h[0], a01 = h[1], a02 = h[2], a11 = h[3], a12 = h[4], a22 = h[5];
+    const double q = (a00 + a11 + a22) * (1.0 / 3.0);
+    const double b00 = a00 - q, b11 = a11 - q, b22 = a22 - q;
+    const double off = fma(a01, a01, fma(a02, a02, a12 * a12));
+    const double p2 = (fma(b00, b00, fma(b11, b11, b22 * b22)) + 2.0 * off) * (1.0 / 6.0);
+    const double m0 = fma(b11, b22, -(a12 * a12));
+    const double m1 = fma(a01, b22, -(a12 * a02));
+    const double m2 = fma(a01, a12, -(b11 * a02));
+    const double det = fma(b00, m0, fma(-a01, m1, a02 * m2));
+    float ea, eb, ec;
+    if (p2 > 0.0) {
+        const double y = rsqrt_f64(p2);
+        const double p = p2 * y;
+        double r = 0.5 * det * (y * y * y);
+        const bool neg = r < 0.0;
+        double ra = fabs(r);
+        ra = ra > 1.0 ? 1.0 : ra;
+        double c = fma(fma(fma(fma(-0.004099405456413993, ra, 0.017642364887819385), ra, -0.046005261357895906), ra,
+                           0.16642901838062307), ra, 0.866029853359238);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const double t = c * c;
+            const double f = fma(c, fma(4.0, t, -3.0), -ra);
+            const double fp = fma(12.0, t, -3.0);
+            c = fma(-f, (double)__builtin_amdgcn_rcpf((float)fp), c);
+        }
+        c = c > 1.0 ? 1.0 : c;
+        const double s2 = fma(-c, c, 1.0);
+        const double s = s2 > 0.0 ? s2 * rsqrt_f64(s2) : 0.0;
+        const double t1 = 2.0 * p * c;
+        const double t2 = p * fma(1.7320508075688772, s, c);
+        const double e_max = neg ? q + t2 : q + t1;
+        const double e_min = neg ? q - t1 : q - t2;
+        const double e_mid = 3.0 * q - e_max - e_min;
+        ea = (float)e_min; eb = (float)e_mid; ec = (float)e_max;
+    } else {
+        ea = eb = ec = (float)q;          // p2 == 0 (multiple of the identity) or NaN
+    }
+    sort3_abs(ea, eb, ec, l1, l2, l3);
+}
+
 __device__ __forceinline__ float frangi3(float l1, float l2, float l3, float alpha_sq, float beta_sq, float gamma_sq) {
     const float al2 = fabsf(l2), al3 = fabsf(l3);
     const float ra = al2 / (al3 + 1e-12f);
@@ -164,6 +236,21 @@ __device__ __forceinline__ float frangi3(float l1, float l2, float l3, float alp
     if (l2 > 0.0f) v = 0.0f;
     if (!(fabsf(v) <= 3.402823466e38f)) v = 0.0f;   // nan_to_num(nan=0, posinf=0, neginf=0)
     return v;
+}
+
+// debug / known-answer kernel: eigenvalues (sorted by |.|) and Frangi response of explicit Hessians
+__global__ void __launch_bounds__(256)
+debug_eig_kernel(const float *__restrict__ h6, i64 n, int impl, float alpha_sq, float beta_sq, float gamma_sq,
+                 float *__restrict__ out4) {
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float h[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) h[k] = h6[i * 6 + k];
+    float l1, l2, l3;
+    if (impl == 0) eig3_sorted_abs(h, l1, l2, l3); else eig3_sorted_abs_libm(h, l1, l2, l3);
+    out4[i * 4 + 0] = l1; out4[i * 4 + 1] = l2; out4[i * 4 + 2] = l3;
+    out4[i * 4 + 3] = frangi3(l1, l2, l3, alpha_sq, beta_sq, gamma_sq);
 }
 
 // =================================================================================================
@@ -1726,6 +1813,20 @@ extern "C" int nl_label_store(nl_ctx *c, int32_t *host, int64_t z0, int64_t z1, 
     NL_ENTER(c);
     if (c->i_labels < 0) return nl_fail(err, errlen, NL_ESTATE, "nl_label_store before nl_label_run");
     return store_planes(c, c->f[c->i_labels], host, 4, z0, z1, err, errlen);
+}
+
+// ---------------------------------------------------------------------------------- debug -------
+extern "C" int nl_debug_eig_frangi(nl_ctx *c, const float *h6, int64_t n, int impl, float alpha_sq, float beta_sq,
+                                   float gamma_sq, float *out4, char *err, size_t errlen) {
+    NL_ENTER(c);
+    if (!h6 || !out4 || n < 1 || n * 6 > c->n) return nl_fail(err, errlen, NL_EINVAL, "bad debug batch (n=%lld)", (i64)n);
+    float *d_in = c->f[(c->i_gauss + 1) % 3], *d_out = c->f[(c->i_gauss + 2) % 3];
+    NL_HIP(hipMemcpyAsync(d_in, h6, (size_t)n * 24, hipMemcpyHostToDevice, c->stream));
+    debug_eig_kernel<<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>(d_in, n, impl, alpha_sq, beta_sq, gamma_sq, d_out);
+    NL_CHECK_LAUNCH();
+    NL_HIP(hipMemcpyAsync(out4, d_out, (size_t)n * 16, hipMemcpyDeviceToHost, c->stream));
+    NL_HIP(hipStreamSynchronize(c->stream));
+    return NL_OK;
 }
 
 // --------------------------------------------------------------------------------- timing -------

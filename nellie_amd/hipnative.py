@@ -57,6 +57,7 @@ _PROTOS = {
     "nl_flat_sample_gather": [_p, _int, _i64, _i64, _p, _i64, C.POINTER(_i64)],
     "nl_label_run": [_p, _int, _f32, _i64, _int, C.POINTER(_i64)],
     "nl_label_store": [_p, _p, _i64, _i64],
+    "nl_debug_eig_frangi": [_p, _p, _i64, _int, _f32, _f32, _f32, _p],
     "nl_timer_begin": [_p],
     "nl_timer_end_ms": [_p, C.POINTER(_f32)],
 }
@@ -322,6 +323,13 @@ class Context:
             out = np.empty((z1 - z0, self.shape[1], self.shape[2]), dtype=np.int32)
         assert out.dtype == np.int32 and out.flags.c_contiguous
         self._call("nl_label_store", _ptr(out), z0, z1)
+        return out
+
+    def debug_eig_frangi(self, h6, alpha_sq=0.5, beta_sq=0.5, gamma_sq=1.0, impl=0):
+        h = np.ascontiguousarray(h6, dtype=np.float32)
+        out = np.empty((h.shape[0], 4), dtype=np.float32)
+        self._call("nl_debug_eig_frangi", _ptr(h), h.shape[0], int(impl), float(np.float32(alpha_sq)),
+                   float(np.float32(beta_sq)), float(np.float32(gamma_sq)), _ptr(out))
         return out
 
     # ---------------------------------------------------------------- timing

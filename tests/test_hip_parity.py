@@ -223,3 +223,34 @@ def test_reference_label_tests_on_the_hip_backend(hip):
     assert labels is not None
     assert np.array_equal(original, oc) and np.array_equal(frangi, fc)
     labeler.close()
+
+
+def test_eigen_frangi_known_answers(pipes):
+    """Device eigen-solve + Frangi on explicit Hessians vs numpy.linalg.eigvalsh / the oracle formula."""
+    rng = np.random.default_rng(11)
+    m = 400000
+    scales = rng.choice([1.0, 30.0, 3000.0], size=(m, 1))
+    h = (rng.normal(0, 1, (m, 6)) * scales * np.array([3, 1, 1, 2, 1, 1.5])).astype(np.float32)
+    h[:2000, [1, 2, 4]] = 0                       # diagonal matrices
+    h[2000:4000] = np.repeat(h[2000:4000, :1], 6, axis=1) * np.array([1, 0, 0, 1, 0, 1], np.float32)  # multiples of I
+    h[4000:6000, 3] = h[4000:6000, 0]; h[4000:6000, [1, 2, 4]] *= 1e-4        # near-degenerate pairs
+    h[6000:6100] = 0
+    H = np.stack([np.stack([h[:, 0], h[:, 1], h[:, 2]], -1), np.stack([h[:, 1], h[:, 3], h[:, 4]], -1),
+                  np.stack([h[:, 2], h[:, 4], h[:, 5]], -1)], -2)
+    ev = np.linalg.eigvalsh(H)
+    ref = np.take_along_axis(ev, np.argsort(np.abs(ev), axis=1, kind="stable"), axis=1)
+    gamma_sq = 2.0 * 40.0 ** 2
+    pipe = pipes((40, 256, 256))
+    for impl in (0, 1):
+        out = pipe.ctx.debug_eig_frangi(h, 0.5, 0.5, gamma_sq, impl=impl)
+        norm = np.abs(ref).max(axis=1, keepdims=True) + 1e-30
+        rel = np.abs(out[:, :3] - ref) / norm
+        exact = float(np.mean(out[:, :3] == ref))
+        print(f"impl {impl}: eigenvalues bit-equal to LAPACK {exact * 100:.4f}%, max err/||A|| {rel.max():.2e}")
+        assert rel.max() < 2e-7
+        assert exact > 0.999
+        v_ref = orc.frangi_response(ref.copy(), 0.5, 0.5, gamma_sq)
+        tol = 1e-4 * np.abs(v_ref) + 1e-6
+        ok = np.abs(out[:, 3] - v_ref) <= tol
+        # a 1-ulp eigenvalue difference may flip the sign tests only at |lambda| ~ 0
+        assert ok.mean() > 0.9999, ok.mean()
