@@ -2,6 +2,7 @@
 // C-ABI in include/nellie_amd.h.  Compile with -ffp-contract=off: every float operation
 // below is meant to round exactly where numpy/scipy round.
 #include <stdarg.h>
+#include <stdlib.h>
 #include "nl_common.h"
 
 #define NL_VERSION "nellie_amd-hip 0.1.0 (gfx950)"
@@ -581,25 +582,27 @@ vesselness_kernel(const float *__restrict__ g, float *__restrict__ vmax, uint8_t
 // float64 eigen-solve + Frangi response runs on dense batches of 1024 queue entries.
 // -------------------------------------------------------------------------------------------------
 #define HM_TX 64
-#define HM_TY 16
 #define HM_PW (HM_TX + 4)
-#define HM_PH (HM_TY + 4)
-#define HM_PLANE (HM_PW * HM_PH)
 #define HM_SLOTS 8
 #define HM_ZCHUNK 64
-#define HM_QCAP 2048
-#define HM_LDS_FLOATS_STATS (HM_SLOTS * HM_PLANE + 64)
-#define HM_LDS_FLOATS_VESS (HM_SLOTS * HM_PLANE + 64 + 7 * HM_QCAP)
+template <int TY> struct HMCfg {
+    static constexpr int NT = HM_TX * TY;               // threads per workgroup
+    static constexpr int PH = TY + 4;
+    static constexpr int PLANE = HM_PW * PH;
+    static constexpr int QCAP = 2 * NT;                 // queue ring: < NT waiting + <= NT appended per plane
+    static constexpr int lds_floats(int mode) { return HM_SLOTS * PLANE + 64 + (mode == 1 ? 7 * QCAP : 0); }
+};
 
 struct HessR {          // reciprocals (float64) of float32(h) and float32(2h)
     double z, y, x, z2, y2, x2;
 };
 
-template <int MODE>
-__global__ void __launch_bounds__(1024)
-hessian_march_kernel(const float *__restrict__ g, float *__restrict__ vmax, uint8_t *__restrict__ cmask,
+template <int MODE, int TY>
+__global__ void __launch_bounds__(HM_TX * TY)
+hessian_march_kernel(const float *__restrict__ g, float *__restrict__ vmax, unsigned long long *__restrict__ cmask64, int wpr,
                      VolGeom v, HessR hr, VessP vp, int z0, int z1, int ntx, int nty,
                      unsigned int *__restrict__ res, unsigned long long *__restrict__ mask_count) {
+    constexpr int NT = HMCfg<TY>::NT, HM_PLANE = HMCfg<TY>::PLANE, HM_QCAP = HMCfg<TY>::QCAP, HM_TY = TY;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *sp = (float *)smem;                               // [HM_SLOTS][HM_PLANE]
     float *s_red = sp + HM_SLOTS * HM_PLANE;               // 64 floats of reduction scratch
@@ -632,7 +635,7 @@ hessian_march_kernel(const float *__restrict__ g, float *__restrict__ vmax, uint
         yy = yy < 0 ? 0 : (yy > ny - 1 ? ny - 1 : yy);
         xx = xx < 0 ? 0 : (xx > nx - 1 ? nx - 1 : xx);
         off0 = yy * nx + xx;
-        const int e1 = tid + 1024;
+        const int e1 = tid + NT;
         if (e1 < HM_PLANE) {
             int y1 = ybase + e1 / HM_PW, x1 = xbase + e1 % HM_PW;
             y1 = y1 < 0 ? 0 : (y1 > ny - 1 ? ny - 1 : y1);
@@ -657,7 +660,7 @@ hessian_march_kernel(const float *__restrict__ g, float *__restrict__ vmax, uint
             float *dst = sp + (zq & (HM_SLOTS - 1)) * HM_PLANE;
             const float *src = g + (i64)zq * sz;
             dst[tid] = src[off0];
-            if (off1 >= 0) dst[tid + 1024] = src[off1];
+            if (off1 >= 0) dst[tid + NT] = src[off1];
         }
     }
     __syncthreads();
@@ -699,9 +702,9 @@ hessian_march_kernel(const float *__restrict__ g, float *__restrict__ vmax, uint
         if (MODE == 1) {
             // dense eigen batch once the queue holds a full workgroup's worth
             const int tail = *(volatile int *)s_tail;
-            if (tail - head >= 1024) {            // uniform
+            if (tail - head >= NT) {              // uniform
                 process_entry(head + tid);
-                head += 1024;
+                head += NT;
                 __syncthreads();                  // entries read before their ring slots can be re-used
             }
         }
@@ -746,14 +749,20 @@ hessian_march_kernel(const float *__restrict__ g, float *__restrict__ vmax, uint
             } else {
                 const float fr = frob_norm(fsq, vp.max_abs, vp.max_finite);
                 m = vp.use_thr ? (fr > vp.thr) : (fr > 0.0f);
-                if (!m) cmask[(i64)z * sz + (i64)y * nx + x] = 0;        // masks &= h_mask
             }
         }
         if (MODE == 1) {
             // append the masked voxels of this wave to the queue (one LDS atomic per wave)
             const unsigned long long bal = __ballot(m);
+            const int lane = tid & 63;
+            // masks &= h_mask as a bit mask: this wave owns exactly one 64-voxel word of the row
+            if (lane == 0 && y < ny) {
+                const unsigned long long inrow = (nx - (xbase + 2) >= 64) ? ~0ull : ((1ull << (nx - (xbase + 2))) - 1ull);
+                unsigned long long *wp = cmask64 + ((i64)z * ny + y) * wpr + tx;
+                const unsigned long long old = *wp, upd = old & (bal | ~inrow);
+                if (upd != old) *wp = upd;
+            }
             if (bal) {
-                const int lane = tid & 63;
                 const int leader = __builtin_ctzll(bal);
                 int base = 0;
                 if (lane == leader) base = atomicAdd(s_tail, (int)__builtin_popcountll(bal));
@@ -771,7 +780,7 @@ hessian_march_kernel(const float *__restrict__ g, float *__restrict__ vmax, uint
         if (fetch) {
             float *dst = sp + (zn & (HM_SLOTS - 1)) * HM_PLANE;
             dst[tid] = r0;
-            if (off1 >= 0) dst[tid + 1024] = r1;
+            if (off1 >= 0) dst[tid + NT] = r1;
         }
         __syncthreads();
     }
@@ -780,7 +789,7 @@ hessian_march_kernel(const float *__restrict__ g, float *__restrict__ vmax, uint
         const int tail = *(volatile int *)s_tail;
         while (tail - head > 0) {
             if (head + tid < tail) process_entry(head + tid);
-            head += 1024;
+            head += NT;
         }
     }
 
@@ -793,7 +802,7 @@ hessian_march_kernel(const float *__restrict__ g, float *__restrict__ vmax, uint
         __syncthreads();
         if (tid == 0) {
             float a = 0.0f, b = 0.0f, c = 0.0f;
-            for (int k = 0; k < 16; ++k) { a = fmaxf(a, s_red[k]); b = fmaxf(b, s_red[16 + k]); c = fmaxf(c, s_red[32 + k]); }
+            for (int k = 0; k < NT / 64; ++k) { a = fmaxf(a, s_red[k]); b = fmaxf(b, s_red[16 + k]); c = fmaxf(c, s_red[32 + k]); }
             if (a > 0.0f && __float_as_uint(a) > __hip_atomic_load(&res[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&res[0], __float_as_uint(a));
             if (b > 0.0f && __float_as_uint(b) > __hip_atomic_load(&res[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&res[1], __float_as_uint(b));
             if (c > 0.0f) atomicOr(&res[2], 1u);
@@ -805,25 +814,36 @@ hessian_march_kernel(const float *__restrict__ g, float *__restrict__ vmax, uint
         __syncthreads();
         if (tid == 0) {
             unsigned long long t = 0;
-            for (int k = 0; k < 16; ++k) t += s_cnt[k];
+            for (int k = 0; k < NT / 64; ++k) t += s_cnt[k];
             if (t) atomicAdd(mask_count, t);
         }
     }
 }
 
-// vesselness * masks (filtering.py:926); counts voxels > 0 on the owned planes
+// vesselness * masks (filtering.py:926); counts voxels > 0 on the owned planes.
+// The cumulative mask is a bit mask: one 64-bit word per 64 consecutive x of a row (row pitch `wpr` words).
 __global__ void __launch_bounds__(256)
-finish_kernel(float *__restrict__ vmax, const uint8_t *__restrict__ cmask, i64 begin, i64 end,
+finish_kernel(float *__restrict__ vmax, const unsigned long long *__restrict__ cmask64, int wpr, VolGeom v, i64 z0, i64 z1,
               unsigned long long *__restrict__ npos) {
-    const i64 stride = (i64)gridDim.x * blockDim.x;
+    const i64 rows = (z1 - z0) * v.ny;
+    const i64 waves = rows * wpr;
+    const i64 stride = ((i64)gridDim.x * blockDim.x) >> 6;
+    const int lane = threadIdx.x & 63;
     unsigned long long cnt = 0;
-    for (i64 i = begin + (i64)blockIdx.x * blockDim.x + threadIdx.x; i < end; i += stride) {
-        float val = vmax[i];
-        if (!cmask[i]) { val = 0.0f; vmax[i] = 0.0f; }
-        if (val > 0.0f) cnt++;
+    for (i64 w = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < waves; w += stride) {
+        const i64 row = w / wpr;
+        const int seg = (int)(w % wpr);
+        const i64 x = (i64)seg * 64 + lane;
+        if (x < v.nx) {
+            const unsigned long long bits = cmask64[(z0 * v.ny + row) * wpr + seg];
+            const i64 i = (z0 * v.ny + row) * v.nx + x;
+            float val = vmax[i];
+            if (!((bits >> lane) & 1ull)) { val = 0.0f; vmax[i] = 0.0f; }
+            if (val > 0.0f) cnt++;
+        }
     }
     cnt = wave_sum_u64(cnt);
-    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(npos, cnt);
+    if (lane == 0 && cnt) atomicAdd(npos, cnt);
 }
 
 // filtering.py:964-966: mask = f > thr; binary_opening (6-conn cross, border_value 0); f * mask.
@@ -1149,6 +1169,12 @@ static inline unsigned int grid1d(i64 n, int block = 256, i64 cap = 256 * 32) {
 }
 
 static VolGeom geom(const nl_ctx *c) { return VolGeom{c->nzl, c->ny, c->nx, c->gz0, c->gnz}; }
+// tile height of the Hessian kernels (experiment knob; 8 -> 512-thread workgroups, 16 -> 1024)
+static int hm_ty() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("NELLIE_HM_TY"); v = (e && atoi(e) == 16) ? 16 : 8; }
+    return v;
+}
 static HessR hessr(const nl_ctx *c) {
     return HessR{1.0 / (double)c->hz, 1.0 / (double)c->hy, 1.0 / (double)c->hx,
                  1.0 / (double)c->hz2, 1.0 / (double)c->hy2, 1.0 / (double)c->hx2};
@@ -1249,7 +1275,9 @@ extern "C" int nl_ctx_create(nl_ctx **out, int device, int64_t nzl, int64_t ny, 
     };
     bool ok = true;
     for (int k = 0; k < 4 && ok; ++k) ok = alloc((void **)&c->f[k], (size_t)n * 4);
-    for (int k = 0; k < 3 && ok; ++k) ok = alloc((void **)&c->m[k], (size_t)n);
+    // m[0] doubles as the cumulative bit mask of Filter: one 64-bit word per 64 x-voxels of a row
+    const size_t mask_words = (size_t)nzl * ny * ((nx + 63) / 64);
+    for (int k = 0; k < 3 && ok; ++k) ok = alloc((void **)&c->m[k], (k == 0 && mask_words * 8 > (size_t)n) ? mask_words * 8 : (size_t)n);
     if (ok) ok = alloc(&c->d_small, 1 << 16);
     c->blk_cap = (n + SCAN_CHUNK - 1) / SCAN_CHUNK + 1;
     if (ok) ok = alloc(&c->d_blk, (size_t)c->blk_cap * 4);
@@ -1321,7 +1349,7 @@ extern "C" int nl_filter_load(nl_ctx *c, const void *host, int dtype, int64_t z0
     if (rc) return rc;
     // vesselness = zeros, masks = ones (filtering.py:807-808)
     NL_HIP(hipMemsetAsync(c->f[c->i_vmax], 0, (size_t)c->n * 4, c->stream));
-    NL_HIP(hipMemsetAsync(c->m[0], 1, (size_t)c->n, c->stream));
+    NL_HIP(hipMemsetAsync(c->m[0], 0xFF, (size_t)c->nzl * c->ny * ((c->nx + 63) / 64) * 8, c->stream));
     NL_HIP(hipStreamSynchronize(c->stream));
     return NL_OK;
 }
@@ -1362,7 +1390,7 @@ extern "C" int nl_filter_begin(nl_ctx *c, char *err, size_t errlen) {
     }
     NL_CHECK_LAUNCH();
     NL_HIP(hipMemsetAsync(c->f[c->i_vmax], 0, (size_t)c->n * 4, c->stream));
-    NL_HIP(hipMemsetAsync(c->m[0], 1, (size_t)c->n, c->stream));
+    NL_HIP(hipMemsetAsync(c->m[0], 0xFF, (size_t)c->nzl * c->ny * ((c->nx + 63) / 64) * 8, c->stream));
     return NL_OK;
 }
 
@@ -1561,11 +1589,17 @@ extern "C" int nl_hessian_stats(nl_ctx *c, const double spacing[3], float *max_a
     NL_HIP(hipMemsetAsync(res, 0, 16, c->stream));
     {
         ProfScope ps(c, "hessian_stats");
-        const int ntx = (int)((c->nx + HM_TX - 1) / HM_TX), nty = (int)((c->ny + HM_TY - 1) / HM_TY);
+        const int ntx = (int)((c->nx + HM_TX - 1) / HM_TX), nty = (int)((c->ny + 15) / 16);
         const int nzc = (int)((c->own_hi - c->own_lo + HM_ZCHUNK - 1) / HM_ZCHUNK);
         VessP vp{};
-        hessian_march_kernel<0><<<(unsigned)(ntx * nty * nzc), 1024, HM_LDS_FLOATS_STATS * 4, c->stream>>>(
-            c->f[c->i_gauss], nullptr, nullptr, geom(c), hessr(c), vp, (int)c->own_lo, (int)c->own_hi, ntx, nty, res, nullptr);
+        if (hm_ty() == 8) {
+            const int nty8 = (int)((c->ny + 7) / 8);
+            hessian_march_kernel<0, 8><<<(unsigned)(ntx * nty8 * nzc), HMCfg<8>::NT, HMCfg<8>::lds_floats(0) * 4, c->stream>>>(
+                c->f[c->i_gauss], nullptr, nullptr, 0, geom(c), hessr(c), vp, (int)c->own_lo, (int)c->own_hi, ntx, nty8, res, nullptr);
+        } else {
+            hessian_march_kernel<0, 16><<<(unsigned)(ntx * nty * nzc), HMCfg<16>::NT, HMCfg<16>::lds_floats(0) * 4, c->stream>>>(
+                c->f[c->i_gauss], nullptr, nullptr, 0, geom(c), hessr(c), vp, (int)c->own_lo, (int)c->own_hi, ntx, nty, res, nullptr);
+        }
         NL_CHECK_LAUNCH();
     }
     unsigned int *h = (unsigned int *)c->h_small;
@@ -1592,15 +1626,24 @@ extern "C" int nl_vesselness_step(nl_ctx *c, float gamma_sq, float alpha_sq, flo
     VessP vp{gamma_sq, alpha_sq, beta_sq, use_thr, thr, c->frob_max_abs, c->frob_max_finite};
     {
         ProfScope ps(c, "vesselness");
-        const int ntx = (int)((c->nx + HM_TX - 1) / HM_TX), nty = (int)((c->ny + HM_TY - 1) / HM_TY);
+        const int ntx = (int)((c->nx + HM_TX - 1) / HM_TX), nty = (int)((c->ny + 15) / 16);
         const int nzc = (int)((c->own_hi - c->own_lo + HM_ZCHUNK - 1) / HM_ZCHUNK);
         static bool attr_set = false;
         if (!attr_set) {
-            NL_HIP(hipFuncSetAttribute((const void *)hessian_march_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, HM_LDS_FLOATS_VESS * 4));
+            NL_HIP(hipFuncSetAttribute((const void *)hessian_march_kernel<1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, HMCfg<16>::lds_floats(1) * 4));
+            NL_HIP(hipFuncSetAttribute((const void *)hessian_march_kernel<1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, HMCfg<8>::lds_floats(1) * 4));
             attr_set = true;
         }
-        hessian_march_kernel<1><<<(unsigned)(ntx * nty * nzc), 1024, HM_LDS_FLOATS_VESS * 4, c->stream>>>(
-            c->f[c->i_gauss], c->f[c->i_vmax], c->m[0], geom(c), hessr(c), vp, (int)c->own_lo, (int)c->own_hi, ntx, nty, nullptr, d_cnt);
+        const int wpr = (int)((c->nx + 63) / 64);
+        unsigned long long *cm = (unsigned long long *)c->m[0];
+        if (hm_ty() == 8) {
+            const int nty8 = (int)((c->ny + 7) / 8);
+            hessian_march_kernel<1, 8><<<(unsigned)(ntx * nty8 * nzc), HMCfg<8>::NT, HMCfg<8>::lds_floats(1) * 4, c->stream>>>(
+                c->f[c->i_gauss], c->f[c->i_vmax], cm, wpr, geom(c), hessr(c), vp, (int)c->own_lo, (int)c->own_hi, ntx, nty8, nullptr, d_cnt);
+        } else {
+            hessian_march_kernel<1, 16><<<(unsigned)(ntx * nty * nzc), HMCfg<16>::NT, HMCfg<16>::lds_floats(1) * 4, c->stream>>>(
+                c->f[c->i_gauss], c->f[c->i_vmax], cm, wpr, geom(c), hessr(c), vp, (int)c->own_lo, (int)c->own_hi, ntx, nty, nullptr, d_cnt);
+        }
         NL_CHECK_LAUNCH();
     }
     if (mask_count) {
@@ -1618,8 +1661,10 @@ extern "C" int nl_filter_finish(nl_ctx *c, int64_t *n_positive, char *err, size_
     const i64 plane = c->ny * c->nx;
     {
         ProfScope ps(c, "finish");
-        finish_kernel<<<grid1d((c->own_hi - c->own_lo) * plane), 256, 0, c->stream>>>(c->f[c->i_vmax], c->m[0], c->own_lo * plane,
-                                                                                         c->own_hi * plane, d_cnt);
+        const int wpr = (int)((c->nx + 63) / 64);
+        const i64 waves = (c->own_hi - c->own_lo) * c->ny * wpr;
+        finish_kernel<<<grid1d(waves * 64), 256, 0, c->stream>>>(c->f[c->i_vmax], (const unsigned long long *)c->m[0], wpr, geom(c),
+                                                               c->own_lo, c->own_hi, d_cnt);
         NL_CHECK_LAUNCH();
     }
     NL_HIP(hipMemcpyAsync(c->h_small, d_cnt, 8, hipMemcpyDeviceToHost, c->stream));
