@@ -196,6 +196,7 @@ def main():
         del fr, lab
 
     tr = pipe.trace
+    fast_div = int(pipe.ctx.info("fast_div"))
     pipe.close()
 
     cpu = None
@@ -219,7 +220,7 @@ def main():
                 "voxels": int(n_global), "per_gpu_shape": list(shape),
                 "survival_fraction": round(tr.n_positive / n_local, 5), "labels": int(n_labels),
                 "mask_fraction_per_scale": [round(sc.mask_count / n_local, 4) for sc in tr.scales],
-                "host_gen_s": round(t_gen, 1), "h2d_s": round(t_up, 2),
+                "host_gen_s": round(t_gen, 1), "h2d_s": round(t_up, 2), "fast_div_proven": fast_div,
             },
             "roofline": roofline, "cpu_baseline": cpu,
         }

@@ -196,6 +196,10 @@ int nl_label_store(nl_ctx *ctx, int32_t *host, int64_t z0, int64_t z1, char *err
 int nl_debug_eig_frangi(nl_ctx *ctx, const float *h6, int64_t n, int impl, float alpha_sq, float beta_sq,
                         float gamma_sq, float *out4, char *err, size_t errlen);
 
+/* Introspection: "fast_div" (1 when the 3-instruction constant division was proven exact for the
+   current spacings), "hessian_tile_rows", "device_bytes". */
+int nl_ctx_info(nl_ctx *ctx, const char *key, double *value);
+
 /* ------------------------------------------------------------------ timing ------------ */
 /* HIP-event timing on the context stream (bench.py's roofline figures). */
 int nl_timer_begin(nl_ctx *ctx, char *err, size_t errlen);

@@ -5,6 +5,7 @@
 #include <stdlib.h>
 #include "nl_common.h"
 
+#define NL_MASK_SLOTS 8      // per-scale mask bit planes kept before falling back to read-modify-write
 #define NL_VERSION "nellie_amd-hip 0.1.0 (gfx950)"
 
 // =================================================================================================
@@ -538,6 +539,7 @@ struct VessP {
     int use_thr;
     float thr;
     float max_abs, max_finite;
+    int mask_rmw;            // 1: AND into the slot (more scales than mask slots)
 };
 
 __global__ void __launch_bounds__(256)
@@ -584,7 +586,9 @@ vesselness_kernel(const float *__restrict__ g, float *__restrict__ vmax, uint8_t
 #define HM_TX 64
 #define HM_PW (HM_TX + 4)
 #define HM_SLOTS 8
+#define HM_SLOT(z) ((int)((unsigned)(z) & (HM_SLOTS - 1)))
 #define HM_ZCHUNK 64
+#define HM_DEPTH 3
 template <int TY> struct HMCfg {
     static constexpr int NT = HM_TX * TY;               // threads per workgroup
     static constexpr int PH = TY + 4;
@@ -593,14 +597,35 @@ template <int TY> struct HMCfg {
     static constexpr int lds_floats(int mode) { return HM_SLOTS * PLANE + 64 + (mode == 1 ? 7 * QCAP : 0); }
 };
 
-struct HessR {          // reciprocals (float64) of float32(h) and float32(2h)
-    double z, y, x, z2, y2, x2;
+// A constant float32 divisor, two exact implementations of a/d:
+//  FAST : q = a*y; r = fma(-q,d,a); q' = fma(r,y,q) with y = RN(1/d) -- three float32 instructions.  This
+//         sequence is correctly rounded for most but not all d, so nl_hessian_stats PROVES it for the
+//         six divisors in use by exhaustion (divcheck_kernel: all 2^23 significands; scaling a by 2^k
+//         scales q, r, q' exactly, so one binade covers every normal a) before selecting this path.
+//  !FAST: (float)((double)a * RN64(1/d)), exact for every d (see div_c).
+template <bool FAST> struct Dv;
+template <> struct Dv<true> {
+    float d, y;
+    __device__ __forceinline__ float div(float a) const { const float q = a * y; const float r = fmaf(-q, d, a); return fmaf(r, y, q); }
 };
+template <> struct Dv<false> {
+    double r;
+    __device__ __forceinline__ float div(float a) const { return (float)((double)a * r); }
+};
+template <bool FAST> struct HessDv { Dv<FAST> z, y, x, z2, y2, x2; };   // float32(h) and float32(2h) per axis
 
-template <int MODE, int TY>
+__global__ void __launch_bounds__(256)
+divcheck_kernel(float d, float y, unsigned int *__restrict__ bad) {
+    const unsigned int i = blockIdx.x * 256u + threadIdx.x;               // 2^23 significands of [1,2)
+    const float a = __uint_as_float(0x3f800000u | i);
+    Dv<true> dv{d, y};
+    if (dv.div(a) != a / d) atomicOr(bad, 1u);
+}
+
+template <int MODE, int TY, bool FAST>
 __global__ void __launch_bounds__(HM_TX * TY)
 hessian_march_kernel(const float *__restrict__ g, float *__restrict__ vmax, unsigned long long *__restrict__ cmask64, int wpr,
-                     VolGeom v, HessR hr, VessP vp, int z0, int z1, int ntx, int nty,
+                     VolGeom v, HessDv<FAST> hr, VessP vp, int z0, int z1, int ntx, int nty,
                      unsigned int *__restrict__ res, unsigned long long *__restrict__ mask_count) {
     constexpr int NT = HMCfg<TY>::NT, HM_PLANE = HMCfg<TY>::PLANE, HM_QCAP = HMCfg<TY>::QCAP, HM_TY = TY;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -650,17 +675,25 @@ hessian_march_kernel(const float *__restrict__ g, float *__restrict__ vmax, unsi
     };
 
     if (MODE == 1 && tid == 0) *s_tail = 0;
-    // prologue: planes clamp(zc0-2 .. zc0+2)
-    {
-        int last = -1;
-        for (int k = -2; k <= 2; ++k) {
-            const int zq = zclamp(zc0 + k);
-            if (zq == last) continue;
-            last = zq;
-            float *dst = sp + (zq & (HM_SLOTS - 1)) * HM_PLANE;
-            const float *src = g + (i64)zq * sz;
-            dst[tid] = src[off0];
-            if (off1 >= 0) dst[tid + NT] = src[off1];
+    // Planes this chunk ever touches form the contiguous range [pmin, pmax].  The first five go straight
+    // to LDS; the following HM_DEPTH planes are put in flight into registers (memory-level parallelism:
+    // a 3.2 KB plane per workgroup is far too little to cover HBM latency on its own).
+    const int pmin = zclamp(zc0 - 2), pmax = zclamp(zc1 + 1);
+    for (int pz = pmin; pz <= pmax && pz <= zc0 + 2; ++pz) {
+        float *dst = sp + HM_SLOT(pz) * HM_PLANE;
+        const float *src = g + (i64)pz * sz;
+        dst[tid] = src[off0];
+        if (off1 >= 0) dst[tid + NT] = src[off1];
+    }
+    float ra[HM_DEPTH], rb[HM_DEPTH];
+#pragma unroll
+    for (int d = 0; d < HM_DEPTH; ++d) {
+        ra[d] = 0.0f; rb[d] = 0.0f;
+        const int pz = zc0 + 3 + d;
+        if (pz <= pmax) {
+            const float *src = g + (i64)pz * sz;
+            ra[d] = src[off0];
+            if (off1 >= 0) rb[d] = src[off1];
         }
     }
     __syncthreads();
@@ -670,13 +703,13 @@ hessian_march_kernel(const float *__restrict__ g, float *__restrict__ vmax, unsi
     const int jc = ly + 2, ic = lx + 2;
     const int jl = jc - (y_lo ? 0 : 1), jh = jc + (y_hi ? 0 : 1);
     const int il = ic - (x_lo ? 0 : 1), ih = ic + (x_hi ? 0 : 1);
-    const double rdy = (y_lo || y_hi) ? hr.y : hr.y2;
-    const double rdx = (x_lo || x_hi) ? hr.x : hr.x2;
+    const Dv<FAST> rdy = (y_lo || y_hi) ? hr.y : hr.y2;
+    const Dv<FAST> rdx = (x_lo || x_hi) ? hr.x : hr.x2;
     // reciprocal divisor of the first derivative taken AT row j / column i of the tile
-    auto rdy_at = [&](int j) -> double { const int yy = ybase + j; return (yy == 0 || yy == ny - 1) ? hr.y : hr.y2; };
-    auto rdx_at = [&](int i) -> double { const int xx = xbase + i; return (xx == 0 || xx == nx - 1) ? hr.x : hr.x2; };
-    const double rdy_jl = rdy_at(jl), rdy_jh = rdy_at(jh), rdy_jc = rdy_at(jc);
-    const double rdx_il = rdx_at(il), rdx_ih = rdx_at(ih);
+    auto rdy_at = [&](int j) -> Dv<FAST> { const int yy = ybase + j; return (yy == 0 || yy == ny - 1) ? hr.y : hr.y2; };
+    auto rdx_at = [&](int i) -> Dv<FAST> { const int xx = xbase + i; return (xx == 0 || xx == nx - 1) ? hr.x : hr.x2; };
+    const Dv<FAST> rdy_jl = rdy_at(jl), rdy_jh = rdy_at(jh), rdy_jc = rdy_at(jc);
+    const Dv<FAST> rdx_il = rdx_at(il), rdx_ih = rdx_at(ih);
     const int o_cc = jc * HM_PW + ic;
     const int o_hc = jh * HM_PW + ic, o_lc = jl * HM_PW + ic;     // rows jh / jl, column ic
     const int o_ch = jc * HM_PW + ih, o_cl = jc * HM_PW + il;     // row jc, columns ih / il
@@ -708,39 +741,30 @@ hessian_march_kernel(const float *__restrict__ g, float *__restrict__ vmax, unsi
                 __syncthreads();                  // entries read before their ring slots can be re-used
             }
         }
-        // fetch plane z+3 for the next step while this one computes
-        const int zn = zclamp(z + 3);
-        const bool fetch = (z + 1 < zc1) && (zn != zclamp(z + 2));
-        float r0 = 0.0f, r1 = 0.0f;
-        if (fetch) {
-            const float *src = g + (i64)zn * sz;
-            r0 = src[off0];
-            if (off1 >= 0) r1 = src[off1];
-        }
         bool m = false;
         float h[6];
         if (valid) {
             const int gz = gz0 + z;
             const bool z_lo = (gz == 0), z_hi = (gz == gnz - 1);
-            const float *Pm2 = sp + (zclamp(z - 2) & (HM_SLOTS - 1)) * HM_PLANE;
-            const float *Pm1 = sp + (zclamp(z - 1) & (HM_SLOTS - 1)) * HM_PLANE;
-            const float *P0 = sp + (z & (HM_SLOTS - 1)) * HM_PLANE;
-            const float *Pp1 = sp + (zclamp(z + 1) & (HM_SLOTS - 1)) * HM_PLANE;
-            const float *Pp2 = sp + (zclamp(z + 2) & (HM_SLOTS - 1)) * HM_PLANE;
-            const double rdz = (z_lo || z_hi) ? hr.z : hr.z2;
+            const float *Pm2 = sp + HM_SLOT(zclamp(z - 2)) * HM_PLANE;
+            const float *Pm1 = sp + HM_SLOT(zclamp(z - 1)) * HM_PLANE;
+            const float *P0 = sp + HM_SLOT(z) * HM_PLANE;
+            const float *Pp1 = sp + HM_SLOT(zclamp(z + 1)) * HM_PLANE;
+            const float *Pp2 = sp + HM_SLOT(zclamp(z + 2)) * HM_PLANE;
+            const Dv<FAST> rdz = (z_lo || z_hi) ? hr.z : hr.z2;
             // first derivatives along Z at planes z-1, z, z+1 use planes (z-2,z), (z-1,z+1), (z,z+2)
-            const double rdz_m1 = (gz - 1 == 0) ? hr.z : hr.z2;                      // plane z-1 (exists when !z_lo)
-            const double rdz_0 = rdz;
-            const double rdz_p1 = (gz + 1 == gnz - 1) ? hr.z : hr.z2;                // plane z+1 (exists when !z_hi)
+            const Dv<FAST> rdz_m1 = (gz - 1 == 0) ? hr.z : hr.z2;                      // plane z-1 (exists when !z_lo)
+            const Dv<FAST> rdz_0 = rdz;
+            const Dv<FAST> rdz_p1 = (gz + 1 == gnz - 1) ? hr.z : hr.z2;                // plane z+1 (exists when !z_hi)
             // h_zz: outer sites are z+1 (or z at the top face) and z-1 (or z at the bottom face)
-            const float gz_hi = z_hi ? div_c(P0[o_cc] - Pm1[o_cc], rdz_0) : div_c(Pp2[o_cc] - P0[o_cc], rdz_p1);
-            const float gz_lo = z_lo ? div_c(Pp1[o_cc] - P0[o_cc], rdz_0) : div_c(P0[o_cc] - Pm2[o_cc], rdz_m1);
-            h[0] = div_c(gz_hi - gz_lo, rdz);
-            h[1] = div_c(div_c(Pp1[o_hc] - Pm1[o_hc], rdz_0) - div_c(Pp1[o_lc] - Pm1[o_lc], rdz_0), rdy);
-            h[2] = div_c(div_c(Pp1[o_ch] - Pm1[o_ch], rdz_0) - div_c(Pp1[o_cl] - Pm1[o_cl], rdz_0), rdx);
-            h[3] = div_c(div_c(P0[o_hc + HM_PW] - P0[o_hc - HM_PW], rdy_jh) - div_c(P0[o_lc + HM_PW] - P0[o_lc - HM_PW], rdy_jl), rdy);
-            h[4] = div_c(div_c(P0[o_ch + HM_PW] - P0[o_ch - HM_PW], rdy_jc) - div_c(P0[o_cl + HM_PW] - P0[o_cl - HM_PW], rdy_jc), rdx);
-            h[5] = div_c(div_c(P0[o_ch + 1] - P0[o_ch - 1], rdx_ih) - div_c(P0[o_cl + 1] - P0[o_cl - 1], rdx_il), rdx);
+            const float gz_hi = z_hi ? rdz_0.div(P0[o_cc] - Pm1[o_cc]) : rdz_p1.div(Pp2[o_cc] - P0[o_cc]);
+            const float gz_lo = z_lo ? rdz_0.div(Pp1[o_cc] - P0[o_cc]) : rdz_m1.div(P0[o_cc] - Pm2[o_cc]);
+            h[0] = rdz.div(gz_hi - gz_lo);
+            h[1] = rdy.div(rdz_0.div(Pp1[o_hc] - Pm1[o_hc]) - rdz_0.div(Pp1[o_lc] - Pm1[o_lc]));
+            h[2] = rdx.div(rdz_0.div(Pp1[o_ch] - Pm1[o_ch]) - rdz_0.div(Pp1[o_cl] - Pm1[o_cl]));
+            h[3] = rdy.div(rdy_jh.div(P0[o_hc + HM_PW] - P0[o_hc - HM_PW]) - rdy_jl.div(P0[o_lc + HM_PW] - P0[o_lc - HM_PW]));
+            h[4] = rdx.div(rdy_jc.div(P0[o_ch + HM_PW] - P0[o_ch - HM_PW]) - rdy_jc.div(P0[o_cl + HM_PW] - P0[o_cl - HM_PW]));
+            h[5] = rdx.div(rdx_ih.div(P0[o_ch + 1] - P0[o_ch - 1]) - rdx_il.div(P0[o_cl + 1] - P0[o_cl - 1]));
             const float fsq = frob_sq_of(h);
             if (MODE == 0) {
 #pragma unroll
@@ -755,12 +779,11 @@ hessian_march_kernel(const float *__restrict__ g, float *__restrict__ vmax, unsi
             // append the masked voxels of this wave to the queue (one LDS atomic per wave)
             const unsigned long long bal = __ballot(m);
             const int lane = tid & 63;
-            // masks &= h_mask as a bit mask: this wave owns exactly one 64-voxel word of the row
+            // h_mask of this scale as a bit mask: this wave owns exactly one 64-voxel word of the row.  Every
+            // scale writes its own slot (no read-modify-write on the critical path); nl_filter_finish ANDs them.
             if (lane == 0 && y < ny) {
-                const unsigned long long inrow = (nx - (xbase + 2) >= 64) ? ~0ull : ((1ull << (nx - (xbase + 2))) - 1ull);
                 unsigned long long *wp = cmask64 + ((i64)z * ny + y) * wpr + tx;
-                const unsigned long long old = *wp, upd = old & (bal | ~inrow);
-                if (upd != old) *wp = upd;
+                *wp = vp.mask_rmw ? (*wp & bal) : bal;
             }
             if (bal) {
                 const int leader = __builtin_ctzll(bal);
@@ -777,10 +800,21 @@ hessian_march_kernel(const float *__restrict__ g, float *__restrict__ vmax, unsi
                 }
             }
         }
-        if (fetch) {
-            float *dst = sp + (zn & (HM_SLOTS - 1)) * HM_PLANE;
-            dst[tid] = r0;
-            if (off1 >= 0) dst[tid + NT] = r1;
+        // plane z+3 (in flight since HM_DEPTH steps) lands in the ring; plane z+3+HM_DEPTH takes its place in flight
+        if (z + 3 <= pmax) {
+            float *dst = sp + HM_SLOT((z + 3)) * HM_PLANE;
+            dst[tid] = ra[0];
+            if (off1 >= 0) dst[tid + NT] = rb[0];
+        }
+#pragma unroll
+        for (int d = 0; d + 1 < HM_DEPTH; ++d) { ra[d] = ra[d + 1]; rb[d] = rb[d + 1]; }
+        {
+            const int pz = z + 3 + HM_DEPTH;
+            if (pz <= pmax) {
+                const float *src = g + (i64)pz * sz;
+                ra[HM_DEPTH - 1] = src[off0];
+                if (off1 >= 0) rb[HM_DEPTH - 1] = src[off1];
+            }
         }
         __syncthreads();
     }
@@ -823,27 +857,41 @@ hessian_march_kernel(const float *__restrict__ g, float *__restrict__ vmax, unsi
 // vesselness * masks (filtering.py:926); counts voxels > 0 on the owned planes.
 // The cumulative mask is a bit mask: one 64-bit word per 64 consecutive x of a row (row pitch `wpr` words).
 __global__ void __launch_bounds__(256)
-finish_kernel(float *__restrict__ vmax, const unsigned long long *__restrict__ cmask64, int wpr, VolGeom v, i64 z0, i64 z1,
-              unsigned long long *__restrict__ npos) {
-    const i64 rows = (z1 - z0) * v.ny;
-    const i64 waves = rows * wpr;
-    const i64 stride = ((i64)gridDim.x * blockDim.x) >> 6;
-    const int lane = threadIdx.x & 63;
+finish_kernel(float *__restrict__ vmax, const unsigned long long *__restrict__ cmask64, int nslots, i64 slot_words, int wpr,
+              VolGeom v, i64 z0, i64 z1, unsigned long long *__restrict__ npos) {
+    // one thread = 4 consecutive x of one row (they share a mask word); rows are padded to a multiple of 4 here
+    const i64 qpr = (v.nx + 3) / 4;                                    // quads per row
+    const i64 total = (z1 - z0) * v.ny * qpr;
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    const bool vec = (v.nx & 3) == 0;
     unsigned long long cnt = 0;
-    for (i64 w = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < waves; w += stride) {
-        const i64 row = w / wpr;
-        const int seg = (int)(w % wpr);
-        const i64 x = (i64)seg * 64 + lane;
-        if (x < v.nx) {
-            const unsigned long long bits = cmask64[(z0 * v.ny + row) * wpr + seg];
-            const i64 i = (z0 * v.ny + row) * v.nx + x;
-            float val = vmax[i];
-            if (!((bits >> lane) & 1ull)) { val = 0.0f; vmax[i] = 0.0f; }
-            if (val > 0.0f) cnt++;
+    for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+        const i64 row = t / qpr;
+        const i64 x0 = (t % qpr) * 4;
+        unsigned long long bits = ~0ull;
+        for (int k = 0; k < nslots; ++k) bits &= cmask64[k * slot_words + (z0 * v.ny + row) * wpr + (x0 >> 6)];
+        const unsigned int b4 = (unsigned int)(bits >> (x0 & 63)) & 0xFu;
+        float *p = vmax + (z0 * v.ny + row) * v.nx + x0;
+        if (vec) {
+            float4 val = *reinterpret_cast<float4 *>(p);
+            if (b4 != 0xFu) {
+                if (!(b4 & 1u)) val.x = 0.0f;
+                if (!(b4 & 2u)) val.y = 0.0f;
+                if (!(b4 & 4u)) val.z = 0.0f;
+                if (!(b4 & 8u)) val.w = 0.0f;
+                *reinterpret_cast<float4 *>(p) = val;
+            }
+            cnt += (val.x > 0.0f) + (val.y > 0.0f) + (val.z > 0.0f) + (val.w > 0.0f);
+        } else {
+            for (int q = 0; q < 4 && x0 + q < v.nx; ++q) {
+                float val = p[q];
+                if (!((b4 >> q) & 1u)) { val = 0.0f; p[q] = 0.0f; }
+                if (val > 0.0f) cnt++;
+            }
         }
     }
     cnt = wave_sum_u64(cnt);
-    if (lane == 0 && cnt) atomicAdd(npos, cnt);
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(npos, cnt);
 }
 
 // filtering.py:964-966: mask = f > thr; binary_opening (6-conn cross, border_value 0); f * mask.
@@ -1029,22 +1077,34 @@ zero_at_roots_kernel(const int *__restrict__ L, int *__restrict__ area, i64 n) {
 __global__ void __launch_bounds__(256)
 area_count_kernel(const int *__restrict__ L, int *__restrict__ area, i64 nx, i64 nrows) {
     const i64 segs_per_row = (nx + 63) / 64;
-    const i64 wave = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const i64 nwaves = nrows * segs_per_row;
+    const i64 wstride = ((i64)gridDim.x * blockDim.x) >> 6;
     const int lane = threadIdx.x & 63;
-    if (wave >= nrows * segs_per_row) return;
-    const i64 row = wave / segs_per_row, seg = wave % segs_per_row;
-    const i64 x = seg * 64 + lane;
-    const bool inb = x < nx;
-    const int r = inb ? L[row * nx + x] : -1;
-    const bool s = r >= 0;
-    const unsigned long long bal = __ballot(s);
-    if (!s) return;
-    // run leader = lane whose left neighbour is not set; it adds the run length
-    const bool leader = (lane == 0) || !((bal >> (lane - 1)) & 1ull);
-    if (leader) {
-        const unsigned long long rest = ~(bal >> lane);            // first zero above lane ends the run
-        const int len = rest ? __builtin_ctzll(rest) : (64 - lane);
-        atomicAdd(&area[r], len);
+    for (i64 wave = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6; wave < nwaves; wave += wstride) {
+        const i64 row = wave / segs_per_row, seg = wave % segs_per_row;
+        const i64 x = seg * 64 + lane;
+        const int r = (x < nx) ? L[row * nx + x] : -1;
+        const unsigned long long bal = __ballot(r >= 0);
+        if (!bal) continue;                                            // wave-uniform
+        // run leader = set lane whose left neighbour is not set; it carries the run length
+        const bool leader = (r >= 0) && ((lane == 0) || !((bal >> (lane - 1)) & 1ull));
+        int len = 0;
+        if (leader) {
+            const unsigned long long rest = ~(bal >> lane);            // first zero above lane ends the run
+            len = rest ? __builtin_ctzll(rest) : (64 - lane);
+        }
+        // one atomic per DISTINCT root in the segment (runs of one object are usually neighbours)
+        unsigned long long todo = __ballot(leader);
+        while (todo) {
+            const int first = __builtin_ctzll(todo);
+            const int r0 = __shfl(r, first, 64);
+            const bool mine = leader && (r == r0);
+            int sum = mine ? len : 0;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+            if (lane == first) atomicAdd(&area[r0], sum);
+            todo &= ~__ballot(mine);
+        }
     }
 }
 __global__ void __launch_bounds__(256)
@@ -1175,9 +1235,35 @@ static int hm_ty() {
     if (v < 0) { const char *e = getenv("NELLIE_HM_TY"); v = (e && atoi(e) == 16) ? 16 : 8; }
     return v;
 }
-static HessR hessr(const nl_ctx *c) {
-    return HessR{1.0 / (double)c->hz, 1.0 / (double)c->hy, 1.0 / (double)c->hx,
-                 1.0 / (double)c->hz2, 1.0 / (double)c->hy2, 1.0 / (double)c->hx2};
+static Dv<true> dv_fast(float d) { return Dv<true>{d, (float)(1.0 / (double)d)}; }
+static Dv<false> dv_exact(float d) { return Dv<false>{1.0 / (double)d}; }
+static HessDv<true> hessdv_fast(const nl_ctx *c) {
+    return HessDv<true>{dv_fast(c->hz), dv_fast(c->hy), dv_fast(c->hx), dv_fast(c->hz2), dv_fast(c->hy2), dv_fast(c->hx2)};
+}
+static HessDv<false> hessdv_exact(const nl_ctx *c) {
+    return HessDv<false>{dv_exact(c->hz), dv_exact(c->hy), dv_exact(c->hx), dv_exact(c->hz2), dv_exact(c->hy2), dv_exact(c->hx2)};
+}
+// Exhaustive proof that the 3-instruction division is exact for the six divisors in use.
+static int check_fast_div(nl_ctx *c, char *err, size_t errlen) {
+    const float ds[6] = {c->hz, c->hy, c->hx, c->hz2, c->hy2, c->hx2};
+    unsigned int *bad = (unsigned int *)c->d_small + 64;
+    NL_HIP(hipMemsetAsync(bad, 0, 6 * 4, c->stream));
+    for (int k = 0; k < 6; ++k) {
+        const Dv<true> dv = dv_fast(ds[k]);
+        divcheck_kernel<<<(1u << 23) / 256, 256, 0, c->stream>>>(dv.d, dv.y, bad + k);
+    }
+    NL_CHECK_LAUNCH();
+    unsigned int *h = (unsigned int *)c->h_small + 64;
+    NL_HIP(hipMemcpyAsync(h, bad, 6 * 4, hipMemcpyDeviceToHost, c->stream));
+    NL_HIP(hipStreamSynchronize(c->stream));
+    c->fast_div = 1;
+    for (int k = 0; k < 6; ++k) {
+        const bool normal = ds[k] > 1e-30f && ds[k] < 1e30f;
+        if (h[k] || !normal) c->fast_div = 0;
+    }
+    const char *e = getenv("NELLIE_EXACT_DIV");
+    if (e && atoi(e)) c->fast_div = 0;
+    return NL_OK;
 }
 static HessP hessp(const nl_ctx *c) { return HessP{c->hz, c->hy, c->hx, c->hz2, c->hy2, c->hx2}; }
 
@@ -1276,7 +1362,7 @@ extern "C" int nl_ctx_create(nl_ctx **out, int device, int64_t nzl, int64_t ny, 
     bool ok = true;
     for (int k = 0; k < 4 && ok; ++k) ok = alloc((void **)&c->f[k], (size_t)n * 4);
     // m[0] doubles as the cumulative bit mask of Filter: one 64-bit word per 64 x-voxels of a row
-    const size_t mask_words = (size_t)nzl * ny * ((nx + 63) / 64);
+    const size_t mask_words = (size_t)NL_MASK_SLOTS * nzl * ny * ((nx + 63) / 64);
     for (int k = 0; k < 3 && ok; ++k) ok = alloc((void **)&c->m[k], (k == 0 && mask_words * 8 > (size_t)n) ? mask_words * 8 : (size_t)n);
     if (ok) ok = alloc(&c->d_small, 1 << 16);
     c->blk_cap = (n + SCAN_CHUNK - 1) / SCAN_CHUNK + 1;
@@ -1349,7 +1435,7 @@ extern "C" int nl_filter_load(nl_ctx *c, const void *host, int dtype, int64_t z0
     if (rc) return rc;
     // vesselness = zeros, masks = ones (filtering.py:807-808)
     NL_HIP(hipMemsetAsync(c->f[c->i_vmax], 0, (size_t)c->n * 4, c->stream));
-    NL_HIP(hipMemsetAsync(c->m[0], 0xFF, (size_t)c->nzl * c->ny * ((c->nx + 63) / 64) * 8, c->stream));
+    c->mask_slots_used = 0;
     NL_HIP(hipStreamSynchronize(c->stream));
     return NL_OK;
 }
@@ -1390,7 +1476,7 @@ extern "C" int nl_filter_begin(nl_ctx *c, char *err, size_t errlen) {
     }
     NL_CHECK_LAUNCH();
     NL_HIP(hipMemsetAsync(c->f[c->i_vmax], 0, (size_t)c->n * 4, c->stream));
-    NL_HIP(hipMemsetAsync(c->m[0], 0xFF, (size_t)c->nzl * c->ny * ((c->nx + 63) / 64) * 8, c->stream));
+    c->mask_slots_used = 0;
     return NL_OK;
 }
 
@@ -1584,6 +1670,11 @@ extern "C" int nl_hessian_stats(nl_ctx *c, const double spacing[3], float *max_a
         return nl_fail(err, errlen, NL_EINVAL, "Shape of array too small to calculate a numerical gradient, at least (edge_order + 1) elements are required.");
     c->hz = (float)spacing[0]; c->hy = (float)spacing[1]; c->hx = (float)spacing[2];
     c->hz2 = (float)(2.0 * spacing[0]); c->hy2 = (float)(2.0 * spacing[1]); c->hx2 = (float)(2.0 * spacing[2]);
+    if (!c->have_spacing || c->chk_spacing[0] != spacing[0] || c->chk_spacing[1] != spacing[1] || c->chk_spacing[2] != spacing[2]) {
+        int rcx = check_fast_div(c, err, errlen);
+        if (rcx) return rcx;
+        c->chk_spacing[0] = spacing[0]; c->chk_spacing[1] = spacing[1]; c->chk_spacing[2] = spacing[2];
+    }
     c->have_spacing = 1;
     unsigned int *res = (unsigned int *)c->d_small;
     NL_HIP(hipMemsetAsync(res, 0, 16, c->stream));
@@ -1592,14 +1683,14 @@ extern "C" int nl_hessian_stats(nl_ctx *c, const double spacing[3], float *max_a
         const int ntx = (int)((c->nx + HM_TX - 1) / HM_TX), nty = (int)((c->ny + 15) / 16);
         const int nzc = (int)((c->own_hi - c->own_lo + HM_ZCHUNK - 1) / HM_ZCHUNK);
         VessP vp{};
-        if (hm_ty() == 8) {
-            const int nty8 = (int)((c->ny + 7) / 8);
-            hessian_march_kernel<0, 8><<<(unsigned)(ntx * nty8 * nzc), HMCfg<8>::NT, HMCfg<8>::lds_floats(0) * 4, c->stream>>>(
-                c->f[c->i_gauss], nullptr, nullptr, 0, geom(c), hessr(c), vp, (int)c->own_lo, (int)c->own_hi, ntx, nty8, res, nullptr);
-        } else {
-            hessian_march_kernel<0, 16><<<(unsigned)(ntx * nty * nzc), HMCfg<16>::NT, HMCfg<16>::lds_floats(0) * 4, c->stream>>>(
-                c->f[c->i_gauss], nullptr, nullptr, 0, geom(c), hessr(c), vp, (int)c->own_lo, (int)c->own_hi, ntx, nty, res, nullptr);
-        }
+#define NL_LAUNCH_STATS(TYV, FASTV, HR)                                                                                   \
+        hessian_march_kernel<0, TYV, FASTV><<<(unsigned)(ntx * (int)((c->ny + TYV - 1) / TYV) * nzc), HMCfg<TYV>::NT,     \
+                                              HMCfg<TYV>::lds_floats(0) * 4, c->stream>>>(                                \
+            c->f[c->i_gauss], nullptr, nullptr, 0, geom(c), HR, vp, (int)c->own_lo, (int)c->own_hi, ntx,                  \
+            (int)((c->ny + TYV - 1) / TYV), res, nullptr)
+        if (hm_ty() == 8) { if (c->fast_div) NL_LAUNCH_STATS(8, true, hessdv_fast(c)); else NL_LAUNCH_STATS(8, false, hessdv_exact(c)); }
+        else { if (c->fast_div) NL_LAUNCH_STATS(16, true, hessdv_fast(c)); else NL_LAUNCH_STATS(16, false, hessdv_exact(c)); }
+#undef NL_LAUNCH_STATS
         NL_CHECK_LAUNCH();
     }
     unsigned int *h = (unsigned int *)c->h_small;
@@ -1623,27 +1714,32 @@ extern "C" int nl_vesselness_step(nl_ctx *c, float gamma_sq, float alpha_sq, flo
     if (!c->have_spacing) return nl_fail(err, errlen, NL_ESTATE, "nl_vesselness_step before nl_hessian_stats");
     unsigned long long *d_cnt = (unsigned long long *)c->d_small;
     NL_HIP(hipMemsetAsync(d_cnt, 0, 8, c->stream));
-    VessP vp{gamma_sq, alpha_sq, beta_sq, use_thr, thr, c->frob_max_abs, c->frob_max_finite};
+    VessP vp{gamma_sq, alpha_sq, beta_sq, use_thr, thr, c->frob_max_abs, c->frob_max_finite, 0};
     {
         ProfScope ps(c, "vesselness");
         const int ntx = (int)((c->nx + HM_TX - 1) / HM_TX), nty = (int)((c->ny + 15) / 16);
         const int nzc = (int)((c->own_hi - c->own_lo + HM_ZCHUNK - 1) / HM_ZCHUNK);
         static bool attr_set = false;
         if (!attr_set) {
-            NL_HIP(hipFuncSetAttribute((const void *)hessian_march_kernel<1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, HMCfg<16>::lds_floats(1) * 4));
-            NL_HIP(hipFuncSetAttribute((const void *)hessian_march_kernel<1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, HMCfg<8>::lds_floats(1) * 4));
+            NL_HIP(hipFuncSetAttribute((const void *)hessian_march_kernel<1, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, HMCfg<16>::lds_floats(1) * 4));
+            NL_HIP(hipFuncSetAttribute((const void *)hessian_march_kernel<1, 16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, HMCfg<16>::lds_floats(1) * 4));
+            NL_HIP(hipFuncSetAttribute((const void *)hessian_march_kernel<1, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, HMCfg<8>::lds_floats(1) * 4));
+            NL_HIP(hipFuncSetAttribute((const void *)hessian_march_kernel<1, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, HMCfg<8>::lds_floats(1) * 4));
             attr_set = true;
         }
         const int wpr = (int)((c->nx + 63) / 64);
-        unsigned long long *cm = (unsigned long long *)c->m[0];
-        if (hm_ty() == 8) {
-            const int nty8 = (int)((c->ny + 7) / 8);
-            hessian_march_kernel<1, 8><<<(unsigned)(ntx * nty8 * nzc), HMCfg<8>::NT, HMCfg<8>::lds_floats(1) * 4, c->stream>>>(
-                c->f[c->i_gauss], c->f[c->i_vmax], cm, wpr, geom(c), hessr(c), vp, (int)c->own_lo, (int)c->own_hi, ntx, nty8, nullptr, d_cnt);
-        } else {
-            hessian_march_kernel<1, 16><<<(unsigned)(ntx * nty * nzc), HMCfg<16>::NT, HMCfg<16>::lds_floats(1) * 4, c->stream>>>(
-                c->f[c->i_gauss], c->f[c->i_vmax], cm, wpr, geom(c), hessr(c), vp, (int)c->own_lo, (int)c->own_hi, ntx, nty, nullptr, d_cnt);
-        }
+        const i64 slot_words = c->nzl * c->ny * wpr;
+        int slot = c->mask_slots_used;
+        if (slot >= NL_MASK_SLOTS) { slot = NL_MASK_SLOTS - 1; vp.mask_rmw = 1; } else c->mask_slots_used++;
+        unsigned long long *cm = (unsigned long long *)c->m[0] + (i64)slot * slot_words;
+#define NL_LAUNCH_VESS(TYV, FASTV, HR)                                                                                    \
+        hessian_march_kernel<1, TYV, FASTV><<<(unsigned)(ntx * (int)((c->ny + TYV - 1) / TYV) * nzc), HMCfg<TYV>::NT,     \
+                                              HMCfg<TYV>::lds_floats(1) * 4, c->stream>>>(                                \
+            c->f[c->i_gauss], c->f[c->i_vmax], cm, wpr, geom(c), HR, vp, (int)c->own_lo, (int)c->own_hi, ntx,             \
+            (int)((c->ny + TYV - 1) / TYV), nullptr, d_cnt)
+        if (hm_ty() == 8) { if (c->fast_div) NL_LAUNCH_VESS(8, true, hessdv_fast(c)); else NL_LAUNCH_VESS(8, false, hessdv_exact(c)); }
+        else { if (c->fast_div) NL_LAUNCH_VESS(16, true, hessdv_fast(c)); else NL_LAUNCH_VESS(16, false, hessdv_exact(c)); }
+#undef NL_LAUNCH_VESS
         NL_CHECK_LAUNCH();
     }
     if (mask_count) {
@@ -1662,9 +1758,9 @@ extern "C" int nl_filter_finish(nl_ctx *c, int64_t *n_positive, char *err, size_
     {
         ProfScope ps(c, "finish");
         const int wpr = (int)((c->nx + 63) / 64);
-        const i64 waves = (c->own_hi - c->own_lo) * c->ny * wpr;
-        finish_kernel<<<grid1d(waves * 64), 256, 0, c->stream>>>(c->f[c->i_vmax], (const unsigned long long *)c->m[0], wpr, geom(c),
-                                                               c->own_lo, c->own_hi, d_cnt);
+        const i64 quads = (c->own_hi - c->own_lo) * c->ny * ((c->nx + 3) / 4);
+        finish_kernel<<<grid1d(quads, 256, 256 * 16), 256, 0, c->stream>>>(c->f[c->i_vmax], (const unsigned long long *)c->m[0], c->mask_slots_used,
+                                                               c->nzl * c->ny * wpr, wpr, geom(c), c->own_lo, c->own_hi, d_cnt);
         NL_CHECK_LAUNCH();
     }
     NL_HIP(hipMemcpyAsync(c->h_small, d_cnt, 8, hipMemcpyDeviceToHost, c->stream));
@@ -1825,7 +1921,7 @@ extern "C" int nl_label_run(nl_ctx *c, int has_thr, float thr, int64_t min_area,
     if ((rc = run_ccl<1, 26>(c, mA, L, err, errlen))) return rc;
     zero_at_roots_kernel<<<grid1d(n), 256, 0, c->stream>>>(L, aux, n);
     NL_CHECK_LAUNCH();
-    area_count_kernel<<<(unsigned)((waves * 64 + 255) / 256), 256, 0, c->stream>>>(L, aux, c->nx, nrows);
+    area_count_kernel<<<grid1d(waves * 64, 256, 256 * 16), 256, 0, c->stream>>>(L, aux, c->nx, nrows);
     NL_CHECK_LAUNCH();
     const int ma = (int)(min_area > 0x7fffffff ? 0x7fffffff : min_area);
     keep_large_kernel<<<grid1d(n), 256, 0, c->stream>>>(L, aux, mB, ma, n);
@@ -1861,6 +1957,15 @@ extern "C" int nl_label_store(nl_ctx *c, int32_t *host, int64_t z0, int64_t z1, 
 }
 
 // ---------------------------------------------------------------------------------- debug -------
+extern "C" int nl_ctx_info(nl_ctx *c, const char *key, double *value) {
+    if (!c || !key || !value) return NL_EINVAL;
+    if (!strcmp(key, "fast_div")) *value = c->fast_div;
+    else if (!strcmp(key, "hessian_tile_rows")) *value = hm_ty();
+    else if (!strcmp(key, "device_bytes")) *value = (double)nl_ctx_bytes(c->nzl, c->ny, c->nx);
+    else return NL_EINVAL;
+    return NL_OK;
+}
+
 extern "C" int nl_debug_eig_frangi(nl_ctx *c, const float *h6, int64_t n, int impl, float alpha_sq, float beta_sq,
                                    float gamma_sq, float *out4, char *err, size_t errlen) {
     NL_ENTER(c);

@@ -40,8 +40,11 @@ struct nl_ctx {
     float hz = 1, hy = 1, hx = 1;            // float32(h)
     float hz2 = 2, hy2 = 2, hx2 = 2;         // float32(2.0*h)
     int have_spacing = 0;
+    int fast_div = 0;                        // 3-instruction division proven exact for the spacings in use
+    double chk_spacing[3] = {0, 0, 0};
     float frob_max_abs = 1.0f, frob_max_finite = 0.0f;
     int frangi_ready = 0;
+    int mask_slots_used = 0;   // per-scale h_mask bit planes written since the frame began
 
     hipEvent_t t0 = nullptr, t1 = nullptr;
     int prof_on = 0;

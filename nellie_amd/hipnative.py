@@ -69,6 +69,7 @@ _PLAIN = {
     "nl_prof_enable": (_int, [_p, _int]),
     "nl_prof_get": (_int, [_p, C.c_char_p, C.POINTER(_f64), C.POINTER(_i64)]),
     "nl_prof_reset": (_int, [_p]),
+    "nl_ctx_info": (_int, [_p, C.c_char_p, C.POINTER(_f64)]),
 }
 ALL_SYMBOLS = sorted(list(_PROTOS) + list(_PLAIN))
 
@@ -340,6 +341,12 @@ class Context:
         ms = _f32(0)
         self._call("nl_timer_end_ms", C.byref(ms))
         return float(ms.value)
+
+    def info(self, key: str) -> float:
+        v = _f64(0)
+        if self.lib.cdll.nl_ctx_info(self._h, key.encode(), C.byref(v)) != NL_OK:
+            raise KeyError(key)
+        return float(v.value)
 
     def prof_enable(self, on=True):
         self.lib.cdll.nl_prof_enable(self._h, 1 if on else 0)
