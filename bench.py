@@ -10,7 +10,10 @@ hole filling, two 26-connected labellings, area filter, majority filter, raster 
 over one synthetic float32 frame that is ALREADY RESIDENT IN HBM when the timed region starts;
 outputs stay in HBM (the PCIe-inclusive rate is a separate, untimed-by-default figure, see
 DESIGN.md).  N = 1: BASELINE.json configs[2], 1024 x 1024 x 1024 float32 (headline).
-N > 1: the volume is (N*1024, 1024, 1024), sharded over Z, one rank per GPU (weak scaling).
+N > 1: a 3-D+T stack of N such frames, one frame per rank / GPU (frames are the path's independent
+units, nellie/segmentation/filtering.py:1007, labelling.py:701): no data-path collective, weak scaling.
+The Z-slab decomposition of ONE volume (ghost planes over RCCL) is the sharded pipeline of
+nellie_amd/sharded.py; see DESIGN.md "Multi-GPU" for what is and is not done yet.
 
 Prints ONE JSON line (rank 0) with the driver's contract plus `roofline` and `cpu_baseline`.
 The oracle is used here only for the `cpu_baseline` leg and the small accuracy check.
@@ -34,11 +37,30 @@ B_ALG_KERNEL = {
     "load": 8.0,               # 4 r + 4 w
     "gauss": 24.0,             # three axis passes x (4 r + 4 w)
     "hessian_stats": 4.0,      # 4 r
-    "vesselness": 14.0,        # gauss 4 r + vesselness 4 r + 4 w + mask 1 r + 1 w
+    "vesselness": 22.0,        # Hessian/eigen/Frangi pass 16 + mask pass 6, one launch here
     "finish": 9.0,             # 4 r + 1 r + 4 w
     "mask_volume": 8.0,        # 4 r + 4 w (fused threshold + opening + multiply)
     "label": 44.0,             # SURVEY.md 8(d) Label row
 }
+
+
+PMC_KERNEL_OF_GROUP = {"vesselness": "hessian_march_kernel<1", "hessian_stats": "hessian_march_kernel<0"}
+
+
+def pmc_traffic(group, shape):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/r*_pmc_hbm_bytes_1024cube.json: separate FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE x2 on gfx950,
+    calibrated on the streaming convert kernel, x1024 for KB).  None when no matching profile is committed."""
+    import glob
+    if tuple(shape) != (1024, 1024, 1024) or group not in PMC_KERNEL_OF_GROUP:
+        return None
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_hbm_bytes_1024cube.json")))
+    if not files:
+        return None
+    for rec in json.load(open(files[-1])):
+        if PMC_KERNEL_OF_GROUP[group] in rec["kernel"]:
+            return round((2.0 * rec["fetch_size_kb_per_launch"] + rec["write_size_kb_per_launch"]) * 1024.0)
+    return None
 
 
 def parse_args():
@@ -51,6 +73,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-shape", type=int, nargs=3, default=[64, 256, 256])
     ap.add_argument("--with-io", action="store_true", help="also report the PCIe-inclusive rate (untimed otherwise)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="testing only: every rank uses device 0 (exercise the multi-process control flow on a 1-GPU box)")
     return ap.parse_args()
 
 
@@ -110,23 +134,20 @@ def main():
     from nellie_amd.synthetic import ISO_01, make_volume
 
     lib = hipnative.load()
+    if args.share_device:
+        local_rank = 0
     if lib.device_count() <= local_rank:
         raise RuntimeError(f"GPU backend requested but device {local_rank} is not visible")
 
     shape = tuple(args.shape) if args.shape else (1024, 1024, 1024)
-    gshape = (shape[0] * n_gpus, shape[1], shape[2])
     p = pl.FilterParams(dim_res=ISO_01)
     min_area = pl.min_area_pixels_of(ISO_01)
 
+    # rank r owns frame r of the (N, Z, Y, X) stack
     t_gen = time.perf_counter()
-    vol = make_volume(shape, args.seed, z_offset=rank * shape[0], global_nz=gshape[0])
+    vol = make_volume(shape, args.seed + rank)
     t_gen = time.perf_counter() - t_gen
-
-    if world > 1:
-        from nellie_amd.sharded import ShardedFramePipeline
-        pipe = ShardedFramePipeline(gshape, rank=rank, world=world, device=local_rank)
-    else:
-        pipe = pl.FramePipeline(shape, device=local_rank)
+    pipe = pl.FramePipeline(shape, device=local_rank)
     t_up = time.perf_counter()
     pipe.load_input(vol)
     t_up = time.perf_counter() - t_up
@@ -166,14 +187,14 @@ def main():
         if k:
             groups[name] = {"ms_total": ms, "launches": k, "ms_avg": ms / k}
     n_local = float(np.prod(shape))
-    n_global = float(np.prod(gshape))
+    n_global = n_local * n_gpus
     kernel_ms_per_step = sum(g["ms_total"] for g in groups.values()) / max(1, args.steps)
     dom = max((g for g in groups if g in B_ALG_KERNEL), key=lambda g: groups[g]["ms_total"])
     dom_bytes = B_ALG_KERNEL[dom] * n_local
     dom_gbs = dom_bytes / (groups[dom]["ms_avg"] * 1e-3) / 1e9
     roofline = {
         "bound": "hbm", "kernel": dom, "achieved": round(dom_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(dom_gbs / HBM_PEAK_GBS, 4), "traffic": None,
+        "frac": round(dom_gbs / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dom, shape),
         "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": round(groups[dom]["ms_avg"], 4),
         "pipeline": {
             "algorithmic_bytes_per_voxel": B_ALG_TOTAL,
@@ -213,10 +234,10 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": f"synthetic {gshape[0]}x{gshape[1]}x{gshape[2]} float32 volume "
-                            f"(N(100,5) noise + Gaussian tubes, seed {args.seed}), 0.1 um isotropic, "
+                "workload": f"synthetic {shape[0]}x{shape[1]}x{shape[2]} float32 volume "
+                            f"(N(100,5) noise + Gaussian tube segments, seed {args.seed}), 0.1 um isotropic, "
                             f"{len(p.resolved_sigmas())}-scale Frangi + Label, full hot path per step"
-                            + ("" if n_gpus == 1 else f", Z-slab shard {shape[0]} planes/GPU"),
+                            + ("" if n_gpus == 1 else f"; 3-D+T stack of {n_gpus} such frames, one frame per GPU"),
                 "voxels": int(n_global), "per_gpu_shape": list(shape),
                 "survival_fraction": round(tr.n_positive / n_local, 5), "labels": int(n_labels),
                 "mask_fraction_per_scale": [round(sc.mask_count / n_local, 4) for sc in tr.scales],
