@@ -1227,6 +1227,8 @@ relabel_kernel(const int *__restrict__ L, const int *__restrict__ newid, int *__
     }
 }
 
+#include "label_runs.inc"
+
 // =================================================================================================
 // host side: context, launch helpers, C-ABI
 // =================================================================================================
@@ -1331,6 +1333,7 @@ extern "C" int nl_ctx_destroy(nl_ctx *c) {
     if (c->d_small) hipFree(c->d_small);
     if (c->d_input) hipFree(c->d_input);
     if (c->d_blk) hipFree(c->d_blk);
+    if (c->d_rows) hipFree(c->d_rows);
     if (c->h_small) hipHostFree(c->h_small);
     if (c->t0) hipEventDestroy(c->t0);
     if (c->t1) hipEventDestroy(c->t1);
@@ -1372,7 +1375,14 @@ extern "C" int nl_ctx_create(nl_ctx **out, int device, int64_t nzl, int64_t ny, 
     for (int k = 0; k < 4 && ok; ++k) ok = alloc((void **)&c->f[k], (size_t)n * 4);
     // m[0] doubles as the cumulative bit mask of Filter: one 64-bit word per 64 x-voxels of a row
     const size_t mask_words = (size_t)NL_MASK_SLOTS * nzl * ny * ((nx + 63) / 64);
-    for (int k = 0; k < 3 && ok; ++k) ok = alloc((void **)&c->m[k], (k == 0 && mask_words * 8 > (size_t)n) ? mask_words * 8 : (size_t)n);
+    const size_t plane_words_bytes = (size_t)nzl * ny * ((nx + 63) / 64) * 8;     // one bit plane
+    for (int k = 0; k < 3 && ok; ++k) {
+        size_t bytes = (size_t)n;
+        if (k == 0 && mask_words * 8 > bytes) bytes = mask_words * 8;
+        if (plane_words_bytes > bytes) bytes = plane_words_bytes;
+        ok = alloc((void **)&c->m[k], bytes);
+    }
+    if (ok) ok = alloc((void **)&c->d_rows, ((size_t)nzl * ny + 2) * 2 * 4);
     if (ok) ok = alloc(&c->d_small, 1 << 16);
     c->blk_cap = (n + SCAN_CHUNK - 1) / SCAN_CHUNK + 1;
     if (ok) ok = alloc(&c->d_blk, (size_t)c->blk_cap * 4);
@@ -1899,11 +1909,10 @@ static int run_ccl(nl_ctx *c, const uint8_t *mask, int *L, char *err, size_t err
     return NL_OK;
 }
 
-extern "C" int nl_label_run(nl_ctx *c, int has_thr, float thr, int64_t min_area, int fill_holes, int64_t *n_labels,
+// Voxel-level variant (first implementation): kept as the fallback for rows longer than 65535 voxels or
+// pathological masks with more than N/2 runs, and as an A/B reference (NELLIE_LABEL_VOXEL=1).
+static int label_run_voxels(nl_ctx *c, int has_thr, float thr, int64_t min_area, int fill_holes, int64_t *n_labels,
                             char *err, size_t errlen) {
-    NL_ENTER(c);
-    if (!c->frangi_ready) return nl_fail(err, errlen, NL_ESTATE, "nl_label_run before a Frangi volume exists");
-    if (c->nzl != c->gnz) return nl_fail(err, errlen, NL_EINVAL, "nl_label_run works on a whole volume (use the sharded entry points for slabs)");
     // buffers: frangi = f[i_vmax]; the other three float volumes serve as int32 scratch
     int free_idx[3], nf = 0;
     for (int k = 0; k < 4; ++k) if (k != c->i_vmax) free_idx[nf++] = k;
@@ -1955,6 +1964,132 @@ extern "C" int nl_label_run(nl_ctx *c, int has_thr, float thr, int64_t min_area,
     NL_HIP(hipMemcpyAsync(c->h_small, d_total, 8, hipMemcpyDeviceToHost, c->stream));
     NL_HIP(hipStreamSynchronize(c->stream));
     if (n_labels) *n_labels = (int64_t)(*(unsigned long long *)c->h_small);
+    c->i_labels = free_idx[2];
+    return NL_OK;
+}
+
+
+// exclusive scan of n u32 values (in -> out); returns nothing, total = out[n-1] + in[n-1]
+static int scan_excl_u32(nl_ctx *c, const unsigned int *in, unsigned int *out, i64 n, char *err, size_t errlen) {
+    const i64 nblk = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    unsigned int *blk = (unsigned int *)c->d_blk;
+    unsigned long long *d_total = (unsigned long long *)c->d_small + 16;
+    chunk_sum_kernel<<<(unsigned)nblk, 256, 0, c->stream>>>(in, n, blk);
+    NL_CHECK_LAUNCH();
+    blk_scan_kernel<<<1, 1024, 0, c->stream>>>(blk, nblk, d_total);
+    NL_CHECK_LAUNCH();
+    chunk_scan_kernel<<<(unsigned)nblk, 256, 0, c->stream>>>(in, out, n, blk);
+    NL_CHECK_LAUNCH();
+    return NL_OK;
+}
+
+struct RunSet { RunRec *runs; int *parent; unsigned int *row_off; i64 nruns; };
+
+// runs of `bits` (or of its complement) + union-find over them, flattened
+template <int CONN>
+static int build_components(nl_ctx *c, const unsigned long long *bits, int invert, RunSet &rs, i64 cap, bool *overflow,
+                            char *err, size_t errlen) {
+    const i64 nrows = c->nzl * c->ny;
+    const int wpr = (int)((c->nx + 63) / 64);
+    unsigned int *counts = c->d_rows, *row_off = c->d_rows + (nrows + 2);
+    NL_HIP(hipMemsetAsync(counts + nrows, 0, 4, c->stream));
+    rl_count_kernel<<<(unsigned)((nrows + 255) / 256), 256, 0, c->stream>>>(bits, invert, counts, nrows, wpr, (int)c->nx);
+    NL_CHECK_LAUNCH();
+    int rc = scan_excl_u32(c, counts, row_off, nrows + 1, err, errlen);
+    if (rc) return rc;
+    NL_HIP(hipMemcpyAsync(c->h_small, row_off + nrows, 4, hipMemcpyDeviceToHost, c->stream));
+    NL_HIP(hipStreamSynchronize(c->stream));
+    rs.nruns = (i64)(*(unsigned int *)c->h_small);
+    rs.row_off = row_off;
+    *overflow = rs.nruns > cap;
+    if (*overflow || rs.nruns == 0) return NL_OK;
+    rl_emit_kernel<<<(unsigned)((nrows + 255) / 256), 256, 0, c->stream>>>(bits, invert, row_off, rs.runs, rs.parent, nrows, wpr, (int)c->nx);
+    NL_CHECK_LAUNCH();
+    const unsigned g = (unsigned)((rs.nruns + 255) / 256);
+    rl_union_kernel<CONN><<<g, 256, 0, c->stream>>>(rs.runs, row_off, rs.parent, rs.nruns, (int)c->ny);
+    NL_CHECK_LAUNCH();
+    ccl_flatten_kernel<<<grid1d(rs.nruns), 256, 0, c->stream>>>(rs.parent, rs.nruns);
+    NL_CHECK_LAUNCH();
+    return NL_OK;
+}
+
+extern "C" int nl_label_run(nl_ctx *c, int has_thr, float thr, int64_t min_area, int fill_holes, int64_t *n_labels,
+                            char *err, size_t errlen) {
+    NL_ENTER(c);
+    if (!c->frangi_ready) return nl_fail(err, errlen, NL_ESTATE, "nl_label_run before a Frangi volume exists");
+    if (c->nzl != c->gnz) return nl_fail(err, errlen, NL_EINVAL, "nl_label_run works on a whole volume (use the sharded entry points for slabs)");
+    static int force_voxel = -1;
+    if (force_voxel < 0) { const char *e = getenv("NELLIE_LABEL_VOXEL"); force_voxel = (e && atoi(e)) ? 1 : 0; }
+    if (force_voxel || c->nx > 65535) return label_run_voxels(c, has_thr, thr, min_area, fill_holes, n_labels, err, errlen);
+
+    int free_idx[3], nf = 0;
+    for (int k = 0; k < 4; ++k) if (k != c->i_vmax) free_idx[nf++] = k;
+    const i64 n = c->n;
+    const i64 nrows = c->nzl * c->ny;
+    const int wpr = (int)((c->nx + 63) / 64);
+    const i64 nwords = nrows * wpr;
+    const i64 cap = n / 2;                                    // runs that fit the scratch volumes
+    RunSet rs;
+    rs.runs = (RunRec *)c->f[free_idx[0]];                    // 8 B x cap  = 4N bytes
+    rs.parent = (int *)c->f[free_idx[1]];                     // 4 B x cap  = 2N bytes
+    int *aux = rs.parent + cap;                               // 4 B x cap  = 2N bytes (areas, then new ids)
+    int *out = (int *)c->f[free_idx[2]];
+    unsigned long long *bitsA = (unsigned long long *)c->m[1], *bitsB = (unsigned long long *)c->m[2];
+    uint8_t *flag = c->m[0];
+    bool overflow = false;
+    int rc;
+    ProfScope ps(c, "label");
+    rl_threshold_pack_kernel<<<grid1d(nwords * 64, 256, 256 * 32), 256, 0, c->stream>>>(c->f[c->i_vmax], bitsA, has_thr, thr, (int)c->nx, nrows, wpr);
+    NL_CHECK_LAUNCH();
+    if (fill_holes) {
+        // binary_fill_holes: 6-connected background components that reach no face become foreground
+        if ((rc = build_components<6>(c, bitsA, 1, rs, cap, &overflow, err, errlen))) return rc;
+        if (overflow) return label_run_voxels(c, has_thr, thr, min_area, fill_holes, n_labels, err, errlen);
+        if (rs.nruns) {
+            const unsigned g = (unsigned)((rs.nruns + 255) / 256);
+            NL_HIP(hipMemsetAsync(flag, 0, (size_t)rs.nruns, c->stream));
+            rl_border_kernel<<<g, 256, 0, c->stream>>>(rs.runs, rs.parent, flag, rs.nruns, geom(c));
+            NL_CHECK_LAUNCH();
+            rl_fill_kernel<<<g, 256, 0, c->stream>>>(rs.runs, rs.parent, flag, bitsA, rs.nruns, wpr);
+            NL_CHECK_LAUNCH();
+        }
+    }
+    // first labelling + small-object removal
+    if ((rc = build_components<26>(c, bitsA, 0, rs, cap, &overflow, err, errlen))) return rc;
+    if (overflow) return label_run_voxels(c, has_thr, thr, min_area, fill_holes, n_labels, err, errlen);
+    NL_HIP(hipMemsetAsync(bitsB, 0, (size_t)nwords * 8, c->stream));
+    if (rs.nruns) {
+        const unsigned g = (unsigned)((rs.nruns + 255) / 256);
+        NL_HIP(hipMemsetAsync(aux, 0, (size_t)rs.nruns * 4, c->stream));
+        rl_area_kernel<<<(unsigned)((rs.nruns + RL_CHUNK - 1) / RL_CHUNK), 256, 0, c->stream>>>(rs.runs, rs.parent, aux, rs.nruns);
+        NL_CHECK_LAUNCH();
+        const int ma = (int)(min_area > 0x7fffffff ? 0x7fffffff : min_area);
+        rl_keep_kernel<<<g, 256, 0, c->stream>>>(rs.runs, rs.parent, aux, ma, bitsB, rs.nruns, wpr);
+        NL_CHECK_LAUNCH();
+    }
+    // majority smoothing, second labelling
+    majority_bits_kernel<<<(unsigned)((nwords + 255) / 256), 256, 0, c->stream>>>(bitsB, bitsA, geom(c), wpr);
+    NL_CHECK_LAUNCH();
+    if ((rc = build_components<26>(c, bitsA, 0, rs, cap, &overflow, err, errlen))) return rc;
+    if (overflow) return label_run_voxels(c, has_thr, thr, min_area, fill_holes, n_labels, err, errlen);
+    unsigned long long total = 0;
+    if (rs.nruns) {
+        const i64 nblk = (rs.nruns + SCAN_CHUNK - 1) / SCAN_CHUNK;
+        unsigned int *blk = (unsigned int *)c->d_blk;
+        unsigned long long *d_total = (unsigned long long *)c->d_small;
+        root_count_kernel<<<(unsigned)nblk, 256, 0, c->stream>>>(rs.parent, rs.nruns, blk);
+        NL_CHECK_LAUNCH();
+        blk_scan_kernel<<<1, 1024, 0, c->stream>>>(blk, nblk, d_total);
+        NL_CHECK_LAUNCH();
+        root_assign_kernel<<<(unsigned)nblk, 256, 0, c->stream>>>(rs.parent, rs.nruns, blk, aux);
+        NL_CHECK_LAUNCH();
+        NL_HIP(hipMemcpyAsync(c->h_small, d_total, 8, hipMemcpyDeviceToHost, c->stream));
+    }
+    rl_paint_kernel<<<grid1d(nrows * 64, 256, 256 * 32), 256, 0, c->stream>>>(bitsA, rs.row_off, rs.parent, aux, out, nrows, wpr, (int)c->nx);
+    NL_CHECK_LAUNCH();
+    NL_HIP(hipStreamSynchronize(c->stream));
+    if (rs.nruns) total = *(unsigned long long *)c->h_small;
+    if (n_labels) *n_labels = (int64_t)total;
     c->i_labels = free_idx[2];
     return NL_OK;
 }

@@ -35,6 +35,7 @@ struct nl_ctx {
     void *d_small = nullptr;   // scratch for reductions / histograms / weights (64 KiB)
     void *h_small = nullptr;   // pinned mirror
     void *d_blk = nullptr;     // per-block partials for scans
+    unsigned int *d_rows = nullptr;   // per-row run counts and offsets (Label on runs)
     i64 blk_cap = 0;
 
     float hz = 1, hy = 1, hx = 1;            // float32(h)
