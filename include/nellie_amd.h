@@ -146,13 +146,16 @@ int nl_set_frob_norm(nl_ctx *ctx, float max_abs, float max_finite, char *err, si
      v          = Frangi(eigvalsh(H) sorted by |.|) on h_mask, 0 elsewhere (filtering.py:574-585, 744-766)
      vesselness = maximum(vesselness, v); masks &= h_mask    (filtering.py:850-851)
    The host calls it only when the mask is non-empty (filtering.py:843-844).
-   `mask_count` (may be NULL) receives the number of owned voxels in h_mask. */
+   Planes [z0, z1) are processed (z0 = z1 = -1: the owned planes; a slab passes own +-2 so that the
+   opening of nl_mask_volume finds valid neighbours).  `mask_count` (may be NULL) receives the number
+   of OWNED voxels in h_mask. */
 int nl_vesselness_step(nl_ctx *ctx, float gamma_sq, float alpha_sq, float beta_sq,
-                       int use_thr, float thr, int64_t *mask_count, char *err, size_t errlen);
+                       int use_thr, float thr, int64_t z0, int64_t z1, int64_t *mask_count,
+                       char *err, size_t errlen);
 
-/* vesselness * masks (filtering.py:926) -> NL_FIELD_FRANGI.  n_positive = number of owned
-   voxels > 0 (the `sum > 0` test of filtering.py:1016-1017). */
-int nl_filter_finish(nl_ctx *ctx, int64_t *n_positive, char *err, size_t errlen);
+/* vesselness * masks (filtering.py:926) -> NL_FIELD_FRANGI on planes [z0, z1) (-1, -1: owned).
+   n_positive = number of OWNED voxels > 0 (the `sum > 0` test of filtering.py:1016-1017). */
+int nl_filter_finish(nl_ctx *ctx, int64_t z0, int64_t z1, int64_t *n_positive, char *err, size_t errlen);
 
 /* filtering.py:964-966: mask = frangi > thr; binary_opening (6-connected cross, one
    iteration, border 0); frangi *= mask. */
@@ -163,6 +166,28 @@ int nl_filter_store(nl_ctx *ctx, float *host, int64_t z0, int64_t z1, char *err,
 
 /* Debug / test access: D2H of the current Gaussian volume, local planes [z0, z1). */
 int nl_gauss_store(nl_ctx *ctx, float *host, int64_t z0, int64_t z1, char *err, size_t errlen);
+
+/* ------------------------------------------------------------------ Z-slabs ----------- */
+/* The reference has no distributed code; these entry points are new functionality: a
+   volume too large for one device is cut into Z-slabs, one context per GPU, ghost planes exchanged
+   between Z neighbours over RCCL/xGMI, scalars and histograms all-reduced. */
+
+/* D2H / H2D of arbitrary local planes of a float field (NL_FIELD_GAUSS / NL_FIELD_FRANGI): the
+   host-mediated exchange used by tests and by communicators without RCCL. */
+int nl_planes_get(nl_ctx *ctx, int field, int64_t z0, int64_t z1, float *host, char *err, size_t errlen);
+int nl_planes_put(nl_ctx *ctx, int field, int64_t z0, int64_t z1, const float *host, char *err, size_t errlen);
+
+/* RCCL communicator: rank 0 calls nl_comm_unique_id (128 bytes), distributes it out of band, every rank
+   calls nl_comm_init on its context. */
+int nl_comm_unique_id(char *id128, char *err, size_t errlen);
+int nl_comm_init(nl_ctx *ctx, int world, int rank, const char *id128, char *err, size_t errlen);
+
+/* Exchange `depth` ghost planes of a float field with both Z neighbours (ncclSend/ncclRecv in one group,
+   asynchronous on the context stream). */
+int nl_halo_exchange(nl_ctx *ctx, int field, int64_t depth, char *err, size_t errlen);
+
+/* All-reduce of a few host values through RCCL: dtype 0 = int64, 1 = float32; op 0 = sum, 1 = min, 2 = max. */
+int nl_allreduce(nl_ctx *ctx, void *host_inout, int64_t count, int dtype, int op, char *err, size_t errlen);
 
 /* ------------------------------------------------------------------ Label ------------- */
 

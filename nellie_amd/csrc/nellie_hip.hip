@@ -3,6 +3,7 @@
 // below is meant to round exactly where numpy/scipy round.
 #include <stdarg.h>
 #include <stdlib.h>
+#include <rccl/rccl.h>
 #include "nl_common.h"
 
 #define NL_MASK_SLOTS 8      // per-scale mask bit planes kept before falling back to read-modify-write
@@ -549,6 +550,7 @@ struct VessP {
     float thr;
     float max_abs, max_finite;
     int mask_rmw;            // 1: AND into the slot (more scales than mask slots)
+    int cnt_lo, cnt_hi;      // planes whose masked voxels are counted (the owned ones)
 };
 
 __global__ void __launch_bounds__(256)
@@ -805,7 +807,7 @@ hessian_march_kernel(const float *__restrict__ g, float *__restrict__ vmax, unsi
 #pragma unroll
                     for (int k = 0; k < 6; ++k) q_h[k * HM_QCAP + slot] = h[k];
                     q_i[slot] = (int)((i64)z * sz + (i64)y * nx + x);
-                    cnt++;
+                    if (z >= vp.cnt_lo && z < vp.cnt_hi) cnt++;
                 }
             }
         }
@@ -867,7 +869,7 @@ hessian_march_kernel(const float *__restrict__ g, float *__restrict__ vmax, unsi
 // The cumulative mask is a bit mask: one 64-bit word per 64 consecutive x of a row (row pitch `wpr` words).
 __global__ void __launch_bounds__(256)
 finish_kernel(float *__restrict__ vmax, const unsigned long long *__restrict__ cmask64, int nslots, i64 slot_words, int wpr,
-              VolGeom v, i64 z0, i64 z1, unsigned long long *__restrict__ npos) {
+              VolGeom v, i64 z0, i64 z1, i64 cnt_lo, i64 cnt_hi, unsigned long long *__restrict__ npos) {
     // one thread = 4 consecutive x of one row (they share a mask word); rows are padded to a multiple of 4 here
     const i64 qpr = (v.nx + 3) / 4;                                    // quads per row
     const i64 total = (z1 - z0) * v.ny * qpr;
@@ -877,6 +879,8 @@ finish_kernel(float *__restrict__ vmax, const unsigned long long *__restrict__ c
     for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
         const i64 row = t / qpr;
         const i64 x0 = (t % qpr) * 4;
+        const i64 zloc = z0 + row / v.ny;
+        const bool counted = zloc >= cnt_lo && zloc < cnt_hi;
         unsigned long long bits = ~0ull;
         for (int k = 0; k < nslots; ++k) bits &= cmask64[k * slot_words + (z0 * v.ny + row) * wpr + (x0 >> 6)];
         const unsigned int b4 = (unsigned int)(bits >> (x0 & 63)) & 0xFu;
@@ -890,12 +894,12 @@ finish_kernel(float *__restrict__ vmax, const unsigned long long *__restrict__ c
                 if (!(b4 & 8u)) val.w = 0.0f;
                 *reinterpret_cast<float4 *>(p) = val;
             }
-            cnt += (val.x > 0.0f) + (val.y > 0.0f) + (val.z > 0.0f) + (val.w > 0.0f);
+            if (counted) cnt += (val.x > 0.0f) + (val.y > 0.0f) + (val.z > 0.0f) + (val.w > 0.0f);
         } else {
             for (int q = 0; q < 4 && x0 + q < v.nx; ++q) {
                 float val = p[q];
                 if (!((b4 >> q) & 1u)) { val = 0.0f; p[q] = 0.0f; }
-                if (val > 0.0f) cnt++;
+                if (counted && val > 0.0f) cnt++;
             }
         }
     }
@@ -1337,6 +1341,7 @@ extern "C" int nl_ctx_destroy(nl_ctx *c) {
     if (c->h_small) hipHostFree(c->h_small);
     if (c->t0) hipEventDestroy(c->t0);
     if (c->t1) hipEventDestroy(c->t1);
+    if (c->comm) ncclCommDestroy((ncclComm_t)c->comm);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
     return NL_OK;
@@ -1728,16 +1733,18 @@ extern "C" int nl_set_frob_norm(nl_ctx *c, float max_abs, float max_finite, char
 }
 
 extern "C" int nl_vesselness_step(nl_ctx *c, float gamma_sq, float alpha_sq, float beta_sq, int use_thr, float thr,
-                                  int64_t *mask_count, char *err, size_t errlen) {
+                                  int64_t z0, int64_t z1, int64_t *mask_count, char *err, size_t errlen) {
     NL_ENTER(c);
+    if (z0 < 0 && z1 < 0) { z0 = c->own_lo; z1 = c->own_hi; }
+    if (z0 < 0 || z1 > c->nzl || z0 >= z1) return nl_fail(err, errlen, NL_EINVAL, "bad plane range [%lld,%lld)", (i64)z0, (i64)z1);
     if (!c->have_spacing) return nl_fail(err, errlen, NL_ESTATE, "nl_vesselness_step before nl_hessian_stats");
     unsigned long long *d_cnt = (unsigned long long *)c->d_small;
     NL_HIP(hipMemsetAsync(d_cnt, 0, 8, c->stream));
-    VessP vp{gamma_sq, alpha_sq, beta_sq, use_thr, thr, c->frob_max_abs, c->frob_max_finite, 0};
+    VessP vp{gamma_sq, alpha_sq, beta_sq, use_thr, thr, c->frob_max_abs, c->frob_max_finite, 0, (int)c->own_lo, (int)c->own_hi};
     {
         ProfScope ps(c, "vesselness");
         const int ntx = (int)((c->nx + HM_TX - 1) / HM_TX), nty = (int)((c->ny + 15) / 16);
-        const int nzc = (int)((c->own_hi - c->own_lo + HM_ZCHUNK - 1) / HM_ZCHUNK);
+        const int nzc = (int)((z1 - z0 + HM_ZCHUNK - 1) / HM_ZCHUNK);
         static bool attr_set = false;
         if (!attr_set) {
             NL_HIP(hipFuncSetAttribute((const void *)hessian_march_kernel<1, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, HMCfg<16>::lds_floats(1) * 4));
@@ -1754,7 +1761,7 @@ extern "C" int nl_vesselness_step(nl_ctx *c, float gamma_sq, float alpha_sq, flo
 #define NL_LAUNCH_VESS(TYV, FASTV, HR)                                                                                    \
         hessian_march_kernel<1, TYV, FASTV><<<(unsigned)(ntx * (int)((c->ny + TYV - 1) / TYV) * nzc), HMCfg<TYV>::NT,     \
                                               HMCfg<TYV>::lds_floats(1) * 4, c->stream>>>(                                \
-            c->f[c->i_gauss], c->f[c->i_vmax], cm, wpr, geom(c), HR, vp, (int)c->own_lo, (int)c->own_hi, ntx,             \
+            c->f[c->i_gauss], c->f[c->i_vmax], cm, wpr, geom(c), HR, vp, (int)z0, (int)z1, ntx,             \
             (int)((c->ny + TYV - 1) / TYV), nullptr, d_cnt)
         if (hm_ty() == 8) { if (c->fast_div) NL_LAUNCH_VESS(8, true, hessdv_fast(c)); else NL_LAUNCH_VESS(8, false, hessdv_exact(c)); }
         else { if (c->fast_div) NL_LAUNCH_VESS(16, true, hessdv_fast(c)); else NL_LAUNCH_VESS(16, false, hessdv_exact(c)); }
@@ -1769,17 +1776,19 @@ extern "C" int nl_vesselness_step(nl_ctx *c, float gamma_sq, float alpha_sq, flo
     return NL_OK;
 }
 
-extern "C" int nl_filter_finish(nl_ctx *c, int64_t *n_positive, char *err, size_t errlen) {
+extern "C" int nl_filter_finish(nl_ctx *c, int64_t z0, int64_t z1, int64_t *n_positive, char *err, size_t errlen) {
     NL_ENTER(c);
+    if (z0 < 0 && z1 < 0) { z0 = c->own_lo; z1 = c->own_hi; }
+    if (z0 < 0 || z1 > c->nzl || z0 >= z1) return nl_fail(err, errlen, NL_EINVAL, "bad plane range [%lld,%lld)", (i64)z0, (i64)z1);
     unsigned long long *d_cnt = (unsigned long long *)c->d_small;
     NL_HIP(hipMemsetAsync(d_cnt, 0, 8, c->stream));
     const i64 plane = c->ny * c->nx;
     {
         ProfScope ps(c, "finish");
         const int wpr = (int)((c->nx + 63) / 64);
-        const i64 quads = (c->own_hi - c->own_lo) * c->ny * ((c->nx + 3) / 4);
+        const i64 quads = (z1 - z0) * c->ny * ((c->nx + 3) / 4);
         finish_kernel<<<grid1d(quads, 256, 256 * 16), 256, 0, c->stream>>>(c->f[c->i_vmax], (const unsigned long long *)c->m[0], c->mask_slots_used,
-                                                               c->nzl * c->ny * wpr, wpr, geom(c), c->own_lo, c->own_hi, d_cnt);
+                                                               c->nzl * c->ny * wpr, wpr, geom(c), z0, z1, c->own_lo, c->own_hi, d_cnt);
         NL_CHECK_LAUNCH();
     }
     NL_HIP(hipMemcpyAsync(c->h_small, d_cnt, 8, hipMemcpyDeviceToHost, c->stream));
@@ -1823,6 +1832,100 @@ extern "C" int nl_filter_store(nl_ctx *c, float *host, int64_t z0, int64_t z1, c
 extern "C" int nl_gauss_store(nl_ctx *c, float *host, int64_t z0, int64_t z1, char *err, size_t errlen) {
     NL_ENTER(c);
     return store_planes(c, c->f[c->i_gauss], host, 4, z0, z1, err, errlen);
+}
+
+// ------------------------------------------------------------------------------ slab helpers ----
+static float *field_ptr(nl_ctx *c, int field) {
+    if (field == NL_FIELD_GAUSS) return c->f[c->i_gauss];
+    if (field == NL_FIELD_FRANGI) return c->f[c->i_vmax];
+    return nullptr;
+}
+
+extern "C" int nl_planes_get(nl_ctx *c, int field, int64_t z0, int64_t z1, float *host, char *err, size_t errlen) {
+    NL_ENTER(c);
+    float *p = field_ptr(c, field);
+    if (!p) return nl_fail(err, errlen, NL_EINVAL, "nl_planes_get: field %d has no volume", field);
+    return store_planes(c, p, host, 4, z0, z1, err, errlen);
+}
+
+extern "C" int nl_planes_put(nl_ctx *c, int field, int64_t z0, int64_t z1, const float *host, char *err, size_t errlen) {
+    NL_ENTER(c);
+    float *p = field_ptr(c, field);
+    if (!p || !host || z0 < 0 || z1 > c->nzl || z0 >= z1) return nl_fail(err, errlen, NL_EINVAL, "nl_planes_put: bad field or plane range");
+    const i64 plane = c->ny * c->nx;
+    NL_HIP(hipMemcpyAsync(p + z0 * plane, host, (size_t)(z1 - z0) * plane * 4, hipMemcpyHostToDevice, c->stream));
+    NL_HIP(hipStreamSynchronize(c->stream));
+    return NL_OK;
+}
+
+#define NL_NCCL(expr)                                                                                  \
+    do {                                                                                               \
+        ncclResult_t r_ = (expr);                                                                      \
+        if (r_ != ncclSuccess) return nl_fail(err, errlen, NL_ECOMM, "%s: %s", #expr, ncclGetErrorString(r_)); \
+    } while (0)
+
+extern "C" int nl_comm_unique_id(char *id128, char *err, size_t errlen) {
+    if (!id128) return nl_fail(err, errlen, NL_EINVAL, "id buffer is NULL");
+    ncclUniqueId id;
+    NL_NCCL(ncclGetUniqueId(&id));
+    static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
+    memcpy(id128, &id, 128);
+    return NL_OK;
+}
+
+extern "C" int nl_comm_init(nl_ctx *c, int world, int rank, const char *id128, char *err, size_t errlen) {
+    NL_ENTER(c);
+    if (!id128 || world < 1 || rank < 0 || rank >= world) return nl_fail(err, errlen, NL_EINVAL, "bad communicator arguments");
+    ncclUniqueId id;
+    memcpy(&id, id128, 128);
+    ncclComm_t comm;
+    NL_NCCL(ncclCommInitRank(&comm, world, id, rank));
+    c->comm = comm; c->world = world; c->rank = rank;
+    return NL_OK;
+}
+
+// Ghost-plane exchange with the Z neighbours over RCCL (xGMI): this rank's first / last `depth` owned planes
+// go to the neighbour's ghost planes, and the neighbours' go into ours.  Asynchronous on the context stream.
+extern "C" int nl_halo_exchange(nl_ctx *c, int field, int64_t depth, char *err, size_t errlen) {
+    NL_ENTER(c);
+    if (!c->comm) return nl_fail(err, errlen, NL_ESTATE, "nl_halo_exchange before nl_comm_init");
+    float *p = field_ptr(c, field);
+    if (!p) return nl_fail(err, errlen, NL_EINVAL, "nl_halo_exchange: field %d has no volume", field);
+    const i64 plane = c->ny * c->nx;
+    const bool has_lo = c->rank > 0, has_hi = c->rank + 1 < c->world;
+    if (depth < 1 || depth > c->own_hi - c->own_lo || (has_lo && depth > c->own_lo) || (has_hi && depth > c->nzl - c->own_hi))
+        return nl_fail(err, errlen, NL_EINVAL, "halo depth %lld does not fit the slab (own %lld, ghosts %lld/%lld)", (i64)depth,
+                       (i64)(c->own_hi - c->own_lo), (i64)c->own_lo, (i64)(c->nzl - c->own_hi));
+    ncclComm_t comm = (ncclComm_t)c->comm;
+    ProfScope ps(c, "halo");
+    NL_NCCL(ncclGroupStart());
+    if (has_lo) {
+        NL_NCCL(ncclSend(p + c->own_lo * plane, (size_t)(depth * plane), ncclFloat, c->rank - 1, comm, c->stream));
+        NL_NCCL(ncclRecv(p + (c->own_lo - depth) * plane, (size_t)(depth * plane), ncclFloat, c->rank - 1, comm, c->stream));
+    }
+    if (has_hi) {
+        NL_NCCL(ncclSend(p + (c->own_hi - depth) * plane, (size_t)(depth * plane), ncclFloat, c->rank + 1, comm, c->stream));
+        NL_NCCL(ncclRecv(p + c->own_hi * plane, (size_t)(depth * plane), ncclFloat, c->rank + 1, comm, c->stream));
+    }
+    NL_NCCL(ncclGroupEnd());
+    return NL_OK;
+}
+
+// Small all-reduce of host values through RCCL: dtype 0 = int64, 1 = float32; op 0 = sum, 1 = min, 2 = max.
+extern "C" int nl_allreduce(nl_ctx *c, void *host_inout, int64_t count, int dtype, int op, char *err, size_t errlen) {
+    NL_ENTER(c);
+    if (!c->comm) return nl_fail(err, errlen, NL_ESTATE, "nl_allreduce before nl_comm_init");
+    const size_t es = dtype == 0 ? 8 : 4;
+    if (!host_inout || count < 1 || (size_t)count * es > (1 << 15) || dtype < 0 || dtype > 1 || op < 0 || op > 2)
+        return nl_fail(err, errlen, NL_EINVAL, "bad all-reduce arguments");
+    memcpy(c->h_small, host_inout, (size_t)count * es);
+    NL_HIP(hipMemcpyAsync(c->d_small, c->h_small, (size_t)count * es, hipMemcpyHostToDevice, c->stream));
+    const ncclRedOp_t ops[3] = {ncclSum, ncclMin, ncclMax};
+    NL_NCCL(ncclAllReduce(c->d_small, c->d_small, (size_t)count, dtype == 0 ? ncclInt64 : ncclFloat, ops[op], (ncclComm_t)c->comm, c->stream));
+    NL_HIP(hipMemcpyAsync(c->h_small, c->d_small, (size_t)count * es, hipMemcpyDeviceToHost, c->stream));
+    NL_HIP(hipStreamSynchronize(c->stream));
+    memcpy(host_inout, c->h_small, (size_t)count * es);
+    return NL_OK;
 }
 
 // ---------------------------------------------------------------------------------- Label -------

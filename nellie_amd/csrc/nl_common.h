@@ -47,6 +47,9 @@ struct nl_ctx {
     int frangi_ready = 0;
     int mask_slots_used = 0;   // per-scale h_mask bit planes written since the frame began
 
+    void *comm = nullptr;             // ncclComm_t (RCCL), set by nl_comm_init
+    int world = 1, rank = 0;
+
     hipEvent_t t0 = nullptr, t1 = nullptr;
     int prof_on = 0;
     std::map<std::string, std::vector<ProfRec>> prof;

@@ -47,8 +47,14 @@ _PROTOS = {
     "nl_sample_hist": [_p, _int, _i64, _i64, _i64, _p, _int, _p],
     "nl_hessian_stats": [_p, C.POINTER(_f64), C.POINTER(_f32), C.POINTER(_f32), C.POINTER(_int)],
     "nl_set_frob_norm": [_p, _f32, _f32],
-    "nl_vesselness_step": [_p, _f32, _f32, _f32, _int, _f32, C.POINTER(_i64)],
-    "nl_filter_finish": [_p, C.POINTER(_i64)],
+    "nl_vesselness_step": [_p, _f32, _f32, _f32, _int, _f32, _i64, _i64, C.POINTER(_i64)],
+    "nl_filter_finish": [_p, _i64, _i64, C.POINTER(_i64)],
+    "nl_planes_get": [_p, _int, _i64, _i64, _p],
+    "nl_planes_put": [_p, _int, _i64, _i64, _p],
+    "nl_comm_unique_id": [C.c_char_p],
+    "nl_comm_init": [_p, _int, _int, C.c_char_p],
+    "nl_halo_exchange": [_p, _int, _i64],
+    "nl_allreduce": [_p, _p, _i64, _int, _int],
     "nl_mask_volume": [_p, _f32],
     "nl_filter_store": [_p, _p, _i64, _i64],
     "nl_gauss_store": [_p, _p, _i64, _i64],
@@ -144,6 +150,13 @@ def load() -> _Lib:
                 "(run `python -m nellie_amd.build`); nellie_amd has no CPU fallback")
         _LIB = _Lib(LIB_PATH)
     return _LIB
+
+
+def comm_unique_id() -> bytes:
+    """128-byte RCCL unique id (rank 0 creates it and hands it to the other ranks out of band)."""
+    buf = C.create_string_buffer(128)
+    load().call("nl_comm_unique_id", buf)
+    return buf.raw
 
 
 def gpu_available() -> bool:
@@ -259,18 +272,42 @@ class Context:
     def set_frob_norm(self, max_abs, max_finite):
         self._call("nl_set_frob_norm", float(max_abs), float(max_finite))
 
-    def vesselness_step(self, gamma_sq, alpha_sq, beta_sq, thr, want_count=True):
+    def vesselness_step(self, gamma_sq, alpha_sq, beta_sq, thr, want_count=True, z0=-1, z1=-1):
         n = _i64(0)
         use = 0 if thr is None else 1
         self._call("nl_vesselness_step", float(np.float32(gamma_sq)), float(np.float32(alpha_sq)),
                    float(np.float32(beta_sq)), use, float(np.float32(0.0 if thr is None else thr)),
-                   C.byref(n) if want_count else None)
+                   int(z0), int(z1), C.byref(n) if want_count else None)
         return int(n.value)
 
-    def filter_finish(self) -> int:
+    def filter_finish(self, z0=-1, z1=-1) -> int:
         n = _i64(0)
-        self._call("nl_filter_finish", C.byref(n))
+        self._call("nl_filter_finish", int(z0), int(z1), C.byref(n))
         return int(n.value)
+
+    # ---------------------------------------------------------------- Z-slabs
+    def planes_get(self, field, z0, z1):
+        out = np.empty((z1 - z0, self.shape[1], self.shape[2]), dtype=np.float32)
+        self._call("nl_planes_get", int(field), int(z0), int(z1), _ptr(out))
+        return out
+
+    def planes_put(self, field, z0, z1, planes):
+        a = np.ascontiguousarray(planes, dtype=np.float32)
+        assert a.shape == (z1 - z0, self.shape[1], self.shape[2])
+        self._call("nl_planes_put", int(field), int(z0), int(z1), _ptr(a))
+
+    def comm_init(self, world, rank, uid: bytes):
+        assert len(uid) == 128
+        self._call("nl_comm_init", int(world), int(rank), uid)
+
+    def halo_exchange(self, field, depth):
+        self._call("nl_halo_exchange", int(field), int(depth))
+
+    def allreduce(self, arr: np.ndarray, op: str):
+        a = np.ascontiguousarray(arr)
+        assert a.dtype in (np.int64, np.float32)
+        self._call("nl_allreduce", _ptr(a), a.size, 0 if a.dtype == np.int64 else 1, {"sum": 0, "min": 1, "max": 2}[op])
+        return a
 
     def mask_volume(self, thr):
         self._call("nl_mask_volume", float(np.float32(thr)))

@@ -167,15 +167,40 @@ class FrameTrace:
 class FramePipeline:
     """One (Z, Y, X) frame on one GPU, resident in HBM across Filter and Label."""
 
-    def __init__(self, shape, device: int = 0):
-        self.shape = tuple(int(s) for s in shape)
+    def __init__(self, shape, device: int = 0, ctx=None):
+        self.shape = tuple(int(s) for s in shape)      # the GLOBAL frame shape (thresholds sample its lattice)
         if len(self.shape) != 3:
             raise ValueError("FramePipeline takes a (Z, Y, X) shape")
-        self.ctx = hipnative.Context(self.shape, device=device)
+        self.ctx = ctx if ctx is not None else hipnative.Context(self.shape, device=device)
         self.trace = FrameTrace()
 
     def close(self):
         self.ctx.close()
+
+    # ---- hooks a Z-slab pipeline overrides (nellie_amd/sharded.py); identity on a single GPU -------------
+    def _after_load(self, p):
+        pass
+
+    def _gauss_range(self, rz):
+        return 0, self.shape[0]
+
+    def _vess_range(self):
+        return -1, -1
+
+    def _reduce_minmax(self, mn, mx, npos):
+        return mn, mx, npos
+
+    def _reduce_counts(self, counts):
+        return counts
+
+    def _reduce_stats(self, max_abs, max_fsq, any_inf):
+        return max_abs, max_fsq, any_inf
+
+    def _reduce_sum(self, n):
+        return n
+
+    def _gather(self, samples):
+        return samples
 
     # ------------------------------------------------------------------ Filter
     def load_input(self, frame):
@@ -184,11 +209,11 @@ class FramePipeline:
 
     def _threshold_from_field(self, fld, strides):
         """min(triangle, otsu) over the positive lattice samples of a device field, or None if none."""
-        mn, mx, npos = self.ctx.sample_minmax(fld, strides)
+        mn, mx, npos = self._reduce_minmax(*self.ctx.sample_minmax(fld, strides))
         if npos == 0:
             return None
         edges = histogram_edges(mn, mx, 256)
-        counts = self.ctx.sample_hist(fld, strides, edges)
+        counts = self._reduce_counts(self.ctx.sample_hist(fld, strides, edges))
         return float(min_triangle_otsu(counts, edges))
 
     def compute_vesselness(self, frame, p: FilterParams, mask: bool = True):
@@ -201,7 +226,8 @@ class FramePipeline:
         if frame is None:
             ctx.filter_begin()          # restart from the frame kept resident by load_input()
         else:
-            ctx.filter_load(np.asarray(frame))
+            self._load(frame)
+        self._after_load(p)
         zr = z_ratio_of(p.dim_res)
         spacing = spacing_of(p.dim_res)
         sigmas = p.resolved_sigmas()
@@ -210,14 +236,16 @@ class FramePipeline:
         beta_sq = float(p.beta_sq)
         for sigma, delta in zip(sigmas, cascade_deltas(sigmas, zr)):
             if any(s > 0 for s in delta):
-                ctx.gauss_step(*[gaussian_weights(d) for d in delta])
+                ws = [gaussian_weights(d) for d in delta]
+                z0, z1 = self._gauss_range(0 if ws[0] is None else (len(ws[0]) - 1) // 2)
+                ctx.gauss_step(*ws, z0=z0, z1=z1)
             # gamma (filtering.py:365-380, 839-840)
             gamma = self._threshold_from_field(FIELD_GAUSS, strides)
             if gamma is None or gamma <= 0:
                 gamma = _EPS32
             gamma_sq = 2.0 * (float(gamma) ** 2)
             # Hessian statistics (filtering.py:555-562)
-            max_abs32, max_fsq32, any_inf = ctx.hessian_stats(spacing)
+            max_abs32, max_fsq32, any_inf = self._reduce_stats(*ctx.hessian_stats(spacing))
             max_abs = float(max_abs32)
             if max_abs <= 0:
                 max_abs = 1.0
@@ -241,15 +269,20 @@ class FramePipeline:
                 nonempty = bool(max_frob > thr_cmp)
             count = 0
             if nonempty:                                         # filtering.py:843-844
-                count = ctx.vesselness_step(gamma_sq, alpha_sq, beta_sq, thr_cmp)
+                vz0, vz1 = self._vess_range()
+                count = self._reduce_sum(ctx.vesselness_step(gamma_sq, alpha_sq, beta_sq, thr_cmp, z0=vz0, z1=vz1))
             self.trace.scales.append(ScaleTrace(float(sigma), float(gamma), max_abs, thr, count, not nonempty))
-        self.trace.n_positive = ctx.filter_finish()
+        vz0, vz1 = self._vess_range()
+        self.trace.n_positive = self._reduce_sum(ctx.filter_finish(vz0, vz1))
         return self.trace.n_positive
+
+    def _load(self, frame):
+        self.ctx.filter_load(np.asarray(frame))
 
     def mask_volume(self, p: FilterParams):
         """filtering.py:952-967 on the device-resident frame."""
         strides = sample_strides(self.shape, int(p.max_threshold_samples))
-        sample = self.ctx.sample_gather(FIELD_FRANGI, strides)
+        sample = self._gather(self.ctx.sample_gather(FIELD_FRANGI, strides))
         positive = sample[sample > 0]
         if positive.size == 0:
             return None
@@ -283,13 +316,13 @@ class FramePipeline:
         values = np.zeros(0, np.float32)
         found = False
         for offset in offsets:
-            sample = self.ctx.flat_sample_gather(FIELD_FRANGI, offset, step)
+            sample = self._gather(self.ctx.flat_sample_gather(FIELD_FRANGI, offset, step))
             values = sample[sample > 0]
             if values.size > 0 or step == 1:
                 found = True
                 break
         if not found:
-            full = self.ctx.flat_sample_gather(FIELD_FRANGI, 0, 1)     # rare: every strided sample empty
+            full = self._gather(self.ctx.flat_sample_gather(FIELD_FRANGI, 0, 1))     # rare: every strided sample empty
             if full.size == 0 or float(full.max()) <= 0:
                 values = values[:0]
             else:
