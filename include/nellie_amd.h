@@ -211,6 +211,18 @@ int nl_flat_sample_gather(nl_ctx *ctx, int field, int64_t offset, int64_t step,
 int nl_label_run(nl_ctx *ctx, int has_thr, float thr, int64_t min_area, int fill_holes,
                  int64_t *n_labels, char *err, size_t errlen);
 
+/* Label on Z-slabs.  The thresholded mask is 1 bit/voxel, so instead of stitching per-slab labellings
+   every rank (1) packs `frangi > thr` of its OWN planes into a GLOBAL bit mask (nl_label_pack), (2) the bit
+   planes are all-gathered (nl_label_bits_allgather over RCCL, or nl_label_bits_get/put through the host),
+   (3) the run-level labelling of labelling.py:484-509 runs on the global mask on every rank
+   (nl_label_run_global) and each rank paints only its own planes.  slab_plane0 has world+1 entries: the first
+   global plane of every rank's slab, then gnz.  Rows are (global plane * ny + y). */
+int nl_label_pack(nl_ctx *ctx, int has_thr, float thr, char *err, size_t errlen);
+int nl_label_bits_get(nl_ctx *ctx, int64_t row0, int64_t nrows, uint64_t *host, char *err, size_t errlen);
+int nl_label_bits_put(nl_ctx *ctx, int64_t row0, int64_t nrows, const uint64_t *host, char *err, size_t errlen);
+int nl_label_bits_allgather(nl_ctx *ctx, const int64_t *slab_plane0, char *err, size_t errlen);
+int nl_label_run_global(nl_ctx *ctx, int64_t min_area, int fill_holes, int64_t *n_labels, char *err, size_t errlen);
+
 /* D2H of the int32 label volume, local planes [z0, z1) (labelling.py:727-729). */
 int nl_label_store(nl_ctx *ctx, int32_t *host, int64_t z0, int64_t z1, char *err, size_t errlen);
 

@@ -1338,6 +1338,9 @@ extern "C" int nl_ctx_destroy(nl_ctx *c) {
     if (c->d_input) hipFree(c->d_input);
     if (c->d_blk) hipFree(c->d_blk);
     if (c->d_rows) hipFree(c->d_rows);
+    if (c->gbits[0]) hipFree(c->gbits[0]);
+    if (c->gbits[1]) hipFree(c->gbits[1]);
+    if (c->grows) hipFree(c->grows);
     if (c->h_small) hipHostFree(c->h_small);
     if (c->t0) hipEventDestroy(c->t0);
     if (c->t1) hipEventDestroy(c->t1);
@@ -2088,93 +2091,87 @@ static int scan_excl_u32(nl_ctx *c, const unsigned int *in, unsigned int *out, i
 
 struct RunSet { RunRec *runs; int *parent; unsigned int *row_off; i64 nruns; };
 
+// Geometry the run-level Label works on: the whole (global) volume as rows of bit-packed words.
+struct LabelGeo {
+    i64 nz, ny, nx;            // volume the masks describe (the global one for a Z-slab run)
+    i64 nrows; int wpr; i64 nwords;
+    unsigned int *rows;        // 2 x (nrows + 2) u32: run counts, run offsets
+    unsigned long long *bitsA, *bitsB;
+    i64 paint_row0, paint_row1;   // rows this context paints ...
+    int *paint_out;               // ... into this int32 buffer (row paint_row0 first)
+};
+
 // runs of `bits` (or of its complement) + union-find over them, flattened
 template <int CONN>
-static int build_components(nl_ctx *c, const unsigned long long *bits, int invert, RunSet &rs, i64 cap, bool *overflow,
-                            char *err, size_t errlen) {
-    const i64 nrows = c->nzl * c->ny;
-    const int wpr = (int)((c->nx + 63) / 64);
-    unsigned int *counts = c->d_rows, *row_off = c->d_rows + (nrows + 2);
-    NL_HIP(hipMemsetAsync(counts + nrows, 0, 4, c->stream));
-    rl_count_kernel<<<(unsigned)((nrows + 255) / 256), 256, 0, c->stream>>>(bits, invert, counts, nrows, wpr, (int)c->nx);
+static int build_components(nl_ctx *c, const LabelGeo &g, const unsigned long long *bits, int invert, RunSet &rs, i64 cap,
+                            bool *overflow, char *err, size_t errlen) {
+    unsigned int *counts = g.rows, *row_off = g.rows + (g.nrows + 2);
+    NL_HIP(hipMemsetAsync(counts + g.nrows, 0, 4, c->stream));
+    rl_count_kernel<<<(unsigned)((g.nrows + 255) / 256), 256, 0, c->stream>>>(bits, invert, counts, g.nrows, g.wpr, (int)g.nx);
     NL_CHECK_LAUNCH();
-    int rc = scan_excl_u32(c, counts, row_off, nrows + 1, err, errlen);
+    int rc = scan_excl_u32(c, counts, row_off, g.nrows + 1, err, errlen);
     if (rc) return rc;
-    NL_HIP(hipMemcpyAsync(c->h_small, row_off + nrows, 4, hipMemcpyDeviceToHost, c->stream));
+    NL_HIP(hipMemcpyAsync(c->h_small, row_off + g.nrows, 4, hipMemcpyDeviceToHost, c->stream));
     NL_HIP(hipStreamSynchronize(c->stream));
     rs.nruns = (i64)(*(unsigned int *)c->h_small);
     rs.row_off = row_off;
     *overflow = rs.nruns > cap;
     if (*overflow || rs.nruns == 0) return NL_OK;
-    rl_emit_kernel<<<(unsigned)((nrows + 255) / 256), 256, 0, c->stream>>>(bits, invert, row_off, rs.runs, rs.parent, nrows, wpr, (int)c->nx);
+    rl_emit_kernel<<<(unsigned)((g.nrows + 255) / 256), 256, 0, c->stream>>>(bits, invert, row_off, rs.runs, rs.parent, g.nrows, g.wpr, (int)g.nx);
     NL_CHECK_LAUNCH();
-    const unsigned g = (unsigned)((rs.nruns + 255) / 256);
-    rl_union_kernel<CONN><<<g, 256, 0, c->stream>>>(rs.runs, row_off, rs.parent, rs.nruns, (int)c->ny);
+    const unsigned gr = (unsigned)((rs.nruns + 255) / 256);
+    rl_union_kernel<CONN><<<gr, 256, 0, c->stream>>>(rs.runs, row_off, rs.parent, rs.nruns, (int)g.ny);
     NL_CHECK_LAUNCH();
     ccl_flatten_kernel<<<grid1d(rs.nruns), 256, 0, c->stream>>>(rs.parent, rs.nruns);
     NL_CHECK_LAUNCH();
     return NL_OK;
 }
 
-extern "C" int nl_label_run(nl_ctx *c, int has_thr, float thr, int64_t min_area, int fill_holes, int64_t *n_labels,
-                            char *err, size_t errlen) {
-    NL_ENTER(c);
-    if (!c->frangi_ready) return nl_fail(err, errlen, NL_ESTATE, "nl_label_run before a Frangi volume exists");
-    if (c->nzl != c->gnz) return nl_fail(err, errlen, NL_EINVAL, "nl_label_run works on a whole volume (use the sharded entry points for slabs)");
-    static int force_voxel = -1;
-    if (force_voxel < 0) { const char *e = getenv("NELLIE_LABEL_VOXEL"); force_voxel = (e && atoi(e)) ? 1 : 0; }
-    if (force_voxel || c->nx > 65535) return label_run_voxels(c, has_thr, thr, min_area, fill_holes, n_labels, err, errlen);
-
+// labelling.py:484-509 on a bit-packed mask (bitsA holds `frame > thr` on entry).  *overflow: more runs than scratch.
+static int label_core(nl_ctx *c, const LabelGeo &g, int64_t min_area, int fill_holes, int64_t *n_labels, bool *overflow,
+                      char *err, size_t errlen) {
     int free_idx[3], nf = 0;
     for (int k = 0; k < 4; ++k) if (k != c->i_vmax) free_idx[nf++] = k;
-    const i64 n = c->n;
-    const i64 nrows = c->nzl * c->ny;
-    const int wpr = (int)((c->nx + 63) / 64);
-    const i64 nwords = nrows * wpr;
-    const i64 cap = n / 2;                                    // runs that fit the scratch volumes
+    const i64 cap = c->n / 2;                                 // runs that fit the scratch volumes
     RunSet rs;
     rs.runs = (RunRec *)c->f[free_idx[0]];                    // 8 B x cap  = 4N bytes
     rs.parent = (int *)c->f[free_idx[1]];                     // 4 B x cap  = 2N bytes
     int *aux = rs.parent + cap;                               // 4 B x cap  = 2N bytes (areas, then new ids)
-    int *out = (int *)c->f[free_idx[2]];
-    unsigned long long *bitsA = (unsigned long long *)c->m[1], *bitsB = (unsigned long long *)c->m[2];
     uint8_t *flag = c->m[0];
-    bool overflow = false;
+    const VolGeom vg{g.nz, g.ny, g.nx, 0, g.nz};             // boundary rules of the whole volume
     int rc;
-    ProfScope ps(c, "label");
-    rl_threshold_pack_kernel<<<grid1d(nwords * 64, 256, 256 * 32), 256, 0, c->stream>>>(c->f[c->i_vmax], bitsA, has_thr, thr, (int)c->nx, nrows, wpr);
-    NL_CHECK_LAUNCH();
+    *overflow = false;
     if (fill_holes) {
         // binary_fill_holes: 6-connected background components that reach no face become foreground
-        if ((rc = build_components<6>(c, bitsA, 1, rs, cap, &overflow, err, errlen))) return rc;
-        if (overflow) return label_run_voxels(c, has_thr, thr, min_area, fill_holes, n_labels, err, errlen);
+        if ((rc = build_components<6>(c, g, g.bitsA, 1, rs, cap, overflow, err, errlen))) return rc;
+        if (*overflow) return NL_OK;
         if (rs.nruns) {
-            const unsigned g = (unsigned)((rs.nruns + 255) / 256);
+            const unsigned gr = (unsigned)((rs.nruns + 255) / 256);
             NL_HIP(hipMemsetAsync(flag, 0, (size_t)rs.nruns, c->stream));
-            rl_border_kernel<<<g, 256, 0, c->stream>>>(rs.runs, rs.parent, flag, rs.nruns, geom(c));
+            rl_border_kernel<<<gr, 256, 0, c->stream>>>(rs.runs, rs.parent, flag, rs.nruns, vg);
             NL_CHECK_LAUNCH();
-            rl_fill_kernel<<<g, 256, 0, c->stream>>>(rs.runs, rs.parent, flag, bitsA, rs.nruns, wpr);
+            rl_fill_kernel<<<gr, 256, 0, c->stream>>>(rs.runs, rs.parent, flag, g.bitsA, rs.nruns, g.wpr);
             NL_CHECK_LAUNCH();
         }
     }
     // first labelling + small-object removal
-    if ((rc = build_components<26>(c, bitsA, 0, rs, cap, &overflow, err, errlen))) return rc;
-    if (overflow) return label_run_voxels(c, has_thr, thr, min_area, fill_holes, n_labels, err, errlen);
-    NL_HIP(hipMemsetAsync(bitsB, 0, (size_t)nwords * 8, c->stream));
+    if ((rc = build_components<26>(c, g, g.bitsA, 0, rs, cap, overflow, err, errlen))) return rc;
+    if (*overflow) return NL_OK;
+    NL_HIP(hipMemsetAsync(g.bitsB, 0, (size_t)g.nwords * 8, c->stream));
     if (rs.nruns) {
-        const unsigned g = (unsigned)((rs.nruns + 255) / 256);
+        const unsigned gr = (unsigned)((rs.nruns + 255) / 256);
         NL_HIP(hipMemsetAsync(aux, 0, (size_t)rs.nruns * 4, c->stream));
         rl_area_kernel<<<(unsigned)((rs.nruns + RL_CHUNK - 1) / RL_CHUNK), 256, 0, c->stream>>>(rs.runs, rs.parent, aux, rs.nruns);
         NL_CHECK_LAUNCH();
         const int ma = (int)(min_area > 0x7fffffff ? 0x7fffffff : min_area);
-        rl_keep_kernel<<<g, 256, 0, c->stream>>>(rs.runs, rs.parent, aux, ma, bitsB, rs.nruns, wpr);
+        rl_keep_kernel<<<gr, 256, 0, c->stream>>>(rs.runs, rs.parent, aux, ma, g.bitsB, rs.nruns, g.wpr);
         NL_CHECK_LAUNCH();
     }
     // majority smoothing, second labelling
-    majority_bits_kernel<<<(unsigned)((nwords + 255) / 256), 256, 0, c->stream>>>(bitsB, bitsA, geom(c), wpr);
+    majority_bits_kernel<<<(unsigned)((g.nwords + 255) / 256), 256, 0, c->stream>>>(g.bitsB, g.bitsA, vg, g.wpr);
     NL_CHECK_LAUNCH();
-    if ((rc = build_components<26>(c, bitsA, 0, rs, cap, &overflow, err, errlen))) return rc;
-    if (overflow) return label_run_voxels(c, has_thr, thr, min_area, fill_holes, n_labels, err, errlen);
+    if ((rc = build_components<26>(c, g, g.bitsA, 0, rs, cap, overflow, err, errlen))) return rc;
+    if (*overflow) return NL_OK;
     unsigned long long total = 0;
     if (rs.nruns) {
         const i64 nblk = (rs.nruns + SCAN_CHUNK - 1) / SCAN_CHUNK;
@@ -2188,12 +2185,133 @@ extern "C" int nl_label_run(nl_ctx *c, int has_thr, float thr, int64_t min_area,
         NL_CHECK_LAUNCH();
         NL_HIP(hipMemcpyAsync(c->h_small, d_total, 8, hipMemcpyDeviceToHost, c->stream));
     }
-    rl_paint_kernel<<<grid1d(nrows * 64, 256, 256 * 32), 256, 0, c->stream>>>(bitsA, rs.row_off, rs.parent, aux, out, nrows, wpr, (int)c->nx);
+    rl_paint_kernel<<<grid1d((g.paint_row1 - g.paint_row0) * 64, 256, 256 * 32), 256, 0, c->stream>>>(
+        g.bitsA, rs.row_off, rs.parent, aux, g.paint_out, g.paint_row0, g.paint_row1, g.wpr, (int)g.nx);
     NL_CHECK_LAUNCH();
     NL_HIP(hipStreamSynchronize(c->stream));
     if (rs.nruns) total = *(unsigned long long *)c->h_small;
     if (n_labels) *n_labels = (int64_t)total;
     c->i_labels = free_idx[2];
+    return NL_OK;
+}
+
+static int label_out_index(const nl_ctx *c) {
+    int last = -1;
+    for (int k = 0; k < 4; ++k) if (k != c->i_vmax) last = k;
+    return last;
+}
+
+extern "C" int nl_label_run(nl_ctx *c, int has_thr, float thr, int64_t min_area, int fill_holes, int64_t *n_labels,
+                            char *err, size_t errlen) {
+    NL_ENTER(c);
+    if (!c->frangi_ready) return nl_fail(err, errlen, NL_ESTATE, "nl_label_run before a Frangi volume exists");
+    if (c->nzl != c->gnz) return nl_fail(err, errlen, NL_EINVAL, "nl_label_run works on a whole volume (Z-slabs: nl_label_pack / nl_label_run_global)");
+    static int force_voxel = -1;
+    if (force_voxel < 0) { const char *e = getenv("NELLIE_LABEL_VOXEL"); force_voxel = (e && atoi(e)) ? 1 : 0; }
+    if (force_voxel || c->nx > 65535) return label_run_voxels(c, has_thr, thr, min_area, fill_holes, n_labels, err, errlen);
+    LabelGeo g;
+    g.nz = c->nzl; g.ny = c->ny; g.nx = c->nx;
+    g.nrows = c->nzl * c->ny; g.wpr = (int)((c->nx + 63) / 64); g.nwords = g.nrows * g.wpr;
+    g.rows = c->d_rows;
+    g.bitsA = (unsigned long long *)c->m[1]; g.bitsB = (unsigned long long *)c->m[2];
+    g.paint_row0 = 0; g.paint_row1 = g.nrows; g.paint_out = (int *)c->f[label_out_index(c)];
+    ProfScope ps(c, "label");
+    rl_threshold_pack_kernel<<<grid1d(g.nwords * 64, 256, 256 * 32), 256, 0, c->stream>>>(c->f[c->i_vmax], g.bitsA, has_thr, thr,
+                                                                                          (int)c->nx, g.nrows, g.wpr);
+    NL_CHECK_LAUNCH();
+    bool overflow = false;
+    int rc = label_core(c, g, min_area, fill_holes, n_labels, &overflow, err, errlen);
+    if (rc) return rc;
+    if (overflow) return label_run_voxels(c, has_thr, thr, min_area, fill_holes, n_labels, err, errlen);
+    return NL_OK;
+}
+
+// ---- Z-slab Label: every rank packs the mask bits of its own planes into a GLOBAL bit mask (1 bit/voxel,
+// gnz*ny*nx/8 bytes), the bit planes are all-gathered, and the run-level labelling (cheap: it scales with the
+// number of runs, not voxels) runs redundantly on the global mask on every rank, which then paints only its own
+// planes.  Exact by construction: it IS the single-volume algorithm.
+static int ensure_global_label_buffers(nl_ctx *c, char *err, size_t errlen) {
+    const i64 grows = c->gnz * c->ny;
+    const int wpr = (int)((c->nx + 63) / 64);
+    if (!c->gbits[0]) {
+        NL_HIP(hipMalloc((void **)&c->gbits[0], (size_t)grows * wpr * 8));
+        NL_HIP(hipMalloc((void **)&c->gbits[1], (size_t)grows * wpr * 8));
+        NL_HIP(hipMalloc((void **)&c->grows, ((size_t)grows + 2) * 2 * 4));
+        if ((grows + 1 + SCAN_CHUNK - 1) / SCAN_CHUNK + 1 > c->blk_cap) {
+            hipFree(c->d_blk);
+            c->blk_cap = (grows + 1 + SCAN_CHUNK - 1) / SCAN_CHUNK + 1;
+            NL_HIP(hipMalloc(&c->d_blk, (size_t)c->blk_cap * 4));
+        }
+    }
+    return NL_OK;
+}
+
+extern "C" int nl_label_pack(nl_ctx *c, int has_thr, float thr, char *err, size_t errlen) {
+    NL_ENTER(c);
+    if (!c->frangi_ready) return nl_fail(err, errlen, NL_ESTATE, "nl_label_pack before a Frangi volume exists");
+    if (c->nx > 65535) return nl_fail(err, errlen, NL_EINVAL, "rows longer than 65535 voxels are not supported on Z-slabs");
+    int rc = ensure_global_label_buffers(c, err, errlen);
+    if (rc) return rc;
+    const int wpr = (int)((c->nx + 63) / 64);
+    const i64 own_rows = (c->own_hi - c->own_lo) * c->ny;
+    const i64 row0 = (c->gz0 + c->own_lo) * c->ny;
+    ProfScope ps(c, "label");
+    rl_threshold_pack_kernel<<<grid1d(own_rows * wpr * 64, 256, 256 * 32), 256, 0, c->stream>>>(
+        c->f[c->i_vmax] + c->own_lo * c->ny * c->nx, c->gbits[0] + row0 * wpr, has_thr, thr, (int)c->nx, own_rows, wpr);
+    NL_CHECK_LAUNCH();
+    return NL_OK;
+}
+
+// host access to bit-mask rows [row0, row0+nrows) of the global mask (tests / communicators without RCCL)
+extern "C" int nl_label_bits_get(nl_ctx *c, int64_t row0, int64_t nrows, uint64_t *host, char *err, size_t errlen) {
+    NL_ENTER(c);
+    const int wpr = (int)((c->nx + 63) / 64);
+    if (!c->gbits[0] || !host || row0 < 0 || nrows < 1 || row0 + nrows > c->gnz * c->ny) return nl_fail(err, errlen, NL_EINVAL, "bad bit-mask row range");
+    NL_HIP(hipMemcpyAsync(host, c->gbits[0] + row0 * wpr, (size_t)nrows * wpr * 8, hipMemcpyDeviceToHost, c->stream));
+    NL_HIP(hipStreamSynchronize(c->stream));
+    return NL_OK;
+}
+extern "C" int nl_label_bits_put(nl_ctx *c, int64_t row0, int64_t nrows, const uint64_t *host, char *err, size_t errlen) {
+    NL_ENTER(c);
+    const int wpr = (int)((c->nx + 63) / 64);
+    if (!c->gbits[0] || !host || row0 < 0 || nrows < 1 || row0 + nrows > c->gnz * c->ny) return nl_fail(err, errlen, NL_EINVAL, "bad bit-mask row range");
+    NL_HIP(hipMemcpyAsync(c->gbits[0] + row0 * wpr, host, (size_t)nrows * wpr * 8, hipMemcpyHostToDevice, c->stream));
+    NL_HIP(hipStreamSynchronize(c->stream));
+    return NL_OK;
+}
+
+// all-gather of the mask bit planes over RCCL: rank r broadcasts the rows of its own planes (slab_plane0[r] ..)
+extern "C" int nl_label_bits_allgather(nl_ctx *c, const int64_t *slab_plane0, char *err, size_t errlen) {
+    NL_ENTER(c);
+    if (!c->comm) return nl_fail(err, errlen, NL_ESTATE, "nl_label_bits_allgather before nl_comm_init");
+    if (!c->gbits[0] || !slab_plane0) return nl_fail(err, errlen, NL_ESTATE, "nl_label_bits_allgather before nl_label_pack");
+    const int wpr = (int)((c->nx + 63) / 64);
+    ProfScope ps(c, "halo");
+    NL_NCCL(ncclGroupStart());
+    for (int r = 0; r < c->world; ++r) {
+        const i64 p0 = slab_plane0[r], p1 = slab_plane0[r + 1];        // world + 1 entries, last = gnz
+        unsigned long long *ptr = c->gbits[0] + p0 * c->ny * wpr;
+        NL_NCCL(ncclBroadcast(ptr, ptr, (size_t)((p1 - p0) * c->ny * wpr), ncclUint64, r, (ncclComm_t)c->comm, c->stream));
+    }
+    NL_NCCL(ncclGroupEnd());
+    return NL_OK;
+}
+
+extern "C" int nl_label_run_global(nl_ctx *c, int64_t min_area, int fill_holes, int64_t *n_labels, char *err, size_t errlen) {
+    NL_ENTER(c);
+    if (!c->gbits[0]) return nl_fail(err, errlen, NL_ESTATE, "nl_label_run_global before nl_label_pack");
+    LabelGeo g;
+    g.nz = c->gnz; g.ny = c->ny; g.nx = c->nx;
+    g.nrows = c->gnz * c->ny; g.wpr = (int)((c->nx + 63) / 64); g.nwords = g.nrows * g.wpr;
+    g.rows = c->grows;
+    g.bitsA = c->gbits[0]; g.bitsB = c->gbits[1];
+    g.paint_row0 = (c->gz0 + c->own_lo) * c->ny; g.paint_row1 = (c->gz0 + c->own_hi) * c->ny;
+    g.paint_out = (int *)c->f[label_out_index(c)] + c->own_lo * c->ny * c->nx;
+    ProfScope ps(c, "label");
+    bool overflow = false;
+    int rc = label_core(c, g, min_area, fill_holes, n_labels, &overflow, err, errlen);
+    if (rc) return rc;
+    if (overflow) return nl_fail(err, errlen, NL_ENOMEM, "the global mask has more runs than this slab's scratch volumes hold [out of memory]");
     return NL_OK;
 }
 

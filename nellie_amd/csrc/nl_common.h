@@ -36,6 +36,8 @@ struct nl_ctx {
     void *h_small = nullptr;   // pinned mirror
     void *d_blk = nullptr;     // per-block partials for scans
     unsigned int *d_rows = nullptr;   // per-row run counts and offsets (Label on runs)
+    unsigned long long *gbits[2] = {nullptr, nullptr};   // Z-slab Label: GLOBAL bit masks (lazily allocated)
+    unsigned int *grows = nullptr;                       // ... and the global per-row arrays
     i64 blk_cap = 0;
 
     float hz = 1, hy = 1, hx = 1;            // float32(h)

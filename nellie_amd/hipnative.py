@@ -63,6 +63,11 @@ _PROTOS = {
     "nl_flat_sample_gather": [_p, _int, _i64, _i64, _p, _i64, C.POINTER(_i64)],
     "nl_label_run": [_p, _int, _f32, _i64, _int, C.POINTER(_i64)],
     "nl_label_store": [_p, _p, _i64, _i64],
+    "nl_label_pack": [_p, _int, _f32],
+    "nl_label_bits_get": [_p, _i64, _i64, _p],
+    "nl_label_bits_put": [_p, _i64, _i64, _p],
+    "nl_label_bits_allgather": [_p, _p],
+    "nl_label_run_global": [_p, _i64, _int, C.POINTER(_i64)],
     "nl_debug_eig_frangi": [_p, _p, _i64, _int, _f32, _f32, _f32, _p],
     "nl_timer_begin": [_p],
     "nl_timer_end_ms": [_p, C.POINTER(_f32)],
@@ -353,6 +358,28 @@ class Context:
         has = 0 if thr is None else 1
         self._call("nl_label_run", has, float(np.float32(0.0 if thr is None else thr)), int(min_area),
                    1 if fill_holes else 0, C.byref(n))
+        return int(n.value)
+
+    def label_pack(self, thr):
+        has = 0 if thr is None else 1
+        self._call("nl_label_pack", has, float(np.float32(0.0 if thr is None else thr)))
+
+    def label_bits_get(self, row0, nrows):
+        out = np.empty((nrows, (self.shape[2] + 63) // 64), dtype=np.uint64)
+        self._call("nl_label_bits_get", int(row0), int(nrows), _ptr(out))
+        return out
+
+    def label_bits_put(self, row0, words):
+        a = np.ascontiguousarray(words, dtype=np.uint64)
+        self._call("nl_label_bits_put", int(row0), a.shape[0], _ptr(a))
+
+    def label_bits_allgather(self, slab_plane0):
+        a = np.ascontiguousarray(slab_plane0, dtype=np.int64)
+        self._call("nl_label_bits_allgather", _ptr(a))
+
+    def label_run_global(self, min_area, fill_holes=True) -> int:
+        n = _i64(0)
+        self._call("nl_label_run_global", int(min_area), 1 if fill_holes else 0, C.byref(n))
         return int(n.value)
 
     def label_store(self, z0=0, z1=None, out=None):

@@ -42,6 +42,14 @@ class ThreadComm:
     def allgather(self, arr):
         return np.concatenate(self._all(np.array(arr, copy=True)))
 
+    def allgather_mask_bits(self, ctx, slab_plane0):
+        ny = ctx.shape[1]
+        p0, p1 = slab_plane0[self.rank], slab_plane0[self.rank + 1]
+        mine = ctx.label_bits_get(p0 * ny, (p1 - p0) * ny)
+        for r, words in enumerate(self._all(mine)):
+            if r != self.rank:
+                ctx.label_bits_put(slab_plane0[r] * ny, words)
+
 
 class GlooComm:
     """torch.distributed (gloo) version of the same, for the world_size-2 CPU tests."""

@@ -1,7 +1,7 @@
 """
 GPU test of the Z-slab Filter on the real HIP engine: `world` contexts on ONE device, one Python thread per
 rank, ghost planes exchanged through nl_planes_get / nl_planes_put ("fake multi-GPU").
-The concatenated slabs must equal the single-context result BIT FOR BIT (every cross-slab quantity is an
+Filter AND Label: the concatenated slabs must equal the single-context result BIT FOR BIT (every cross-slab quantity is an
 integer sum, a min or a max, or is recomputed from identical inputs).  The RCCL path differs only in how the
 same planes and scalars travel.
 """
@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _run_sharded(gshape, dr, seed, world):
-    from nellie_amd.pipeline import FilterParams
+    from nellie_amd.pipeline import FilterParams, min_area_pixels_of
     from nellie_amd.sharded import ShardedFramePipeline, slab_range
     from nellie_amd.synthetic import make_volume
     group = ThreadGroup(world)
@@ -29,7 +29,10 @@ def _run_sharded(gshape, dr, seed, world):
             own = make_volume((o1 - o0,) + tuple(gshape[1:]), seed, z_offset=o0, global_nz=gshape[0])
             pipe = ShardedFramePipeline(gshape, rank, world, lambda ctx: ThreadComm(group, rank), p)
             pipe.filter(own, p)
-            out[rank] = (pipe.download_frangi(), pipe.frangi_threshold(), [s.mask_count for s in pipe.trace.scales])
+            thr = pipe.frangi_threshold()
+            n = pipe.label(thr, min_area_pixels_of(dr))
+            out[rank] = (pipe.download_frangi(), thr, [s.mask_count for s in pipe.trace.scales],
+                         pipe.download_labels(), n)
             pipe.close()
         except Exception as exc:  # noqa: BLE001
             errs.append(exc)
@@ -58,13 +61,18 @@ def test_zslab_filter_equals_single_gpu(hip, gshape, aniso, world):
     ref = single.download_frangi()
     ref_thr = single.frangi_threshold()
     ref_counts = [s.mask_count for s in single.trace.scales]
+    ref_n = single.label(ref_thr, pl.min_area_pixels_of(dr))
+    ref_lab = single.download_labels()
     single.close()
     parts = _run_sharded(gshape, dr, 91, world)
     got = np.concatenate([p_[0] for p_ in parts])
     assert np.array_equal(got, ref), f"{int((got != ref).sum())} voxels differ"
-    for _, thr, counts in parts:
-        assert thr == ref_thr and counts == ref_counts
+    for _, thr, counts, _, n in parts:
+        assert thr == ref_thr and counts == ref_counts and n == ref_n
     assert (ref > 0).any()
+    lab = np.concatenate([p_[3] for p_ in parts])
+    assert np.array_equal(lab, ref_lab), f"{int((lab != ref_lab).sum())} label voxels differ"
+    assert ref_n >= 1
 
 
 def test_rccl_communicator_world1(hip):
