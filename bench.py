@@ -30,6 +30,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
+RESULT_HOLDER = {}
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); 6290 GB/s measured copy
 B_ALG_TOTAL = 301.0            # Filter 257 + Label 44 bytes/voxel
 # algorithmic bytes per voxel of one launch of each kernel group (DESIGN.md "Kernels")
@@ -73,6 +74,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-shape", type=int, nargs=3, default=[64, 256, 256])
     ap.add_argument("--with-io", action="store_true", help="also report the PCIe-inclusive rate (untimed otherwise)")
+    ap.add_argument("--no-zslab-check", action="store_true", help="N > 1: skip the RCCL Z-slab equality check")
+    ap.add_argument("--zslab-timeout", type=float, default=240.0)
     ap.add_argument("--share-device", action="store_true",
                     help="testing only: every rank uses device 0 (exercise the multi-process control flow on a 1-GPU box)")
     return ap.parse_args()
@@ -114,6 +117,55 @@ def accuracy_check(pl, vol, ref_fr, ref_lab):
     pipe.close()
     return {"frangi_within_tol": ok, "frangi_max_norm_err": float(err.max() / scale) if scale else 0.0,
             "labels_bit_exact_given_same_frangi": lab_ok}
+
+
+def zslab_check(dist, rank, world, local_rank, gshape=None):
+    """
+    Z-slab decomposition of ONE volume across the ranks (nellie_amd/sharded.py): ghost planes, all-reduces and the
+    mask bit planes travel over RCCL/xGMI.  Every rank checks its own slab against a single-GPU run of the same
+    volume, bit for bit.  Small volume: this is a correctness + plumbing check on real hardware, not the metric.
+    """
+    import torch
+    from nellie_amd import hipnative
+    from nellie_amd import pipeline as pl
+    from nellie_amd.sharded import RcclComm, ShardedFramePipeline, slab_range
+    from nellie_amd.synthetic import ISO_01, make_volume
+    gshape = gshape or (48 * world, 192, 256)
+    p = pl.FilterParams(dim_res=ISO_01)
+    min_area = pl.min_area_pixels_of(ISO_01)
+    box = [hipnative.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+
+    def host_gather(a):
+        out = [None] * world
+        dist.all_gather_object(out, np.asarray(a))
+        return np.concatenate(out)
+
+    o0, o1 = slab_range(gshape[0], world, rank)
+    vol = make_volume(gshape, 4242)
+    pipe = ShardedFramePipeline(gshape, rank, world, lambda ctx: RcclComm(ctx, world, rank, box[0], host_gather), p,
+                                device=local_rank)
+    pipe.load_input(vol[o0:o1])
+    t0 = time.perf_counter()
+    pipe.filter(None, p)
+    thr = pipe.frangi_threshold()
+    n = pipe.label(thr, min_area)
+    pipe.ctx.sync()
+    ms = (time.perf_counter() - t0) * 1e3
+    fr, lab = pipe.download_frangi(), pipe.download_labels()
+    halo_ms, halo_n = pipe.ctx.prof_get("halo")
+    pipe.close()
+    single = pl.FramePipeline(gshape, device=local_rank)
+    single.filter(vol, p)
+    ok_fr = bool(np.array_equal(single.download_frangi()[o0:o1], fr))
+    single.label(single.frangi_threshold(), min_area)
+    ok_lab = bool(np.array_equal(single.download_labels()[o0:o1], lab))
+    single.close()
+    flags = torch.tensor([int(ok_fr), int(ok_lab)], dtype=torch.int64)
+    dist.all_reduce(flags, op=dist.ReduceOp.MIN)
+    return {"volume": list(gshape), "world": world, "halo_planes": pipe.halo, "labels": int(n),
+            "frangi_equal_to_single_gpu": bool(flags[0]), "labels_equal_to_single_gpu": bool(flags[1]),
+            "first_pass_ms": round(ms, 1), "transport": "RCCL ncclSend/ncclRecv + ncclAllReduce + ncclBroadcast"}
 
 
 def main():
@@ -220,13 +272,13 @@ def main():
     fast_div = int(pipe.ctx.info("fast_div"))
     pipe.close()
 
-    cpu = None
-    acc = None
-    if rank == 0 and not args.no_cpu_baseline:
-        cpu, (cvol, cfr, clab) = cpu_baseline(tuple(args.cpu_shape), 1234)
-        acc = accuracy_check(pl, cvol, cfr, clab)
-
+    out = None
     if rank == 0:
+        cpu = None
+        acc = None
+        if not args.no_cpu_baseline:
+            cpu, (cvol, cfr, clab) = cpu_baseline(tuple(args.cpu_shape), 1234)
+            acc = accuracy_check(pl, cvol, cfr, clab)
         value = n_global * args.steps / elapsed / 1e6
         out = {
             "metric": "Mvoxel/s multiscale Frangi (5 sigma) + Label, float32", "value": round(value, 1),
@@ -249,10 +301,41 @@ def main():
             out["accuracy"] = acc
         if io is not None:
             out["io"] = io
-        print(json.dumps(out))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+
+    if dist is None:
+        print(json.dumps(out), flush=True)
+        return
+
+    # N > 1: optionally prove the Z-slab decomposition on the real GPUs (RCCL), guarded so that a communication
+    # problem can never cost the measured line: a watchdog thread prints the line without the check and leaves
+    # if the check has not come back in time (the main thread may be blocked inside a collective).
+    import threading
+    lock = threading.Lock()
+    state = {"printed": False}
+
+    def emit(extra):
+        with lock:
+            if rank == 0 and not state["printed"]:
+                state["printed"] = True
+                line = dict(out)
+                if extra is not None:
+                    line["zslab"] = extra
+                print(json.dumps(line), flush=True)
+
+    zslab = None
+    if not args.no_zslab_check and not args.share_device:
+        def watchdog():
+            time.sleep(args.zslab_timeout)
+            emit({"error": f"no answer within {args.zslab_timeout} s"})
+            os._exit(0)
+        threading.Thread(target=watchdog, daemon=True).start()
+        try:
+            zslab = zslab_check(dist, rank, world, local_rank)
+        except Exception as exc:  # noqa: BLE001
+            zslab = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+    emit(zslab)
+    sys.stdout.flush()
+    os._exit(0)      # skip collective teardown: nothing after the JSON line may hang the job
 
 
 if __name__ == "__main__":
