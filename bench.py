@@ -98,7 +98,7 @@ def cpu_baseline(shape, seed):
         "sample": f"oracle Filter+Label on a synthetic {shape[0]}x{shape[1]}x{shape[2]} float32 volume "
                   f"(same generator, seed {seed}); Filter {n / (t1 - t0) / 1e6:.3f} Mvoxel/s, "
                   f"Label {n / (t2 - t1) / 1e6:.2f} Mvoxel/s, {float(np.mean(fr > 0)) * 100:.2f}% voxels survive, "
-                  f"{int(lab.max())} labels; numpy/scipy-free single thread of {os.cpu_count()} host cores",
+                  f"{int(lab.max())} labels; numpy oracle, 1 thread of {os.cpu_count()} host cores",
     }, (vol, fr, lab)
 
 

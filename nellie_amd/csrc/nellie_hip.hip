@@ -551,6 +551,7 @@ struct VessP {
     float max_abs, max_finite;
     int mask_rmw;            // 1: AND into the slot (more scales than mask slots)
     int cnt_lo, cnt_hi;      // planes whose masked voxels are counted (the owned ones)
+    int first;               // 1: first evaluated scale of the frame -> vesselness is written, not max-ed (no memset needed)
 };
 
 __global__ void __launch_bounds__(256)
@@ -739,7 +740,7 @@ hessian_march_kernel(const float *__restrict__ g, float *__restrict__ vmax, unsi
         float l1, l2, l3;
         eig3_sorted_abs(h, l1, l2, l3);
         const float val = frangi3(l1, l2, l3, vp.alpha_sq, vp.beta_sq, vp.gamma_sq);
-        if (val > vmax[c]) vmax[c] = val;
+        if (vp.first || val > vmax[c]) vmax[c] = val;
     };
 
     for (int z = zc0; z < zc1; ++z) {
@@ -907,31 +908,59 @@ finish_kernel(float *__restrict__ vmax, const unsigned long long *__restrict__ c
     if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(npos, cnt);
 }
 
-// filtering.py:964-966: mask = f > thr; binary_opening (6-conn cross, border_value 0); f * mask.
-// Global-face aware along Z (ghost planes are real neighbours); requires 2 valid planes around.
+// filtering.py:964-966: mask = f > thr; binary_opening (6-conn cross, one iteration, border_value 0); f * mask.
+// Done on BIT masks: pack (rl_threshold_pack_kernel), erode, dilate (word-wide logic on 1 bit/voxel), apply.
+// Planes [z0, z1) are produced from planes [z0-1, z1+1) of the input bits; neighbours outside the GLOBAL volume
+// count as 0 (border_value), ghost planes of a slab are real neighbours.
+template <int DILATE>
 __global__ void __launch_bounds__(256)
-mask_volume_kernel(const float *__restrict__ f, float *__restrict__ out, VolGeom v, float thr, i64 z0, i64 z1) {
-    const i64 x = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    const i64 y = blockIdx.y;
-    const i64 z = z0 + blockIdx.z;
-    if (x >= v.nx) return;
-    const i64 sy = v.nx, sz = v.ny * v.nx;
-    const i64 c = z * sz + y * sy + x;
-    const float val = f[c];
-    if (!(val != 0.0f)) { out[c] = val * 0.0f; return; }   // 0 * mask == 0 whatever the mask
-    auto in_vol = [&](i64 zz, i64 yy, i64 xx) -> bool {
-        const i64 gg = v.gz0 + zz;
-        return gg >= 0 && gg < v.gnz && yy >= 0 && yy < v.ny && xx >= 0 && xx < v.nx;
-    };
-    auto M = [&](i64 zz, i64 yy, i64 xx) -> bool { return in_vol(zz, yy, xx) && (f[zz * sz + yy * sy + xx] > thr); };
-    auto E = [&](i64 zz, i64 yy, i64 xx) -> bool {      // erosion at (zz,yy,xx); outside the volume = false
-        if (!in_vol(zz, yy, xx)) return false;
-        return M(zz, yy, xx) && M(zz - 1, yy, xx) && M(zz + 1, yy, xx) && M(zz, yy - 1, xx) && M(zz, yy + 1, xx) &&
-               M(zz, yy, xx - 1) && M(zz, yy, xx + 1);
-    };
-    const bool opened = E(z, y, x) || E(z - 1, y, x) || E(z + 1, y, x) || E(z, y - 1, x) || E(z, y + 1, x) ||
-                        E(z, y, x - 1) || E(z, y, x + 1);
-    out[c] = opened ? val : val * 0.0f;
+bits_morph6_kernel(const unsigned long long *__restrict__ in, unsigned long long *__restrict__ out, VolGeom v, int wpr, i64 z0, i64 z1) {
+    const i64 nw = (z1 - z0) * v.ny * wpr;
+    const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nw) return;
+    const int w = (int)(t % wpr);
+    const i64 row_in_range = t / wpr;
+    const i64 y = row_in_range % v.ny, z = z0 + row_in_range / v.ny;
+    const i64 row = z * v.ny + y;
+    const unsigned long long cur = in[row * wpr + w];
+    const unsigned long long lft = (cur << 1) | ((w > 0) ? (in[row * wpr + w - 1] >> 63) : 0ull);           // x-1
+    const unsigned long long rgt = (cur >> 1) | ((w + 1 < wpr) ? (in[row * wpr + w + 1] << 63) : 0ull);    // x+1
+    const i64 gz = v.gz0 + z;
+    const unsigned long long up = (gz > 0) ? in[(row - v.ny) * wpr + w] : 0ull;
+    const unsigned long long dn = (gz < v.gnz - 1) ? in[(row + v.ny) * wpr + w] : 0ull;
+    const unsigned long long no = (y > 0) ? in[(row - 1) * wpr + w] : 0ull;
+    const unsigned long long so = (y < v.ny - 1) ? in[(row + 1) * wpr + w] : 0ull;
+    unsigned long long r = DILATE ? (cur | lft | rgt | up | dn | no | so) : (cur & lft & rgt & up & dn & no & so);
+    const int rem = (int)v.nx - w * 64;
+    if (rem < 64) r &= (1ull << rem) - 1ull;          // keep the tail bits of a row at 0
+    out[row * wpr + w] = r;
+}
+
+__global__ void __launch_bounds__(256)
+apply_bits_kernel(const float *__restrict__ f, const unsigned long long *__restrict__ bits, float *__restrict__ out, VolGeom v,
+                  int wpr, i64 z0, i64 z1) {
+    const i64 qpr = (v.nx + 3) / 4;
+    const i64 total = (z1 - z0) * v.ny * qpr;
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    const bool vec = (v.nx & 3) == 0;
+    for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+        const i64 row = z0 * v.ny + t / qpr;
+        const i64 x0 = (t % qpr) * 4;
+        const unsigned int b4 = (unsigned int)(bits[row * wpr + (x0 >> 6)] >> (x0 & 63)) & 0xFu;
+        const float *p = f + row * v.nx + x0;
+        float *o = out + row * v.nx + x0;
+        if (vec) {
+            float4 a = *reinterpret_cast<const float4 *>(p);
+            // frame * mask: a False mask gives +-0 with the sign of the value, exactly numpy's float * bool
+            if (!(b4 & 1u)) a.x *= 0.0f;
+            if (!(b4 & 2u)) a.y *= 0.0f;
+            if (!(b4 & 4u)) a.z *= 0.0f;
+            if (!(b4 & 8u)) a.w *= 0.0f;
+            *reinterpret_cast<float4 *>(o) = a;
+        } else {
+            for (int k = 0; k < 4 && x0 + k < v.nx; ++k) o[k] = ((b4 >> k) & 1u) ? p[k] : p[k] * 0.0f;
+        }
+    }
 }
 
 // =================================================================================================
@@ -1460,8 +1489,8 @@ extern "C" int nl_filter_load(nl_ctx *c, const void *host, int dtype, int64_t z0
     const i64 plane = c->ny * c->nx;
     int rc = upload_convert(c, host, dtype, c->f[0] + z0 * plane, (z1 - z0) * plane, err, errlen);
     if (rc) return rc;
-    // vesselness = zeros, masks = ones (filtering.py:807-808)
-    NL_HIP(hipMemsetAsync(c->f[c->i_vmax], 0, (size_t)c->n * 4, c->stream));
+    // vesselness = zeros, masks = ones (filtering.py:807-808): implicit -- the first evaluated scale writes
+    // vesselness instead of max-ing it and nl_filter_finish zeroes whatever the masks reject
     c->mask_slots_used = 0;
     NL_HIP(hipStreamSynchronize(c->stream));
     return NL_OK;
@@ -1502,7 +1531,6 @@ extern "C" int nl_filter_begin(nl_ctx *c, char *err, size_t errlen) {
         case NL_I64: convert_kernel<int64_t><<<g, 256, 0, c->stream>>>((const int64_t *)c->d_input, c->f[0], c->n); break;
     }
     NL_CHECK_LAUNCH();
-    NL_HIP(hipMemsetAsync(c->f[c->i_vmax], 0, (size_t)c->n * 4, c->stream));
     c->mask_slots_used = 0;
     return NL_OK;
 }
@@ -1743,7 +1771,8 @@ extern "C" int nl_vesselness_step(nl_ctx *c, float gamma_sq, float alpha_sq, flo
     if (!c->have_spacing) return nl_fail(err, errlen, NL_ESTATE, "nl_vesselness_step before nl_hessian_stats");
     unsigned long long *d_cnt = (unsigned long long *)c->d_small;
     NL_HIP(hipMemsetAsync(d_cnt, 0, 8, c->stream));
-    VessP vp{gamma_sq, alpha_sq, beta_sq, use_thr, thr, c->frob_max_abs, c->frob_max_finite, 0, (int)c->own_lo, (int)c->own_hi};
+    VessP vp{gamma_sq, alpha_sq, beta_sq, use_thr, thr, c->frob_max_abs, c->frob_max_finite, 0, (int)c->own_lo, (int)c->own_hi,
+             c->mask_slots_used == 0 ? 1 : 0};
     {
         ProfScope ps(c, "vesselness");
         const int ntx = (int)((c->nx + HM_TX - 1) / HM_TX), nty = (int)((c->ny + 15) / 16);
@@ -1786,6 +1815,8 @@ extern "C" int nl_filter_finish(nl_ctx *c, int64_t z0, int64_t z1, int64_t *n_po
     unsigned long long *d_cnt = (unsigned long long *)c->d_small;
     NL_HIP(hipMemsetAsync(d_cnt, 0, 8, c->stream));
     const i64 plane = c->ny * c->nx;
+    if (c->mask_slots_used == 0)       // every scale was skipped: vesselness was never written
+        NL_HIP(hipMemsetAsync(c->f[c->i_vmax] + z0 * plane, 0, (size_t)(z1 - z0) * plane * 4, c->stream));
     {
         ProfScope ps(c, "finish");
         const int wpr = (int)((c->nx + 63) / 64);
@@ -1808,8 +1839,21 @@ extern "C" int nl_mask_volume(nl_ctx *c, float thr, char *err, size_t errlen) {
     for (int k = 0; k < 3; ++k) if (k != c->i_gauss) { dst = k; break; }
     {
         ProfScope ps(c, "mask_volume");
-        const dim3 grid((unsigned)((c->nx + 255) / 256), (unsigned)c->ny, (unsigned)(c->own_hi - c->own_lo));
-        mask_volume_kernel<<<grid, 256, 0, c->stream>>>(c->f[c->i_vmax], c->f[dst], geom(c), thr, c->own_lo, c->own_hi);
+        const int wpr = (int)((c->nx + 63) / 64);
+        const VolGeom v = geom(c);
+        // planes whose bits exist: own +-2 clipped to the slab (ghost planes beyond a true face do not exist)
+        const i64 m0 = c->own_lo - 2 > 0 ? c->own_lo - 2 : 0, m1 = c->own_hi + 2 < c->nzl ? c->own_hi + 2 : c->nzl;
+        const i64 e0 = c->own_lo - 1 > 0 ? c->own_lo - 1 : 0, e1 = c->own_hi + 1 < c->nzl ? c->own_hi + 1 : c->nzl;
+        unsigned long long *bM = (unsigned long long *)c->m[1], *bE = (unsigned long long *)c->m[2], *bD = (unsigned long long *)c->m[0];
+        rl_threshold_pack_kernel<<<grid1d((m1 - m0) * c->ny * wpr * 64, 256, 256 * 32), 256, 0, c->stream>>>(
+            c->f[c->i_vmax] + m0 * c->ny * c->nx, bM + m0 * c->ny * wpr, 1, thr, (int)c->nx, (m1 - m0) * c->ny, wpr);
+        NL_CHECK_LAUNCH();
+        bits_morph6_kernel<0><<<(unsigned)(((e1 - e0) * c->ny * wpr + 255) / 256), 256, 0, c->stream>>>(bM, bE, v, wpr, e0, e1);
+        NL_CHECK_LAUNCH();
+        bits_morph6_kernel<1><<<(unsigned)(((c->own_hi - c->own_lo) * c->ny * wpr + 255) / 256), 256, 0, c->stream>>>(bE, bD, v, wpr, c->own_lo, c->own_hi);
+        NL_CHECK_LAUNCH();
+        apply_bits_kernel<<<grid1d((c->own_hi - c->own_lo) * c->ny * ((c->nx + 3) / 4), 256, 256 * 32), 256, 0, c->stream>>>(
+            c->f[c->i_vmax], bD, c->f[dst], v, wpr, c->own_lo, c->own_hi);
         NL_CHECK_LAUNCH();
     }
     // swap roles: old vmax volume joins the gauss ping-pong set
