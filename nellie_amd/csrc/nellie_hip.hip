@@ -3,6 +3,7 @@
 // below is meant to round exactly where numpy/scipy round.
 #include <stdarg.h>
 #include <stdlib.h>
+#include <type_traits>
 #include <rccl/rccl.h>
 #include "nl_common.h"
 
@@ -598,7 +599,7 @@ vesselness_kernel(const float *__restrict__ g, float *__restrict__ vmax, uint8_t
 #define HM_TX 64
 #define HM_PW (HM_TX + 4)
 #define HM_SLOTS 8
-#define HM_SLOT(z) ((int)((unsigned)(z) & (HM_SLOTS - 1)))
+#define HM_RSLOT(zz) ((int)(((unsigned)((zz) - zc0 + HM_SLOTS)) & (HM_SLOTS - 1)))   // ring slot relative to the chunk start
 #define HM_ZCHUNK 64
 #define HM_DEPTH 3
 template <int TY> struct HMCfg {
@@ -692,7 +693,7 @@ hessian_march_kernel(const float *__restrict__ g, float *__restrict__ vmax, unsi
     // a 3.2 KB plane per workgroup is far too little to cover HBM latency on its own).
     const int pmin = zclamp(zc0 - 2), pmax = zclamp(zc1 + 1);
     for (int pz = pmin; pz <= pmax && pz <= zc0 + 2; ++pz) {
-        float *dst = sp + HM_SLOT(pz) * HM_PLANE;
+        float *dst = sp + HM_RSLOT(pz) * HM_PLANE;
         const float *src = g + (i64)pz * sz;
         dst[tid] = src[off0];
         if (off1 >= 0) dst[tid + NT] = src[off1];
@@ -743,7 +744,28 @@ hessian_march_kernel(const float *__restrict__ g, float *__restrict__ vmax, unsi
         if (vp.first || val > vmax[c]) vmax[c] = val;
     };
 
-    for (int z = zc0; z < zc1; ++z) {
+    // Hessian of the voxel from five plane tiles (float32, numpy's rounding points)
+    auto compute_h = [&](const float *Pm2, const float *Pm1, const float *P0, const float *Pp1, const float *Pp2,
+                         const bool z_lo, const bool z_hi, const Dv<FAST> rdz, const Dv<FAST> rdz_m1, const Dv<FAST> rdz_p1,
+                         float h[6]) {
+        const Dv<FAST> rdz_0 = rdz;
+        // h_zz: outer sites are z+1 (or z at the top face) and z-1 (or z at the bottom face); the first derivatives
+        // along Z at planes z-1, z, z+1 use planes (z-2,z), (z-1,z+1), (z,z+2)
+        const float gz_hi = z_hi ? rdz_0.div(P0[o_cc] - Pm1[o_cc]) : rdz_p1.div(Pp2[o_cc] - P0[o_cc]);
+        const float gz_lo = z_lo ? rdz_0.div(Pp1[o_cc] - P0[o_cc]) : rdz_m1.div(P0[o_cc] - Pm2[o_cc]);
+        h[0] = rdz.div(gz_hi - gz_lo);
+        h[1] = rdy.div(rdz_0.div(Pp1[o_hc] - Pm1[o_hc]) - rdz_0.div(Pp1[o_lc] - Pm1[o_lc]));
+        h[2] = rdx.div(rdz_0.div(Pp1[o_ch] - Pm1[o_ch]) - rdz_0.div(Pp1[o_cl] - Pm1[o_cl]));
+        h[3] = rdy.div(rdy_jh.div(P0[o_hc + HM_PW] - P0[o_hc - HM_PW]) - rdy_jl.div(P0[o_lc + HM_PW] - P0[o_lc - HM_PW]));
+        h[4] = rdx.div(rdy_jc.div(P0[o_ch + HM_PW] - P0[o_ch - HM_PW]) - rdy_jc.div(P0[o_cl + HM_PW] - P0[o_cl - HM_PW]));
+        h[5] = rdx.div(rdx_ih.div(P0[o_ch + 1] - P0[o_ch - 1]) - rdx_il.div(P0[o_cl + 1] - P0[o_cl - 1]));
+    };
+
+    // One plane step.  U >= 0: the ring slot of plane z is the compile-time constant U (the Z loop is unrolled by
+    // HM_SLOTS and slots are taken relative to the chunk start), the planes z-2..z+2 all exist (interior), so every
+    // LDS address is a per-lane base + immediate and no select is needed.  U < 0: generic step (faces, loop tail).
+    auto step = [&](const int z, auto uc) {
+        constexpr int U = decltype(uc)::value;
         if (MODE == 1) {
             // dense eigen batch once the queue holds a full workgroup's worth
             const int tail = *(volatile int *)s_tail;
@@ -756,27 +778,17 @@ hessian_march_kernel(const float *__restrict__ g, float *__restrict__ vmax, unsi
         bool m = false;
         float h[6];
         if (valid) {
-            const int gz = gz0 + z;
-            const bool z_lo = (gz == 0), z_hi = (gz == gnz - 1);
-            const float *Pm2 = sp + HM_SLOT(zclamp(z - 2)) * HM_PLANE;
-            const float *Pm1 = sp + HM_SLOT(zclamp(z - 1)) * HM_PLANE;
-            const float *P0 = sp + HM_SLOT(z) * HM_PLANE;
-            const float *Pp1 = sp + HM_SLOT(zclamp(z + 1)) * HM_PLANE;
-            const float *Pp2 = sp + HM_SLOT(zclamp(z + 2)) * HM_PLANE;
-            const Dv<FAST> rdz = (z_lo || z_hi) ? hr.z : hr.z2;
-            // first derivatives along Z at planes z-1, z, z+1 use planes (z-2,z), (z-1,z+1), (z,z+2)
-            const Dv<FAST> rdz_m1 = (gz - 1 == 0) ? hr.z : hr.z2;                      // plane z-1 (exists when !z_lo)
-            const Dv<FAST> rdz_0 = rdz;
-            const Dv<FAST> rdz_p1 = (gz + 1 == gnz - 1) ? hr.z : hr.z2;                // plane z+1 (exists when !z_hi)
-            // h_zz: outer sites are z+1 (or z at the top face) and z-1 (or z at the bottom face)
-            const float gz_hi = z_hi ? rdz_0.div(P0[o_cc] - Pm1[o_cc]) : rdz_p1.div(Pp2[o_cc] - P0[o_cc]);
-            const float gz_lo = z_lo ? rdz_0.div(Pp1[o_cc] - P0[o_cc]) : rdz_m1.div(P0[o_cc] - Pm2[o_cc]);
-            h[0] = rdz.div(gz_hi - gz_lo);
-            h[1] = rdy.div(rdz_0.div(Pp1[o_hc] - Pm1[o_hc]) - rdz_0.div(Pp1[o_lc] - Pm1[o_lc]));
-            h[2] = rdx.div(rdz_0.div(Pp1[o_ch] - Pm1[o_ch]) - rdz_0.div(Pp1[o_cl] - Pm1[o_cl]));
-            h[3] = rdy.div(rdy_jh.div(P0[o_hc + HM_PW] - P0[o_hc - HM_PW]) - rdy_jl.div(P0[o_lc + HM_PW] - P0[o_lc - HM_PW]));
-            h[4] = rdx.div(rdy_jc.div(P0[o_ch + HM_PW] - P0[o_ch - HM_PW]) - rdy_jc.div(P0[o_cl + HM_PW] - P0[o_cl - HM_PW]));
-            h[5] = rdx.div(rdx_ih.div(P0[o_ch + 1] - P0[o_ch - 1]) - rdx_il.div(P0[o_cl + 1] - P0[o_cl - 1]));
+            if (U >= 0) {
+                compute_h(sp + ((U + 6) & 7) * HM_PLANE, sp + ((U + 7) & 7) * HM_PLANE, sp + (U & 7) * HM_PLANE,
+                          sp + ((U + 1) & 7) * HM_PLANE, sp + ((U + 2) & 7) * HM_PLANE, false, false, hr.z2, hr.z2, hr.z2, h);
+            } else {
+                const int gz = gz0 + z;
+                const bool z_lo = (gz == 0), z_hi = (gz == gnz - 1);
+                compute_h(sp + HM_RSLOT(zclamp(z - 2)) * HM_PLANE, sp + HM_RSLOT(zclamp(z - 1)) * HM_PLANE,
+                          sp + HM_RSLOT(z) * HM_PLANE, sp + HM_RSLOT(zclamp(z + 1)) * HM_PLANE,
+                          sp + HM_RSLOT(zclamp(z + 2)) * HM_PLANE, z_lo, z_hi, (z_lo || z_hi) ? hr.z : hr.z2,
+                          (gz - 1 == 0) ? hr.z : hr.z2, (gz + 1 == gnz - 1) ? hr.z : hr.z2, h);
+            }
             const float fsq = frob_sq_of(h);
             if (MODE == 0) {
 #pragma unroll
@@ -814,7 +826,7 @@ hessian_march_kernel(const float *__restrict__ g, float *__restrict__ vmax, unsi
         }
         // plane z+3 (in flight since HM_DEPTH steps) lands in the ring; plane z+3+HM_DEPTH takes its place in flight
         if (z + 3 <= pmax) {
-            float *dst = sp + HM_SLOT((z + 3)) * HM_PLANE;
+            float *dst = sp + ((U >= 0) ? ((U + 3) & 7) : HM_RSLOT(z + 3)) * HM_PLANE;
             dst[tid] = ra[0];
             if (off1 >= 0) dst[tid + NT] = rb[0];
         }
@@ -829,6 +841,24 @@ hessian_march_kernel(const float *__restrict__ g, float *__restrict__ vmax, unsi
             }
         }
         __syncthreads();
+    };
+
+    {
+        int z = zc0;
+        for (; z + HM_SLOTS <= zc1; z += HM_SLOTS) {
+            // all eight planes interior (z-2 >= global 0, z+7+2 <= global last)?  (z - zc0) % 8 == 0 here.
+            // (only the statistics kernel is unrolled: in the vesselness kernel the eight inlined copies of the
+            //  eigen batch push the register count from 84 to 135 and cost more than the static slots gain)
+            if (MODE == 0 && gz0 + z >= 2 && gz0 + z + HM_SLOTS - 1 <= gnz - 3) {
+                step(z + 0, std::integral_constant<int, 0>{}); step(z + 1, std::integral_constant<int, 1>{});
+                step(z + 2, std::integral_constant<int, 2>{}); step(z + 3, std::integral_constant<int, 3>{});
+                step(z + 4, std::integral_constant<int, 4>{}); step(z + 5, std::integral_constant<int, 5>{});
+                step(z + 6, std::integral_constant<int, 6>{}); step(z + 7, std::integral_constant<int, 7>{});
+            } else {
+                for (int u = 0; u < HM_SLOTS; ++u) step(z + u, std::integral_constant<int, -1>{});
+            }
+        }
+        for (; z < zc1; ++z) step(z, std::integral_constant<int, -1>{});
     }
     if (MODE == 1) {
         // drain the queue
