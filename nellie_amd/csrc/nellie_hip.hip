@@ -383,6 +383,67 @@ gauss_march_kernel(const float *__restrict__ in, float *__restrict__ out, VolGeo
     }
 }
 
+// Fused Y + X pass (the Y and X radii of a cascade step are always equal: sigma_vec = (s/z_ratio, s, s)).
+// A 320-thread workgroup owns 256 output columns of one Z plane and walks a chunk of rows: every thread marches
+// down ITS column (256 outputs + R reflected halo columns on each side) with the float64 sliding window of the Y
+// pass, rounds to float32 exactly like the stand-alone pass, and drops the value into a double-buffered LDS row;
+// after one barrier the 256 output threads take the X pass from that row.  The intermediate volume between the Y
+// and the X pass never exists in HBM: 8 B/voxel instead of 16.
+#define GYX_COLS 256
+#define GYX_THREADS 320
+template <int R>
+__global__ void __launch_bounds__(GYX_THREADS)
+gauss_yx_kernel(const float *__restrict__ in, float *__restrict__ out, VolGeom v, i64 z0, i64 z1, GaussWS gwy, GaussWS gwx) {
+    constexpr int W = 2 * R + 1;
+    __shared__ float rowbuf[2][GYX_COLS + 2 * GM_MAX_R];
+    const int pos = threadIdx.x;                                  // position in the staged row
+    const i64 x0 = (i64)blockIdx.x * GYX_COLS;
+    const i64 z = z0 + blockIdx.z;
+    const i64 c0 = (i64)blockIdx.y * GM_CHUNK;
+    const i64 c1 = c0 + GM_CHUNK < v.ny ? c0 + GM_CHUNK : v.ny;
+    const bool active = pos < GYX_COLS + 2 * R;
+    const i64 xcol = reflect_idx(x0 - R + pos, v.nx);             // the column this thread filters along Y
+    const i64 xout = x0 + pos - R;                                // the output column of an output thread
+    const bool writer = pos >= R && pos < R + GYX_COLS && xout < v.nx;
+    const i64 sy = v.nx;
+    const i64 base = z * v.ny * v.nx + xcol;
+    auto ld = [&](i64 p) -> double { return (double)in[base + reflect_idx(p, v.ny) * sy]; };
+    double win[W];
+    if (active) {
+#pragma unroll
+        for (int k = 0; k < W - 1; ++k) win[k + 1] = ld(c0 - R + k);
+    }
+    for (i64 p0 = c0; p0 < c1; p0 += W) {
+#pragma unroll
+        for (int ph = 0; ph < W; ++ph) {
+            const i64 p = p0 + ph;
+            if (p < c1) {                                          // uniform
+                const int buf = (int)(p & 1);
+                if (active) {
+                    win[ph] = ld(p + R);
+                    double tmp = win[(ph + 1 + R) % W] * gwy.w[0];
+#pragma unroll
+                    for (int j = R; j >= 1; --j) {
+                        const double s = win[(ph + 1 + R - j) % W] + win[(ph + 1 + R + j) % W];
+                        tmp = tmp + s * gwy.w[j];
+                    }
+                    rowbuf[buf][pos] = (float)tmp;                 // the float32 store between the two passes
+                }
+                __syncthreads();
+                if (writer) {
+                    double tmp = (double)rowbuf[buf][pos] * gwx.w[0];
+#pragma unroll
+                    for (int j = R; j >= 1; --j) {
+                        const double s = (double)rowbuf[buf][pos - j] + (double)rowbuf[buf][pos + j];
+                        tmp = tmp + s * gwx.w[j];
+                    }
+                    out[(z * v.ny + p) * v.nx + xout] = (float)tmp;
+                }
+            }
+        }
+    }
+}
+
 #define GX_SEG 1024
 template <int R>
 __global__ void __launch_bounds__(256)
@@ -1627,7 +1688,25 @@ extern "C" int nl_gauss_step(nl_ctx *c, const double *wz, int rz, const double *
         NL_CHECK_LAUNCH();
         src = dst;
     }
-    if (wy) {
+    bool fused_yx = false;
+    if (wy && wx && ry == rx && ry >= 1 && ry <= GM_MAX_R && !getenv("NELLIE_NO_FUSED_YX")) {
+        GaussW gy, gx;
+        if ((rc = fill_gw(gy, wy, ry, err, errlen))) return rc;
+        if ((rc = fill_gw(gx, wx, rx, err, errlen))) return rc;
+        GaussWS wsy, wsx;
+        for (int k = 0; k <= GM_MAX_R; ++k) { wsy.w[k] = k <= ry ? gy.w[k] : 0.0; wsx.w[k] = k <= rx ? gx.w[k] : 0.0; }
+        const int dst = (src + 1) % 3;
+        const dim3 g2((unsigned)((c->nx + GYX_COLS - 1) / GYX_COLS), (unsigned)((c->ny + GM_CHUNK - 1) / GM_CHUNK), (unsigned)(z1 - z0));
+        switch (ry) {
+#define NL_YX(RR) case RR: gauss_yx_kernel<RR><<<g2, GYX_THREADS, 0, c->stream>>>(c->f[src], c->f[dst], v, z0, z1, wsy, wsx); break;
+            NL_YX(1) NL_YX(2) NL_YX(3) NL_YX(4) NL_YX(5) NL_YX(6) NL_YX(7) NL_YX(8)
+#undef NL_YX
+        }
+        NL_CHECK_LAUNCH();
+        src = dst;
+        fused_yx = true;
+    }
+    if (wy && !fused_yx) {
         if ((rc = fill_gw(gw, wy, ry, err, errlen))) return rc;
         const int dst = (src + 1) % 3;
         if (!launch_gauss_fast<1>(c, c->f[src], c->f[dst], v, z0, z1, gw))
@@ -1635,7 +1714,7 @@ extern "C" int nl_gauss_step(nl_ctx *c, const double *wz, int rz, const double *
         NL_CHECK_LAUNCH();
         src = dst;
     }
-    if (wx) {
+    if (wx && !fused_yx) {
         if ((rc = fill_gw(gw, wx, rx, err, errlen))) return rc;
         const int dst = (src + 1) % 3;
         if (!launch_gauss_fast<2>(c, c->f[src], c->f[dst], v, z0, z1, gw))
