@@ -10,1347 +10,12 @@
 #define NL_MASK_SLOTS 8      // per-scale mask bit planes kept before falling back to read-modify-write
 #define NL_VERSION "nellie_amd-hip 0.1.0 (gfx950)"
 
-// =================================================================================================
-// device helpers
-// =================================================================================================
-struct VolGeom {
-    i64 nzl, ny, nx;   // local shape
-    i64 gz0, gnz;      // global placement of local plane 0, global plane count
-};
-
-struct HessP {
-    float hz, hy, hx;      // float32(h)      : one-sided divisor at a face
-    float hz2, hy2, hx2;   // float32(2.0*h)  : central divisor
-};
-
-// scipy NI_EXTEND_REFLECT (d c b a | a b c d | d c b a)
-__device__ __forceinline__ i64 reflect_idx(i64 i, i64 n) {
-    if (i >= 0 && i < n) return i;
-    i64 p = 2 * n;
-    i %= p;
-    if (i < 0) i += p;
-    return i >= n ? p - 1 - i : i;
-}
-
-// Exactly rounded float32 division by a constant d, given rcp = RN64(1/d):
-//   a/d = (float)((double)a * rcp).
-// Why it is exact: a/d can never sit closer than ~2^-48 (relative) to a float32 rounding boundary
-// (a - m*d is a non-zero integer multiple of 2^-47 for 24-bit a, d and a 25-bit midpoint m), while the
-// float64 product carries a relative error <= 2^-52, so the final rounding lands on the IEEE quotient.
-// (Sub-normal quotients are the one exception; differences of image intensities never get there.)
-// 3 instructions instead of the ~12 of an IEEE division; checked bit-for-bit on 1.2e9 operands.
-__device__ __forceinline__ float div_c(float a, double rcp) { return (float)((double)a * rcp); }
-
-// wave64 reductions (CDNA wavefront = 64 lanes)
-__device__ __forceinline__ float wave_max_f(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
-}
-__device__ __forceinline__ float wave_min_f(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
-    return v;
-}
-__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-__device__ __forceinline__ int wave_or_i(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o, 64);
-    return v;
-}
-
-// -------------------------------------------------------------------------------------------------
-// np.gradient applied twice (filtering.py:518-536), fused: every first derivative is rounded to
-// float32 (true IEEE division by float32(2h) / float32(h)) before it is differenced again.
-// Faces use clamped indices + the one-sided divisor, independently at both stages.
-// Component order = the reference's (hxx,hxy,hxz,hyy,hyz,hzz) with "x" = axis 0 (Z).
-// -------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void hessian_at(const float *__restrict__ g, const VolGeom &v, const HessP &hp,
-                                           i64 z, i64 y, i64 x, float h[6]) {
-    const i64 sy = v.nx, sz = v.ny * v.nx;
-    const i64 gz = v.gz0 + z;
-    // outer-difference sites and divisors
-    const bool z_lo = (gz == 0), z_hi = (gz == v.gnz - 1);
-    const bool y_lo = (y == 0), y_hi = (y == v.ny - 1);
-    const bool x_lo = (x == 0), x_hi = (x == v.nx - 1);
-    const i64 zl = z_lo ? z : z - 1, zh = z_hi ? z : z + 1;
-    const i64 yl = y_lo ? y : y - 1, yh = y_hi ? y : y + 1;
-    const i64 xl = x_lo ? x : x - 1, xh = x_hi ? x : x + 1;
-    const float dz = (z_lo || z_hi) ? hp.hz : hp.hz2;
-    const float dy = (y_lo || y_hi) ? hp.hy : hp.hy2;
-    const float dx = (x_lo || x_hi) ? hp.hx : hp.hx2;
-
-    auto F = [&](i64 zz, i64 yy, i64 xx) -> float { return g[zz * sz + yy * sy + xx]; };
-    auto GZ = [&](i64 zz, i64 yy, i64 xx) -> float {
-        const i64 gg = v.gz0 + zz;
-        const bool lo = (gg == 0), hi = (gg == v.gnz - 1);
-        const float a = F(lo ? zz : zz - 1, yy, xx), b = F(hi ? zz : zz + 1, yy, xx);
-        return (b - a) / ((lo || hi) ? hp.hz : hp.hz2);
-    };
-    auto GY = [&](i64 zz, i64 yy, i64 xx) -> float {
-        const bool lo = (yy == 0), hi = (yy == v.ny - 1);
-        const float a = F(zz, lo ? yy : yy - 1, xx), b = F(zz, hi ? yy : yy + 1, xx);
-        return (b - a) / ((lo || hi) ? hp.hy : hp.hy2);
-    };
-    auto GX = [&](i64 zz, i64 yy, i64 xx) -> float {
-        const bool lo = (xx == 0), hi = (xx == v.nx - 1);
-        const float a = F(zz, yy, lo ? xx : xx - 1), b = F(zz, yy, hi ? xx : xx + 1);
-        return (b - a) / ((lo || hi) ? hp.hx : hp.hx2);
-    };
-    h[0] = (GZ(zh, y, x) - GZ(zl, y, x)) / dz;   // hxx = d0 g0
-    h[1] = (GZ(z, yh, x) - GZ(z, yl, x)) / dy;   // hxy = d1 g0
-    h[2] = (GZ(z, y, xh) - GZ(z, y, xl)) / dx;   // hxz = d2 g0
-    h[3] = (GY(z, yh, x) - GY(z, yl, x)) / dy;   // hyy = d1 g1
-    h[4] = (GY(z, y, xh) - GY(z, y, xl)) / dx;   // hyz = d2 g1
-    h[5] = (GX(z, y, xh) - GX(z, y, xl)) / dx;   // hzz = d2 g2
-}
-
-// filtering.py:538-543, float32, numpy's left-to-right association
-__device__ __forceinline__ float frob_sq_of(const float h[6]) {
-    const float a = h[0] * h[0] + h[3] * h[3] + h[5] * h[5];
-    const float b = 2.0f * (h[1] * h[1] + h[2] * h[2] + h[4] * h[4]);
-    return a + b;
-}
-
-// frob = sqrt(frob_sq)/max_abs with +inf -> max finite (filtering.py:421-426, 562)
-__device__ __forceinline__ float frob_norm(float fsq, float max_abs, float max_finite) {
-    float fr = sqrtf(fsq) / max_abs;
-    if (isinf(fr)) fr = max_finite;
-    return fr;
-}
-
-// -------------------------------------------------------------------------------------------------
-// numpy.linalg.eigvalsh on a float32 3x3 symmetric matrix = float64 LAPACK result cast to
-// float32 (numpy/linalg/_linalg.py computes in double).  Closed form in float64 (Smith 1961),
-// then the |lambda| ordering of filtering.py:583-584 and the Frangi response of
-// filtering.py:744-766 in float32.
-// -------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void eig3_sorted_abs_libm(const float h[6], float &l1, float &l2, float &l3) {
-    const double a00 = h[0], a01 = h[1], a02 = h[2], a11 = h[3], a12 = h[4], a22 = h[5];
-    const double q = (a00 + a11 + a22) / 3.0;
-    const double b00 = a00 - q, b11 = a11 - q, b22 = a22 - q;
-    const double p2 = (b00 * b00 + b11 * b11 + b22 * b22 + 2.0 * (a01 * a01 + a02 * a02 + a12 * a12)) / 6.0;
-    const double p = sqrt(p2);
-    const double det = b00 * (b11 * b22 - a12 * a12) - a01 * (a01 * b22 - a12 * a02) + a02 * (a01 * a12 - b11 * a02);
-    double r = (p2 > 0.0) ? det / (2.0 * p2 * p) : 0.0;
-    r = r < -1.0 ? -1.0 : (r > 1.0 ? 1.0 : r);
-    const double phi = acos(r) / 3.0;
-    const double e_max = q + 2.0 * p * cos(phi);
-    const double e_min = q + 2.0 * p * cos(phi + 2.0943951023931953 /* 2*pi/3 */);
-    const double e_mid = 3.0 * q - e_max - e_min;
-    float a = (float)e_min, b = (float)e_mid, c = (float)e_max;   // ascending, as eigvalsh returns
-    // stable insertion sort by |.| (numpy argsort of 3 elements)
-    float ka = fabsf(a), kb = fabsf(b), kc = fabsf(c);
-    if (kb < ka) { float t = a; a = b; b = t; t = ka; ka = kb; kb = t; }
-    if (kc < kb) {
-        float t = b; b = c; c = t; t = kb; kb = kc; kc = t;
-        if (kb < ka) { t = a; a = b; b = t; t = ka; ka = kb; kb = t; }
-    }
-    l1 = a; l2 = b; l3 = c;
-}
-
-// 1/sqrt(x) in float64 from the hardware estimate + two Newton steps (x > 0, normal range)
-__device__ __forceinline__ double rsqrt_f64(double x) {
-    double y = __builtin_amdgcn_rsq(x);
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const double t = x * y;
-        const double e = fma(-t, y, 1.0);
-        y = fma(0.5 * y, e, y);
-    }
-    return y;
-}
-
-// Stable |lambda| ordering of three ascending values (numpy argsort on 3 elements = insertion sort)
-__device__ __forceinline__ void sort3_abs(float a, float b, float c, float &l1, float &l2, float &l3) {
-    float ka = fabsf(a), kb = fabsf(b), kc = fabsf(c);
-    if (kb < ka) { float t = a; a = b; b = t; t = ka; ka = kb; kb = t; }
-    if (kc < kb) {
-        float t = b; b = c; c = t; t = kb; kb = kc; kc = t;
-        if (kb < ka) { t = a; a = b; b = t; t = ka; ka = kb; kb = t; }
-    }
-    l1 = a; l2 = b; l3 = c;
-}
-
-// Production eigen-solve: the same closed form, no libm.  With r = det(B)/(2 p^3) in [-1,1] and
-// phi = acos(|r|)/3 in [0, pi/6], c = cos(phi) is the largest root of 4c^3 - 3c = |r| (c in [0.866,1],
-// derivative 12c^2-3 in [6,9]: well conditioned): degree-4 starting polynomial (4.5e-6) + two Newton
-// steps with a float32 reciprocal of the derivative -> 1e-16.  s = sin(phi) = sqrt(1-c^2).
-//   r >= 0: e_max = q + 2pc, e_min = q - p(c + sqrt3 s);   r < 0: e_min = q - 2pc, e_max = q + p(c + sqrt3 s)
-// Accuracy ~1e-16 * ||A|| (near-degenerate pairs ~1e-8 * ||A||, exactly like the acos form), so the
-// float32-rounded eigenvalues equal LAPACK's except with probability ~1e-9 per value.
-__device__ __forceinline__ void eig3_sorted_abs(const float h[6], float &l1, float &l2, float &l3) {
-    const double a00 = h[0], a01 = h[1], a02 = h[2], a11 = h[3], a12 = h[4], a22 = h[5];
-    const double q = (a00 + a11 + a22) * (1.0 / 3.0);
-    const double b00 = a00 - q, b11 = a11 - q, b22 = a22 - q;
-    const double off = fma(a01, a01, fma(a02, a02, a12 * a12));
-    const double p2 = (fma(b00, b00, fma(b11, b11, b22 * b22)) + 2.0 * off) * (1.0 / 6.0);
-    const double m0 = fma(b11, b22, -(a12 * a12));
-    const double m1 = fma(a01, b22, -(a12 * a02));
-    const double m2 = fma(a01, a12, -(b11 * a02));
-    const double det = fma(b00, m0, fma(-a01, m1, a02 * m2));
-    float ea, eb, ec;
-    if (p2 > 0.0) {
-        const double y = rsqrt_f64(p2);
-        const double p = p2 * y;
-        double r = 0.5 * det * (y * y * y);
-        const bool neg = r < 0.0;
-        double ra = fabs(r);
-        ra = ra > 1.0 ? 1.0 : ra;
-        double c = fma(fma(fma(fma(-0.004099405456413993, ra, 0.017642364887819385), ra, -0.046005261357895906), ra,
-                           0.16642901838062307), ra, 0.866029853359238);
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const double t = c * c;
-            const double f = fma(c, fma(4.0, t, -3.0), -ra);
-            const double fp = fma(12.0, t, -3.0);
-            c = fma(-f, (double)__builtin_amdgcn_rcpf((float)fp), c);
-        }
-        c = c > 1.0 ? 1.0 : c;
-        const double s2 = fma(-c, c, 1.0);
-        const double s = s2 > 0.0 ? s2 * rsqrt_f64(s2) : 0.0;
-        const double t1 = 2.0 * p * c;
-        const double t2 = p * fma(1.7320508075688772, s, c);
-        const double e_max = neg ? q + t2 : q + t1;
-        const double e_min = neg ? q - t1 : q - t2;
-        const double e_mid = 3.0 * q - e_max - e_min;
-        ea = (float)e_min; eb = (float)e_mid; ec = (float)e_max;
-    } else {
-        ea = eb = ec = (float)q;          // p2 == 0 (multiple of the identity) or NaN
-    }
-    sort3_abs(ea, eb, ec, l1, l2, l3);
-}
-
-__device__ __forceinline__ float frangi3(float l1, float l2, float l3, float alpha_sq, float beta_sq, float gamma_sq) {
-    const float al2 = fabsf(l2), al3 = fabsf(l3);
-    const float ra = al2 / (al3 + 1e-12f);
-    const float ra_sq = ra * ra;
-    const float rb = al2 / (sqrtf(fabsf(l2 * l3)) + 1e-12f);
-    const float rb_sq = rb * rb;
-    const float s_sq = l1 * l1 + l2 * l2 + l3 * l3;
-    const float A = 1.0f - expf(-(ra_sq / alpha_sq));
-    const float B = expf(-(rb_sq / beta_sq));
-    const float C = 1.0f - expf(-(s_sq / gamma_sq));
-    float v = A * B * C;
-    if (l3 > 0.0f) v = 0.0f;
-    if (l2 > 0.0f) v = 0.0f;
-    if (!(fabsf(v) <= 3.402823466e38f)) v = 0.0f;   // nan_to_num(nan=0, posinf=0, neginf=0)
-    return v;
-}
-
-// debug / known-answer kernel: eigenvalues (sorted by |.|) and Frangi response of explicit Hessians
-__global__ void __launch_bounds__(256)
-debug_eig_kernel(const float *__restrict__ h6, i64 n, int impl, float alpha_sq, float beta_sq, float gamma_sq,
-                 float *__restrict__ out4) {
-    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float h[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) h[k] = h6[i * 6 + k];
-    float l1, l2, l3;
-    if (impl == 0) eig3_sorted_abs(h, l1, l2, l3); else eig3_sorted_abs_libm(h, l1, l2, l3);
-    out4[i * 4 + 0] = l1; out4[i * 4 + 1] = l2; out4[i * 4 + 2] = l3;
-    out4[i * 4 + 3] = frangi3(l1, l2, l3, alpha_sq, beta_sq, gamma_sq);
-}
-
-// =================================================================================================
-// kernels: dtype conversion
-// =================================================================================================
-template <typename T>
-__global__ void convert_kernel(const T *__restrict__ src, float *__restrict__ dst, i64 n) {
-    i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    const i64 stride = (i64)gridDim.x * blockDim.x;
-    for (; i < n; i += stride) dst[i] = (float)src[i];
-}
-
-template <typename T>
-__global__ void intensity_mask_kernel(const T *__restrict__ orig, float *__restrict__ frangi, double thresh, i64 n) {
-    i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    const i64 stride = (i64)gridDim.x * blockDim.x;
-    for (; i < n; i += stride) {
-        // frangi * mask with mask bool: False -> +0.0 * x (keeps numpy's signed zero / nan semantics simple: x finite >= 0)
-        if (!((double)orig[i] > thresh)) frangi[i] = frangi[i] * 0.0f;
-    }
-}
-
-__global__ void fill_f32_kernel(float *p, float v, i64 n) {
-    i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    const i64 stride = (i64)gridDim.x * blockDim.x;
-    for (; i < n; i += stride) p[i] = v;
-}
-
-// =================================================================================================
-// kernels: separable Gaussian (scipy correlate1d, symmetric branch, float64 accumulate)
-//   tmp = in[0]*w[r];  for j = r..1: tmp += (in[-j] + in[+j]) * w[r-j];  out = (float)tmp
-// One thread per output voxel; lanes run along X so every tap is a coalesced row read.
-// =================================================================================================
-#define NL_MAX_RADIUS 63
-struct GaussW { double w[NL_MAX_RADIUS + 1]; int r; };   // w[k] = weight at distance k from the centre
-
-template <int AXIS>
-__global__ void __launch_bounds__(256)
-gauss_axis_kernel(const float *__restrict__ in, float *__restrict__ out, VolGeom v, i64 z0, i64 z1, GaussW gw) {
-    const i64 x = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    const i64 y = blockIdx.y;
-    const i64 z = z0 + blockIdx.z;
-    if (x >= v.nx) return;
-    const i64 sy = v.nx, sz = v.ny * v.nx;
-    const i64 c = z * sz + y * sy + x;
-    double tmp = (double)in[c] * gw.w[0];
-    for (int j = gw.r; j >= 1; --j) {
-        i64 il, ih;
-        if (AXIS == 0) {
-            il = (reflect_idx(v.gz0 + z - j, v.gnz) - v.gz0) * sz + y * sy + x;
-            ih = (reflect_idx(v.gz0 + z + j, v.gnz) - v.gz0) * sz + y * sy + x;
-        } else if (AXIS == 1) {
-            il = z * sz + reflect_idx(y - j, v.ny) * sy + x;
-            ih = z * sz + reflect_idx(y + j, v.ny) * sy + x;
-        } else {
-            il = z * sz + y * sy + reflect_idx(x - j, v.nx);
-            ih = z * sz + y * sy + reflect_idx(x + j, v.nx);
-        }
-        const double s = (double)in[il] + (double)in[ih];
-        tmp = tmp + s * gw.w[j];
-    }
-    out[c] = (float)tmp;
-}
-
-// -------------------------------------------------------------------------------------------------
-// v2 Gaussian passes.  Same arithmetic (scipy's order, float64), every input read from HBM once:
-//  * Z and Y passes: a thread owns one (.., x) column position and MARCHES along the filtered axis
-//    with a sliding window of 2R+1 float64 values in registers (static indexing through a fully
-//    unrolled phase loop); lanes run along X so every load/store is a coalesced 256-B row piece.
-//  * X pass: a workgroup stages a row piece (+-R halo, reflected) in LDS, each thread then computes
-//    4 consecutive outputs from 4+2R staged values and stores them as one float4.
-// Radii above GM_MAX_R fall back to the one-thread-per-voxel kernel above.
-// -------------------------------------------------------------------------------------------------
-#define GM_MAX_R 8
-#define GM_CHUNK 128
-struct GaussWS { double w[GM_MAX_R + 1]; };
-
-// AXIS 0: line = Z (grid over y-groups, x-tiles, z-chunks); AXIS 1: line = Y (grid over z-groups, x-tiles, y-chunks)
-template <int AXIS, int R>
-__global__ void __launch_bounds__(256)
-gauss_march_kernel(const float *__restrict__ in, float *__restrict__ out, VolGeom v, i64 z0, i64 z1, GaussWS gw) {
-    constexpr int W = 2 * R + 1;
-    const int lx = threadIdx.x & 63, lo = threadIdx.x >> 6;      // 64 x-positions x 4 "other" positions
-    const i64 x = (i64)blockIdx.x * 64 + lx;
-    const i64 sy = v.nx, sz = v.ny * v.nx;
-    i64 other, c0, c1, n_line, line_stride, base;
-    if (AXIS == 0) {
-        other = (i64)blockIdx.y * 4 + lo;                         // y
-        c0 = z0 + (i64)blockIdx.z * GM_CHUNK;
-        c1 = c0 + GM_CHUNK < z1 ? c0 + GM_CHUNK : z1;
-        if (other >= v.ny || x >= v.nx) return;
-        line_stride = sz; base = other * sy + x;
-    } else {
-        other = z0 + (i64)blockIdx.y * 4 + lo;                    // z
-        c0 = (i64)blockIdx.z * GM_CHUNK;
-        c1 = c0 + GM_CHUNK < v.ny ? c0 + GM_CHUNK : v.ny;
-        if (other >= z1 || x >= v.nx) return;
-        line_stride = sy; base = other * sz + x;
-    }
-    n_line = (AXIS == 0) ? v.gnz : v.ny;
-    const i64 goff = (AXIS == 0) ? v.gz0 : 0;                     // line coordinate of local index 0
-    auto ld = [&](i64 p) -> double {                               // p = local line index, may be outside
-        const i64 q = reflect_idx(goff + p, n_line) - goff;
-        return (double)in[base + q * line_stride];
-    };
-    double win[W];
-#pragma unroll
-    for (int k = 0; k < W - 1; ++k) win[k + 1] = ld(c0 - R + k);   // slots 1..W-1 hold c0-R .. c0+R-1
-    for (i64 p0 = c0; p0 < c1; p0 += W) {
-#pragma unroll
-        for (int ph = 0; ph < W; ++ph) {
-            const i64 p = p0 + ph;
-            if (p < c1) {
-                // the newest value (p+R) replaces the oldest slot, which is slot `ph`
-                win[ph] = ld(p + R);
-                // window position t (0..2R) = line index p-R+t lives in slot (ph + 1 + t) % W
-                double tmp = win[(ph + 1 + R) % W] * gw.w[0];
-#pragma unroll
-                for (int j = R; j >= 1; --j) {
-                    const double s = win[(ph + 1 + R - j) % W] + win[(ph + 1 + R + j) % W];
-                    tmp = tmp + s * gw.w[j];
-                }
-                out[base + p * line_stride] = (float)tmp;
-            }
-        }
-    }
-}
-
-// Fused Y + X pass (the Y and X radii of a cascade step are always equal: sigma_vec = (s/z_ratio, s, s)).
-// A 320-thread workgroup owns 256 output columns of one Z plane and walks a chunk of rows: every thread marches
-// down ITS column (256 outputs + R reflected halo columns on each side) with the float64 sliding window of the Y
-// pass, rounds to float32 exactly like the stand-alone pass, and drops the value into a double-buffered LDS row;
-// after one barrier the 256 output threads take the X pass from that row.  The intermediate volume between the Y
-// and the X pass never exists in HBM: 8 B/voxel instead of 16.
-#define GYX_COLS 256
-#define GYX_THREADS 320
-template <int R>
-__global__ void __launch_bounds__(GYX_THREADS)
-gauss_yx_kernel(const float *__restrict__ in, float *__restrict__ out, VolGeom v, i64 z0, i64 z1, GaussWS gwy, GaussWS gwx) {
-    constexpr int W = 2 * R + 1;
-    __shared__ float rowbuf[2][GYX_COLS + 2 * GM_MAX_R];
-    const int pos = threadIdx.x;                                  // position in the staged row
-    const i64 x0 = (i64)blockIdx.x * GYX_COLS;
-    const i64 z = z0 + blockIdx.z;
-    const i64 c0 = (i64)blockIdx.y * GM_CHUNK;
-    const i64 c1 = c0 + GM_CHUNK < v.ny ? c0 + GM_CHUNK : v.ny;
-    const bool active = pos < GYX_COLS + 2 * R;
-    const i64 xcol = reflect_idx(x0 - R + pos, v.nx);             // the column this thread filters along Y
-    const i64 xout = x0 + pos - R;                                // the output column of an output thread
-    const bool writer = pos >= R && pos < R + GYX_COLS && xout < v.nx;
-    const i64 sy = v.nx;
-    const i64 base = z * v.ny * v.nx + xcol;
-    auto ld = [&](i64 p) -> double { return (double)in[base + reflect_idx(p, v.ny) * sy]; };
-    double win[W];
-    if (active) {
-#pragma unroll
-        for (int k = 0; k < W - 1; ++k) win[k + 1] = ld(c0 - R + k);
-    }
-    for (i64 p0 = c0; p0 < c1; p0 += W) {
-#pragma unroll
-        for (int ph = 0; ph < W; ++ph) {
-            const i64 p = p0 + ph;
-            if (p < c1) {                                          // uniform
-                const int buf = (int)(p & 1);
-                if (active) {
-                    win[ph] = ld(p + R);
-                    double tmp = win[(ph + 1 + R) % W] * gwy.w[0];
-#pragma unroll
-                    for (int j = R; j >= 1; --j) {
-                        const double s = win[(ph + 1 + R - j) % W] + win[(ph + 1 + R + j) % W];
-                        tmp = tmp + s * gwy.w[j];
-                    }
-                    rowbuf[buf][pos] = (float)tmp;                 // the float32 store between the two passes
-                }
-                __syncthreads();
-                if (writer) {
-                    double tmp = (double)rowbuf[buf][pos] * gwx.w[0];
-#pragma unroll
-                    for (int j = R; j >= 1; --j) {
-                        const double s = (double)rowbuf[buf][pos - j] + (double)rowbuf[buf][pos + j];
-                        tmp = tmp + s * gwx.w[j];
-                    }
-                    out[(z * v.ny + p) * v.nx + xout] = (float)tmp;
-                }
-            }
-        }
-    }
-}
-
-#define GX_SEG 1024
-template <int R>
-__global__ void __launch_bounds__(256)
-gauss_x_kernel(const float *__restrict__ in, float *__restrict__ out, VolGeom v, i64 z0, i64 z1, GaussWS gw, int vec4) {
-    __shared__ float row[GX_SEG + 2 * GM_MAX_R];
-    const i64 y = blockIdx.y, z = z0 + blockIdx.z;
-    const i64 xs = (i64)blockIdx.x * GX_SEG;                       // first output of this segment
-    const i64 rb = (z * v.ny + y) * v.nx;
-    const int tid = threadIdx.x;
-    const i64 seg = (v.nx - xs < GX_SEG) ? v.nx - xs : GX_SEG;
-    for (int e = tid; e < seg + 2 * R; e += 256) row[e] = in[rb + reflect_idx(xs - R + e, v.nx)];
-    __syncthreads();
-    const int o = tid * 4;
-    if (o >= seg) return;
-    double d[4 + 2 * R];
-#pragma unroll
-    for (int k = 0; k < 4 + 2 * R; ++k) d[k] = (o + k < seg + 2 * R) ? (double)row[o + k] : 0.0;
-    float res[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        double tmp = d[q + R] * gw.w[0];
-#pragma unroll
-        for (int j = R; j >= 1; --j) tmp = tmp + (d[q + R - j] + d[q + R + j]) * gw.w[j];
-        res[q] = (float)tmp;
-    }
-    float *dst = out + rb + xs + o;
-    if (vec4 && o + 3 < seg) {
-        *reinterpret_cast<float4 *>(dst) = make_float4(res[0], res[1], res[2], res[3]);
-    } else {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) if (o + q < seg) dst[q] = res[q];
-    }
-}
-
-// =================================================================================================
-// kernels: lattice sampling (strided subsample for the thresholds)
-// =================================================================================================
-struct Lattice {
-    i64 sz, sy, sx;      // strides (global lattice)
-    i64 cz, cy, cx;      // lattice extent on the owned planes
-    i64 zfirst;          // local z of the first owned lattice plane
-};
-
-struct FieldSrc {
-    const float *p;      // gauss (GAUSS/FROB) or frangi
-    int field;
-    HessP hp;
-    float max_abs, max_finite;
-};
-
-__device__ __forceinline__ float field_value(const FieldSrc &fs, const VolGeom &v, i64 z, i64 y, i64 x) {
-    if (fs.field == NL_FIELD_FROB) {
-        float h[6];
-        hessian_at(fs.p, v, fs.hp, z, y, x, h);
-        return frob_norm(frob_sq_of(h), fs.max_abs, fs.max_finite);
-    }
-    return fs.p[(z * v.ny + y) * v.nx + x];
-}
-
-__global__ void __launch_bounds__(256)
-sample_gather_kernel(FieldSrc fs, VolGeom v, Lattice L, float *__restrict__ out) {
-    const i64 total = L.cz * L.cy * L.cx;
-    i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const i64 ix = i % L.cx, iy = (i / L.cx) % L.cy, iz = i / (L.cx * L.cy);
-    out[i] = field_value(fs, v, L.zfirst + iz * L.sz, iy * L.sy, ix * L.sx);
-}
-
-// results: [0] = min bits (uint), [1] = max bits (uint), [2..3] = count (u64).  Grid-stride, one set of
-// atomics per workgroup (per-wave atomics on three shared words cost ~0.5 ms at 1e6 samples).
-__global__ void __launch_bounds__(256)
-sample_minmax_kernel(FieldSrc fs, VolGeom v, Lattice L, unsigned int *__restrict__ res) {
-    __shared__ float s_mn[4], s_mx[4];
-    __shared__ unsigned long long s_c[4];
-    const i64 total = L.cz * L.cy * L.cx;
-    const i64 stride = (i64)gridDim.x * blockDim.x;
-    float mn = __int_as_float(0x7f800000), mx = 0.0f;
-    unsigned long long cnt = 0;
-    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        const i64 ix = i % L.cx, iy = (i / L.cx) % L.cy, iz = i / (L.cx * L.cy);
-        const float val = field_value(fs, v, L.zfirst + iz * L.sz, iy * L.sy, ix * L.sx);
-        if (val > 0.0f) { mn = fminf(mn, val); mx = fmaxf(mx, val); cnt++; }
-    }
-    mn = wave_min_f(mn); mx = wave_max_f(mx); cnt = wave_sum_u64(cnt);
-    const int w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { s_mn[w] = mn; s_mx[w] = mx; s_c[w] = cnt; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int k = 1; k < 4; ++k) { mn = fminf(mn, s_mn[k]); mx = fmaxf(mx, s_mx[k]); cnt += s_c[k]; }
-        if (cnt) {
-            // positive floats order like their bit patterns
-            atomicMin(&res[0], __float_as_uint(mn));
-            atomicMax(&res[1], __float_as_uint(mx));
-            atomicAdd((unsigned long long *)(res + 2), cnt);
-        }
-    }
-}
-
-// numpy histogram fast path, float32 (numpy/lib/_histograms_impl.py): see include/nellie_amd.h
-__global__ void __launch_bounds__(256)
-sample_hist_kernel(FieldSrc fs, VolGeom v, Lattice L, const float *__restrict__ edges, int nbins,
-                   unsigned long long *__restrict__ counts) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *s_edges = (float *)smem;                          // nbins+1
-    unsigned int *s_cnt = (unsigned int *)(s_edges + nbins + 1 + ((nbins + 1) & 1));   // nbins
-    for (int k = threadIdx.x; k <= nbins; k += blockDim.x) s_edges[k] = edges[k];
-    for (int k = threadIdx.x; k < nbins; k += blockDim.x) s_cnt[k] = 0;
-    __syncthreads();
-    const float first = s_edges[0], last = s_edges[nbins];
-    const float denom = last - first;
-    const i64 total = L.cz * L.cy * L.cx;
-    const i64 stride = (i64)gridDim.x * blockDim.x;
-    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        const i64 ix = i % L.cx, iy = (i / L.cx) % L.cy, iz = i / (L.cx * L.cy);
-        const float a = field_value(fs, v, L.zfirst + iz * L.sz, iy * L.sy, ix * L.sx);
-        if (a > 0.0f && a >= first && a <= last) {
-            const float fi = ((a - first) / denom) * (float)nbins;
-            int idx = (int)fi;
-            if (idx == nbins) idx -= 1;
-            if (a < s_edges[idx]) idx -= 1;
-            if (a >= s_edges[idx + 1] && idx != nbins - 1) idx += 1;
-            atomicAdd(&s_cnt[idx], 1u);
-        }
-    }
-    __syncthreads();
-    for (int k = threadIdx.x; k < nbins; k += blockDim.x)
-        if (s_cnt[k]) atomicAdd(&counts[k], (unsigned long long)s_cnt[k]);
-}
-
-__global__ void __launch_bounds__(256)
-flat_gather_kernel(const float *__restrict__ p, i64 base, i64 offset, i64 step, i64 count, float *__restrict__ out) {
-    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < count) out[i] = p[base + offset + i * step];
-}
-
-// =================================================================================================
-// kernels: Hessian statistics and the per-scale vesselness update
-// =================================================================================================
-// res: [0] max|h| bits, [1] max finite frob_sq bits, [2] any_inf
-__global__ void __launch_bounds__(256)
-hessian_stats_kernel(const float *__restrict__ g, VolGeom v, HessP hp, i64 z0, i64 z1, unsigned int *__restrict__ res) {
-    const i64 x = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    const i64 y = blockIdx.y;
-    const i64 z = z0 + blockIdx.z;
-    float mabs = 0.0f, mfrob = 0.0f;
-    int inf = 0;
-    if (x < v.nx) {
-        float h[6];
-        hessian_at(g, v, hp, z, y, x, h);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) mabs = fmaxf(mabs, fabsf(h[k]));
-        const float fsq = frob_sq_of(h);
-        if (isinf(fsq)) inf = 1; else mfrob = fmaxf(mfrob, fsq);   // fmaxf drops NaN
-    }
-    mabs = wave_max_f(mabs); mfrob = wave_max_f(mfrob); inf = wave_or_i(inf);
-    if ((threadIdx.x & 63) == 0) {
-        if (mabs > 0.0f) atomicMax(&res[0], __float_as_uint(mabs));
-        if (mfrob > 0.0f) atomicMax(&res[1], __float_as_uint(mfrob));
-        if (inf) atomicOr(&res[2], 1u);
-    }
-}
-
-struct VessP {
-    float gamma_sq, alpha_sq, beta_sq;
-    int use_thr;
-    float thr;
-    float max_abs, max_finite;
-    int mask_rmw;            // 1: AND into the slot (more scales than mask slots)
-    int cnt_lo, cnt_hi;      // planes whose masked voxels are counted (the owned ones)
-    int first;               // 1: first evaluated scale of the frame -> vesselness is written, not max-ed (no memset needed)
-};
-
-__global__ void __launch_bounds__(256)
-vesselness_kernel(const float *__restrict__ g, float *__restrict__ vmax, uint8_t *__restrict__ cmask,
-                  VolGeom v, HessP hp, VessP vp, i64 z0, i64 z1, unsigned long long *__restrict__ mask_count) {
-    const i64 x = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    const i64 y = blockIdx.y;
-    const i64 z = z0 + blockIdx.z;
-    unsigned long long cnt = 0;
-    if (x < v.nx) {
-        const i64 c = (z * v.ny + y) * v.nx + x;
-        float h[6];
-        hessian_at(g, v, hp, z, y, x, h);
-        const float fr = frob_norm(frob_sq_of(h), vp.max_abs, vp.max_finite);
-        const bool m = vp.use_thr ? (fr > vp.thr) : (fr > 0.0f);
-        if (m) {
-            float l1, l2, l3;
-            eig3_sorted_abs(h, l1, l2, l3);
-            const float val = frangi3(l1, l2, l3, vp.alpha_sq, vp.beta_sq, vp.gamma_sq);
-            const float old = vmax[c];
-            if (val > old) vmax[c] = val;      // np.maximum(vesselness, vessel_scale); both finite, >= 0
-            cnt = 1;
-        } else {
-            cmask[c] = 0;                      // masks &= h_mask
-        }
-    }
-    cnt = wave_sum_u64(cnt);
-    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(mask_count, cnt);
-}
-
-// -------------------------------------------------------------------------------------------------
-// v3: Z-marching, LDS-tiled Hessian kernel (MODE 0 = statistics, MODE 1 = vesselness update).
-// A 1024-thread workgroup owns a 16(y) x 64(x) column tile and walks a chunk of Z planes.  Each
-// plane tile (+-2 halo, indices clamped at the volume faces so the padding replicates the edge
-// voxels) is read from HBM once into an 8-slot LDS ring; the next plane is fetched into registers
-// while the current one is computed (one barrier per plane).  All 24 stencil taps come from LDS.
-// Edge rules: with replicated padding f(clamp(q-1)) is simply tile[q-1]; only the divisor
-// (float32(h) at a face, float32(2h) inside) and the outer difference sites need selects.
-// Divisions by the six constant spacings go through div_c (exactly rounded, see above).
-// MODE 1 only evaluates eigenvalues where the Frobenius mask holds (15-25 % of the voxels, scattered):
-// masked voxels are COMPACTED into an LDS queue (6 Hessian components + voxel index) and the
-// float64 eigen-solve + Frangi response runs on dense batches of 1024 queue entries.
-// -------------------------------------------------------------------------------------------------
-#define HM_TX 64
-#define HM_PW (HM_TX + 4)
-#define HM_SLOTS 8
-#define HM_RSLOT(zz) ((int)(((unsigned)((zz) - zc0 + HM_SLOTS)) & (HM_SLOTS - 1)))   // ring slot relative to the chunk start
-#define HM_ZCHUNK 64
-#define HM_DEPTH 3
-template <int TY> struct HMCfg {
-    static constexpr int NT = HM_TX * TY;               // threads per workgroup
-    static constexpr int PH = TY + 4;
-    static constexpr int PLANE = HM_PW * PH;
-    static constexpr int QCAP = 2 * NT;                 // queue ring: < NT waiting + <= NT appended per plane
-    static constexpr int lds_floats(int mode) { return HM_SLOTS * PLANE + 64 + (mode == 1 ? 7 * QCAP : 0); }
-};
-
-// A constant float32 divisor, two exact implementations of a/d:
-//  FAST : q = a*y; r = fma(-q,d,a); q' = fma(r,y,q) with y = RN(1/d) -- three float32 instructions.  This
-//         sequence is correctly rounded for most but not all d, so nl_hessian_stats PROVES it for the
-//         six divisors in use by exhaustion (divcheck_kernel: all 2^23 significands; scaling a by 2^k
-//         scales q, r, q' exactly, so one binade covers every normal a) before selecting this path.
-//  !FAST: (float)((double)a * RN64(1/d)), exact for every d (see div_c).
-template <bool FAST> struct Dv;
-template <> struct Dv<true> {
-    float d, y;
-    __device__ __forceinline__ float div(float a) const { const float q = a * y; const float r = fmaf(-q, d, a); return fmaf(r, y, q); }
-};
-template <> struct Dv<false> {
-    double r;
-    __device__ __forceinline__ float div(float a) const { return (float)((double)a * r); }
-};
-template <bool FAST> struct HessDv { Dv<FAST> z, y, x, z2, y2, x2; };   // float32(h) and float32(2h) per axis
-
-__global__ void __launch_bounds__(256)
-divcheck_kernel(float d, float y, unsigned int *__restrict__ bad) {
-    const unsigned int i = blockIdx.x * 256u + threadIdx.x;               // 2^23 significands of [1,2)
-    const float a = __uint_as_float(0x3f800000u | i);
-    Dv<true> dv{d, y};
-    if (dv.div(a) != a / d) atomicOr(bad, 1u);
-}
-
-template <int MODE, int TY, bool FAST>
-__global__ void __launch_bounds__(HM_TX * TY)
-hessian_march_kernel(const float *__restrict__ g, float *__restrict__ vmax, unsigned long long *__restrict__ cmask64, int wpr,
-                     VolGeom v, HessDv<FAST> hr, VessP vp, int z0, int z1, int ntx, int nty,
-                     unsigned int *__restrict__ res, unsigned long long *__restrict__ mask_count) {
-    constexpr int NT = HMCfg<TY>::NT, HM_PLANE = HMCfg<TY>::PLANE, HM_QCAP = HMCfg<TY>::QCAP, HM_TY = TY;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *sp = (float *)smem;                               // [HM_SLOTS][HM_PLANE]
-    float *s_red = sp + HM_SLOTS * HM_PLANE;               // 64 floats of reduction scratch
-    float *q_h = s_red + 64;                                 // [6][HM_QCAP]   (MODE 1)
-    int *q_i = (int *)(q_h + 6 * HM_QCAP);                   // [HM_QCAP]      (MODE 1)
-    int *s_tail = (int *)s_red + 48;                         // queue tail     (MODE 1)
-    const int tid = threadIdx.x;
-    const int lx = tid & 63, ly = tid >> 6;
-    // XCD-aware remap: workgroup b runs on XCD b % 8; give each XCD a contiguous run of tiles so that
-    // neighbouring tiles (shared halos) meet in the same L2.  Speed only, never correctness.
-    const unsigned nblk = gridDim.x;
-    unsigned bid = blockIdx.x;
-    if ((nblk & 7u) == 0u) bid = (bid & 7u) * (nblk >> 3) + (bid >> 3);
-    const int tx = bid % ntx;
-    const int ty = (bid / ntx) % nty;
-    const int zc = bid / (ntx * nty);
-    const int zc0 = z0 + zc * HM_ZCHUNK;
-    const int zc1 = (zc0 + HM_ZCHUNK < z1) ? zc0 + HM_ZCHUNK : z1;
-    const int nx = (int)v.nx, ny = (int)v.ny;
-    const i64 sz = v.ny * v.nx;
-    const int gz0 = (int)v.gz0, gnz = (int)v.gnz;
-    const int xbase = tx * HM_TX - 2, ybase = ty * HM_TY - 2;
-    const int x = xbase + 2 + lx, y = ybase + 2 + ly;
-    const bool valid = (x < nx) && (y < ny);
-
-    // the (up to) two tile elements this thread stages per plane (in-plane offsets fit 32 bits)
-    int off0, off1 = -1;
-    {
-        int yy = ybase + tid / HM_PW, xx = xbase + tid % HM_PW;
-        yy = yy < 0 ? 0 : (yy > ny - 1 ? ny - 1 : yy);
-        xx = xx < 0 ? 0 : (xx > nx - 1 ? nx - 1 : xx);
-        off0 = yy * nx + xx;
-        const int e1 = tid + NT;
-        if (e1 < HM_PLANE) {
-            int y1 = ybase + e1 / HM_PW, x1 = xbase + e1 % HM_PW;
-            y1 = y1 < 0 ? 0 : (y1 > ny - 1 ? ny - 1 : y1);
-            x1 = x1 < 0 ? 0 : (x1 > nx - 1 ? nx - 1 : x1);
-            off1 = y1 * nx + x1;
-        }
-    }
-    // clamp a local plane index to the GLOBAL volume
-    auto zclamp = [&](int zz) -> int {
-        const int gg = gz0 + zz;
-        return gg < 0 ? -gz0 : (gg > gnz - 1 ? gnz - 1 - gz0 : zz);
-    };
-
-    if (MODE == 1 && tid == 0) *s_tail = 0;
-    // Planes this chunk ever touches form the contiguous range [pmin, pmax].  The first five go straight
-    // to LDS; the following HM_DEPTH planes are put in flight into registers (memory-level parallelism:
-    // a 3.2 KB plane per workgroup is far too little to cover HBM latency on its own).
-    const int pmin = zclamp(zc0 - 2), pmax = zclamp(zc1 + 1);
-    for (int pz = pmin; pz <= pmax && pz <= zc0 + 2; ++pz) {
-        float *dst = sp + HM_RSLOT(pz) * HM_PLANE;
-        const float *src = g + (i64)pz * sz;
-        dst[tid] = src[off0];
-        if (off1 >= 0) dst[tid + NT] = src[off1];
-    }
-    float ra[HM_DEPTH], rb[HM_DEPTH];
-#pragma unroll
-    for (int d = 0; d < HM_DEPTH; ++d) {
-        ra[d] = 0.0f; rb[d] = 0.0f;
-        const int pz = zc0 + 3 + d;
-        if (pz <= pmax) {
-            const float *src = g + (i64)pz * sz;
-            ra[d] = src[off0];
-            if (off1 >= 0) rb[d] = src[off1];
-        }
-    }
-    __syncthreads();
-
-    // per-lane in-plane geometry (constant along Z)
-    const bool y_lo = (y == 0), y_hi = (y == ny - 1), x_lo = (x == 0), x_hi = (x == nx - 1);
-    const int jc = ly + 2, ic = lx + 2;
-    const int jl = jc - (y_lo ? 0 : 1), jh = jc + (y_hi ? 0 : 1);
-    const int il = ic - (x_lo ? 0 : 1), ih = ic + (x_hi ? 0 : 1);
-    const Dv<FAST> rdy = (y_lo || y_hi) ? hr.y : hr.y2;
-    const Dv<FAST> rdx = (x_lo || x_hi) ? hr.x : hr.x2;
-    // reciprocal divisor of the first derivative taken AT row j / column i of the tile
-    auto rdy_at = [&](int j) -> Dv<FAST> { const int yy = ybase + j; return (yy == 0 || yy == ny - 1) ? hr.y : hr.y2; };
-    auto rdx_at = [&](int i) -> Dv<FAST> { const int xx = xbase + i; return (xx == 0 || xx == nx - 1) ? hr.x : hr.x2; };
-    const Dv<FAST> rdy_jl = rdy_at(jl), rdy_jh = rdy_at(jh), rdy_jc = rdy_at(jc);
-    const Dv<FAST> rdx_il = rdx_at(il), rdx_ih = rdx_at(ih);
-    const int o_cc = jc * HM_PW + ic;
-    const int o_hc = jh * HM_PW + ic, o_lc = jl * HM_PW + ic;     // rows jh / jl, column ic
-    const int o_ch = jc * HM_PW + ih, o_cl = jc * HM_PW + il;     // row jc, columns ih / il
-
-    float mabs = 0.0f, mfrob = 0.0f;
-    int anyinf = 0;
-    unsigned long long cnt = 0;
-    int head = 0;
-
-    auto process_entry = [&](int e) {
-        const int slot = e & (HM_QCAP - 1);
-        float h[6];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) h[k] = q_h[k * HM_QCAP + slot];
-        const int c = q_i[slot];
-        float l1, l2, l3;
-        eig3_sorted_abs(h, l1, l2, l3);
-        const float val = frangi3(l1, l2, l3, vp.alpha_sq, vp.beta_sq, vp.gamma_sq);
-        if (vp.first || val > vmax[c]) vmax[c] = val;
-    };
-
-    // Hessian of the voxel from five plane tiles (float32, numpy's rounding points)
-    auto compute_h = [&](const float *Pm2, const float *Pm1, const float *P0, const float *Pp1, const float *Pp2,
-                         const bool z_lo, const bool z_hi, const Dv<FAST> rdz, const Dv<FAST> rdz_m1, const Dv<FAST> rdz_p1,
-                         float h[6]) {
-        const Dv<FAST> rdz_0 = rdz;
-        // h_zz: outer sites are z+1 (or z at the top face) and z-1 (or z at the bottom face); the first derivatives
-        // along Z at planes z-1, z, z+1 use planes (z-2,z), (z-1,z+1), (z,z+2)
-        const float gz_hi = z_hi ? rdz_0.div(P0[o_cc] - Pm1[o_cc]) : rdz_p1.div(Pp2[o_cc] - P0[o_cc]);
-        const float gz_lo = z_lo ? rdz_0.div(Pp1[o_cc] - P0[o_cc]) : rdz_m1.div(P0[o_cc] - Pm2[o_cc]);
-        h[0] = rdz.div(gz_hi - gz_lo);
-        h[1] = rdy.div(rdz_0.div(Pp1[o_hc] - Pm1[o_hc]) - rdz_0.div(Pp1[o_lc] - Pm1[o_lc]));
-        h[2] = rdx.div(rdz_0.div(Pp1[o_ch] - Pm1[o_ch]) - rdz_0.div(Pp1[o_cl] - Pm1[o_cl]));
-        h[3] = rdy.div(rdy_jh.div(P0[o_hc + HM_PW] - P0[o_hc - HM_PW]) - rdy_jl.div(P0[o_lc + HM_PW] - P0[o_lc - HM_PW]));
-        h[4] = rdx.div(rdy_jc.div(P0[o_ch + HM_PW] - P0[o_ch - HM_PW]) - rdy_jc.div(P0[o_cl + HM_PW] - P0[o_cl - HM_PW]));
-        h[5] = rdx.div(rdx_ih.div(P0[o_ch + 1] - P0[o_ch - 1]) - rdx_il.div(P0[o_cl + 1] - P0[o_cl - 1]));
-    };
-
-    // One plane step.  U >= 0: the ring slot of plane z is the compile-time constant U (the Z loop is unrolled by
-    // HM_SLOTS and slots are taken relative to the chunk start), the planes z-2..z+2 all exist (interior), so every
-    // LDS address is a per-lane base + immediate and no select is needed.  U < 0: generic step (faces, loop tail).
-    auto step = [&](const int z, auto uc) {
-        constexpr int U = decltype(uc)::value;
-        if (MODE == 1) {
-            // dense eigen batch once the queue holds a full workgroup's worth
-            const int tail = *(volatile int *)s_tail;
-            if (tail - head >= NT) {              // uniform
-                process_entry(head + tid);
-                head += NT;
-                __syncthreads();                  // entries read before their ring slots can be re-used
-            }
-        }
-        bool m = false;
-        float h[6];
-        if (valid) {
-            if (U >= 0) {
-                compute_h(sp + ((U + 6) & 7) * HM_PLANE, sp + ((U + 7) & 7) * HM_PLANE, sp + (U & 7) * HM_PLANE,
-                          sp + ((U + 1) & 7) * HM_PLANE, sp + ((U + 2) & 7) * HM_PLANE, false, false, hr.z2, hr.z2, hr.z2, h);
-            } else {
-                const int gz = gz0 + z;
-                const bool z_lo = (gz == 0), z_hi = (gz == gnz - 1);
-                compute_h(sp + HM_RSLOT(zclamp(z - 2)) * HM_PLANE, sp + HM_RSLOT(zclamp(z - 1)) * HM_PLANE,
-                          sp + HM_RSLOT(z) * HM_PLANE, sp + HM_RSLOT(zclamp(z + 1)) * HM_PLANE,
-                          sp + HM_RSLOT(zclamp(z + 2)) * HM_PLANE, z_lo, z_hi, (z_lo || z_hi) ? hr.z : hr.z2,
-                          (gz - 1 == 0) ? hr.z : hr.z2, (gz + 1 == gnz - 1) ? hr.z : hr.z2, h);
-            }
-            const float fsq = frob_sq_of(h);
-            if (MODE == 0) {
-#pragma unroll
-                for (int k = 0; k < 6; ++k) mabs = fmaxf(mabs, fabsf(h[k]));
-                if (isinf(fsq)) anyinf = 1; else mfrob = fmaxf(mfrob, fsq);
-            } else {
-                const float fr = frob_norm(fsq, vp.max_abs, vp.max_finite);
-                m = vp.use_thr ? (fr > vp.thr) : (fr > 0.0f);
-            }
-        }
-        if (MODE == 1) {
-            // append the masked voxels of this wave to the queue (one LDS atomic per wave)
-            const unsigned long long bal = __ballot(m);
-            const int lane = tid & 63;
-            // h_mask of this scale as a bit mask: this wave owns exactly one 64-voxel word of the row.  Every
-            // scale writes its own slot (no read-modify-write on the critical path); nl_filter_finish ANDs them.
-            if (lane == 0 && y < ny) {
-                unsigned long long *wp = cmask64 + ((i64)z * ny + y) * wpr + tx;
-                *wp = vp.mask_rmw ? (*wp & bal) : bal;
-            }
-            if (bal) {
-                const int leader = __builtin_ctzll(bal);
-                int base = 0;
-                if (lane == leader) base = atomicAdd(s_tail, (int)__builtin_popcountll(bal));
-                base = __shfl(base, leader, 64);
-                if (m) {
-                    const int rank = (int)__builtin_popcountll(bal & ((1ull << lane) - 1ull));
-                    const int slot = (base + rank) & (HM_QCAP - 1);
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) q_h[k * HM_QCAP + slot] = h[k];
-                    q_i[slot] = (int)((i64)z * sz + (i64)y * nx + x);
-                    if (z >= vp.cnt_lo && z < vp.cnt_hi) cnt++;
-                }
-            }
-        }
-        // plane z+3 (in flight since HM_DEPTH steps) lands in the ring; plane z+3+HM_DEPTH takes its place in flight
-        if (z + 3 <= pmax) {
-            float *dst = sp + ((U >= 0) ? ((U + 3) & 7) : HM_RSLOT(z + 3)) * HM_PLANE;
-            dst[tid] = ra[0];
-            if (off1 >= 0) dst[tid + NT] = rb[0];
-        }
-#pragma unroll
-        for (int d = 0; d + 1 < HM_DEPTH; ++d) { ra[d] = ra[d + 1]; rb[d] = rb[d + 1]; }
-        {
-            const int pz = z + 3 + HM_DEPTH;
-            if (pz <= pmax) {
-                const float *src = g + (i64)pz * sz;
-                ra[HM_DEPTH - 1] = src[off0];
-                if (off1 >= 0) rb[HM_DEPTH - 1] = src[off1];
-            }
-        }
-        __syncthreads();
-    };
-
-    {
-        int z = zc0;
-        for (; z + HM_SLOTS <= zc1; z += HM_SLOTS) {
-            // all eight planes interior (z-2 >= global 0, z+7+2 <= global last)?  (z - zc0) % 8 == 0 here.
-            // (only the statistics kernel is unrolled: in the vesselness kernel the eight inlined copies of the
-            //  eigen batch push the register count from 84 to 135 and cost more than the static slots gain)
-            if (MODE == 0 && gz0 + z >= 2 && gz0 + z + HM_SLOTS - 1 <= gnz - 3) {
-                step(z + 0, std::integral_constant<int, 0>{}); step(z + 1, std::integral_constant<int, 1>{});
-                step(z + 2, std::integral_constant<int, 2>{}); step(z + 3, std::integral_constant<int, 3>{});
-                step(z + 4, std::integral_constant<int, 4>{}); step(z + 5, std::integral_constant<int, 5>{});
-                step(z + 6, std::integral_constant<int, 6>{}); step(z + 7, std::integral_constant<int, 7>{});
-            } else {
-                for (int u = 0; u < HM_SLOTS; ++u) step(z + u, std::integral_constant<int, -1>{});
-            }
-        }
-        for (; z < zc1; ++z) step(z, std::integral_constant<int, -1>{});
-    }
-    if (MODE == 1) {
-        // drain the queue
-        const int tail = *(volatile int *)s_tail;
-        while (tail - head > 0) {
-            if (head + tid < tail) process_entry(head + tid);
-            head += NT;
-        }
-    }
-
-    // one set of atomics per workgroup
-    const int w = tid >> 6;
-    __syncthreads();
-    if (MODE == 0) {
-        mabs = wave_max_f(mabs); mfrob = wave_max_f(mfrob); anyinf = wave_or_i(anyinf);
-        if ((tid & 63) == 0) { s_red[w] = mabs; s_red[16 + w] = mfrob; s_red[32 + w] = anyinf ? 1.0f : 0.0f; }
-        __syncthreads();
-        if (tid == 0) {
-            float a = 0.0f, b = 0.0f, c = 0.0f;
-            for (int k = 0; k < NT / 64; ++k) { a = fmaxf(a, s_red[k]); b = fmaxf(b, s_red[16 + k]); c = fmaxf(c, s_red[32 + k]); }
-            if (a > 0.0f && __float_as_uint(a) > __hip_atomic_load(&res[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&res[0], __float_as_uint(a));
-            if (b > 0.0f && __float_as_uint(b) > __hip_atomic_load(&res[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&res[1], __float_as_uint(b));
-            if (c > 0.0f) atomicOr(&res[2], 1u);
-        }
-    } else {
-        cnt = wave_sum_u64(cnt);
-        unsigned long long *s_cnt = (unsigned long long *)s_red;
-        if ((tid & 63) == 0) s_cnt[w] = cnt;
-        __syncthreads();
-        if (tid == 0) {
-            unsigned long long t = 0;
-            for (int k = 0; k < NT / 64; ++k) t += s_cnt[k];
-            if (t) atomicAdd(mask_count, t);
-        }
-    }
-}
-
-// vesselness * masks (filtering.py:926); counts voxels > 0 on the owned planes.
-// The cumulative mask is a bit mask: one 64-bit word per 64 consecutive x of a row (row pitch `wpr` words).
-__global__ void __launch_bounds__(256)
-finish_kernel(float *__restrict__ vmax, const unsigned long long *__restrict__ cmask64, int nslots, i64 slot_words, int wpr,
-              VolGeom v, i64 z0, i64 z1, i64 cnt_lo, i64 cnt_hi, unsigned long long *__restrict__ npos) {
-    // one thread = 4 consecutive x of one row (they share a mask word); rows are padded to a multiple of 4 here
-    const i64 qpr = (v.nx + 3) / 4;                                    // quads per row
-    const i64 total = (z1 - z0) * v.ny * qpr;
-    const i64 stride = (i64)gridDim.x * blockDim.x;
-    const bool vec = (v.nx & 3) == 0;
-    unsigned long long cnt = 0;
-    for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
-        const i64 row = t / qpr;
-        const i64 x0 = (t % qpr) * 4;
-        const i64 zloc = z0 + row / v.ny;
-        const bool counted = zloc >= cnt_lo && zloc < cnt_hi;
-        unsigned long long bits = ~0ull;
-        for (int k = 0; k < nslots; ++k) bits &= cmask64[k * slot_words + (z0 * v.ny + row) * wpr + (x0 >> 6)];
-        const unsigned int b4 = (unsigned int)(bits >> (x0 & 63)) & 0xFu;
-        float *p = vmax + (z0 * v.ny + row) * v.nx + x0;
-        if (vec) {
-            float4 val = *reinterpret_cast<float4 *>(p);
-            if (b4 != 0xFu) {
-                if (!(b4 & 1u)) val.x = 0.0f;
-                if (!(b4 & 2u)) val.y = 0.0f;
-                if (!(b4 & 4u)) val.z = 0.0f;
-                if (!(b4 & 8u)) val.w = 0.0f;
-                *reinterpret_cast<float4 *>(p) = val;
-            }
-            if (counted) cnt += (val.x > 0.0f) + (val.y > 0.0f) + (val.z > 0.0f) + (val.w > 0.0f);
-        } else {
-            for (int q = 0; q < 4 && x0 + q < v.nx; ++q) {
-                float val = p[q];
-                if (!((b4 >> q) & 1u)) { val = 0.0f; p[q] = 0.0f; }
-                if (counted && val > 0.0f) cnt++;
-            }
-        }
-    }
-    cnt = wave_sum_u64(cnt);
-    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(npos, cnt);
-}
-
-// filtering.py:964-966: mask = f > thr; binary_opening (6-conn cross, one iteration, border_value 0); f * mask.
-// Done on BIT masks: pack (rl_threshold_pack_kernel), erode, dilate (word-wide logic on 1 bit/voxel), apply.
-// Planes [z0, z1) are produced from planes [z0-1, z1+1) of the input bits; neighbours outside the GLOBAL volume
-// count as 0 (border_value), ghost planes of a slab are real neighbours.
-template <int DILATE>
-__global__ void __launch_bounds__(256)
-bits_morph6_kernel(const unsigned long long *__restrict__ in, unsigned long long *__restrict__ out, VolGeom v, int wpr, i64 z0, i64 z1) {
-    const i64 nw = (z1 - z0) * v.ny * wpr;
-    const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nw) return;
-    const int w = (int)(t % wpr);
-    const i64 row_in_range = t / wpr;
-    const i64 y = row_in_range % v.ny, z = z0 + row_in_range / v.ny;
-    const i64 row = z * v.ny + y;
-    const unsigned long long cur = in[row * wpr + w];
-    const unsigned long long lft = (cur << 1) | ((w > 0) ? (in[row * wpr + w - 1] >> 63) : 0ull);           // x-1
-    const unsigned long long rgt = (cur >> 1) | ((w + 1 < wpr) ? (in[row * wpr + w + 1] << 63) : 0ull);    // x+1
-    const i64 gz = v.gz0 + z;
-    const unsigned long long up = (gz > 0) ? in[(row - v.ny) * wpr + w] : 0ull;
-    const unsigned long long dn = (gz < v.gnz - 1) ? in[(row + v.ny) * wpr + w] : 0ull;
-    const unsigned long long no = (y > 0) ? in[(row - 1) * wpr + w] : 0ull;
-    const unsigned long long so = (y < v.ny - 1) ? in[(row + 1) * wpr + w] : 0ull;
-    unsigned long long r = DILATE ? (cur | lft | rgt | up | dn | no | so) : (cur & lft & rgt & up & dn & no & so);
-    const int rem = (int)v.nx - w * 64;
-    if (rem < 64) r &= (1ull << rem) - 1ull;          // keep the tail bits of a row at 0
-    out[row * wpr + w] = r;
-}
-
-__global__ void __launch_bounds__(256)
-apply_bits_kernel(const float *__restrict__ f, const unsigned long long *__restrict__ bits, float *__restrict__ out, VolGeom v,
-                  int wpr, i64 z0, i64 z1) {
-    const i64 qpr = (v.nx + 3) / 4;
-    const i64 total = (z1 - z0) * v.ny * qpr;
-    const i64 stride = (i64)gridDim.x * blockDim.x;
-    const bool vec = (v.nx & 3) == 0;
-    for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
-        const i64 row = z0 * v.ny + t / qpr;
-        const i64 x0 = (t % qpr) * 4;
-        const unsigned int b4 = (unsigned int)(bits[row * wpr + (x0 >> 6)] >> (x0 & 63)) & 0xFu;
-        const float *p = f + row * v.nx + x0;
-        float *o = out + row * v.nx + x0;
-        if (vec) {
-            float4 a = *reinterpret_cast<const float4 *>(p);
-            // frame * mask: a False mask gives +-0 with the sign of the value, exactly numpy's float * bool
-            if (!(b4 & 1u)) a.x *= 0.0f;
-            if (!(b4 & 2u)) a.y *= 0.0f;
-            if (!(b4 & 4u)) a.z *= 0.0f;
-            if (!(b4 & 8u)) a.w *= 0.0f;
-            *reinterpret_cast<float4 *>(o) = a;
-        } else {
-            for (int k = 0; k < 4 && x0 + k < v.nx; ++k) o[k] = ((b4 >> k) & 1u) ? p[k] : p[k] * 0.0f;
-        }
-    }
-}
-
-// =================================================================================================
-// kernels: Label (labelling.py:467-509)
-// =================================================================================================
-__global__ void __launch_bounds__(256)
-threshold_kernel(const float *__restrict__ f, uint8_t *__restrict__ m, int has_thr, float thr, i64 n) {
-    const i64 stride = (i64)gridDim.x * blockDim.x;
-    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-        m[i] = (has_thr && f[i] > thr) ? 1 : 0;
-}
-
-// ---- lock-free union-find on int32 parent array; root = minimum raster index of the set ----------
-__device__ __forceinline__ int uf_load(const int *L, int i) {
-    return __hip_atomic_load(L + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ int uf_find(const int *L, int i) {
-    int p = uf_load(L, i);
-    while (p != i) { i = p; p = uf_load(L, i); }
-    return i;
-}
-__device__ __forceinline__ void uf_union(int *L, int a, int b) {
-    while (true) {
-        a = uf_find(L, a);
-        b = uf_find(L, b);
-        if (a == b) return;
-        if (a < b) { int t = a; a = b; b = t; }          // a > b : hang a under b
-        const int old = atomicMin(&L[a], b);
-        if (old == a) return;
-        a = old;                                          // someone re-rooted a meanwhile: retry from there
-    }
-}
-
-// FG = 1: components of m != 0; FG = 0: components of m == 0 (background, for fill-holes)
-template <int FG>
-__device__ __forceinline__ bool is_set(const uint8_t *m, i64 i) { return FG ? (m[i] != 0) : (m[i] == 0); }
-
-// init: every voxel of the set points at the start of its X-run within its 64-lane segment.
-template <int FG>
-__global__ void __launch_bounds__(256)
-ccl_init_kernel(const uint8_t *__restrict__ m, int *__restrict__ L, i64 nx, i64 nrows) {
-    // one wave per 64-voxel row segment
-    const i64 segs_per_row = (nx + 63) / 64;
-    const i64 wave = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int lane = threadIdx.x & 63;
-    if (wave >= nrows * segs_per_row) return;
-    const i64 row = wave / segs_per_row, seg = wave % segs_per_row;
-    const i64 x = seg * 64 + lane;
-    const bool inb = x < nx;
-    const i64 i = row * nx + x;
-    const bool s = inb && is_set<FG>(m, i);
-    const unsigned long long bal = __ballot(s);
-    if (!inb) return;
-    if (!s) { L[i] = -1; return; }
-    // highest zero bit below `lane` -> run start
-    const unsigned long long below = (~bal) & ((lane == 0) ? 0ull : ((~0ull) >> (64 - lane)));
-    const int start = below ? (64 - __builtin_clzll(below)) : 0;
-    L[i] = (int)(row * nx + seg * 64 + start);
-}
-
-// merge: unions with the raster-preceding rows, skipping connections the X-neighbour already made.
-//   CONN = 26: rows (dz,dy) in {(-1,-1),(-1,0),(-1,+1),(0,-1)}, columns x-1..x+1
-//   CONN = 6 : rows (-1,0) and (0,-1), column x
-template <int FG, int CONN>
-__global__ void __launch_bounds__(256)
-ccl_merge_kernel(const uint8_t *__restrict__ m, int *__restrict__ L, i64 nz, i64 ny, i64 nx) {
-    const i64 x = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    const i64 y = blockIdx.y, z = blockIdx.z;
-    if (x >= nx) return;
-    const i64 i = (z * ny + y) * nx + x;
-    if (!is_set<FG>(m, i)) return;
-    const bool left = (x > 0) && is_set<FG>(m, i - 1);
-    if (left && (x & 63) == 0) uf_union(L, (int)i, (int)(i - 1));   // stitch 64-lane segments of a run
-    auto row = [&](i64 zz, i64 yy) {
-        if (zz < 0 || yy < 0 || yy >= ny) return;
-        const i64 b = (zz * ny + yy) * nx;
-        const bool c0 = is_set<FG>(m, b + x);
-        if (CONN == 6) {
-            if (!c0) return;
-            if (left && is_set<FG>(m, b + x - 1)) return;          // same two runs already joined at x-1
-            uf_union(L, (int)i, (int)(b + x));
-        } else {
-            const bool cm = (x > 0) && is_set<FG>(m, b + x - 1);
-            const bool cp = (x + 1 < nx) && is_set<FG>(m, b + x + 1);
-            if (left) {
-                // x-1 (same run as us) already reached every set voxel in columns <= x of that row,
-                // and column x+1 hangs off column x when that one is set
-                if (cp && !c0) uf_union(L, (int)i, (int)(b + x + 1));
-            } else {
-                if (c0) uf_union(L, (int)i, (int)(b + x));
-                else {
-                    if (cm) uf_union(L, (int)i, (int)(b + x - 1));
-                    if (cp) uf_union(L, (int)i, (int)(b + x + 1));
-                }
-            }
-        }
-    };
-    if (CONN == 6) {
-        row(z - 1, y);
-        row(z, y - 1);
-    } else {
-        row(z - 1, y - 1);
-        row(z - 1, y);
-        row(z - 1, y + 1);
-        row(z, y - 1);
-    }
-}
-
-__global__ void __launch_bounds__(256)
-ccl_flatten_kernel(int *__restrict__ L, i64 n) {
-    const i64 stride = (i64)gridDim.x * blockDim.x;
-    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const int p = L[i];
-        if (p >= 0 && p != (int)i) {
-            const int r = uf_find(L, p);
-            if (r != p) L[i] = r;
-        }
-    }
-}
-
-// fill holes: background components touching the GLOBAL volume border stay background
-__global__ void __launch_bounds__(256)
-border_mark_kernel(const int *__restrict__ L, uint8_t *__restrict__ flag, VolGeom v) {
-    const i64 stride = (i64)gridDim.x * blockDim.x;
-    const i64 n = v.nzl * v.ny * v.nx;
-    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const int r = L[i];
-        if (r < 0) continue;
-        const i64 x = i % v.nx, y = (i / v.nx) % v.ny, z = i / (v.nx * v.ny);
-        const i64 gz = v.gz0 + z;
-        if (gz == 0 || gz == v.gnz - 1 || y == 0 || y == v.ny - 1 || x == 0 || x == v.nx - 1) flag[r] = 1;
-    }
-}
-__global__ void __launch_bounds__(256)
-clear_root_flags_kernel(const int *__restrict__ L, uint8_t *__restrict__ flag, i64 n) {
-    const i64 stride = (i64)gridDim.x * blockDim.x;
-    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-        if (L[i] == (int)i) flag[i] = 0;
-}
-__global__ void __launch_bounds__(256)
-fill_holes_apply_kernel(const int *__restrict__ L, const uint8_t *__restrict__ flag, uint8_t *__restrict__ m, i64 n) {
-    const i64 stride = (i64)gridDim.x * blockDim.x;
-    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const int r = L[i];
-        if (r >= 0 && !flag[r]) m[i] = 1;       // enclosed background -> foreground
-    }
-}
-
-// areas: zero at roots, then one atomicAdd per X-run segment (bincount, labelling.py:495)
-__global__ void __launch_bounds__(256)
-zero_at_roots_kernel(const int *__restrict__ L, int *__restrict__ area, i64 n) {
-    const i64 stride = (i64)gridDim.x * blockDim.x;
-    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-        if (L[i] == (int)i) area[i] = 0;
-}
-__global__ void __launch_bounds__(256)
-area_count_kernel(const int *__restrict__ L, int *__restrict__ area, i64 nx, i64 nrows) {
-    const i64 segs_per_row = (nx + 63) / 64;
-    const i64 nwaves = nrows * segs_per_row;
-    const i64 wstride = ((i64)gridDim.x * blockDim.x) >> 6;
-    const int lane = threadIdx.x & 63;
-    for (i64 wave = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6; wave < nwaves; wave += wstride) {
-        const i64 row = wave / segs_per_row, seg = wave % segs_per_row;
-        const i64 x = seg * 64 + lane;
-        const int r = (x < nx) ? L[row * nx + x] : -1;
-        const unsigned long long bal = __ballot(r >= 0);
-        if (!bal) continue;                                            // wave-uniform
-        // run leader = set lane whose left neighbour is not set; it carries the run length
-        const bool leader = (r >= 0) && ((lane == 0) || !((bal >> (lane - 1)) & 1ull));
-        int len = 0;
-        if (leader) {
-            const unsigned long long rest = ~(bal >> lane);            // first zero above lane ends the run
-            len = rest ? __builtin_ctzll(rest) : (64 - lane);
-        }
-        // one atomic per DISTINCT root in the segment (runs of one object are usually neighbours)
-        unsigned long long todo = __ballot(leader);
-        while (todo) {
-            const int first = __builtin_ctzll(todo);
-            const int r0 = __shfl(r, first, 64);
-            const bool mine = leader && (r == r0);
-            int sum = mine ? len : 0;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-            if (lane == first) atomicAdd(&area[r0], sum);
-            todo &= ~__ballot(mine);
-        }
-    }
-}
-__global__ void __launch_bounds__(256)
-keep_large_kernel(const int *__restrict__ L, const int *__restrict__ area, uint8_t *__restrict__ m, int min_area, i64 n) {
-    const i64 stride = (i64)gridDim.x * blockDim.x;
-    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const int r = L[i];
-        m[i] = (r >= 0 && area[r] >= min_area) ? 1 : 0;
-    }
-}
-
-// uniform_filter(float32 mask, size=3, mode='reflect') > 0.5  ==  >= 14 of the 27 clamped neighbours
-__global__ void __launch_bounds__(256)
-majority_kernel(const uint8_t *__restrict__ m, uint8_t *__restrict__ out, VolGeom v) {
-    const i64 x = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    const i64 y = blockIdx.y, z = blockIdx.z;
-    if (x >= v.nx) return;
-    int cnt = 0;
-#pragma unroll
-    for (int dz = -1; dz <= 1; ++dz) {
-        i64 zz = z + dz;
-        const i64 gg = v.gz0 + zz;
-        if (gg < 0) zz = z; else if (gg >= v.gnz) zz = z;          // reflect == clamp for a 3-window
-#pragma unroll
-        for (int dy = -1; dy <= 1; ++dy) {
-            i64 yy = y + dy;
-            yy = yy < 0 ? 0 : (yy >= v.ny ? v.ny - 1 : yy);
-            const i64 b = (zz * v.ny + yy) * v.nx;
-            const i64 xm = x > 0 ? x - 1 : 0, xp = x + 1 < v.nx ? x + 1 : v.nx - 1;
-            cnt += (int)m[b + xm] + (int)m[b + x] + (int)m[b + xp];
-        }
-    }
-    out[(z * v.ny + y) * v.nx + x] = cnt >= 14 ? 1 : 0;
-}
-
-// raster renumbering of roots: ids 1..K in order of the root (= first voxel) index
-#define SCAN_CHUNK 4096
-__global__ void __launch_bounds__(256)
-root_count_kernel(const int *__restrict__ L, i64 n, unsigned int *__restrict__ blk) {
-    const i64 base = (i64)blockIdx.x * SCAN_CHUNK;
-    unsigned long long cnt = 0;
-    for (int k = threadIdx.x; k < SCAN_CHUNK; k += 256) {
-        const i64 i = base + k;
-        if (i < n && L[i] == (int)i) cnt++;
-    }
-    __shared__ unsigned int s[4];
-    cnt = wave_sum_u64(cnt);
-    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = (unsigned int)cnt;
-    __syncthreads();
-    if (threadIdx.x == 0) blk[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
-}
-// single block exclusive scan of the per-chunk counts (nblk <= a few 1e5)
-__global__ void __launch_bounds__(1024)
-blk_scan_kernel(unsigned int *__restrict__ blk, i64 nblk, unsigned long long *__restrict__ total) {
-    __shared__ unsigned int s_w[16];
-    __shared__ unsigned int s_carry;
-    if (threadIdx.x == 0) s_carry = 0;
-    __syncthreads();
-    for (i64 base = 0; base < nblk; base += 1024) {
-        const i64 i = base + threadIdx.x;
-        const unsigned int val = (i < nblk) ? blk[i] : 0u;
-        unsigned int inc = val;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const unsigned int t = __shfl_up(inc, o, 64);
-            if ((threadIdx.x & 63) >= o) inc += t;
-        }
-        if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = inc;
-        __syncthreads();
-        unsigned int woff = 0;
-        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) woff += s_w[w];
-        const unsigned int carry = s_carry;
-        if (i < nblk) blk[i] = carry + woff + inc - val;
-        __syncthreads();
-        if (threadIdx.x == 1023) s_carry = carry + woff + inc;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) *total = s_carry;
-}
-// newid[root] = rank + 1 (ordered within a chunk by a serial-in-wave ballot scan)
-__global__ void __launch_bounds__(256)
-root_assign_kernel(const int *__restrict__ L, i64 n, const unsigned int *__restrict__ blk, int *__restrict__ newid) {
-    const i64 base = (i64)blockIdx.x * SCAN_CHUNK;
-    __shared__ unsigned int s_w[4];
-    __shared__ unsigned int s_run;
-    if (threadIdx.x == 0) s_run = blk[blockIdx.x];
-    __syncthreads();
-    for (int k0 = 0; k0 < SCAN_CHUNK; k0 += 256) {
-        const i64 i = base + k0 + threadIdx.x;
-        const bool isroot = (i < n) && (L[i] == (int)i);
-        const unsigned long long bal = __ballot(isroot);
-        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-        const unsigned int before = (unsigned int)__builtin_popcountll(bal & ((lane == 0) ? 0ull : ((~0ull) >> (64 - lane))));
-        if (lane == 0) s_w[w] = (unsigned int)__builtin_popcountll(bal);
-        __syncthreads();
-        unsigned int woff = 0;
-        for (int q = 0; q < w; ++q) woff += s_w[q];
-        const unsigned int run = s_run;
-        if (isroot) newid[i] = (int)(run + woff + before + 1);
-        __syncthreads();
-        if (threadIdx.x == 0) s_run = run + s_w[0] + s_w[1] + s_w[2] + s_w[3];
-        __syncthreads();
-    }
-}
-__global__ void __launch_bounds__(256)
-relabel_kernel(const int *__restrict__ L, const int *__restrict__ newid, int *__restrict__ out, i64 n) {
-    const i64 stride = (i64)gridDim.x * blockDim.x;
-    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const int r = L[i];
-        out[i] = r >= 0 ? newid[r] : 0;
-    }
-}
-
+#include "device_math.inc"
+#include "convert.inc"
+#include "gauss.inc"
+#include "sampling.inc"
+#include "hessian.inc"
+#include "label_voxels.inc"
 #include "label_runs.inc"
 
 // =================================================================================================

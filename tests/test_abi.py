@@ -62,7 +62,7 @@ def test_product_never_imports_the_oracle():
     pkg = os.path.join(REPO, "nellie_amd")
     for root, _, files in os.walk(pkg):
         for f in files:
-            if f.endswith((".py", ".hip", ".h")):
+            if f.endswith((".py", ".hip", ".h", ".inc")):
                 src = open(os.path.join(root, f)).read()
                 assert "oracle" not in src.replace("no oracle", ""), f"{f} mentions the oracle"
 
