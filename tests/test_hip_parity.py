@@ -254,3 +254,24 @@ def test_eigen_frangi_known_answers(pipes):
         ok = np.abs(out[:, 3] - v_ref) <= tol
         # a 1-ulp eigenvalue difference may flip the sign tests only at |lambda| ~ 0
         assert ok.mean() > 0.9999, ok.mean()
+
+
+def test_run_on_disk_layout(hip, tmp_path):
+    """nellie_amd.run.run() on files: re-saved input + im_preprocessed (float32) + im_instance_label (int32)
+    under nellie_output/nellie_necessities/, reopened through the memory maps, equal to the oracle."""
+    import os
+    from nellie_amd.im_info.verifier import ImInfo
+    from nellie_amd.run import run
+    from nellie_amd.synthetic import ISO_01, make_volume
+    vols = np.stack([make_volume((24, 48, 48), 40 + t) for t in range(2)])
+    im_info = ImInfo(vols, dim_res=ISO_01, output_dir=str(tmp_path), name="stack")
+    run(im_info, device="gpu")
+    fr_path, lab_path = im_info.pipeline_paths["im_preprocessed"], im_info.pipeline_paths["im_instance_label"]
+    assert os.path.dirname(fr_path).endswith(os.path.join("nellie_output", "nellie_necessities"))
+    fr = im_info.get_memmap(fr_path, read_mode="r")
+    lab = im_info.get_memmap(lab_path, read_mode="r")
+    assert fr.dtype == np.float32 and lab.dtype == np.int32 and fr.shape == vols.shape == lab.shape
+    assert np.array_equal(im_info.get_memmap(im_info.im_path, read_mode="r"), vols), "input file was modified"
+    for t in range(2):
+        assert_frangi_close(np.asarray(fr[t]), orc.filter_frame(vols[t], ISO_01), f"t={t}")
+        assert np.array_equal(np.asarray(lab[t]), orc.label_frame(np.asarray(fr[t]), ISO_01))
