@@ -226,6 +226,20 @@ int nl_label_run_global(nl_ctx *ctx, int64_t min_area, int fill_holes, int64_t *
 /* D2H of the int32 label volume, local planes [z0, z1) (labelling.py:727-729). */
 int nl_label_store(nl_ctx *ctx, int32_t *host, int64_t z0, int64_t z1, char *err, size_t errlen);
 
+/* ------------------------------------------------------------------ frame streaming --- */
+/* 3-D+T stacks: the reference moves every frame with a blocking xp.asarray / .get() (filtering.py:924, 1023;
+   labelling.py:546, 727).  These entry points overlap the three legs instead: frame t+1 host->HBM on a copy
+   stream (nl_input_load_async into slot 0/1, nl_input_select before nl_filter_begin), frame t computing, frame
+   t-1's outputs HBM->host on a second copy stream (nl_outputs_stage: device copies into staging volumes;
+   nl_outputs_fetch_async; nl_outputs_wait).  Host buffers must come from nl_pinned_alloc. */
+int nl_pinned_alloc(void **ptr, int64_t bytes, char *err, size_t errlen);
+int nl_pinned_free(void *ptr);
+int nl_input_load_async(nl_ctx *ctx, int slot, const void *host_pinned, int dtype, char *err, size_t errlen);
+int nl_input_select(nl_ctx *ctx, int slot, char *err, size_t errlen);
+int nl_outputs_stage(nl_ctx *ctx, int with_labels, char *err, size_t errlen);
+int nl_outputs_fetch_async(nl_ctx *ctx, float *frangi_pinned, int32_t *labels_pinned, char *err, size_t errlen);
+int nl_outputs_wait(nl_ctx *ctx, char *err, size_t errlen);
+
 /* ------------------------------------------------------------------ test hooks -------- */
 /* Known-answer hook for the fused device routine (filtering.py:581-585 + 744-766): for n explicit
    Hessians h6[n][6] = (hxx,hxy,hxz,hyy,hyz,hzz) writes out4[n][4] = (l1,l2,l3 sorted by |.|, Frangi

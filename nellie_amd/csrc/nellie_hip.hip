@@ -120,7 +120,14 @@ extern "C" int nl_ctx_destroy(nl_ctx *c) {
     for (int k = 0; k < 4; ++k) if (c->f[k]) hipFree(c->f[k]);
     for (int k = 0; k < 3; ++k) if (c->m[k]) hipFree(c->m[k]);
     if (c->d_small) hipFree(c->d_small);
-    if (c->d_input) hipFree(c->d_input);
+    if (c->d_input && !c->input_borrowed) hipFree(c->d_input);
+    for (int k = 0; k < 2; ++k) { if (c->d_in_slot[k]) hipFree(c->d_in_slot[k]); if (c->ev_in[k]) hipEventDestroy(c->ev_in[k]); }
+    if (c->d_stage_fr) hipFree(c->d_stage_fr);
+    if (c->d_stage_lab) hipFree(c->d_stage_lab);
+    if (c->ev_staged) hipEventDestroy(c->ev_staged);
+    if (c->ev_fetched) hipEventDestroy(c->ev_fetched);
+    if (c->copy_in) hipStreamDestroy(c->copy_in);
+    if (c->copy_out) hipStreamDestroy(c->copy_out);
     if (c->d_blk) hipFree(c->d_blk);
     if (c->d_rows) hipFree(c->d_rows);
     if (c->gbits[0]) hipFree(c->gbits[0]);
@@ -258,6 +265,7 @@ extern "C" int nl_input_load(nl_ctx *c, const void *host, int dtype, int64_t z0,
     const size_t es = dtype_size(dtype);
     if (!es) return nl_fail(err, errlen, NL_EINVAL, "unsupported dtype code %d", dtype);
     if (!host || z0 < 0 || z1 > c->nzl || z0 >= z1) return nl_fail(err, errlen, NL_EINVAL, "bad plane range [%lld,%lld)", (i64)z0, (i64)z1);
+    if (c->d_input && c->input_borrowed) { c->d_input = nullptr; c->input_borrowed = 0; }
     if (c->d_input && c->input_dtype != dtype) { hipFree(c->d_input); c->d_input = nullptr; }
     if (!c->d_input) NL_HIP(hipMalloc(&c->d_input, (size_t)c->n * es));
     c->input_dtype = dtype;
@@ -1137,6 +1145,90 @@ extern "C" int nl_label_store(nl_ctx *c, int32_t *host, int64_t z0, int64_t z1, 
     NL_ENTER(c);
     if (c->i_labels < 0) return nl_fail(err, errlen, NL_ESTATE, "nl_label_store before nl_label_run");
     return store_planes(c, c->f[c->i_labels], host, 4, z0, z1, err, errlen);
+}
+
+// ------------------------------------------------------------------------------ frame streaming ---
+// 3-D+T stacks (BASELINE config 5): frame t+1 travels host -> HBM on a copy stream while frame t computes, and the
+// outputs of frame t-1 travel back on a second copy stream.  Host buffers must be pinned (nl_pinned_alloc) for the
+// copies to be asynchronous.
+extern "C" int nl_pinned_alloc(void **ptr, int64_t bytes, char *err, size_t errlen) {
+    if (!ptr || bytes < 1) return nl_fail(err, errlen, NL_EINVAL, "bad pinned allocation request");
+    hipError_t e = hipHostMalloc(ptr, (size_t)bytes, hipHostMallocDefault);
+    if (e != hipSuccess) return nl_fail(err, errlen, NL_ENOMEM, "hipHostMalloc(%lld): %s [out of memory]", (i64)bytes, hipGetErrorString(e));
+    return NL_OK;
+}
+extern "C" int nl_pinned_free(void *ptr) { if (ptr) hipHostFree(ptr); return NL_OK; }
+
+static int stream_init(nl_ctx *c, char *err, size_t errlen) {
+    if (c->copy_in) return NL_OK;
+    NL_HIP(hipStreamCreateWithFlags(&c->copy_in, hipStreamNonBlocking));
+    NL_HIP(hipStreamCreateWithFlags(&c->copy_out, hipStreamNonBlocking));
+    for (int k = 0; k < 2; ++k) NL_HIP(hipEventCreateWithFlags(&c->ev_in[k], hipEventDisableTiming));
+    NL_HIP(hipEventCreateWithFlags(&c->ev_staged, hipEventDisableTiming));
+    NL_HIP(hipEventCreateWithFlags(&c->ev_fetched, hipEventDisableTiming));
+    NL_HIP(hipEventRecord(c->ev_fetched, c->copy_out));       // "nothing pending"
+    return NL_OK;
+}
+
+// H2D of a whole local frame into input slot 0/1 on the copy stream (returns at once)
+extern "C" int nl_input_load_async(nl_ctx *c, int slot, const void *host_pinned, int dtype, char *err, size_t errlen) {
+    NL_ENTER(c);
+    const size_t es = dtype_size(dtype);
+    if (!es || !host_pinned || slot < 0 || slot > 1) return nl_fail(err, errlen, NL_EINVAL, "bad async load arguments");
+    int rc = stream_init(c, err, errlen);
+    if (rc) return rc;
+    if (c->d_in_slot[slot] && c->in_bytes[slot] < (size_t)c->n * es) { hipFree(c->d_in_slot[slot]); c->d_in_slot[slot] = nullptr; }
+    if (!c->d_in_slot[slot]) { NL_HIP(hipMalloc(&c->d_in_slot[slot], (size_t)c->n * es)); c->in_bytes[slot] = (size_t)c->n * es; }
+    c->in_dtype[slot] = dtype;
+    NL_HIP(hipMemcpyAsync(c->d_in_slot[slot], host_pinned, (size_t)c->n * es, hipMemcpyHostToDevice, c->copy_in));
+    NL_HIP(hipEventRecord(c->ev_in[slot], c->copy_in));
+    return NL_OK;
+}
+
+// make the compute stream wait for that slot and use it as the resident input of the next nl_filter_begin
+extern "C" int nl_input_select(nl_ctx *c, int slot, char *err, size_t errlen) {
+    NL_ENTER(c);
+    if (slot < 0 || slot > 1 || !c->d_in_slot[slot]) return nl_fail(err, errlen, NL_ESTATE, "input slot %d was never loaded", slot);
+    NL_HIP(hipStreamWaitEvent(c->stream, c->ev_in[slot], 0));
+    if (c->d_input && !c->input_borrowed) hipFree(c->d_input);
+    c->d_input = c->d_in_slot[slot];
+    c->input_borrowed = 1;
+    c->input_dtype = c->in_dtype[slot];
+    return NL_OK;
+}
+
+// D2D of the frame's outputs into staging volumes (compute stream), so the next frame may overwrite the originals
+extern "C" int nl_outputs_stage(nl_ctx *c, int with_labels, char *err, size_t errlen) {
+    NL_ENTER(c);
+    int rc = stream_init(c, err, errlen);
+    if (rc) return rc;
+    if (!c->d_stage_fr) NL_HIP(hipMalloc((void **)&c->d_stage_fr, (size_t)c->n * 4));
+    if (with_labels && !c->d_stage_lab) NL_HIP(hipMalloc((void **)&c->d_stage_lab, (size_t)c->n * 4));
+    if (with_labels && c->i_labels < 0) return nl_fail(err, errlen, NL_ESTATE, "nl_outputs_stage(with_labels) before nl_label_run");
+    NL_HIP(hipStreamWaitEvent(c->stream, c->ev_fetched, 0));   // the previous frame's fetch has left the staging volumes
+    NL_HIP(hipMemcpyAsync(c->d_stage_fr, c->f[c->i_vmax], (size_t)c->n * 4, hipMemcpyDeviceToDevice, c->stream));
+    if (with_labels) NL_HIP(hipMemcpyAsync(c->d_stage_lab, c->f[c->i_labels], (size_t)c->n * 4, hipMemcpyDeviceToDevice, c->stream));
+    NL_HIP(hipEventRecord(c->ev_staged, c->stream));
+    return NL_OK;
+}
+
+// D2H of the staged outputs on the second copy stream (returns at once); nl_outputs_wait blocks until they landed
+extern "C" int nl_outputs_fetch_async(nl_ctx *c, float *frangi_pinned, int32_t *labels_pinned, char *err, size_t errlen) {
+    NL_ENTER(c);
+    if (!c->copy_out || !c->d_stage_fr) return nl_fail(err, errlen, NL_ESTATE, "nl_outputs_fetch_async before nl_outputs_stage");
+    NL_HIP(hipStreamWaitEvent(c->copy_out, c->ev_staged, 0));
+    if (frangi_pinned) NL_HIP(hipMemcpyAsync(frangi_pinned, c->d_stage_fr, (size_t)c->n * 4, hipMemcpyDeviceToHost, c->copy_out));
+    if (labels_pinned) {
+        if (!c->d_stage_lab) return nl_fail(err, errlen, NL_ESTATE, "labels were not staged");
+        NL_HIP(hipMemcpyAsync(labels_pinned, c->d_stage_lab, (size_t)c->n * 4, hipMemcpyDeviceToHost, c->copy_out));
+    }
+    NL_HIP(hipEventRecord(c->ev_fetched, c->copy_out));
+    return NL_OK;
+}
+extern "C" int nl_outputs_wait(nl_ctx *c, char *err, size_t errlen) {
+    NL_ENTER(c);
+    if (c->ev_fetched) NL_HIP(hipEventSynchronize(c->ev_fetched));
+    return NL_OK;
 }
 
 // ---------------------------------------------------------------------------------- debug -------

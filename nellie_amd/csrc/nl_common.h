@@ -32,6 +32,16 @@ struct nl_ctx {
 
     void *d_input = nullptr;   // optional resident raw frame (nl_input_load)
     int input_dtype = -1;
+    int input_borrowed = 0;           // d_input points at a streaming slot (not owned)
+    // frame streaming (nl_input_load_async & co)
+    hipStream_t copy_in = nullptr, copy_out = nullptr;
+    void *d_in_slot[2] = {nullptr, nullptr};
+    size_t in_bytes[2] = {0, 0};
+    int in_dtype[2] = {-1, -1};
+    hipEvent_t ev_in[2] = {nullptr, nullptr};
+    hipEvent_t ev_staged = nullptr, ev_fetched = nullptr;
+    float *d_stage_fr = nullptr;
+    int *d_stage_lab = nullptr;
     void *d_small = nullptr;   // scratch for reductions / histograms / weights (64 KiB)
     void *h_small = nullptr;   // pinned mirror
     void *d_blk = nullptr;     // per-block partials for scans

@@ -68,6 +68,12 @@ _PROTOS = {
     "nl_label_bits_put": [_p, _i64, _i64, _p],
     "nl_label_bits_allgather": [_p, _p],
     "nl_label_run_global": [_p, _i64, _int, C.POINTER(_i64)],
+    "nl_pinned_alloc": [C.POINTER(_p), _i64],
+    "nl_input_load_async": [_p, _int, _p, _int],
+    "nl_input_select": [_p, _int],
+    "nl_outputs_stage": [_p, _int],
+    "nl_outputs_fetch_async": [_p, _p, _p],
+    "nl_outputs_wait": [_p],
     "nl_debug_eig_frangi": [_p, _p, _i64, _int, _f32, _f32, _f32, _p],
     "nl_timer_begin": [_p],
     "nl_timer_end_ms": [_p, C.POINTER(_f32)],
@@ -80,6 +86,7 @@ _PLAIN = {
     "nl_prof_enable": (_int, [_p, _int]),
     "nl_prof_get": (_int, [_p, C.c_char_p, C.POINTER(_f64), C.POINTER(_i64)]),
     "nl_prof_reset": (_int, [_p]),
+    "nl_pinned_free": (_int, [_p]),
     "nl_ctx_info": (_int, [_p, C.c_char_p, C.POINTER(_f64)]),
 }
 ALL_SYMBOLS = sorted(list(_PROTOS) + list(_PLAIN))
@@ -162,6 +169,29 @@ def comm_unique_id() -> bytes:
     buf = C.create_string_buffer(128)
     load().call("nl_comm_unique_id", buf)
     return buf.raw
+
+
+class PinnedArray:
+    """A numpy array over page-locked host memory (hipHostMalloc): asynchronous copies need it."""
+
+    def __init__(self, shape, dtype):
+        self.lib = load()
+        self.dtype = np.dtype(dtype)
+        self.shape = tuple(int(s) for s in shape)
+        nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        p = _p()
+        self.lib.call("nl_pinned_alloc", C.byref(p), nbytes)
+        self._p = p
+        buf = (C.c_char * nbytes).from_address(p.value)
+        self.array = np.frombuffer(buf, dtype=self.dtype).reshape(self.shape)
+
+    def free(self):
+        if getattr(self, "_p", None):
+            self.array = None
+            self.lib.cdll.nl_pinned_free(self._p)
+            self._p = None
+
+    __del__ = free
 
 
 def gpu_available() -> bool:
@@ -330,6 +360,23 @@ class Context:
         out = np.empty((z1 - z0, self.shape[1], self.shape[2]), dtype=np.float32)
         self._call("nl_gauss_store", _ptr(out), z0, z1)
         return out
+
+    # ---------------------------------------------------------------- frame streaming
+    def input_load_async(self, slot, pinned: "PinnedArray"):
+        self._call("nl_input_load_async", int(slot), pinned._p, DTYPE_CODES[pinned.dtype])
+
+    def input_select(self, slot):
+        self._call("nl_input_select", int(slot))
+
+    def outputs_stage(self, with_labels=True):
+        self._call("nl_outputs_stage", 1 if with_labels else 0)
+
+    def outputs_fetch_async(self, frangi: "PinnedArray", labels: "PinnedArray" = None):
+        self._call("nl_outputs_fetch_async", frangi._p if frangi is not None else None,
+                   labels._p if labels is not None else None)
+
+    def outputs_wait(self):
+        self._call("nl_outputs_wait")
 
     # ---------------------------------------------------------------- Label
     def label_load_frangi(self, frangi: np.ndarray, z0=0, z1=None):

@@ -11,6 +11,31 @@ from nellie_amd.segmentation.filtering import Filter
 from nellie_amd.segmentation.labelling import Label
 
 
+def run_streamed(im_info, viewer=None, device_index=0):
+    """
+    Filter + Label of every frame with the three legs overlapped (nellie_amd/streaming.py): same two files as
+    `run()`, default parameters only (no remove_edges / intensity thresholds), 3-D frames.
+    """
+    from nellie_amd.pipeline import FilterParams
+    from nellie_amd.streaming import StreamedSegmenter
+    if im_info.no_z:
+        raise NotImplementedError("streaming covers 3-D frames")
+    im = im_info.get_memmap(im_info.im_path)
+    fr = im_info.allocate_memory(im_info.pipeline_paths["im_preprocessed"], dtype="float32",
+                                 description="frangi filtered im", return_memmap=True)
+    lab = im_info.allocate_memory(im_info.pipeline_paths["im_instance_label"], dtype="int32",
+                                  description="instance segmentation", return_memmap=True)
+    seg = StreamedSegmenter(im.shape[1:], im.dtype, FilterParams(dim_res=im_info.dim_res), device=device_index)
+    try:
+        def status(t, n):
+            if viewer is not None:
+                viewer.status = f"Preprocessing + extracting organelles. Frame: {t + 1} of {n}."
+        seg.run(im, fr, lab, status=status)
+    finally:
+        seg.close()
+    return im_info
+
+
 def run(im_info, remove_edges=False, otsu_thresh_intensity=False, threshold=None, timeit=False, device="auto",
         low_memory=False):
     t0 = time.perf_counter() if timeit else None
