@@ -234,6 +234,8 @@ int nl_label_store(nl_ctx *ctx, int32_t *host, int64_t z0, int64_t z1, char *err
    nl_outputs_fetch_async; nl_outputs_wait).  Host buffers must come from nl_pinned_alloc. */
 int nl_pinned_alloc(void **ptr, int64_t bytes, char *err, size_t errlen);
 int nl_pinned_free(void *ptr);
+int nl_host_register(void *ptr, int64_t bytes, char *err, size_t errlen);   /* page-lock caller-owned memory */
+int nl_host_unregister(void *ptr);
 int nl_input_load_async(nl_ctx *ctx, int slot, const void *host_pinned, int dtype, char *err, size_t errlen);
 int nl_input_select(nl_ctx *ctx, int slot, char *err, size_t errlen);
 int nl_outputs_stage(nl_ctx *ctx, int with_labels, char *err, size_t errlen);

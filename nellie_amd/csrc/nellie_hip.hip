@@ -1158,6 +1158,14 @@ extern "C" int nl_pinned_alloc(void **ptr, int64_t bytes, char *err, size_t errl
     return NL_OK;
 }
 extern "C" int nl_pinned_free(void *ptr) { if (ptr) hipHostFree(ptr); return NL_OK; }
+// page-lock memory the caller already owns (a numpy array): copies from / into it become asynchronous too
+extern "C" int nl_host_register(void *ptr, int64_t bytes, char *err, size_t errlen) {
+    if (!ptr || bytes < 1) return nl_fail(err, errlen, NL_EINVAL, "bad host registration request");
+    hipError_t e = hipHostRegister(ptr, (size_t)bytes, hipHostRegisterDefault);
+    if (e != hipSuccess) { (void)hipGetLastError(); return nl_fail(err, errlen, NL_EHIP, "hipHostRegister(%lld bytes): %s", (i64)bytes, hipGetErrorString(e)); }
+    return NL_OK;
+}
+extern "C" int nl_host_unregister(void *ptr) { if (ptr) (void)hipHostUnregister(ptr); return NL_OK; }
 
 static int stream_init(nl_ctx *c, char *err, size_t errlen) {
     if (c->copy_in) return NL_OK;

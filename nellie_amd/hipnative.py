@@ -69,6 +69,7 @@ _PROTOS = {
     "nl_label_bits_allgather": [_p, _p],
     "nl_label_run_global": [_p, _i64, _int, C.POINTER(_i64)],
     "nl_pinned_alloc": [C.POINTER(_p), _i64],
+    "nl_host_register": [_p, _i64],
     "nl_input_load_async": [_p, _int, _p, _int],
     "nl_input_select": [_p, _int],
     "nl_outputs_stage": [_p, _int],
@@ -87,6 +88,7 @@ _PLAIN = {
     "nl_prof_get": (_int, [_p, C.c_char_p, C.POINTER(_f64), C.POINTER(_i64)]),
     "nl_prof_reset": (_int, [_p]),
     "nl_pinned_free": (_int, [_p]),
+    "nl_host_unregister": (_int, [_p]),
     "nl_ctx_info": (_int, [_p, C.c_char_p, C.POINTER(_f64)]),
 }
 ALL_SYMBOLS = sorted(list(_PROTOS) + list(_PLAIN))
@@ -192,6 +194,31 @@ class PinnedArray:
             self._p = None
 
     __del__ = free
+
+
+class RegisteredArray:
+    """Page-locks an existing C-contiguous numpy array for the lifetime of this object (hipHostRegister).
+    `ok` is False when the runtime refuses (e.g. some file-backed maps): callers then stage through PinnedArray."""
+
+    def __init__(self, array: np.ndarray):
+        self.array = array
+        self.ok = False
+        self._ptr = None
+        if isinstance(array, np.ndarray) and array.flags.c_contiguous and array.flags.writeable and array.nbytes > 0:
+            try:
+                load().call("nl_host_register", _ptr(array), array.nbytes)
+                self.ok = True
+                self._ptr = _ptr(array)
+            except Exception:
+                self.ok = False
+
+    def release(self):
+        if self._ptr is not None:
+            load().cdll.nl_host_unregister(self._ptr)
+            self._ptr = None
+            self.ok = False
+
+    __del__ = release
 
 
 def gpu_available() -> bool:
@@ -362,8 +389,12 @@ class Context:
         return out
 
     # ---------------------------------------------------------------- frame streaming
-    def input_load_async(self, slot, pinned: "PinnedArray"):
-        self._call("nl_input_load_async", int(slot), pinned._p, DTYPE_CODES[pinned.dtype])
+    def input_load_async(self, slot, pinned):
+        """`pinned`: a PinnedArray, or a numpy view into registered (page-locked) memory."""
+        if isinstance(pinned, np.ndarray):
+            self._call("nl_input_load_async", int(slot), _ptr(pinned), DTYPE_CODES[pinned.dtype])
+        else:
+            self._call("nl_input_load_async", int(slot), pinned._p, DTYPE_CODES[pinned.dtype])
 
     def input_select(self, slot):
         self._call("nl_input_select", int(slot))
@@ -371,9 +402,12 @@ class Context:
     def outputs_stage(self, with_labels=True):
         self._call("nl_outputs_stage", 1 if with_labels else 0)
 
-    def outputs_fetch_async(self, frangi: "PinnedArray", labels: "PinnedArray" = None):
-        self._call("nl_outputs_fetch_async", frangi._p if frangi is not None else None,
-                   labels._p if labels is not None else None)
+    def outputs_fetch_async(self, frangi, labels=None):
+        def ptr(a):
+            if a is None:
+                return None
+            return _ptr(a) if isinstance(a, np.ndarray) else a._p
+        self._call("nl_outputs_fetch_async", ptr(frangi), ptr(labels))
 
     def outputs_wait(self):
         self._call("nl_outputs_wait")

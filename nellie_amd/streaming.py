@@ -34,6 +34,7 @@ class StreamedSegmenter:
         self.lab_buf = [hipnative.PinnedArray(self.shape, np.int32) for _ in range(2)]
         self.io = ThreadPoolExecutor(max_workers=2)
         self.stats = []
+        self._reg_in = None
 
     def close(self):
         self.io.shutdown(wait=True)
@@ -42,14 +43,33 @@ class StreamedSegmenter:
             b.free()
 
     def _stage_in(self, frames, t, slot):
-        """host thread: stack -> pinned buffer, then the asynchronous H2D of that slot"""
+        """host thread: the asynchronous H2D of that slot -- straight from the stack when it is page-locked,
+        else through a pinned staging buffer"""
+        if self._reg_in is not None and self._reg_in.ok:
+            self.pipe.ctx.input_load_async(slot, frames[t])
+            return
         np.copyto(self.in_buf[slot].array, frames[t], casting="unsafe")
         self.pipe.ctx.input_load_async(slot, self.in_buf[slot])
 
     def run(self, frames, out_frangi, out_labels, status=None, flush=True):
-        """frames: (T, Z, Y, X) array / memmap; out_*: writable (T, Z, Y, X) float32 / int32 arrays (memmaps)."""
+        """frames: (T, Z, Y, X) array / memmap; out_*: writable (T, Z, Y, X) float32 / int32 arrays (memmaps).
+        In-memory arrays are page-locked in place (hipHostRegister) so that no host-side staging copy is needed."""
         ctx = self.pipe.ctx
         num_t = len(frames)
+        plain = lambda a: isinstance(a, np.ndarray) and not isinstance(a, np.memmap)   # noqa: E731
+        self._reg_in = hipnative.RegisteredArray(frames) if plain(frames) and frames.dtype == self.in_buf[0].dtype else None
+        reg_fr = hipnative.RegisteredArray(out_frangi) if plain(out_frangi) and out_frangi.dtype == np.float32 else None
+        reg_lab = hipnative.RegisteredArray(out_labels) if plain(out_labels) and out_labels.dtype == np.int32 else None
+        direct_out = bool(reg_fr and reg_fr.ok and reg_lab and reg_lab.ok)
+        try:
+            return self._run(ctx, frames, out_frangi, out_labels, num_t, status, flush, direct_out)
+        finally:
+            for r in (self._reg_in, reg_fr, reg_lab):
+                if r is not None:
+                    r.release()
+            self._reg_in = None
+
+    def _run(self, ctx, frames, out_frangi, out_labels, num_t, status, flush, direct_out):
         load = self.io.submit(self._stage_in, frames, 0, 0)
         pending = None                                        # (t, slot, future that waits + writes)
         for t in range(num_t):
@@ -69,10 +89,15 @@ class StreamedSegmenter:
             if pending is not None:
                 pending.result()                              # frame t-1 landed on the host and in the memmaps
             ctx.outputs_stage(True)
-            ctx.outputs_fetch_async(self.fr_buf[slot], self.lab_buf[slot])
+            if direct_out:
+                ctx.outputs_fetch_async(out_frangi[t], out_labels[t])
+            else:
+                ctx.outputs_fetch_async(self.fr_buf[slot], self.lab_buf[slot])
 
             def drain(tt=t, ss=slot):
                 ctx.outputs_wait()
+                if direct_out:
+                    return
                 out_frangi[tt] = self.fr_buf[ss].array
                 out_labels[tt] = self.lab_buf[ss].array
                 if flush and hasattr(out_frangi, "flush"):
