@@ -521,10 +521,33 @@ def compute_vesselness(frame, dim_res, sigmas=None, alpha_sq=0.5, beta_sq=0.5,
     return vesselness, masks
 
 
-def run_frame(frame, dim_res, **kw):
-    """filtering.py:910-933 (3-D, remove_edges=False): vesselness * masks."""
+def remove_edges(frangi_frame):
+    """filtering.py:969-1000 (3-D branch): per Z slice, zero 15 rows at both ends of the row bounding box."""
+    frangi_frame = frangi_frame.copy()
+    margin = 15
+    for z_idx in range(frangi_frame.shape[0]):
+        slice_im = frangi_frame[z_idx]
+        rows = np.any(slice_im, axis=1)
+        cols = np.any(slice_im, axis=0)
+        if (not rows.any()) or (not cols.any()):
+            continue
+        rmin, rmax = np.where(rows)[0][[0, -1]]
+        height = max(0, int(rmax) - int(rmin) + 1)
+        if height <= 0:
+            continue
+        use = min(margin, height)
+        frangi_frame[z_idx, rmin:rmin + use, :] = 0
+        frangi_frame[z_idx, rmax - use + 1:rmax + 1, :] = 0
+    return frangi_frame
+
+
+def run_frame(frame, dim_res, remove_edges_flag=False, **kw):
+    """filtering.py:910-933 (3-D): vesselness * masks, then the optional edge removal."""
     vesselness, masks = compute_vesselness(frame, dim_res, **kw)
-    return vesselness * masks
+    out = vesselness * masks
+    if remove_edges_flag:
+        out = remove_edges(out)
+    return out
 
 
 def percentile_linear_f32(values: np.ndarray, q: float):
@@ -612,28 +635,44 @@ def min_area_pixels(dim_res, min_radius_um=0.25):
     return max(1, int(np.ceil(volume_px)))
 
 
-def sample_nonzero(frame, max_samples=1_000_000):
-    """labelling.py:385-438 (no mask arguments: the default path)."""
+def sample_nonzero(frame, max_samples=1_000_000, mask_frame=None, mask_thresh=None):
+    """labelling.py:385-438: strided positives, optionally only where `mask_frame > mask_thresh`."""
     flat = frame.reshape(-1)
     if flat.size == 0:
         return flat
+    mflat = None if mask_frame is None or mask_thresh is None else mask_frame.reshape(-1)
     max_samples = max(1, int(max_samples))
     step = max(int(flat.size) // max_samples, 1)
     offsets = (0, step // 2) if step > 1 and step // 2 > 0 else (0,)
     values = flat[:0]
     for offset in offsets:
         sample = flat[offset::step]
-        values = sample[sample > 0]
+        if mflat is None:
+            values = sample[sample > 0]
+        else:
+            values = sample[(sample > 0) & (mflat[offset::step] > mask_thresh)]
         if values.size > 0 or step == 1:
             return values
     if float(flat.max()) <= 0:
         return values
-    return flat[flat > 0]
+    if mflat is None:
+        return flat[flat > 0]
+    return flat[(flat > 0) & (mflat > mask_thresh)]
 
 
-def frangi_threshold(frangi, max_samples=1_000_000, nbins=256):
+def intensity_otsu(original, max_samples=1_000_000, nbins=256):
+    """labelling.py:457-465: Otsu threshold of the strided positive intensities (None if there are none)."""
+    values = sample_nonzero(original, max_samples)
+    if values.size == 0:
+        return None
+    flat = np.asarray(values).reshape(-1)
+    counts, edges = np.histogram(flat, bins=nbins, range=(flat.min(), flat.max()))
+    return otsu_from_hist(counts, edges)
+
+
+def frangi_threshold(frangi, max_samples=1_000_000, nbins=256, mask_frame=None, mask_thresh=None):
     """labelling.py:440-455: log10-domain min(triangle, otsu); None when no positive sample."""
-    values = sample_nonzero(frangi, max_samples)
+    values = sample_nonzero(frangi, max_samples, mask_frame, mask_thresh)
     if values.size == 0:
         return None
     log_values = np.log10(values)
@@ -699,9 +738,20 @@ def get_labels(frangi, frangi_thresh, min_area):
 
 
 def label_frame(frangi, dim_res, min_radius_um=0.25, max_samples=1_000_000, nbins=256,
-                return_thr=False):
-    """labelling.py:511-532 (defaults: no intensity threshold) + 538-556."""
-    thr = frangi_threshold(frangi, max_samples, nbins)
+                return_thr=False, original=None, otsu_thresh_intensity=False, threshold=None):
+    """labelling.py:511-532 + 538-556, including the optional intensity masking of the Frangi frame."""
+    intensity_thresh = None
+    if otsu_thresh_intensity:
+        intensity_thresh = intensity_otsu(original, max_samples, nbins)
+        if intensity_thresh is None:
+            intensity_thresh = 0
+    elif threshold is not None:
+        intensity_thresh = threshold
+    if intensity_thresh is not None:
+        thr = frangi_threshold(frangi, max_samples, nbins, mask_frame=original, mask_thresh=intensity_thresh)
+        frangi = frangi * (np.asarray(original) > intensity_thresh)
+    else:
+        thr = frangi_threshold(frangi, max_samples, nbins)
     _, labels = get_labels(frangi, thr, min_area_pixels(dim_res, min_radius_um))
     return (labels, thr) if return_thr else labels
 

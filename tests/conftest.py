@@ -45,7 +45,8 @@ def load_golden(name):
     return g
 
 
-FILTER_CASES = [n for n in golden_names() if not n.startswith("labelonly")]
+FILTER_CASES = [n for n in golden_names() if not n.startswith(("labelonly", "labelintensity", "removeedges"))]
+LABEL_INTENSITY_CASES = golden_names("labelintensity")
 LABEL_ONLY_CASES = golden_names("labelonly")
 
 

@@ -127,8 +127,8 @@ def run_filter_case(Filter, vol, dim_res, **kw):
     return out
 
 
-def run_label_case(Label, vol, frangi, dim_res):
-    lab = Label(im_info(frangi.shape, dim_res), num_t=1, device="cpu")
+def run_label_case(Label, vol, frangi, dim_res, **kw):
+    lab = Label(im_info(frangi.shape, dim_res), num_t=1, device="cpu", **kw)
     ithr, fthr = lab._compute_frame_thresholds(vol, frangi)
     labels = lab._run_frame_full_volume(0, vol, frangi, ithr, fthr)
     return dict(label_thr=np.float64(np.nan if fthr is None else fthr),
@@ -234,6 +234,15 @@ def main():
     # (viii) single sigma
     full_case("singlesigma_24x48x48_s1", make_volume((24, 48, 48), 1), ISO_01,
               min_radius_um=0.25, max_radius_um=0.375)
+    # remove_edges=True (filtering.py:969-1000), tall enough in Y for the 15-row margins to leave something
+    full_case("removeedges_16x96x40_s8", make_volume((16, 96, 40), 8), ISO_01, remove_edges=True)
+    # Label with intensity masking (labelling.py:511-532, 550-552): Otsu on the original, and a fixed threshold
+    vol = make_volume((24, 48, 48), 1)
+    base = run_filter_case(Filter, vol, ISO_01)
+    for tag, kw in (("otsu", dict(otsu_thresh_intensity=True)), ("fixed", dict(threshold=108.5))):
+        lab = run_label_case(Label, vol, base["frangi"], ISO_01, **kw)
+        save(f"labelintensity_{tag}_24x48x48_s1", input=vol, frangi=base["frangi"], dim_res=np.array([0.1, 0.1, 0.1]),
+             otsu=np.int64(tag == "otsu"), threshold=np.float64(kw.get("threshold", np.nan)), **lab)
     # (ix) Label alone on a crafted Frangi-like volume
     lv = label_only_volume((24, 48, 48), 11)
     lab = run_label_case(Label, lv, lv, ISO_01)

@@ -12,7 +12,7 @@ import zlib
 import numpy as np
 import pytest
 
-from conftest import FILTER_CASES, LABEL_ONLY_CASES, load_golden
+from conftest import FILTER_CASES, LABEL_INTENSITY_CASES, LABEL_ONLY_CASES, load_golden
 from oracle import nellie_oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -293,3 +293,26 @@ def test_streamed_stack_equals_per_stage_run(hip, tmp_path):
         y = b.get_memmap(b.pipeline_paths[key], read_mode="r")
         assert x.dtype == y.dtype and np.array_equal(x, y), key
     assert np.asarray(b.get_memmap(b.pipeline_paths["im_instance_label"], read_mode="r")).max() >= 1
+
+
+def test_remove_edges_golden(hip):
+    """Filter(remove_edges=True) behind the stage API (filtering.py:931-932, 969-1000)."""
+    from fakes import ArrayImInfo
+    from nellie_amd.segmentation.filtering import Filter
+    g = load_golden("removeedges_16x96x40_s8")
+    im_info = ArrayImInfo(g["input"][None], g["dim_res_dict"])
+    Filter(im_info, remove_edges=True).run()
+    assert_masked_close(np.asarray(im_info.store["frangi"][0]), g["frangi"], g["run_frame"], g["percentile_thr"])
+
+
+@pytest.mark.parametrize("name", LABEL_INTENSITY_CASES)
+def test_label_intensity_threshold_golden(name, hip):
+    """Label(otsu_thresh_intensity=True) / Label(threshold=...) behind the stage API (labelling.py:511-532, 550-552)."""
+    from fakes import ArrayImInfo
+    from nellie_amd.segmentation.labelling import Label
+    g = load_golden(name)
+    im_info = ArrayImInfo(g["input"][None], g["dim_res_dict"])
+    im_info.store["frangi"] = g["frangi"][None]
+    kw = dict(otsu_thresh_intensity=True) if int(g["otsu"]) else dict(threshold=float(g["threshold"]))
+    Label(im_info, **kw).run()
+    assert np.array_equal(np.asarray(im_info.store["labels"][0]), g["labels"])

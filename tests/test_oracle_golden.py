@@ -9,7 +9,7 @@ import zlib
 import numpy as np
 import pytest
 
-from conftest import FILTER_CASES, LABEL_ONLY_CASES, load_golden
+from conftest import FILTER_CASES, LABEL_INTENSITY_CASES, LABEL_ONLY_CASES, load_golden
 from oracle import nellie_oracle as orc
 
 
@@ -85,3 +85,20 @@ def test_reference_toy_label_semantics():
     for _ in range(2):
         _, labels = orc.get_labels(fr, 0.5, orc.min_area_pixels(dr))
         assert labels.max() == 1 and set(np.unique(labels)) <= {0, 1}
+
+
+def test_remove_edges_matches_reference():
+    g = load_golden("removeedges_16x96x40_s8")
+    fr = orc.run_frame(g["input"], g["dim_res_dict"], remove_edges_flag=True)
+    assert np.array_equal(fr, g["run_frame"])
+    assert np.array_equal(orc.mask_volume(fr), g["frangi"])
+    assert (g["run_frame"] > 0).any()
+
+
+@pytest.mark.parametrize("name", LABEL_INTENSITY_CASES)
+def test_label_with_intensity_threshold_matches_reference(name):
+    g = load_golden(name)
+    kw = dict(otsu_thresh_intensity=True) if int(g["otsu"]) else dict(threshold=float(g["threshold"]))
+    labels, thr = orc.label_frame(g["frangi"], g["dim_res_dict"], return_thr=True, original=g["input"], **kw)
+    assert float(thr) == float(g["label_thr"])
+    assert np.array_equal(labels, g["labels"])
