@@ -545,6 +545,29 @@ extern "C" int nl_set_frob_norm(nl_ctx *c, float max_abs, float max_finite, char
     return NL_OK;
 }
 
+// h_mask = sqrt(frob_sq)/max_abs > thr (or > 0).  sqrt and the division by a positive constant are monotone, so the
+// mask is exactly {frob_sq >= x_min} for the smallest float32 x_min whose image passes the test; it is found by
+// bisection over the (ordered) bit patterns of the non-negative floats, with the same two IEEE operations the
+// volume op would do.  The kernel then needs one compare per voxel instead of a square root and a division.
+static float mask_threshold_on_fsq(float max_abs, int use_thr, float thr) {
+    auto pred = [&](float x) -> bool {
+        volatile float fr = sqrtf(x);
+        fr = fr / max_abs;
+        return use_thr ? (fr > thr) : (fr > 0.0f);
+    };
+    unsigned int lo = 0u, hi = 0x7f800000u;          // hi = +inf bits: "nothing finite passes"
+    float fmaxv; { unsigned int b = 0x7f7fffffu; memcpy(&fmaxv, &b, 4); }
+    if (!pred(fmaxv)) { float inf; memcpy(&inf, &hi, 4); return inf; }
+    hi = 0x7f7fffffu;
+    while (lo < hi) {                                 // smallest pattern with pred true
+        const unsigned int mid = lo + (hi - lo) / 2;
+        float x; memcpy(&x, &mid, 4);
+        if (pred(x)) hi = mid; else lo = mid + 1;
+    }
+    float r; memcpy(&r, &lo, 4);
+    return r;
+}
+
 extern "C" int nl_vesselness_step(nl_ctx *c, float gamma_sq, float alpha_sq, float beta_sq, int use_thr, float thr,
                                   int64_t z0, int64_t z1, int64_t *mask_count, char *err, size_t errlen) {
     NL_ENTER(c);
@@ -554,7 +577,10 @@ extern "C" int nl_vesselness_step(nl_ctx *c, float gamma_sq, float alpha_sq, flo
     unsigned long long *d_cnt = (unsigned long long *)c->d_small;
     NL_HIP(hipMemsetAsync(d_cnt, 0, 8, c->stream));
     VessP vp{gamma_sq, alpha_sq, beta_sq, use_thr, thr, c->frob_max_abs, c->frob_max_finite, 0, (int)c->own_lo, (int)c->own_hi,
-             c->mask_slots_used == 0 ? 1 : 0};
+             c->mask_slots_used == 0 ? 1 : 0, 0.0f, 0};
+    vp.fsq_min = mask_threshold_on_fsq(c->frob_max_abs, use_thr, thr);
+    vp.m_inf = use_thr ? (c->frob_max_finite > thr) : (c->frob_max_finite > 0.0f);
+    if (vp.fsq_min == 0.0f && !use_thr) { /* frob > 0 <=> frob_sq > 0 unless sqrt underflows: keep the bisected value */ }
     {
         ProfScope ps(c, "vesselness");
         const int ntx = (int)((c->nx + HM_TX - 1) / HM_TX), nty = (int)((c->ny + 15) / 16);
