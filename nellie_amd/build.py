@@ -42,9 +42,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
            "-fPIC", "-shared", "-Wno-unused-value",
            "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
-    rccl = "/opt/rocm/lib/librccl.so"
-    if os.path.exists(rccl):
-        cmd += ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
+    cmd += ["-ldl"]          # RCCL is dlopen()ed on first use (nl_comm_*), never linked
     if verbose:
         print("[nellie_amd.build]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -4,8 +4,42 @@
 #include <stdarg.h>
 #include <stdlib.h>
 #include <type_traits>
+#include <dlfcn.h>
 #include <rccl/rccl.h>
 #include "nl_common.h"
+
+// RCCL is loaded on first use (dlopen) instead of being linked: librccl.so is ~570 MB and would be paged in by every
+// single-GPU process that merely loads this library.
+struct RcclApi {
+    void *handle = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclBroadcast) Broadcast = nullptr;
+    bool ok = false;
+};
+static RcclApi &rccl() {
+    static RcclApi api;
+    if (!api.handle) {
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        for (const char *n : names) { api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (api.handle) break; }
+        if (api.handle) {
+#define NL_SYM(F) api.F = (decltype(api.F))dlsym(api.handle, "nccl" #F)
+            NL_SYM(GetUniqueId); NL_SYM(CommInitRank); NL_SYM(CommDestroy); NL_SYM(GetErrorString); NL_SYM(GroupStart);
+            NL_SYM(GroupEnd); NL_SYM(Send); NL_SYM(Recv); NL_SYM(AllReduce); NL_SYM(Broadcast);
+#undef NL_SYM
+            api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.GetErrorString && api.GroupStart &&
+                     api.GroupEnd && api.Send && api.Recv && api.AllReduce && api.Broadcast;
+        }
+    }
+    return api;
+}
 
 #define NL_MASK_SLOTS 8      // per-scale mask bit planes kept before falling back to read-modify-write
 #define NL_VERSION "nellie_amd-hip 0.1.0 (gfx950)"
@@ -136,7 +170,7 @@ extern "C" int nl_ctx_destroy(nl_ctx *c) {
     if (c->h_small) hipHostFree(c->h_small);
     if (c->t0) hipEventDestroy(c->t0);
     if (c->t1) hipEventDestroy(c->t1);
-    if (c->comm) ncclCommDestroy((ncclComm_t)c->comm);
+    if (c->comm && rccl().ok) rccl().CommDestroy((ncclComm_t)c->comm);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
     return NL_OK;
@@ -715,14 +749,15 @@ extern "C" int nl_planes_put(nl_ctx *c, int field, int64_t z0, int64_t z1, const
 
 #define NL_NCCL(expr)                                                                                  \
     do {                                                                                               \
+        if (!rccl().ok) return nl_fail(err, errlen, NL_ECOMM, "librccl.so could not be loaded");         \
         ncclResult_t r_ = (expr);                                                                      \
-        if (r_ != ncclSuccess) return nl_fail(err, errlen, NL_ECOMM, "%s: %s", #expr, ncclGetErrorString(r_)); \
+        if (r_ != ncclSuccess) return nl_fail(err, errlen, NL_ECOMM, "%s: %s", #expr, rccl().GetErrorString(r_)); \
     } while (0)
 
 extern "C" int nl_comm_unique_id(char *id128, char *err, size_t errlen) {
     if (!id128) return nl_fail(err, errlen, NL_EINVAL, "id buffer is NULL");
     ncclUniqueId id;
-    NL_NCCL(ncclGetUniqueId(&id));
+    NL_NCCL(rccl().GetUniqueId(&id));
     static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
     memcpy(id128, &id, 128);
     return NL_OK;
@@ -734,7 +769,7 @@ extern "C" int nl_comm_init(nl_ctx *c, int world, int rank, const char *id128, c
     ncclUniqueId id;
     memcpy(&id, id128, 128);
     ncclComm_t comm;
-    NL_NCCL(ncclCommInitRank(&comm, world, id, rank));
+    NL_NCCL(rccl().CommInitRank(&comm, world, id, rank));
     c->comm = comm; c->world = world; c->rank = rank;
     return NL_OK;
 }
@@ -753,16 +788,16 @@ extern "C" int nl_halo_exchange(nl_ctx *c, int field, int64_t depth, char *err, 
                        (i64)(c->own_hi - c->own_lo), (i64)c->own_lo, (i64)(c->nzl - c->own_hi));
     ncclComm_t comm = (ncclComm_t)c->comm;
     ProfScope ps(c, "halo");
-    NL_NCCL(ncclGroupStart());
+    NL_NCCL(rccl().GroupStart());
     if (has_lo) {
-        NL_NCCL(ncclSend(p + c->own_lo * plane, (size_t)(depth * plane), ncclFloat, c->rank - 1, comm, c->stream));
-        NL_NCCL(ncclRecv(p + (c->own_lo - depth) * plane, (size_t)(depth * plane), ncclFloat, c->rank - 1, comm, c->stream));
+        NL_NCCL(rccl().Send(p + c->own_lo * plane, (size_t)(depth * plane), ncclFloat, c->rank - 1, comm, c->stream));
+        NL_NCCL(rccl().Recv(p + (c->own_lo - depth) * plane, (size_t)(depth * plane), ncclFloat, c->rank - 1, comm, c->stream));
     }
     if (has_hi) {
-        NL_NCCL(ncclSend(p + (c->own_hi - depth) * plane, (size_t)(depth * plane), ncclFloat, c->rank + 1, comm, c->stream));
-        NL_NCCL(ncclRecv(p + c->own_hi * plane, (size_t)(depth * plane), ncclFloat, c->rank + 1, comm, c->stream));
+        NL_NCCL(rccl().Send(p + (c->own_hi - depth) * plane, (size_t)(depth * plane), ncclFloat, c->rank + 1, comm, c->stream));
+        NL_NCCL(rccl().Recv(p + c->own_hi * plane, (size_t)(depth * plane), ncclFloat, c->rank + 1, comm, c->stream));
     }
-    NL_NCCL(ncclGroupEnd());
+    NL_NCCL(rccl().GroupEnd());
     return NL_OK;
 }
 
@@ -776,7 +811,7 @@ extern "C" int nl_allreduce(nl_ctx *c, void *host_inout, int64_t count, int dtyp
     memcpy(c->h_small, host_inout, (size_t)count * es);
     NL_HIP(hipMemcpyAsync(c->d_small, c->h_small, (size_t)count * es, hipMemcpyHostToDevice, c->stream));
     const ncclRedOp_t ops[3] = {ncclSum, ncclMin, ncclMax};
-    NL_NCCL(ncclAllReduce(c->d_small, c->d_small, (size_t)count, dtype == 0 ? ncclInt64 : ncclFloat, ops[op], (ncclComm_t)c->comm, c->stream));
+    NL_NCCL(rccl().AllReduce(c->d_small, c->d_small, (size_t)count, dtype == 0 ? ncclInt64 : ncclFloat, ops[op], (ncclComm_t)c->comm, c->stream));
     NL_HIP(hipMemcpyAsync(c->h_small, c->d_small, (size_t)count * es, hipMemcpyDeviceToHost, c->stream));
     NL_HIP(hipStreamSynchronize(c->stream));
     memcpy(host_inout, c->h_small, (size_t)count * es);
@@ -1139,13 +1174,13 @@ extern "C" int nl_label_bits_allgather(nl_ctx *c, const int64_t *slab_plane0, ch
     if (!c->gbits[0] || !slab_plane0) return nl_fail(err, errlen, NL_ESTATE, "nl_label_bits_allgather before nl_label_pack");
     const int wpr = (int)((c->nx + 63) / 64);
     ProfScope ps(c, "halo");
-    NL_NCCL(ncclGroupStart());
+    NL_NCCL(rccl().GroupStart());
     for (int r = 0; r < c->world; ++r) {
         const i64 p0 = slab_plane0[r], p1 = slab_plane0[r + 1];        // world + 1 entries, last = gnz
         unsigned long long *ptr = c->gbits[0] + p0 * c->ny * wpr;
-        NL_NCCL(ncclBroadcast(ptr, ptr, (size_t)((p1 - p0) * c->ny * wpr), ncclUint64, r, (ncclComm_t)c->comm, c->stream));
+        NL_NCCL(rccl().Broadcast(ptr, ptr, (size_t)((p1 - p0) * c->ny * wpr), ncclUint64, r, (ncclComm_t)c->comm, c->stream));
     }
-    NL_NCCL(ncclGroupEnd());
+    NL_NCCL(rccl().GroupEnd());
     return NL_OK;
 }
 
