@@ -41,7 +41,7 @@ static RcclApi &rccl() {
     return api;
 }
 
-#define NL_MASK_SLOTS 8      // per-scale mask bit planes kept before falling back to read-modify-write
+#define NL_MASK_SLOTS 2      // cumulative h_mask bit planes (ping-pong between consecutive scales)
 #define NL_VERSION "nellie_amd-hip 0.1.0 (gfx950)"
 
 #include "device_math.inc"
@@ -141,9 +141,18 @@ extern "C" int nl_device_name(int device, char *name, size_t namelen, char *err,
     return NL_OK;
 }
 
+// Entries of the global eigen queue: one launch of the vesselness kernel covers as many planes as fit
+// (every voxel can produce at most one entry), capped at 2^28 entries (7 GiB) for big volumes.
+static int64_t vq_capacity(int64_t n, int64_t plane) {
+    static int64_t lim = 0;                 // NELLIE_VQ_CAP: test knob (entries) to force several launches on small volumes
+    if (!lim) { const char *e = getenv("NELLIE_VQ_CAP"); lim = (e && atoll(e) > 0) ? atoll(e) : ((int64_t)1 << 28); }
+    int64_t cap = n < lim ? n : lim;
+    return cap > plane ? cap : plane;
+}
+
 extern "C" int64_t nl_ctx_bytes(int64_t nz_local, int64_t ny, int64_t nx) {
     const int64_t n = nz_local * ny * nx;
-    return n * (4 * 4 + 3) + (1 << 16) + ((n + SCAN_CHUNK - 1) / SCAN_CHUNK + 1) * 4;
+    return n * (4 * 4 + 3) + vq_capacity(n, ny * nx) * 28 + (1 << 16) + ((n + SCAN_CHUNK - 1) / SCAN_CHUNK + 1) * 4;
 }
 
 extern "C" int nl_ctx_destroy(nl_ctx *c) {
@@ -163,6 +172,7 @@ extern "C" int nl_ctx_destroy(nl_ctx *c) {
     if (c->copy_in) hipStreamDestroy(c->copy_in);
     if (c->copy_out) hipStreamDestroy(c->copy_out);
     if (c->d_blk) hipFree(c->d_blk);
+    if (c->d_vq) hipFree(c->d_vq);
     if (c->d_rows) hipFree(c->d_rows);
     if (c->gbits[0]) hipFree(c->gbits[0]);
     if (c->gbits[1]) hipFree(c->gbits[1]);
@@ -218,6 +228,8 @@ extern "C" int nl_ctx_create(nl_ctx **out, int device, int64_t nzl, int64_t ny, 
     }
     if (ok) ok = alloc((void **)&c->d_rows, ((size_t)nzl * ny + 2) * 2 * 4);
     if (ok) ok = alloc(&c->d_small, 1 << 16);
+    c->vq_cap = (unsigned int)vq_capacity(n, ny * nx);
+    if (ok) ok = alloc((void **)&c->d_vq, (size_t)c->vq_cap * 28);
     c->blk_cap = (n + SCAN_CHUNK - 1) / SCAN_CHUNK + 1;
     if (ok) ok = alloc(&c->d_blk, (size_t)c->blk_cap * 4);
     if (ok && hipHostMalloc(&c->h_small, 1 << 16, hipHostMallocDefault) != hipSuccess) {
@@ -557,7 +569,7 @@ extern "C" int nl_hessian_stats(nl_ctx *c, const double spacing[3], float *max_a
 #define NL_LAUNCH_STATS(TYV, FASTV, HR)                                                                                   \
         hessian_march_kernel<0, TYV, FASTV><<<(unsigned)(ntx * (int)((c->ny + TYV - 1) / TYV) * nzc), HMCfg<TYV>::NT,     \
                                               HMCfg<TYV>::lds_floats(0) * 4, c->stream>>>(                                \
-            c->f[c->i_gauss], nullptr, nullptr, 0, geom(c), HR, vp, (int)c->own_lo, (int)c->own_hi, ntx,                  \
+            c->f[c->i_gauss], nullptr, nullptr, nullptr, 0, geom(c), HR, vp, VQueue{}, (int)c->own_lo, (int)c->own_hi, ntx,                  \
             (int)((c->ny + TYV - 1) / TYV), res, nullptr)
         if (hm_ty() == 8) { if (c->fast_div) NL_LAUNCH_STATS(8, true, hessdv_fast(c)); else NL_LAUNCH_STATS(8, false, hessdv_exact(c)); }
         else { if (c->fast_div) NL_LAUNCH_STATS(16, true, hessdv_fast(c)); else NL_LAUNCH_STATS(16, false, hessdv_exact(c)); }
@@ -618,7 +630,6 @@ extern "C" int nl_vesselness_step(nl_ctx *c, float gamma_sq, float alpha_sq, flo
     {
         ProfScope ps(c, "vesselness");
         const int ntx = (int)((c->nx + HM_TX - 1) / HM_TX), nty = (int)((c->ny + 15) / 16);
-        const int nzc = (int)((z1 - z0 + HM_ZCHUNK - 1) / HM_ZCHUNK);
         static bool attr_set = false;
         if (!attr_set) {
             NL_HIP(hipFuncSetAttribute((const void *)hessian_march_kernel<1, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, HMCfg<16>::lds_floats(1) * 4));
@@ -629,16 +640,31 @@ extern "C" int nl_vesselness_step(nl_ctx *c, float gamma_sq, float alpha_sq, flo
         }
         const int wpr = (int)((c->nx + 63) / 64);
         const i64 slot_words = c->nzl * c->ny * wpr;
-        int slot = c->mask_slots_used;
-        if (slot >= NL_MASK_SLOTS) { slot = NL_MASK_SLOTS - 1; vp.mask_rmw = 1; } else c->mask_slots_used++;
-        unsigned long long *cm = (unsigned long long *)c->m[0] + (i64)slot * slot_words;
+        // cumulative h_mask (AND over the scales so far): scale k reads slot (k-1)&1 and writes slot k&1
+        const int k_scale = c->mask_slots_used++;
+        vp.have_prev = k_scale > 0;
+        unsigned long long *cm = (unsigned long long *)c->m[0] + (i64)(k_scale & 1) * slot_words;
+        const unsigned long long *pm = (unsigned long long *)c->m[0] + (i64)((k_scale + 1) & 1) * slot_words;
+        // one launch covers as many planes as the global queue can take in the worst case (every voxel queued)
+        const i64 plane = c->ny * c->nx;
+        const i64 planes_per_launch = (i64)c->vq_cap / plane;
+        unsigned int *d_tail = (unsigned int *)c->d_small + 8;
+        const VQueue vq{c->d_vq, (int *)(c->d_vq + (size_t)6 * c->vq_cap), d_tail, c->vq_cap};
 #define NL_LAUNCH_VESS(TYV, FASTV, HR)                                                                                    \
         hessian_march_kernel<1, TYV, FASTV><<<(unsigned)(ntx * (int)((c->ny + TYV - 1) / TYV) * nzc), HMCfg<TYV>::NT,     \
                                               HMCfg<TYV>::lds_floats(1) * 4, c->stream>>>(                                \
-            c->f[c->i_gauss], c->f[c->i_vmax], cm, wpr, geom(c), HR, vp, (int)z0, (int)z1, ntx,             \
+            c->f[c->i_gauss], c->f[c->i_vmax], cm, pm, wpr, geom(c), HR, vp, vq, (int)za, (int)zb, ntx,                   \
             (int)((c->ny + TYV - 1) / TYV), nullptr, d_cnt)
-        if (hm_ty() == 8) { if (c->fast_div) NL_LAUNCH_VESS(8, true, hessdv_fast(c)); else NL_LAUNCH_VESS(8, false, hessdv_exact(c)); }
-        else { if (c->fast_div) NL_LAUNCH_VESS(16, true, hessdv_fast(c)); else NL_LAUNCH_VESS(16, false, hessdv_exact(c)); }
+        for (i64 za = z0; za < z1; za += planes_per_launch) {
+            const i64 zb = za + planes_per_launch < z1 ? za + planes_per_launch : z1;
+            const int nzc = (int)((zb - za + HM_ZCHUNK - 1) / HM_ZCHUNK);
+            NL_HIP(hipMemsetAsync(d_tail, 0, 4, c->stream));
+            if (hm_ty() == 8) { if (c->fast_div) NL_LAUNCH_VESS(8, true, hessdv_fast(c)); else NL_LAUNCH_VESS(8, false, hessdv_exact(c)); }
+            else { if (c->fast_div) NL_LAUNCH_VESS(16, true, hessdv_fast(c)); else NL_LAUNCH_VESS(16, false, hessdv_exact(c)); }
+            NL_CHECK_LAUNCH();
+            vesselness_queue_kernel<<<256 * 16, 256, 0, c->stream>>>(vq.h, vq.idx, d_tail, vq.cap, c->f[c->i_vmax], za * plane, vp);
+            NL_CHECK_LAUNCH();
+        }
 #undef NL_LAUNCH_VESS
         NL_CHECK_LAUNCH();
     }
@@ -663,8 +689,10 @@ extern "C" int nl_filter_finish(nl_ctx *c, int64_t z0, int64_t z1, int64_t *n_po
         ProfScope ps(c, "finish");
         const int wpr = (int)((c->nx + 63) / 64);
         const i64 quads = (z1 - z0) * c->ny * ((c->nx + 3) / 4);
-        finish_kernel<<<grid1d(quads, 256, 256 * 16), 256, 0, c->stream>>>(c->f[c->i_vmax], (const unsigned long long *)c->m[0], c->mask_slots_used,
-                                                               c->nzl * c->ny * wpr, wpr, geom(c), z0, z1, c->own_lo, c->own_hi, d_cnt);
+        const i64 slot_words = c->nzl * c->ny * wpr;
+        const int last = c->mask_slots_used > 0 ? ((c->mask_slots_used - 1) & 1) : 0;      // the slot of the last scale = AND of all
+        finish_kernel<<<grid1d(quads, 256, 256 * 16), 256, 0, c->stream>>>(c->f[c->i_vmax], (const unsigned long long *)c->m[0] + last * slot_words,
+                                                               c->mask_slots_used > 0 ? 1 : 0, slot_words, wpr, geom(c), z0, z1, c->own_lo, c->own_hi, d_cnt);
         NL_CHECK_LAUNCH();
     }
     NL_HIP(hipMemcpyAsync(c->h_small, d_cnt, 8, hipMemcpyDeviceToHost, c->stream));

@@ -44,6 +44,8 @@ struct nl_ctx {
     int *d_stage_lab = nullptr;
     void *d_small = nullptr;   // scratch for reductions / histograms / weights (64 KiB)
     void *h_small = nullptr;   // pinned mirror
+    float *d_vq = nullptr;     // global queue of voxels to eigen-solve: [6][vq_cap] floats + [vq_cap] int32
+    unsigned int vq_cap = 0;
     void *d_blk = nullptr;     // per-block partials for scans
     unsigned int *d_rows = nullptr;   // per-row run counts and offsets (Label on runs)
     unsigned long long *gbits[2] = {nullptr, nullptr};   // Z-slab Label: GLOBAL bit masks (lazily allocated)

@@ -99,6 +99,9 @@ def test_two_slabs_equal_one_volume_at_1024_cube(full_run):
     if errs:
         raise errs[0]
     for o0, o1, fr, lab, thr, n in out:
-        assert thr == full_run["thr"] and n == full_run["n"]
-        assert np.array_equal(fr, full_run["frangi"][o0:o1])
-        assert np.array_equal(lab, full_run["labels"][o0:o1])
+        assert thr == full_run["thr"], (thr, full_run["thr"])
+        assert n == full_run["n"], (n, full_run["n"])
+        ref = full_run["frangi"][o0:o1]
+        assert np.array_equal(fr, ref), f"slab [{o0},{o1}): {int((fr != ref).sum())} Frangi voxels differ, first at {np.argwhere(fr != ref)[:4].tolist()}"
+        ref = full_run["labels"][o0:o1]
+        assert np.array_equal(lab, ref), f"slab [{o0},{o1}): {int((lab != ref).sum())} label voxels differ, first at {np.argwhere(lab != ref)[:4].tolist()}"
