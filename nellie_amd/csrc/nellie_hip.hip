@@ -141,18 +141,25 @@ extern "C" int nl_device_name(int device, char *name, size_t namelen, char *err,
     return NL_OK;
 }
 
-// Entries of the global eigen queue: one launch of the vesselness kernel covers as many planes as fit
-// (every voxel can produce at most one entry), capped at 2^28 entries (7 GiB) for big volumes.
-static int64_t vq_capacity(int64_t n, int64_t plane) {
-    static int64_t lim = 0;                 // NELLIE_VQ_CAP: test knob (entries) to force several launches on small volumes
+// Global eigen queue: every wave of the vesselness kernel owns HM_REGION entries (32 bytes each), so one launch
+// needs (padded plane) x (Z chunks x HM_ZCHUNK) entries.  A launch covers as many Z chunks as fit 2^28 entries
+// (8 GiB); smaller volumes go in one launch.  NELLIE_VQ_CAP (entries) is a test knob to force several launches.
+static int64_t vq_padded_plane(int64_t ny, int64_t nx) { return ((nx + HM_TX - 1) / HM_TX) * HM_TX * (((ny + 15) / 16) * 16); }
+static int64_t vq_chunks(int64_t nzl, int64_t ny, int64_t nx) {
+    static int64_t lim = 0;
     if (!lim) { const char *e = getenv("NELLIE_VQ_CAP"); lim = (e && atoll(e) > 0) ? atoll(e) : ((int64_t)1 << 28); }
-    int64_t cap = n < lim ? n : lim;
-    return cap > plane ? cap : plane;
+    const int64_t per_chunk = vq_padded_plane(ny, nx) * HM_ZCHUNK;
+    int64_t chunks = lim / per_chunk;
+    const int64_t need = (nzl + HM_ZCHUNK - 1) / HM_ZCHUNK;
+    if (chunks > need) chunks = need;
+    return chunks < 1 ? 1 : chunks;
 }
+static int64_t vq_entries(int64_t nzl, int64_t ny, int64_t nx) { return vq_chunks(nzl, ny, nx) * vq_padded_plane(ny, nx) * HM_ZCHUNK; }
 
 extern "C" int64_t nl_ctx_bytes(int64_t nz_local, int64_t ny, int64_t nx) {
     const int64_t n = nz_local * ny * nx;
-    return n * (4 * 4 + 3) + vq_capacity(n, ny * nx) * 28 + (1 << 16) + ((n + SCAN_CHUNK - 1) / SCAN_CHUNK + 1) * 4;
+    const int64_t qe = vq_entries(nz_local, ny, nx);
+    return n * (4 * 4 + 3) + qe * 32 + qe / HM_REGION * 4 + (1 << 16) + ((n + SCAN_CHUNK - 1) / SCAN_CHUNK + 1) * 4;
 }
 
 extern "C" int nl_ctx_destroy(nl_ctx *c) {
@@ -173,6 +180,7 @@ extern "C" int nl_ctx_destroy(nl_ctx *c) {
     if (c->copy_out) hipStreamDestroy(c->copy_out);
     if (c->d_blk) hipFree(c->d_blk);
     if (c->d_vq) hipFree(c->d_vq);
+    if (c->d_vq_count) hipFree(c->d_vq_count);
     if (c->d_rows) hipFree(c->d_rows);
     if (c->gbits[0]) hipFree(c->gbits[0]);
     if (c->gbits[1]) hipFree(c->gbits[1]);
@@ -228,8 +236,12 @@ extern "C" int nl_ctx_create(nl_ctx **out, int device, int64_t nzl, int64_t ny, 
     }
     if (ok) ok = alloc((void **)&c->d_rows, ((size_t)nzl * ny + 2) * 2 * 4);
     if (ok) ok = alloc(&c->d_small, 1 << 16);
-    c->vq_cap = (unsigned int)vq_capacity(n, ny * nx);
-    if (ok) ok = alloc((void **)&c->d_vq, (size_t)c->vq_cap * 28);
+    c->vq_chunks = (int)vq_chunks(nzl, ny, nx);
+    {
+        const size_t qe = (size_t)vq_entries(nzl, ny, nx);
+        if (ok) ok = alloc((void **)&c->d_vq, qe * 32);
+        if (ok) ok = alloc((void **)&c->d_vq_count, qe / HM_REGION * 4);
+    }
     c->blk_cap = (n + SCAN_CHUNK - 1) / SCAN_CHUNK + 1;
     if (ok) ok = alloc(&c->d_blk, (size_t)c->blk_cap * 4);
     if (ok && hipHostMalloc(&c->h_small, 1 << 16, hipHostMallocDefault) != hipSuccess) {
@@ -568,8 +580,8 @@ extern "C" int nl_hessian_stats(nl_ctx *c, const double spacing[3], float *max_a
         VessP vp{};
 #define NL_LAUNCH_STATS(TYV, FASTV, HR)                                                                                   \
         hessian_march_kernel<0, TYV, FASTV><<<(unsigned)(ntx * (int)((c->ny + TYV - 1) / TYV) * nzc), HMCfg<TYV>::NT,     \
-                                              HMCfg<TYV>::lds_floats(0) * 4, c->stream>>>(                                \
-            c->f[c->i_gauss], nullptr, nullptr, nullptr, 0, geom(c), HR, vp, VQueue{}, (int)c->own_lo, (int)c->own_hi, ntx,                  \
+                                              HMCfg<TYV>::lds_floats() * 4, c->stream>>>(                                 \
+            c->f[c->i_gauss], nullptr, nullptr, 0, geom(c), HR, vp, VQueue{}, (int)c->own_lo, (int)c->own_hi, ntx,                  \
             (int)((c->ny + TYV - 1) / TYV), res, nullptr)
         if (hm_ty() == 8) { if (c->fast_div) NL_LAUNCH_STATS(8, true, hessdv_fast(c)); else NL_LAUNCH_STATS(8, false, hessdv_exact(c)); }
         else { if (c->fast_div) NL_LAUNCH_STATS(16, true, hessdv_fast(c)); else NL_LAUNCH_STATS(16, false, hessdv_exact(c)); }
@@ -629,15 +641,7 @@ extern "C" int nl_vesselness_step(nl_ctx *c, float gamma_sq, float alpha_sq, flo
     if (vp.fsq_min == 0.0f && !use_thr) { /* frob > 0 <=> frob_sq > 0 unless sqrt underflows: keep the bisected value */ }
     {
         ProfScope ps(c, "vesselness");
-        const int ntx = (int)((c->nx + HM_TX - 1) / HM_TX), nty = (int)((c->ny + 15) / 16);
-        static bool attr_set = false;
-        if (!attr_set) {
-            NL_HIP(hipFuncSetAttribute((const void *)hessian_march_kernel<1, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, HMCfg<16>::lds_floats(1) * 4));
-            NL_HIP(hipFuncSetAttribute((const void *)hessian_march_kernel<1, 16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, HMCfg<16>::lds_floats(1) * 4));
-            NL_HIP(hipFuncSetAttribute((const void *)hessian_march_kernel<1, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, HMCfg<8>::lds_floats(1) * 4));
-            NL_HIP(hipFuncSetAttribute((const void *)hessian_march_kernel<1, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, HMCfg<8>::lds_floats(1) * 4));
-            attr_set = true;
-        }
+        const int ntx = (int)((c->nx + HM_TX - 1) / HM_TX);
         const int wpr = (int)((c->nx + 63) / 64);
         const i64 slot_words = c->nzl * c->ny * wpr;
         // cumulative h_mask (AND over the scales so far): scale k reads slot (k-1)&1 and writes slot k&1
@@ -645,24 +649,24 @@ extern "C" int nl_vesselness_step(nl_ctx *c, float gamma_sq, float alpha_sq, flo
         vp.have_prev = k_scale > 0;
         unsigned long long *cm = (unsigned long long *)c->m[0] + (i64)(k_scale & 1) * slot_words;
         const unsigned long long *pm = (unsigned long long *)c->m[0] + (i64)((k_scale + 1) & 1) * slot_words;
-        // one launch covers as many planes as the global queue can take in the worst case (every voxel queued)
+        // one launch covers as many Z chunks as the queue has regions for
         const i64 plane = c->ny * c->nx;
-        const i64 planes_per_launch = (i64)c->vq_cap / plane;
-        unsigned int *d_tail = (unsigned int *)c->d_small + 8;
-        const VQueue vq{c->d_vq, (int *)(c->d_vq + (size_t)6 * c->vq_cap), d_tail, c->vq_cap};
+        const i64 planes_per_launch = (i64)c->vq_chunks * HM_ZCHUNK;
+        const VQueue vq{(float4 *)c->d_vq, c->d_vq_count};
+        const int ty = hm_ty();
+        const int nty = (int)((c->ny + ty - 1) / ty);
 #define NL_LAUNCH_VESS(TYV, FASTV, HR)                                                                                    \
-        hessian_march_kernel<1, TYV, FASTV><<<(unsigned)(ntx * (int)((c->ny + TYV - 1) / TYV) * nzc), HMCfg<TYV>::NT,     \
-                                              HMCfg<TYV>::lds_floats(1) * 4, c->stream>>>(                                \
-            c->f[c->i_gauss], c->f[c->i_vmax], cm, pm, wpr, geom(c), HR, vp, vq, (int)za, (int)zb, ntx,                   \
-            (int)((c->ny + TYV - 1) / TYV), nullptr, d_cnt)
+        hessian_march_kernel<1, TYV, FASTV><<<nblocks, HMCfg<TYV>::NT, HMCfg<TYV>::lds_floats() * 4, c->stream>>>(        \
+            c->f[c->i_gauss], cm, pm, wpr, geom(c), HR, vp, vq, (int)za, (int)zb, ntx, nty, nullptr, d_cnt)
         for (i64 za = z0; za < z1; za += planes_per_launch) {
             const i64 zb = za + planes_per_launch < z1 ? za + planes_per_launch : z1;
             const int nzc = (int)((zb - za + HM_ZCHUNK - 1) / HM_ZCHUNK);
-            NL_HIP(hipMemsetAsync(d_tail, 0, 4, c->stream));
-            if (hm_ty() == 8) { if (c->fast_div) NL_LAUNCH_VESS(8, true, hessdv_fast(c)); else NL_LAUNCH_VESS(8, false, hessdv_exact(c)); }
+            const unsigned nblocks = (unsigned)(ntx * nty * nzc);
+            if (ty == 8) { if (c->fast_div) NL_LAUNCH_VESS(8, true, hessdv_fast(c)); else NL_LAUNCH_VESS(8, false, hessdv_exact(c)); }
             else { if (c->fast_div) NL_LAUNCH_VESS(16, true, hessdv_fast(c)); else NL_LAUNCH_VESS(16, false, hessdv_exact(c)); }
             NL_CHECK_LAUNCH();
-            vesselness_queue_kernel<<<256 * 16, 256, 0, c->stream>>>(vq.h, vq.idx, d_tail, vq.cap, c->f[c->i_vmax], za * plane, vp);
+            const unsigned nregions = nblocks * (unsigned)ty;
+            vesselness_queue_kernel<<<(nregions + 3) / 4, 256, 0, c->stream>>>(vq.ent, vq.count, nregions, c->f[c->i_vmax], za * plane, vp);
             NL_CHECK_LAUNCH();
         }
 #undef NL_LAUNCH_VESS

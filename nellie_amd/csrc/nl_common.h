@@ -44,8 +44,9 @@ struct nl_ctx {
     int *d_stage_lab = nullptr;
     void *d_small = nullptr;   // scratch for reductions / histograms / weights (64 KiB)
     void *h_small = nullptr;   // pinned mirror
-    float *d_vq = nullptr;     // global queue of voxels to eigen-solve: [6][vq_cap] floats + [vq_cap] int32
-    unsigned int vq_cap = 0;
+    float *d_vq = nullptr;     // global queue of voxels to eigen-solve (32-byte entries, one region per wave)
+    unsigned int *d_vq_count = nullptr;   // entries written per region
+    int vq_chunks = 1;         // Z chunks (HM_ZCHUNK planes) one vesselness launch may cover
     void *d_blk = nullptr;     // per-block partials for scans
     unsigned int *d_rows = nullptr;   // per-row run counts and offsets (Label on runs)
     unsigned long long *gbits[2] = {nullptr, nullptr};   // Z-slab Label: GLOBAL bit masks (lazily allocated)
