@@ -388,6 +388,9 @@ static bool launch_gauss_fast(nl_ctx *c, const float *src, float *dst, const Vol
         if (AXIS == 2) launch_gauss_x<RR>(c, src, dst, v, z0, z1, gw);                       \
         else launch_gauss_march<(AXIS == 2 ? 0 : AXIS), RR>(c, src, dst, v, z0, z1, gw);     \
         return true;
+    // the marching kernels reflect at most once: the radius must not exceed the line length
+    const i64 n_line = AXIS == 0 ? c->gnz : (AXIS == 1 ? c->ny : c->nx);
+    if (AXIS != 2 && gw.r > n_line) return false;
     switch (gw.r) {
         NL_GCASE(1) NL_GCASE(2) NL_GCASE(3) NL_GCASE(4) NL_GCASE(5) NL_GCASE(6) NL_GCASE(7) NL_GCASE(8)
         default: return false;
@@ -420,7 +423,7 @@ extern "C" int nl_gauss_step(nl_ctx *c, const double *wz, int rz, const double *
         src = dst;
     }
     bool fused_yx = false;
-    if (wy && wx && ry == rx && ry >= 1 && ry <= GM_MAX_R && !getenv("NELLIE_NO_FUSED_YX")) {
+    if (wy && wx && ry == rx && ry >= 1 && ry <= GM_MAX_R && ry <= c->ny && !getenv("NELLIE_NO_FUSED_YX")) {
         GaussW gy, gx;
         if ((rc = fill_gw(gy, wy, ry, err, errlen))) return rc;
         if ((rc = fill_gw(gx, wx, rx, err, errlen))) return rc;
