@@ -11,7 +11,7 @@ rows.sort(key=lambda r: int(r['Start_Timestamp']))
 half = len(rows)//2
 for r in rows[half:]:
     d = (int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e6
-    if d > 0.3:
+    if d > 0.03:
         print(f"{d:8.3f} ms  {r['Kernel_Name'][:110]}  vgpr={r.get('VGPR_Count','?')} lds={r.get('LDS_Block_Size','?')} wg={r.get('Workgroup_Size','?')}")
 PY
 tail -3 /tmp/kt.log
