@@ -310,8 +310,8 @@ extern "C" int nl_filter_load(nl_ctx *c, const void *host, int dtype, int64_t z0
     const i64 plane = c->ny * c->nx;
     int rc = upload_convert(c, host, dtype, c->f[0] + z0 * plane, (z1 - z0) * plane, err, errlen);
     if (rc) return rc;
-    // vesselness = zeros, masks = ones (filtering.py:807-808): implicit -- the first evaluated scale writes
-    // vesselness instead of max-ing it and nl_filter_finish zeroes whatever the masks reject
+    // vesselness = zeros, masks = ones (filtering.py:807-808): the first evaluated scale zeroes the vesselness
+    // volume and starts the cumulative mask; nl_filter_finish zeroes whatever the masks reject
     c->mask_slots_used = 0;
     NL_HIP(hipStreamSynchronize(c->stream));
     return NL_OK;
@@ -656,6 +656,8 @@ extern "C" int nl_vesselness_step(nl_ctx *c, float gamma_sq, float alpha_sq, flo
         const i64 plane = c->ny * c->nx;
         const i64 planes_per_launch = (i64)c->vq_chunks * HM_ZCHUNK;
         const VQueue vq{(float4 *)c->d_vq, c->d_vq_count};
+        if (vp.first)      // vesselness = zeros (filtering.py:807); only voxels alive in every mask are ever read again
+            NL_HIP(hipMemsetAsync(c->f[c->i_vmax] + z0 * plane, 0, (size_t)(z1 - z0) * plane * 4, c->stream));
         const int ty = hm_ty();
         const int nty = (int)((c->ny + ty - 1) / ty);
 #define NL_LAUNCH_VESS(TYV, FASTV, HR)                                                                                    \
