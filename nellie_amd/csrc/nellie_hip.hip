@@ -69,6 +69,12 @@ static int hm_ty() {
     if (v < 0) { const char *e = getenv("NELLIE_HM_TY"); v = (e && atoi(e) == 16) ? 16 : 8; }
     return v;
 }
+// Hessian kernel generation (experiment knob): 4 = first derivatives shared through LDS (default), 3 = fused per voxel
+static int hess_gen() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("NELLIE_HESS_GEN"); v = (e && atoi(e) == 3) ? 3 : 4; }
+    return v;
+}
 static Dv<true> dv_fast(float d) { return Dv<true>{d, (float)(1.0 / (double)d)}; }
 static Dv<false> dv_exact(float d) { return Dv<false>{1.0 / (double)d}; }
 static HessDv<true> hessdv_fast(const nl_ctx *c) {
@@ -582,10 +588,16 @@ extern "C" int nl_hessian_stats(nl_ctx *c, const double spacing[3], float *max_a
         const int nzc = (int)((c->own_hi - c->own_lo + HM_ZCHUNK - 1) / HM_ZCHUNK);
         VessP vp{};
 #define NL_LAUNCH_STATS(TYV, FASTV, HR)                                                                                   \
-        hessian_march_kernel<0, TYV, FASTV><<<(unsigned)(ntx * (int)((c->ny + TYV - 1) / TYV) * nzc), HMCfg<TYV>::NT,     \
+        if (hess_gen() == 4)                                                                                              \
+            hessian_g_kernel<0, TYV, FASTV><<<(unsigned)(ntx * (int)((c->ny + TYV - 1) / TYV) * nzc), HGCfg<TYV>::NT,     \
+                                              HGCfg<TYV>::lds_bytes(), c->stream>>>(                                      \
+                c->f[c->i_gauss], nullptr, nullptr, 0, geom(c), HR, vp, VQueue{}, (int)c->own_lo, (int)c->own_hi, ntx,    \
+                (int)((c->ny + TYV - 1) / TYV), res, nullptr);                                                            \
+        else                                                                                                              \
+            hessian_march_kernel<0, TYV, FASTV><<<(unsigned)(ntx * (int)((c->ny + TYV - 1) / TYV) * nzc), HMCfg<TYV>::NT, \
                                               HMCfg<TYV>::lds_floats() * 4, c->stream>>>(                                 \
-            c->f[c->i_gauss], nullptr, nullptr, 0, geom(c), HR, vp, VQueue{}, (int)c->own_lo, (int)c->own_hi, ntx,                  \
-            (int)((c->ny + TYV - 1) / TYV), res, nullptr)
+                c->f[c->i_gauss], nullptr, nullptr, 0, geom(c), HR, vp, VQueue{}, (int)c->own_lo, (int)c->own_hi, ntx,    \
+                (int)((c->ny + TYV - 1) / TYV), res, nullptr)
         if (hm_ty() == 8) { if (c->fast_div) NL_LAUNCH_STATS(8, true, hessdv_fast(c)); else NL_LAUNCH_STATS(8, false, hessdv_exact(c)); }
         else { if (c->fast_div) NL_LAUNCH_STATS(16, true, hessdv_fast(c)); else NL_LAUNCH_STATS(16, false, hessdv_exact(c)); }
 #undef NL_LAUNCH_STATS
@@ -661,8 +673,12 @@ extern "C" int nl_vesselness_step(nl_ctx *c, float gamma_sq, float alpha_sq, flo
         const int ty = hm_ty();
         const int nty = (int)((c->ny + ty - 1) / ty);
 #define NL_LAUNCH_VESS(TYV, FASTV, HR)                                                                                    \
-        hessian_march_kernel<1, TYV, FASTV><<<nblocks, HMCfg<TYV>::NT, HMCfg<TYV>::lds_floats() * 4, c->stream>>>(        \
-            c->f[c->i_gauss], cm, pm, wpr, geom(c), HR, vp, vq, (int)za, (int)zb, ntx, nty, nullptr, d_cnt)
+        if (hess_gen() == 4)                                                                                              \
+            hessian_g_kernel<1, TYV, FASTV><<<nblocks, HGCfg<TYV>::NT, HGCfg<TYV>::lds_bytes(), c->stream>>>(             \
+                c->f[c->i_gauss], cm, pm, wpr, geom(c), HR, vp, vq, (int)za, (int)zb, ntx, nty, nullptr, d_cnt);          \
+        else                                                                                                              \
+            hessian_march_kernel<1, TYV, FASTV><<<nblocks, HMCfg<TYV>::NT, HMCfg<TYV>::lds_floats() * 4, c->stream>>>(    \
+                c->f[c->i_gauss], cm, pm, wpr, geom(c), HR, vp, vq, (int)za, (int)zb, ntx, nty, nullptr, d_cnt)
         for (i64 za = z0; za < z1; za += planes_per_launch) {
             const i64 zb = za + planes_per_launch < z1 ? za + planes_per_launch : z1;
             const int nzc = (int)((zb - za + HM_ZCHUNK - 1) / HM_ZCHUNK);
