@@ -153,6 +153,27 @@ int nl_vesselness_step(nl_ctx *ctx, float gamma_sq, float alpha_sq, float beta_s
                        int use_thr, float thr, int64_t z0, int64_t z1, int64_t *mask_count,
                        char *err, size_t errlen);
 
+/* The grid spacing nl_hessian_stats would set, without the statistics pass (needed before NL_FIELD_FROB can be
+   sampled for the bracket of nl_vesselness_spec). */
+int nl_set_spacing(nl_ctx *ctx, const double spacing[3], char *err, size_t errlen);
+
+/* nl_hessian_stats + nl_vesselness_step in ONE walk over the Hessian (filtering.py:555-585), for a mask threshold
+   that is not known yet but predicted to satisfy  fsq_lo <= fsq_min <= fsq_hi  in units of frob_sq (the
+   un-normalised squared Frobenius norm, filtering.py:538-543).  Voxels with frob_sq >= fsq_hi are treated as
+   h_mask, below fsq_lo as not h_mask, the ones in between are parked.  Returns the statistics of
+   nl_hessian_stats plus `overflow` (a queue region was too small).  Nothing is final until
+   nl_vesselness_resolve confirms the bracket; if it cannot (or any_inf / overflow is set) the caller runs
+   nl_vesselness_step as if this call had not happened.  Planes [z0, z1) must cover the owned planes.
+   Availability: nl_ctx_info("vesselness_one_pass"). */
+int nl_vesselness_spec(nl_ctx *ctx, const double spacing[3], float fsq_lo, float fsq_hi, int64_t z0, int64_t z1,
+                       float *max_abs, float *max_frob_sq, int *any_inf, int *overflow, char *err, size_t errlen);
+
+/* Second half of nl_vesselness_spec, with the arguments nl_vesselness_step takes (nl_set_frob_norm first).
+   *hit = 1: the exact threshold lies inside the bracket; the parked voxels got the exact h_mask test and the scale
+   is complete, bit-identical to nl_vesselness_step (`mask_count` as there).  *hit = 0: no effect. */
+int nl_vesselness_resolve(nl_ctx *ctx, float gamma_sq, float alpha_sq, float beta_sq, int use_thr, float thr,
+                          int *hit, int64_t *mask_count, char *err, size_t errlen);
+
 /* vesselness * masks (filtering.py:926) -> NL_FIELD_FRANGI on planes [z0, z1) (-1, -1: owned).
    n_positive = number of OWNED voxels > 0 (the `sum > 0` test of filtering.py:1016-1017). */
 int nl_filter_finish(nl_ctx *ctx, int64_t z0, int64_t z1, int64_t *n_positive, char *err, size_t errlen);

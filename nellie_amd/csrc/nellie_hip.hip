@@ -69,12 +69,6 @@ static int hm_ty() {
     if (v < 0) { const char *e = getenv("NELLIE_HM_TY"); v = (e && atoi(e) == 16) ? 16 : 8; }
     return v;
 }
-// Hessian kernel generation (experiment knob): 4 = first derivatives shared through LDS (default), 3 = fused per voxel
-static int hess_gen() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("NELLIE_HESS_GEN"); v = (e && atoi(e) == 3) ? 3 : 4; }
-    return v;
-}
 static Dv<true> dv_fast(float d) { return Dv<true>{d, (float)(1.0 / (double)d)}; }
 static Dv<false> dv_exact(float d) { return Dv<false>{1.0 / (double)d}; }
 static HessDv<true> hessdv_fast(const nl_ctx *c) {
@@ -161,11 +155,30 @@ static int64_t vq_chunks(int64_t nzl, int64_t ny, int64_t nx) {
     return chunks < 1 ? 1 : chunks;
 }
 static int64_t vq_entries(int64_t nzl, int64_t ny, int64_t nx) { return vq_chunks(nzl, ny, nx) * vq_padded_plane(ny, nx) * HM_ZCHUNK; }
+// One-pass (MODE 2) vesselness needs every region of the whole slab at once, HM_SPEC_CAP entries each; it is
+// offered when that fits NELLIE_SPEC_MAX_GB (default 64) GiB.  Returns 0 when it does not.
+static int64_t vq_spec_regions(int64_t nzl, int64_t ny, int64_t nx) {
+    return vq_padded_plane(ny, nx) / 64 * ((nzl + HM_ZCHUNK - 1) / HM_ZCHUNK);
+}
+static int64_t vq_spec_entries(int64_t nzl, int64_t ny, int64_t nx) {
+    static int64_t lim = -1;
+    if (lim < 0) { const char *e = getenv("NELLIE_SPEC_MAX_GB"); lim = (e ? atoll(e) : 64) << 30; }
+    const int64_t ent = vq_spec_regions(nzl, ny, nx) * HM_SPEC_CAP;
+    return ent * 32 <= lim ? ent : 0;
+}
+static int64_t vq_alloc_entries(int64_t nzl, int64_t ny, int64_t nx) {
+    const int64_t a = vq_entries(nzl, ny, nx), b = vq_spec_entries(nzl, ny, nx);
+    return a > b ? a : b;
+}
+static int64_t vq_alloc_regions(int64_t nzl, int64_t ny, int64_t nx) {
+    const int64_t a = vq_entries(nzl, ny, nx) / HM_REGION, b = vq_spec_entries(nzl, ny, nx) ? vq_spec_regions(nzl, ny, nx) : 0;
+    return a > b ? a : b;
+}
 
 extern "C" int64_t nl_ctx_bytes(int64_t nz_local, int64_t ny, int64_t nx) {
     const int64_t n = nz_local * ny * nx;
-    const int64_t qe = vq_entries(nz_local, ny, nx);
-    return n * (4 * 4 + 3) + qe * 32 + qe / HM_REGION * 4 + (1 << 16) + ((n + SCAN_CHUNK - 1) / SCAN_CHUNK + 1) * 4;
+    const int64_t qe = vq_alloc_entries(nz_local, ny, nx);
+    return n * (4 * 4 + 3) + qe * 32 + vq_alloc_regions(nz_local, ny, nx) * 4 + (1 << 16) + ((n + SCAN_CHUNK - 1) / SCAN_CHUNK + 1) * 4;
 }
 
 extern "C" int nl_ctx_destroy(nl_ctx *c) {
@@ -244,9 +257,10 @@ extern "C" int nl_ctx_create(nl_ctx **out, int device, int64_t nzl, int64_t ny, 
     if (ok) ok = alloc(&c->d_small, 1 << 16);
     c->vq_chunks = (int)vq_chunks(nzl, ny, nx);
     {
-        const size_t qe = (size_t)vq_entries(nzl, ny, nx);
+        const size_t qe = (size_t)vq_alloc_entries(nzl, ny, nx);
         if (ok) ok = alloc((void **)&c->d_vq, qe * 32);
-        if (ok) ok = alloc((void **)&c->d_vq_count, qe / HM_REGION * 4);
+        if (ok) ok = alloc((void **)&c->d_vq_count, (size_t)vq_alloc_regions(nzl, ny, nx) * 4);
+        c->spec_ok = vq_spec_entries(nzl, ny, nx) > 0;
     }
     c->blk_cap = (n + SCAN_CHUNK - 1) / SCAN_CHUNK + 1;
     if (ok) ok = alloc(&c->d_blk, (size_t)c->blk_cap * 4);
@@ -566,9 +580,7 @@ extern "C" int nl_sample_hist(nl_ctx *c, int field, int64_t sz, int64_t sy, int6
     return NL_OK;
 }
 
-extern "C" int nl_hessian_stats(nl_ctx *c, const double spacing[3], float *max_abs, float *max_frob_sq, int *any_inf,
-                                char *err, size_t errlen) {
-    NL_ENTER(c);
+static int set_spacing(nl_ctx *c, const double spacing[3], char *err, size_t errlen) {
     if (!spacing) return nl_fail(err, errlen, NL_EINVAL, "spacing is NULL");
     if (c->gnz < 2 || c->ny < 2 || c->nx < 2)
         return nl_fail(err, errlen, NL_EINVAL, "Shape of array too small to calculate a numerical gradient, at least (edge_order + 1) elements are required.");
@@ -580,6 +592,19 @@ extern "C" int nl_hessian_stats(nl_ctx *c, const double spacing[3], float *max_a
         c->chk_spacing[0] = spacing[0]; c->chk_spacing[1] = spacing[1]; c->chk_spacing[2] = spacing[2];
     }
     c->have_spacing = 1;
+    return NL_OK;
+}
+
+extern "C" int nl_set_spacing(nl_ctx *c, const double spacing[3], char *err, size_t errlen) {
+    NL_ENTER(c);
+    return set_spacing(c, spacing, err, errlen);
+}
+
+extern "C" int nl_hessian_stats(nl_ctx *c, const double spacing[3], float *max_abs, float *max_frob_sq, int *any_inf,
+                                char *err, size_t errlen) {
+    NL_ENTER(c);
+    { int rcs = set_spacing(c, spacing, err, errlen); if (rcs) return rcs; }
+    c->spec_valid = 0;
     unsigned int *res = (unsigned int *)c->d_small;
     NL_HIP(hipMemsetAsync(res, 0, 16, c->stream));
     {
@@ -588,16 +613,10 @@ extern "C" int nl_hessian_stats(nl_ctx *c, const double spacing[3], float *max_a
         const int nzc = (int)((c->own_hi - c->own_lo + HM_ZCHUNK - 1) / HM_ZCHUNK);
         VessP vp{};
 #define NL_LAUNCH_STATS(TYV, FASTV, HR)                                                                                   \
-        if (hess_gen() == 4)                                                                                              \
-            hessian_g_kernel<0, TYV, FASTV><<<(unsigned)(ntx * (int)((c->ny + TYV - 1) / TYV) * nzc), HGCfg<TYV>::NT,     \
-                                              HGCfg<TYV>::lds_bytes(), c->stream>>>(                                      \
-                c->f[c->i_gauss], nullptr, nullptr, 0, geom(c), HR, vp, VQueue{}, (int)c->own_lo, (int)c->own_hi, ntx,    \
-                (int)((c->ny + TYV - 1) / TYV), res, nullptr);                                                            \
-        else                                                                                                              \
-            hessian_march_kernel<0, TYV, FASTV><<<(unsigned)(ntx * (int)((c->ny + TYV - 1) / TYV) * nzc), HMCfg<TYV>::NT, \
-                                              HMCfg<TYV>::lds_floats() * 4, c->stream>>>(                                 \
-                c->f[c->i_gauss], nullptr, nullptr, 0, geom(c), HR, vp, VQueue{}, (int)c->own_lo, (int)c->own_hi, ntx,    \
-                (int)((c->ny + TYV - 1) / TYV), res, nullptr)
+        hessian_g_kernel<0, TYV, FASTV><<<(unsigned)(ntx * (int)((c->ny + TYV - 1) / TYV) * nzc), HGCfg<TYV>::NT,         \
+                                          HGCfg<TYV>::lds_bytes(), c->stream>>>(                                          \
+            c->f[c->i_gauss], nullptr, nullptr, 0, geom(c), HR, vp, VQueue{}, (int)c->own_lo, (int)c->own_hi, ntx,        \
+            (int)((c->ny + TYV - 1) / TYV), res, nullptr)
         if (hm_ty() == 8) { if (c->fast_div) NL_LAUNCH_STATS(8, true, hessdv_fast(c)); else NL_LAUNCH_STATS(8, false, hessdv_exact(c)); }
         else { if (c->fast_div) NL_LAUNCH_STATS(16, true, hessdv_fast(c)); else NL_LAUNCH_STATS(16, false, hessdv_exact(c)); }
 #undef NL_LAUNCH_STATS
@@ -641,6 +660,110 @@ static float mask_threshold_on_fsq(float max_abs, int use_thr, float thr) {
     return r;
 }
 
+static VessP make_vessp(nl_ctx *c, float gamma_sq, float alpha_sq, float beta_sq, int use_thr, float thr) {
+    VessP vp{};
+    vp.gamma_sq = gamma_sq; vp.alpha_sq = alpha_sq; vp.beta_sq = beta_sq; vp.use_thr = use_thr; vp.thr = thr;
+    vp.max_abs = c->frob_max_abs; vp.max_finite = c->frob_max_finite;
+    vp.cnt_lo = (int)c->own_lo; vp.cnt_hi = (int)c->own_hi;
+    vp.first = c->mask_slots_used == 0 ? 1 : 0;
+    vp.fsq_min = mask_threshold_on_fsq(c->frob_max_abs, use_thr, thr);
+    vp.m_inf = use_thr ? (c->frob_max_finite > thr) : (c->frob_max_finite > 0.0f);
+    c->last_fsq_min = vp.fsq_min;
+    return vp;
+}
+
+// ---- one-pass vesselness (MODE 2 of the Hessian kernel + the resolve kernel), see hessian.inc ---------------
+extern "C" int nl_vesselness_spec(nl_ctx *c, const double spacing[3], float fsq_lo, float fsq_hi, int64_t z0, int64_t z1,
+                                  float *max_abs, float *max_frob_sq, int *any_inf, int *overflow, char *err, size_t errlen) {
+    NL_ENTER(c);
+    if (z0 < 0 && z1 < 0) { z0 = c->own_lo; z1 = c->own_hi; }
+    if (z0 < 0 || z1 > c->nzl || z0 >= z1) return nl_fail(err, errlen, NL_EINVAL, "bad plane range [%lld,%lld)", (i64)z0, (i64)z1);
+    if (z0 > c->own_lo || z1 < c->own_hi) return nl_fail(err, errlen, NL_EINVAL, "the plane range must cover the owned planes");
+    if (!c->spec_ok) return nl_fail(err, errlen, NL_ESTATE, "one-pass vesselness is not available for this context (queue too large)");
+    if (!(fsq_lo <= fsq_hi)) return nl_fail(err, errlen, NL_EINVAL, "empty bracket [%g,%g]", (double)fsq_lo, (double)fsq_hi);
+    { int rcs = set_spacing(c, spacing, err, errlen); if (rcs) return rcs; }
+    unsigned long long *d_cnt = (unsigned long long *)c->d_small;
+    unsigned int *res = (unsigned int *)c->d_small + 16;
+    NL_HIP(hipMemsetAsync(c->d_small, 0, 128, c->stream));
+    VessP vp{};
+    vp.cnt_lo = (int)c->own_lo; vp.cnt_hi = (int)c->own_hi;
+    vp.have_prev = c->mask_slots_used > 0;
+    vp.fsq_lo = fsq_lo; vp.fsq_hi = fsq_hi; vp.qcap = HM_SPEC_CAP;
+    {
+        ProfScope ps(c, "vesselness");
+        const int ntx = (int)((c->nx + HM_TX - 1) / HM_TX);
+        const int wpr = (int)((c->nx + 63) / 64);
+        const i64 slot_words = c->nzl * c->ny * wpr;
+        const int k_scale = c->mask_slots_used;          // committed by nl_vesselness_resolve
+        unsigned long long *cm = (unsigned long long *)c->m[0] + (i64)(k_scale & 1) * slot_words;
+        const unsigned long long *pm = (unsigned long long *)c->m[0] + (i64)((k_scale + 1) & 1) * slot_words;
+        const VQueue vq{(float4 *)c->d_vq, c->d_vq_count};
+        const int ty = hm_ty();
+        const int nty = (int)((c->ny + ty - 1) / ty);
+        const int nzc = (int)((z1 - z0 + HM_ZCHUNK - 1) / HM_ZCHUNK);
+        const unsigned nblocks = (unsigned)(ntx * nty * nzc);
+#define NL_LAUNCH_SPEC(TYV, FASTV, HR)                                                                                    \
+        hessian_g_kernel<2, TYV, FASTV><<<nblocks, HGCfg<TYV>::NT, HGCfg<TYV>::lds_bytes(), c->stream>>>(                 \
+            c->f[c->i_gauss], cm, pm, wpr, geom(c), HR, vp, vq, (int)z0, (int)z1, ntx, nty, res, d_cnt)
+        if (ty == 8) { if (c->fast_div) NL_LAUNCH_SPEC(8, true, hessdv_fast(c)); else NL_LAUNCH_SPEC(8, false, hessdv_exact(c)); }
+        else { if (c->fast_div) NL_LAUNCH_SPEC(16, true, hessdv_fast(c)); else NL_LAUNCH_SPEC(16, false, hessdv_exact(c)); }
+#undef NL_LAUNCH_SPEC
+        NL_CHECK_LAUNCH();
+        c->spec_nregions = nblocks * (unsigned)ty;
+    }
+    unsigned int *h = (unsigned int *)c->h_small;
+    NL_HIP(hipMemcpyAsync(h, c->d_small, 128, hipMemcpyDeviceToHost, c->stream));      // [0] count, [16..19] statistics
+    NL_HIP(hipStreamSynchronize(c->stream));
+    c->spec_count = *(unsigned long long *)c->h_small;       // d_small is scratch for the sampling calls in between
+    h += 16;
+    if (max_abs) memcpy(max_abs, &h[0], 4);
+    if (max_frob_sq) memcpy(max_frob_sq, &h[1], 4);
+    if (any_inf) *any_inf = (int)h[2];
+    if (overflow) *overflow = (int)h[3];
+    c->spec_lo = fsq_lo; c->spec_hi = fsq_hi; c->spec_z0 = z0; c->spec_z1 = z1;
+    c->spec_valid = (h[2] == 0 && h[3] == 0) ? 1 : 0;
+    return NL_OK;
+}
+
+// *hit = 1: the exact threshold lies in the bracket of the pass, the scale is complete (mask_count as
+// nl_vesselness_step reports it); *hit = 0: nothing was changed, run nl_vesselness_step.
+extern "C" int nl_vesselness_resolve(nl_ctx *c, float gamma_sq, float alpha_sq, float beta_sq, int use_thr, float thr,
+                                     int *hit, int64_t *mask_count, char *err, size_t errlen) {
+    NL_ENTER(c);
+    if (!hit) return nl_fail(err, errlen, NL_EINVAL, "hit is NULL");
+    *hit = 0;
+    if (!c->spec_valid) return NL_OK;
+    VessP vp = make_vessp(c, gamma_sq, alpha_sq, beta_sq, use_thr, thr);
+    if (!(vp.fsq_min >= c->spec_lo && vp.fsq_min <= c->spec_hi)) { c->spec_valid = 0; return NL_OK; }
+    const i64 plane = c->ny * c->nx, z0 = c->spec_z0, z1 = c->spec_z1;
+    unsigned long long *d_cnt = (unsigned long long *)c->d_small;
+    NL_HIP(hipMemsetAsync(d_cnt, 0, 8, c->stream));
+    vp.qcap = HM_SPEC_CAP;
+    vp.idx_lo = (c->own_lo - z0) * plane; vp.idx_hi = (c->own_hi - z0) * plane;
+    {
+        ProfScope ps(c, "vesselness");
+        const int wpr = (int)((c->nx + 63) / 64);
+        const i64 slot_words = c->nzl * c->ny * wpr;
+        const int k_scale = c->mask_slots_used++;
+        vp.have_prev = k_scale > 0;
+        unsigned long long *cm = (unsigned long long *)c->m[0] + (i64)(k_scale & 1) * slot_words;
+        const unsigned long long *pm = (unsigned long long *)c->m[0] + (i64)((k_scale + 1) & 1) * slot_words;
+        if (vp.first)
+            NL_HIP(hipMemsetAsync(c->f[c->i_vmax] + z0 * plane, 0, (size_t)(z1 - z0) * plane * 4, c->stream));
+        vesselness_queue_kernel<true><<<(c->spec_nregions + 3) / 4, 256, 0, c->stream>>>(
+            (const float4 *)c->d_vq, c->d_vq_count, c->spec_nregions, c->f[c->i_vmax], z0 * plane, vp, cm, pm, wpr, (int)c->ny, (int)c->nx, z0, d_cnt);
+        NL_CHECK_LAUNCH();
+    }
+    c->spec_valid = 0;
+    *hit = 1;
+    if (mask_count) {
+        NL_HIP(hipMemcpyAsync(c->h_small, d_cnt, 8, hipMemcpyDeviceToHost, c->stream));
+        NL_HIP(hipStreamSynchronize(c->stream));
+        *mask_count = (int64_t)(*(unsigned long long *)c->h_small + c->spec_count);
+    }
+    return NL_OK;
+}
+
 extern "C" int nl_vesselness_step(nl_ctx *c, float gamma_sq, float alpha_sq, float beta_sq, int use_thr, float thr,
                                   int64_t z0, int64_t z1, int64_t *mask_count, char *err, size_t errlen) {
     NL_ENTER(c);
@@ -649,11 +772,9 @@ extern "C" int nl_vesselness_step(nl_ctx *c, float gamma_sq, float alpha_sq, flo
     if (!c->have_spacing) return nl_fail(err, errlen, NL_ESTATE, "nl_vesselness_step before nl_hessian_stats");
     unsigned long long *d_cnt = (unsigned long long *)c->d_small;
     NL_HIP(hipMemsetAsync(d_cnt, 0, 8, c->stream));
-    VessP vp{gamma_sq, alpha_sq, beta_sq, use_thr, thr, c->frob_max_abs, c->frob_max_finite, 0, (int)c->own_lo, (int)c->own_hi,
-             c->mask_slots_used == 0 ? 1 : 0, 0.0f, 0};
-    vp.fsq_min = mask_threshold_on_fsq(c->frob_max_abs, use_thr, thr);
-    vp.m_inf = use_thr ? (c->frob_max_finite > thr) : (c->frob_max_finite > 0.0f);
-    if (vp.fsq_min == 0.0f && !use_thr) { /* frob > 0 <=> frob_sq > 0 unless sqrt underflows: keep the bisected value */ }
+    VessP vp = make_vessp(c, gamma_sq, alpha_sq, beta_sq, use_thr, thr);
+    vp.qcap = HM_REGION;
+    c->spec_valid = 0;
     {
         ProfScope ps(c, "vesselness");
         const int ntx = (int)((c->nx + HM_TX - 1) / HM_TX);
@@ -673,12 +794,8 @@ extern "C" int nl_vesselness_step(nl_ctx *c, float gamma_sq, float alpha_sq, flo
         const int ty = hm_ty();
         const int nty = (int)((c->ny + ty - 1) / ty);
 #define NL_LAUNCH_VESS(TYV, FASTV, HR)                                                                                    \
-        if (hess_gen() == 4)                                                                                              \
-            hessian_g_kernel<1, TYV, FASTV><<<nblocks, HGCfg<TYV>::NT, HGCfg<TYV>::lds_bytes(), c->stream>>>(             \
-                c->f[c->i_gauss], cm, pm, wpr, geom(c), HR, vp, vq, (int)za, (int)zb, ntx, nty, nullptr, d_cnt);          \
-        else                                                                                                              \
-            hessian_march_kernel<1, TYV, FASTV><<<nblocks, HMCfg<TYV>::NT, HMCfg<TYV>::lds_floats() * 4, c->stream>>>(    \
-                c->f[c->i_gauss], cm, pm, wpr, geom(c), HR, vp, vq, (int)za, (int)zb, ntx, nty, nullptr, d_cnt)
+        hessian_g_kernel<1, TYV, FASTV><<<nblocks, HGCfg<TYV>::NT, HGCfg<TYV>::lds_bytes(), c->stream>>>(                 \
+            c->f[c->i_gauss], cm, pm, wpr, geom(c), HR, vp, vq, (int)za, (int)zb, ntx, nty, nullptr, d_cnt)
         for (i64 za = z0; za < z1; za += planes_per_launch) {
             const i64 zb = za + planes_per_launch < z1 ? za + planes_per_launch : z1;
             const int nzc = (int)((zb - za + HM_ZCHUNK - 1) / HM_ZCHUNK);
@@ -687,7 +804,8 @@ extern "C" int nl_vesselness_step(nl_ctx *c, float gamma_sq, float alpha_sq, flo
             else { if (c->fast_div) NL_LAUNCH_VESS(16, true, hessdv_fast(c)); else NL_LAUNCH_VESS(16, false, hessdv_exact(c)); }
             NL_CHECK_LAUNCH();
             const unsigned nregions = nblocks * (unsigned)ty;
-            vesselness_queue_kernel<<<(nregions + 3) / 4, 256, 0, c->stream>>>(vq.ent, vq.count, nregions, c->f[c->i_vmax], za * plane, vp);
+            vesselness_queue_kernel<false><<<(nregions + 3) / 4, 256, 0, c->stream>>>(vq.ent, vq.count, nregions, c->f[c->i_vmax], za * plane, vp,
+                                                                                      nullptr, nullptr, wpr, (int)c->ny, (int)c->nx, za, nullptr);
             NL_CHECK_LAUNCH();
         }
 #undef NL_LAUNCH_VESS
@@ -1358,6 +1476,8 @@ extern "C" int nl_ctx_info(nl_ctx *c, const char *key, double *value) {
     if (!c || !key || !value) return NL_EINVAL;
     if (!strcmp(key, "fast_div")) *value = c->fast_div;
     else if (!strcmp(key, "hessian_tile_rows")) *value = hm_ty();
+    else if (!strcmp(key, "vesselness_one_pass")) *value = c->spec_ok;
+    else if (!strcmp(key, "last_fsq_min")) *value = c->last_fsq_min;
     else if (!strcmp(key, "device_bytes")) *value = (double)nl_ctx_bytes(c->nzl, c->ny, c->nx);
     else return NL_EINVAL;
     return NL_OK;

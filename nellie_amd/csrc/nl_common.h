@@ -47,6 +47,13 @@ struct nl_ctx {
     float *d_vq = nullptr;     // global queue of voxels to eigen-solve (32-byte entries, one region per wave)
     unsigned int *d_vq_count = nullptr;   // entries written per region
     int vq_chunks = 1;         // Z chunks (HM_ZCHUNK planes) one vesselness launch may cover
+    int spec_ok = 0;           // the queue can hold a one-pass (MODE 2) vesselness of the whole slab
+    int spec_valid = 0;        // a MODE 2 pass is waiting for nl_vesselness_resolve
+    float spec_lo = 0, spec_hi = 0;
+    i64 spec_z0 = 0, spec_z1 = 0;
+    unsigned int spec_nregions = 0;
+    unsigned long long spec_count = 0;   // owned voxels the pass already counted as h_mask
+    float last_fsq_min = 0;    // the exact mask threshold of the last scale (diagnostics)
     void *d_blk = nullptr;     // per-block partials for scans
     unsigned int *d_rows = nullptr;   // per-row run counts and offsets (Label on runs)
     unsigned long long *gbits[2] = {nullptr, nullptr};   // Z-slab Label: GLOBAL bit masks (lazily allocated)

@@ -48,6 +48,10 @@ _PROTOS = {
     "nl_hessian_stats": [_p, C.POINTER(_f64), C.POINTER(_f32), C.POINTER(_f32), C.POINTER(_int)],
     "nl_set_frob_norm": [_p, _f32, _f32],
     "nl_vesselness_step": [_p, _f32, _f32, _f32, _int, _f32, _i64, _i64, C.POINTER(_i64)],
+    "nl_set_spacing": [_p, C.POINTER(_f64)],
+    "nl_vesselness_spec": [_p, C.POINTER(_f64), _f32, _f32, _i64, _i64, C.POINTER(_f32), C.POINTER(_f32),
+                           C.POINTER(_int), C.POINTER(_int)],
+    "nl_vesselness_resolve": [_p, _f32, _f32, _f32, _int, _f32, C.POINTER(_int), C.POINTER(_i64)],
     "nl_filter_finish": [_p, _i64, _i64, C.POINTER(_i64)],
     "nl_planes_get": [_p, _int, _i64, _i64, _p],
     "nl_planes_put": [_p, _int, _i64, _i64, _p],
@@ -341,6 +345,31 @@ class Context:
                    float(np.float32(beta_sq)), use, float(np.float32(0.0 if thr is None else thr)),
                    int(z0), int(z1), C.byref(n) if want_count else None)
         return int(n.value)
+
+    def one_pass_available(self) -> bool:
+        return bool(self.info("vesselness_one_pass"))
+
+    def set_spacing(self, spacing):
+        sp = (_f64 * 3)(*[float(s) for s in spacing])
+        self._call("nl_set_spacing", sp)
+
+    def vesselness_spec(self, spacing, fsq_lo, fsq_hi, z0=-1, z1=-1):
+        """One walk over the Hessian: statistics + vesselness candidates for fsq_min in [fsq_lo, fsq_hi].
+        Returns (max_abs, max_frob_sq, any_inf, overflow)."""
+        sp = (_f64 * 3)(*[float(s) for s in spacing])
+        ma, mf, inf, ovf = _f32(0), _f32(0), _int(0), _int(0)
+        self._call("nl_vesselness_spec", sp, float(np.float32(fsq_lo)), float(np.float32(fsq_hi)), int(z0), int(z1),
+                   C.byref(ma), C.byref(mf), C.byref(inf), C.byref(ovf))
+        return np.float32(ma.value), np.float32(mf.value), bool(inf.value), bool(ovf.value)
+
+    def vesselness_resolve(self, gamma_sq, alpha_sq, beta_sq, thr):
+        """(hit, mask_count): hit False means the bracket missed and vesselness_step must run."""
+        n, hit = _i64(0), _int(0)
+        use = 0 if thr is None else 1
+        self._call("nl_vesselness_resolve", float(np.float32(gamma_sq)), float(np.float32(alpha_sq)),
+                   float(np.float32(beta_sq)), use, float(np.float32(0.0 if thr is None else thr)),
+                   C.byref(hit), C.byref(n))
+        return bool(hit.value), int(n.value)
 
     def filter_finish(self, z0=-1, z1=-1) -> int:
         n = _i64(0)

@@ -152,6 +152,7 @@ class ScaleTrace:
     frob_thr: Optional[float]
     mask_count: int
     skipped: bool
+    one_pass: bool = False          # the scale needed a single walk over the Hessian (nl_vesselness_spec hit)
 
 
 @dataclass
@@ -173,6 +174,12 @@ class FramePipeline:
             raise ValueError("FramePipeline takes a (Z, Y, X) shape")
         self.ctx = ctx if ctx is not None else hipnative.Context(self.shape, device=device)
         self.trace = FrameTrace()
+        # One walk over the Hessian per scale instead of two (statistics, then masks): the mask threshold is
+        # predicted from the sample lattice and bracketed by a relative margin; a scale whose exact threshold
+        # falls outside the bracket is redone the two-pass way, so results never depend on it.
+        self.one_pass = bool(getattr(self.ctx, "one_pass_available", lambda: False)())
+        self.one_pass_margin = 1e-3
+        self._one_pass_test_scale = 1.0      # tests: shifts the prediction to force a miss
 
     def close(self):
         self.ctx.close()
@@ -216,6 +223,23 @@ class FramePipeline:
         counts = self._reduce_counts(self.ctx.sample_hist(fld, strides, edges))
         return float(min_triangle_otsu(counts, edges))
 
+    def _fsq_bracket(self, strides, division):
+        """Predicted [lo, hi] for the un-normalised frob_sq threshold of the current scale, or None.
+        Normalising by 1 instead of the (unknown) global max |H| rescales samples and threshold alike
+        (filtering.py:421-444), so the histogram threshold of sqrt(frob_sq) predicts sqrt(fsq_min) up to float32
+        rounding -- unless the rounding moves the histogram argmax to another bin, which the bracket then misses."""
+        self.ctx.set_frob_norm(1.0, 0.0)
+        mn, mx, npos = self._reduce_minmax(*self.ctx.sample_minmax(FIELD_FROB, strides))
+        if npos == 0 or not np.isfinite(mx):
+            return None
+        edges = histogram_edges(mn, mx, 256)
+        counts = self._reduce_counts(self.ctx.sample_hist(FIELD_FROB, strides, edges))
+        t = float(min_triangle_otsu(counts, edges)) * self._one_pass_test_scale / division
+        lo, hi = np.float32(t * t * (1.0 - self.one_pass_margin)), np.float32(t * t * (1.0 + self.one_pass_margin))
+        if not (np.isfinite(lo) and np.isfinite(hi) and hi > 0):
+            return None
+        return float(lo), float(hi)
+
     def compute_vesselness(self, frame, p: FilterParams, mask: bool = True):
         """filtering.py:806-853 + 926: leaves `vesselness * masks` on the device; returns #voxels > 0."""
         ctx = self.ctx
@@ -244,8 +268,21 @@ class FramePipeline:
             if gamma is None or gamma <= 0:
                 gamma = _EPS32
             gamma_sq = 2.0 * (float(gamma) ** 2)
-            # Hessian statistics (filtering.py:555-562)
-            max_abs32, max_fsq32, any_inf = self._reduce_stats(*ctx.hessian_stats(spacing))
+            # Hessian statistics (filtering.py:555-562) -- taken together with the vesselness candidates when the
+            # mask threshold can be bracketed beforehand (nl_vesselness_spec), by a pass of their own otherwise
+            spec = False
+            stats = None
+            if self.one_pass and mask and p.frob_thresh_division and p.frob_thresh is None:
+                ctx.set_spacing(spacing)
+                bracket = self._fsq_bracket(strides, float(p.frob_thresh_division))
+                if bracket is not None:
+                    vz0, vz1 = self._vess_range()
+                    ma, mf, inf_, ovf = ctx.vesselness_spec(spacing, bracket[0], bracket[1], z0=vz0, z1=vz1)
+                    stats = self._reduce_stats(ma, mf, inf_)
+                    spec = not stats[2] and self._reduce_sum(int(ovf)) == 0
+            if stats is None:
+                stats = self._reduce_stats(*ctx.hessian_stats(spacing))
+            max_abs32, max_fsq32, any_inf = stats
             max_abs = float(max_abs32)
             if max_abs <= 0:
                 max_abs = 1.0
@@ -268,10 +305,15 @@ class FramePipeline:
                 thr_cmp = np.float32(thr / p.frob_thresh_division)   # weak python scalar vs float32 array
                 nonempty = bool(max_frob > thr_cmp)
             count = 0
+            hit = False
             if nonempty:                                         # filtering.py:843-844
-                vz0, vz1 = self._vess_range()
-                count = self._reduce_sum(ctx.vesselness_step(gamma_sq, alpha_sq, beta_sq, thr_cmp, z0=vz0, z1=vz1))
-            self.trace.scales.append(ScaleTrace(float(sigma), float(gamma), max_abs, thr, count, not nonempty))
+                if spec:
+                    hit, count = ctx.vesselness_resolve(gamma_sq, alpha_sq, beta_sq, thr_cmp)
+                if not hit:
+                    vz0, vz1 = self._vess_range()
+                    count = ctx.vesselness_step(gamma_sq, alpha_sq, beta_sq, thr_cmp, z0=vz0, z1=vz1)
+                count = self._reduce_sum(count)
+            self.trace.scales.append(ScaleTrace(float(sigma), float(gamma), max_abs, thr, count, not nonempty, hit))
         vz0, vz1 = self._vess_range()
         self.trace.n_positive = self._reduce_sum(ctx.filter_finish(vz0, vz1))
         return self.trace.n_positive
