@@ -74,11 +74,13 @@ def pipes(hip):
         p.close()
 
 
+@pytest.mark.parametrize("one_pass", [True, False], ids=["one_pass", "two_pass"])
 @pytest.mark.parametrize("name", FILTER_CASES)
-def test_filter_golden(name, pipes):
+def test_filter_golden(name, one_pass, pipes):
     g = load_golden(name)
     vol = g["input"]
     pipe = pipes(vol.shape)
+    pipe.one_pass = one_pass and pipe.ctx.one_pass_available()
     p = _params(g)
     if "error_type" in g:
         with pytest.raises(ValueError, match=str(g["error_msg"])[:30]):
@@ -104,6 +106,34 @@ def test_filter_golden(name, pipes):
         assert_masked_close(pipe.download_frangi(), g["frangi"], g["run_frame"], g["percentile_thr"])
     else:
         assert_frangi_close(pipe.download_frangi(), g["frangi"], "frangi")
+
+
+@pytest.mark.parametrize("shape,aniso", [((40, 96, 80), False), ((21, 70, 131), True)])
+def test_one_pass_vesselness_equals_two_pass(shape, aniso, hip):
+    """nl_vesselness_spec + nl_vesselness_resolve (one walk over the Hessian per scale) against nl_hessian_stats +
+    nl_vesselness_step (two walks): identical bits, identical trace; a bracket that misses falls back."""
+    from nellie_amd.pipeline import FilterParams, FramePipeline
+    from nellie_amd.synthetic import ANISO_03, ISO_01, make_volume
+    vol = make_volume(shape, 99)
+    p = FilterParams(dim_res=ANISO_03 if aniso else ISO_01)
+    out = {}
+    for mode in ("two", "one", "miss"):
+        pipe = FramePipeline(shape)
+        assert pipe.ctx.one_pass_available()
+        pipe.one_pass = mode != "two"
+        if mode == "miss":
+            pipe._one_pass_test_scale = 1.2
+        pipe.compute_vesselness(vol, p)
+        out[mode] = (pipe.download_frangi(), pipe.trace)
+        pipe.close()
+    f2, t2 = out["two"]
+    for mode in ("one", "miss"):
+        f1, t1 = out[mode]
+        assert np.array_equal(f1.view(np.uint32), f2.view(np.uint32)), mode
+        assert t1.n_positive == t2.n_positive
+        for a, b in zip(t1.scales, t2.scales):
+            assert (a.gamma, a.max_abs, a.frob_thr, a.mask_count, a.skipped) == (b.gamma, b.max_abs, b.frob_thr, b.mask_count, b.skipped)
+            assert a.one_pass == (mode == "one" and not a.skipped)
 
 
 @pytest.mark.parametrize("name", [n for n in FILTER_CASES if n.startswith(("iso", "aniso", "odd", "u16"))])
