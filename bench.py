@@ -45,7 +45,7 @@ B_ALG_KERNEL = {
 }
 
 
-PMC_KERNEL_OF_GROUP = {"vesselness": "hessian_march_kernel<1", "hessian_stats": "hessian_march_kernel<0"}
+PMC_KERNEL_OF_GROUP = {"vesselness": "hessian_g_kernel<2", "hessian_stats": "hessian_g_kernel<0"}
 
 
 def pmc_traffic(group, shape):
@@ -234,7 +234,10 @@ def main():
 
     # per-kernel-group HIP-event times over the timed region (this rank)
     groups = {}
-    for name in ("load", "gauss", "sample", "hessian_stats", "vesselness", "finish", "mask_volume", "label"):
+    # "vesselness" = the marching Hessian pass of a scale (statistics + masks + queue; one launch per scale),
+    # "vesselness_resolve" = the dense eigen/Frangi kernel over its queue; "hessian_stats" only appears when a
+    # scale falls back to the two-pass scheme
+    for name in ("load", "gauss", "sample", "hessian_stats", "vesselness", "vesselness_resolve", "finish", "mask_volume", "label"):
         ms, k = pipe.ctx.prof_get(name)
         if k:
             groups[name] = {"ms_total": ms, "launches": k, "ms_avg": ms / k}
@@ -293,6 +296,7 @@ def main():
                 "voxels": int(n_global), "per_gpu_shape": list(shape),
                 "survival_fraction": round(tr.n_positive / n_local, 5), "labels": int(n_labels),
                 "mask_fraction_per_scale": [round(sc.mask_count / n_local, 4) for sc in tr.scales],
+                "one_pass_scales": int(sum(1 for sc in tr.scales if sc.one_pass)),
                 "host_gen_s": round(t_gen, 1), "h2d_s": round(t_up, 2), "fast_div_proven": fast_div,
             },
             "roofline": roofline, "cpu_baseline": cpu,

@@ -174,6 +174,12 @@ int nl_vesselness_spec(nl_ctx *ctx, const double spacing[3], float fsq_lo, float
 int nl_vesselness_resolve(nl_ctx *ctx, float gamma_sq, float alpha_sq, float beta_sq, int use_thr, float thr,
                           int *hit, int64_t *mask_count, char *err, size_t errlen);
 
+/* The resolve kernel of nl_vesselness_resolve runs on a side stream so that the Gaussian cascade step of the next
+   scale (which touches neither the vesselness volume nor the masks) can overlap it; every entry point that does
+   touch them orders itself after it.  Passing mask_count = NULL to nl_vesselness_resolve keeps the call
+   asynchronous; this returns the count later (and waits for the kernel). */
+int nl_vesselness_count(nl_ctx *ctx, int64_t *mask_count, char *err, size_t errlen);
+
 /* vesselness * masks (filtering.py:926) -> NL_FIELD_FRANGI on planes [z0, z1) (-1, -1: owned).
    n_positive = number of OWNED voxels > 0 (the `sum > 0` test of filtering.py:1016-1017). */
 int nl_filter_finish(nl_ctx *ctx, int64_t z0, int64_t z1, int64_t *n_positive, char *err, size_t errlen);

@@ -195,6 +195,9 @@ extern "C" int nl_ctx_destroy(nl_ctx *c) {
     if (c->d_stage_lab) hipFree(c->d_stage_lab);
     if (c->ev_staged) hipEventDestroy(c->ev_staged);
     if (c->ev_fetched) hipEventDestroy(c->ev_fetched);
+    if (c->side) { hipStreamSynchronize(c->side); hipStreamDestroy(c->side); }
+    if (c->ev_side) hipEventDestroy(c->ev_side);
+    if (c->ev_main) hipEventDestroy(c->ev_main);
     if (c->copy_in) hipStreamDestroy(c->copy_in);
     if (c->copy_out) hipStreamDestroy(c->copy_out);
     if (c->d_blk) hipFree(c->d_blk);
@@ -267,6 +270,11 @@ extern "C" int nl_ctx_create(nl_ctx **out, int device, int64_t nzl, int64_t ny, 
     if (ok && hipHostMalloc(&c->h_small, 1 << 16, hipHostMallocDefault) != hipSuccess) {
         rc = nl_fail(err, errlen, NL_ENOMEM, "hipHostMalloc failed [out of memory]"); ok = false;
     }
+    if (ok && (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
+               hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming) != hipSuccess ||
+               hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming) != hipSuccess)) {
+        rc = nl_fail(err, errlen, NL_EHIP, "stream/event creation failed"); ok = false;
+    }
     if (ok && (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
                hipEventCreate(&c->t0) != hipSuccess || hipEventCreate(&c->t1) != hipSuccess)) {
         rc = nl_fail(err, errlen, NL_EHIP, "stream/event creation failed"); ok = false;
@@ -280,12 +288,21 @@ extern "C" int nl_sync(nl_ctx *c, char *err, size_t errlen) {
     if (!c) return nl_fail(err, errlen, NL_EINVAL, "ctx is NULL");
     NL_HIP(hipSetDevice(c->device));
     NL_HIP(hipStreamSynchronize(c->stream));
+    NL_HIP(hipStreamSynchronize(c->side));
     return NL_OK;
 }
 
 #define NL_ENTER(c)                                                    \
     if (!(c)) return nl_fail(err, errlen, NL_EINVAL, "ctx is NULL");   \
     NL_HIP(hipSetDevice((c)->device));
+
+// Orders the main stream after whatever is still running on the side stream (the resolve kernel of the previous
+// scale).  Called by every entry point that touches the vesselness volume, the mask planes or the queue.
+#define NL_JOIN_SIDE(c)                                                            \
+    if ((c)->side_pending) {                                                       \
+        NL_HIP(hipStreamWaitEvent((c)->stream, (c)->ev_side, 0));                  \
+        (c)->side_pending = 0;                                                     \
+    }
 
 static int upload_convert(nl_ctx *c, const void *host, int dtype, float *dst, i64 count, char *err, size_t errlen) {
     const size_t es = dtype_size(dtype);
@@ -325,6 +342,7 @@ static int upload_convert(nl_ctx *c, const void *host, int dtype, float *dst, i6
 
 extern "C" int nl_filter_load(nl_ctx *c, const void *host, int dtype, int64_t z0, int64_t z1, char *err, size_t errlen) {
     NL_ENTER(c);
+    NL_JOIN_SIDE(c);
     if (!host || z0 < 0 || z1 > c->nzl || z0 >= z1) return nl_fail(err, errlen, NL_EINVAL, "bad plane range [%lld,%lld)", (i64)z0, (i64)z1);
     c->i_gauss = 0; c->i_vmax = 3; c->i_labels = -1; c->frangi_ready = 0;
     const i64 plane = c->ny * c->nx;
@@ -356,6 +374,7 @@ extern "C" int nl_input_load(nl_ctx *c, const void *host, int dtype, int64_t z0,
 // frame = xp.asarray(resident input, dtype=float32); vesselness = 0; masks = 1.  Asynchronous.
 extern "C" int nl_filter_begin(nl_ctx *c, char *err, size_t errlen) {
     NL_ENTER(c);
+    NL_JOIN_SIDE(c);
     if (!c->d_input) return nl_fail(err, errlen, NL_ESTATE, "nl_filter_begin before nl_input_load");
     c->i_gauss = 0; c->i_vmax = 3; c->i_labels = -1; c->frangi_ready = 0;
     ProfScope ps(c, "load");
@@ -679,6 +698,7 @@ extern "C" int nl_vesselness_spec(nl_ctx *c, const double spacing[3], float fsq_
     if (z0 < 0 && z1 < 0) { z0 = c->own_lo; z1 = c->own_hi; }
     if (z0 < 0 || z1 > c->nzl || z0 >= z1) return nl_fail(err, errlen, NL_EINVAL, "bad plane range [%lld,%lld)", (i64)z0, (i64)z1);
     if (z0 > c->own_lo || z1 < c->own_hi) return nl_fail(err, errlen, NL_EINVAL, "the plane range must cover the owned planes");
+    NL_JOIN_SIDE(c);
     if (!c->spec_ok) return nl_fail(err, errlen, NL_ESTATE, "one-pass vesselness is not available for this context (queue too large)");
     if (!(fsq_lo <= fsq_hi)) return nl_fail(err, errlen, NL_EINVAL, "empty bracket [%g,%g]", (double)fsq_lo, (double)fsq_hi);
     { int rcs = set_spacing(c, spacing, err, errlen); if (rcs) return rcs; }
@@ -727,6 +747,18 @@ extern "C" int nl_vesselness_spec(nl_ctx *c, const double spacing[3], float fsq_
 
 // *hit = 1: the exact threshold lies in the bracket of the pass, the scale is complete (mask_count as
 // nl_vesselness_step reports it); *hit = 0: nothing was changed, run nl_vesselness_step.
+// h_mask count of the scale completed by the last nl_vesselness_resolve hit (waits for its kernel).
+extern "C" int nl_vesselness_count(nl_ctx *c, int64_t *mask_count, char *err, size_t errlen) {
+    NL_ENTER(c);
+    if (!mask_count) return nl_fail(err, errlen, NL_EINVAL, "mask_count is NULL");
+    unsigned long long *d_cnt = (unsigned long long *)((char *)c->d_small + (48 << 10));
+    unsigned long long *h_cnt = (unsigned long long *)((char *)c->h_small + (48 << 10));
+    NL_HIP(hipMemcpyAsync(h_cnt, d_cnt, 8, hipMemcpyDeviceToHost, c->side));
+    NL_HIP(hipStreamSynchronize(c->side));
+    *mask_count = (int64_t)(*h_cnt + c->spec_count);
+    return NL_OK;
+}
+
 extern "C" int nl_vesselness_resolve(nl_ctx *c, float gamma_sq, float alpha_sq, float beta_sq, int use_thr, float thr,
                                      int *hit, int64_t *mask_count, char *err, size_t errlen) {
     NL_ENTER(c);
@@ -736,12 +768,16 @@ extern "C" int nl_vesselness_resolve(nl_ctx *c, float gamma_sq, float alpha_sq, 
     VessP vp = make_vessp(c, gamma_sq, alpha_sq, beta_sq, use_thr, thr);
     if (!(vp.fsq_min >= c->spec_lo && vp.fsq_min <= c->spec_hi)) { c->spec_valid = 0; return NL_OK; }
     const i64 plane = c->ny * c->nx, z0 = c->spec_z0, z1 = c->spec_z1;
-    unsigned long long *d_cnt = (unsigned long long *)c->d_small;
-    NL_HIP(hipMemsetAsync(d_cnt, 0, 8, c->stream));
+    // The kernel runs on the side stream, ordered after everything submitted to the main stream so far; the main
+    // stream is free to go on with the Gaussian of the next scale.  Its counter lives outside the sampling scratch.
+    unsigned long long *d_cnt = (unsigned long long *)((char *)c->d_small + (48 << 10));
+    NL_HIP(hipEventRecord(c->ev_main, c->stream));
+    NL_HIP(hipStreamWaitEvent(c->side, c->ev_main, 0));
+    NL_HIP(hipMemsetAsync(d_cnt, 0, 8, c->side));
     vp.qcap = HM_SPEC_CAP;
     vp.idx_lo = (c->own_lo - z0) * plane; vp.idx_hi = (c->own_hi - z0) * plane;
     {
-        ProfScope ps(c, "vesselness");
+        ProfScope ps(c, "vesselness_resolve", c->side);
         const int wpr = (int)((c->nx + 63) / 64);
         const i64 slot_words = c->nzl * c->ny * wpr;
         const int k_scale = c->mask_slots_used++;
@@ -749,17 +785,18 @@ extern "C" int nl_vesselness_resolve(nl_ctx *c, float gamma_sq, float alpha_sq, 
         unsigned long long *cm = (unsigned long long *)c->m[0] + (i64)(k_scale & 1) * slot_words;
         const unsigned long long *pm = (unsigned long long *)c->m[0] + (i64)((k_scale + 1) & 1) * slot_words;
         if (vp.first)
-            NL_HIP(hipMemsetAsync(c->f[c->i_vmax] + z0 * plane, 0, (size_t)(z1 - z0) * plane * 4, c->stream));
-        vesselness_queue_kernel<true><<<(c->spec_nregions + 3) / 4, 256, 0, c->stream>>>(
+            NL_HIP(hipMemsetAsync(c->f[c->i_vmax] + z0 * plane, 0, (size_t)(z1 - z0) * plane * 4, c->side));
+        vesselness_queue_kernel<true><<<(c->spec_nregions + 3) / 4, 256, 0, c->side>>>(
             (const float4 *)c->d_vq, c->d_vq_count, c->spec_nregions, c->f[c->i_vmax], z0 * plane, vp, cm, pm, wpr, (int)c->ny, (int)c->nx, z0, d_cnt);
         NL_CHECK_LAUNCH();
     }
+    NL_HIP(hipEventRecord(c->ev_side, c->side));
+    c->side_pending = 1;
     c->spec_valid = 0;
     *hit = 1;
-    if (mask_count) {
-        NL_HIP(hipMemcpyAsync(c->h_small, d_cnt, 8, hipMemcpyDeviceToHost, c->stream));
-        NL_HIP(hipStreamSynchronize(c->stream));
-        *mask_count = (int64_t)(*(unsigned long long *)c->h_small + c->spec_count);
+    if (mask_count) {        // asking for the count here waits for the kernel; nl_vesselness_count can be called later instead
+        int rcc = nl_vesselness_count(c, mask_count, err, errlen);
+        if (rcc) return rcc;
     }
     return NL_OK;
 }
@@ -770,6 +807,7 @@ extern "C" int nl_vesselness_step(nl_ctx *c, float gamma_sq, float alpha_sq, flo
     if (z0 < 0 && z1 < 0) { z0 = c->own_lo; z1 = c->own_hi; }
     if (z0 < 0 || z1 > c->nzl || z0 >= z1) return nl_fail(err, errlen, NL_EINVAL, "bad plane range [%lld,%lld)", (i64)z0, (i64)z1);
     if (!c->have_spacing) return nl_fail(err, errlen, NL_ESTATE, "nl_vesselness_step before nl_hessian_stats");
+    NL_JOIN_SIDE(c);
     unsigned long long *d_cnt = (unsigned long long *)c->d_small;
     NL_HIP(hipMemsetAsync(d_cnt, 0, 8, c->stream));
     VessP vp = make_vessp(c, gamma_sq, alpha_sq, beta_sq, use_thr, thr);
@@ -823,6 +861,7 @@ extern "C" int nl_filter_finish(nl_ctx *c, int64_t z0, int64_t z1, int64_t *n_po
     NL_ENTER(c);
     if (z0 < 0 && z1 < 0) { z0 = c->own_lo; z1 = c->own_hi; }
     if (z0 < 0 || z1 > c->nzl || z0 >= z1) return nl_fail(err, errlen, NL_EINVAL, "bad plane range [%lld,%lld)", (i64)z0, (i64)z1);
+    NL_JOIN_SIDE(c);
     unsigned long long *d_cnt = (unsigned long long *)c->d_small;
     NL_HIP(hipMemsetAsync(d_cnt, 0, 8, c->stream));
     const i64 plane = c->ny * c->nx;

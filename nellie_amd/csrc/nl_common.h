@@ -53,6 +53,9 @@ struct nl_ctx {
     i64 spec_z0 = 0, spec_z1 = 0;
     unsigned int spec_nregions = 0;
     unsigned long long spec_count = 0;   // owned voxels the pass already counted as h_mask
+    hipStream_t side = nullptr;          // the resolve kernel of scale s runs here, beside the Gaussian of scale s+1
+    hipEvent_t ev_side = nullptr, ev_main = nullptr;
+    int side_pending = 0;                // work on `side` the main stream has not been ordered after yet
     float last_fsq_min = 0;    // the exact mask threshold of the last scale (diagnostics)
     void *d_blk = nullptr;     // per-block partials for scans
     unsigned int *d_rows = nullptr;   // per-row run counts and offsets (Label on runs)
@@ -105,14 +108,15 @@ static inline int nl_fail(char *err, size_t errlen, int code, const char *fmt, .
 // RAII profiling scope: records a HIP-event pair on the context stream around a kernel group.
 struct ProfScope {
     nl_ctx *c; ProfRec r; bool on;
-    ProfScope(nl_ctx *ctx, const char *name) : c(ctx), on(ctx->prof_on != 0) {
+    hipStream_t st;
+    ProfScope(nl_ctx *ctx, const char *name, hipStream_t stream = nullptr) : c(ctx), on(ctx->prof_on != 0), st(stream ? stream : ctx->stream) {
         if (!on) return;
         hipEventCreate(&r.a); hipEventCreate(&r.b);
-        hipEventRecord(r.a, c->stream);
+        hipEventRecord(r.a, st);
         c->prof[name].push_back(r);
         idx = c->prof[name].size() - 1; key = name;
     }
-    ~ProfScope() { if (on) hipEventRecord(c->prof[key][idx].b, c->stream); }
+    ~ProfScope() { if (on) hipEventRecord(c->prof[key][idx].b, st); }
     size_t idx = 0; std::string key;
 };
 

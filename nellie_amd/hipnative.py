@@ -52,6 +52,7 @@ _PROTOS = {
     "nl_vesselness_spec": [_p, C.POINTER(_f64), _f32, _f32, _i64, _i64, C.POINTER(_f32), C.POINTER(_f32),
                            C.POINTER(_int), C.POINTER(_int)],
     "nl_vesselness_resolve": [_p, _f32, _f32, _f32, _int, _f32, C.POINTER(_int), C.POINTER(_i64)],
+    "nl_vesselness_count": [_p, C.POINTER(_i64)],
     "nl_filter_finish": [_p, _i64, _i64, C.POINTER(_i64)],
     "nl_planes_get": [_p, _int, _i64, _i64, _p],
     "nl_planes_put": [_p, _int, _i64, _i64, _p],
@@ -362,14 +363,20 @@ class Context:
                    C.byref(ma), C.byref(mf), C.byref(inf), C.byref(ovf))
         return np.float32(ma.value), np.float32(mf.value), bool(inf.value), bool(ovf.value)
 
-    def vesselness_resolve(self, gamma_sq, alpha_sq, beta_sq, thr):
-        """(hit, mask_count): hit False means the bracket missed and vesselness_step must run."""
-        n, hit = _i64(0), _int(0)
+    def vesselness_resolve(self, gamma_sq, alpha_sq, beta_sq, thr) -> bool:
+        """hit: False means the bracket missed and vesselness_step must run.  Asynchronous on a hit: the kernel runs
+        on the context's side stream, vesselness_count() waits for it and returns the h_mask count."""
+        hit = _int(0)
         use = 0 if thr is None else 1
         self._call("nl_vesselness_resolve", float(np.float32(gamma_sq)), float(np.float32(alpha_sq)),
                    float(np.float32(beta_sq)), use, float(np.float32(0.0 if thr is None else thr)),
-                   C.byref(hit), C.byref(n))
-        return bool(hit.value), int(n.value)
+                   C.byref(hit), None)
+        return bool(hit.value)
+
+    def vesselness_count(self) -> int:
+        n = _i64(0)
+        self._call("nl_vesselness_count", C.byref(n))
+        return int(n.value)
 
     def filter_finish(self, z0=-1, z1=-1) -> int:
         n = _i64(0)

@@ -258,6 +258,14 @@ class FramePipeline:
         strides = sample_strides(self.shape, max_samples)
         alpha_sq = float(p.alpha_sq)
         beta_sq = float(p.beta_sq)
+        pending = None       # trace entry whose h_mask count is still being produced on the side stream
+
+        def settle():
+            nonlocal pending
+            if pending is not None:
+                pending.mask_count = self._reduce_sum(ctx.vesselness_count())
+                pending = None
+
         for sigma, delta in zip(sigmas, cascade_deltas(sigmas, zr)):
             if any(s > 0 for s in delta):
                 ws = [gaussian_weights(d) for d in delta]
@@ -276,6 +284,7 @@ class FramePipeline:
                 ctx.set_spacing(spacing)
                 bracket = self._fsq_bracket(strides, float(p.frob_thresh_division))
                 if bracket is not None:
+                    settle()
                     vz0, vz1 = self._vess_range()
                     ma, mf, inf_, ovf = ctx.vesselness_spec(spacing, bracket[0], bracket[1], z0=vz0, z1=vz1)
                     stats = self._reduce_stats(ma, mf, inf_)
@@ -308,12 +317,16 @@ class FramePipeline:
             hit = False
             if nonempty:                                         # filtering.py:843-844
                 if spec:
-                    hit, count = ctx.vesselness_resolve(gamma_sq, alpha_sq, beta_sq, thr_cmp)
+                    hit = ctx.vesselness_resolve(gamma_sq, alpha_sq, beta_sq, thr_cmp)
                 if not hit:
+                    settle()
                     vz0, vz1 = self._vess_range()
-                    count = ctx.vesselness_step(gamma_sq, alpha_sq, beta_sq, thr_cmp, z0=vz0, z1=vz1)
-                count = self._reduce_sum(count)
+                    count = self._reduce_sum(ctx.vesselness_step(gamma_sq, alpha_sq, beta_sq, thr_cmp, z0=vz0, z1=vz1))
             self.trace.scales.append(ScaleTrace(float(sigma), float(gamma), max_abs, thr, count, not nonempty, hit))
+            if hit:
+                settle()
+                pending = self.trace.scales[-1]      # its kernel overlaps the next scale's Gaussian; count read later
+        settle()
         vz0, vz1 = self._vess_range()
         self.trace.n_positive = self._reduce_sum(ctx.filter_finish(vz0, vz1))
         return self.trace.n_positive
