@@ -62,6 +62,7 @@ static inline unsigned int grid1d(i64 n, int block = 256, i64 cap = 256 * 32) {
     return (unsigned int)g;
 }
 
+static float *gauss_cur(const nl_ctx *c) { return c->gauss_ext ? c->gauss_ext : c->f[c->i_gauss]; }
 static VolGeom geom(const nl_ctx *c) { return VolGeom{c->nzl, c->ny, c->nx, c->gz0, c->gnz}; }
 // tile height of the Hessian kernels (experiment knob; 8 -> 512-thread workgroups, 16 -> 1024)
 static int hm_ty() {
@@ -345,6 +346,7 @@ extern "C" int nl_filter_load(nl_ctx *c, const void *host, int dtype, int64_t z0
     NL_JOIN_SIDE(c);
     if (!host || z0 < 0 || z1 > c->nzl || z0 >= z1) return nl_fail(err, errlen, NL_EINVAL, "bad plane range [%lld,%lld)", (i64)z0, (i64)z1);
     c->i_gauss = 0; c->i_vmax = 3; c->i_labels = -1; c->frangi_ready = 0;
+    c->gauss_ext = nullptr;
     const i64 plane = c->ny * c->nx;
     int rc = upload_convert(c, host, dtype, c->f[0] + z0 * plane, (z1 - z0) * plane, err, errlen);
     if (rc) return rc;
@@ -377,6 +379,14 @@ extern "C" int nl_filter_begin(nl_ctx *c, char *err, size_t errlen) {
     NL_JOIN_SIDE(c);
     if (!c->d_input) return nl_fail(err, errlen, NL_ESTATE, "nl_filter_begin before nl_input_load");
     c->i_gauss = 0; c->i_vmax = 3; c->i_labels = -1; c->frangi_ready = 0;
+    c->mask_slots_used = 0;
+    c->gauss_ext = nullptr;
+    if (c->input_dtype == NL_F32 && !getenv("NELLIE_COPY_INPUT")) {
+        // float32 frames are used where they lie: the cascade never writes its source (ping-pong volumes), so the
+        // first Gaussian pass reads the resident input directly (the reference's gauss = frame view, filtering.py:811)
+        c->gauss_ext = (float *)c->d_input;
+        return NL_OK;
+    }
     ProfScope ps(c, "load");
     const unsigned int g = grid1d(c->n);
     switch (c->input_dtype) {
@@ -448,6 +458,7 @@ extern "C" int nl_gauss_step(nl_ctx *c, const double *wz, int rz, const double *
     const dim3 grid((unsigned)((c->nx + 255) / 256), (unsigned)c->ny, (unsigned)(z1 - z0));
     ProfScope ps(c, "gauss");
     int src = c->i_gauss;
+    const float *srcp = gauss_cur(c);       // the source of the next pass (the borrowed input before the first one)
     GaussW gw;
     int rc;
     if (wz) {
@@ -456,10 +467,10 @@ extern "C" int nl_gauss_step(nl_ctx *c, const double *wz, int rz, const double *
         if ((z0 - rz < 0 && c->gz0 > 0) || (z1 - 1 + rz >= c->nzl && c->gz0 + c->nzl < c->gnz))
             return nl_fail(err, errlen, NL_EINVAL, "Z pass of radius %d on planes [%lld,%lld) reaches outside the local slab", rz, (i64)z0, (i64)z1);
         const int dst = (src + 1) % 3;
-        if (!launch_gauss_fast<0>(c, c->f[src], c->f[dst], v, z0, z1, gw))
-            gauss_axis_kernel<0><<<grid, blk, 0, c->stream>>>(c->f[src], c->f[dst], v, z0, z1, gw);
+        if (!launch_gauss_fast<0>(c, srcp, c->f[dst], v, z0, z1, gw))
+            gauss_axis_kernel<0><<<grid, blk, 0, c->stream>>>(srcp, c->f[dst], v, z0, z1, gw);
         NL_CHECK_LAUNCH();
-        src = dst;
+        src = dst; srcp = c->f[dst];
     }
     bool fused_yx = false;
     if (wy && wx && ry == rx && ry >= 1 && ry <= GM_MAX_R && ry <= c->ny && !getenv("NELLIE_NO_FUSED_YX")) {
@@ -471,31 +482,32 @@ extern "C" int nl_gauss_step(nl_ctx *c, const double *wz, int rz, const double *
         const int dst = (src + 1) % 3;
         const dim3 g2((unsigned)((c->nx + GYX_COLS - 1) / GYX_COLS), (unsigned)((c->ny + GM_CHUNK - 1) / GM_CHUNK), (unsigned)(z1 - z0));
         switch (ry) {
-#define NL_YX(RR) case RR: gauss_yx_kernel<RR><<<g2, GYX_THREADS, 0, c->stream>>>(c->f[src], c->f[dst], v, z0, z1, wsy, wsx); break;
+#define NL_YX(RR) case RR: gauss_yx_kernel<RR><<<g2, GYX_THREADS, 0, c->stream>>>(srcp, c->f[dst], v, z0, z1, wsy, wsx); break;
             NL_YX(1) NL_YX(2) NL_YX(3) NL_YX(4) NL_YX(5) NL_YX(6) NL_YX(7) NL_YX(8)
 #undef NL_YX
         }
         NL_CHECK_LAUNCH();
-        src = dst;
+        src = dst; srcp = c->f[dst];
         fused_yx = true;
     }
     if (wy && !fused_yx) {
         if ((rc = fill_gw(gw, wy, ry, err, errlen))) return rc;
         const int dst = (src + 1) % 3;
-        if (!launch_gauss_fast<1>(c, c->f[src], c->f[dst], v, z0, z1, gw))
-            gauss_axis_kernel<1><<<grid, blk, 0, c->stream>>>(c->f[src], c->f[dst], v, z0, z1, gw);
+        if (!launch_gauss_fast<1>(c, srcp, c->f[dst], v, z0, z1, gw))
+            gauss_axis_kernel<1><<<grid, blk, 0, c->stream>>>(srcp, c->f[dst], v, z0, z1, gw);
         NL_CHECK_LAUNCH();
-        src = dst;
+        src = dst; srcp = c->f[dst];
     }
     if (wx && !fused_yx) {
         if ((rc = fill_gw(gw, wx, rx, err, errlen))) return rc;
         const int dst = (src + 1) % 3;
-        if (!launch_gauss_fast<2>(c, c->f[src], c->f[dst], v, z0, z1, gw))
-            gauss_axis_kernel<2><<<grid, blk, 0, c->stream>>>(c->f[src], c->f[dst], v, z0, z1, gw);
+        if (!launch_gauss_fast<2>(c, srcp, c->f[dst], v, z0, z1, gw))
+            gauss_axis_kernel<2><<<grid, blk, 0, c->stream>>>(srcp, c->f[dst], v, z0, z1, gw);
         NL_CHECK_LAUNCH();
-        src = dst;
+        src = dst; srcp = c->f[dst];
     }
     c->i_gauss = src;
+    if (srcp != c->gauss_ext) c->gauss_ext = nullptr;      // a cascade step ran: the Gaussian now lives in f[src]
     return NL_OK;
 }
 
@@ -514,10 +526,10 @@ static int make_lattice(const nl_ctx *c, i64 sz, i64 sy, i64 sx, Lattice &L, cha
 
 static int make_field(nl_ctx *c, int field, FieldSrc &fs, char *err, size_t errlen) {
     fs.field = field; fs.hp = hessp(c); fs.max_abs = c->frob_max_abs; fs.max_finite = c->frob_max_finite;
-    if (field == NL_FIELD_GAUSS) fs.p = c->f[c->i_gauss];
+    if (field == NL_FIELD_GAUSS) fs.p = gauss_cur(c);
     else if (field == NL_FIELD_FROB) {
         if (!c->have_spacing) return nl_fail(err, errlen, NL_ESTATE, "NL_FIELD_FROB before nl_hessian_stats");
-        fs.p = c->f[c->i_gauss];
+        fs.p = gauss_cur(c);
     } else if (field == NL_FIELD_FRANGI) fs.p = c->f[c->i_vmax];
     else return nl_fail(err, errlen, NL_EINVAL, "unknown field %d", field);
     return NL_OK;
@@ -634,7 +646,7 @@ extern "C" int nl_hessian_stats(nl_ctx *c, const double spacing[3], float *max_a
 #define NL_LAUNCH_STATS(TYV, FASTV, HR)                                                                                   \
         hessian_g_kernel<0, TYV, FASTV><<<(unsigned)(ntx * (int)((c->ny + TYV - 1) / TYV) * nzc), HGCfg<TYV>::NT,         \
                                           HGCfg<TYV>::lds_bytes(), c->stream>>>(                                          \
-            c->f[c->i_gauss], nullptr, nullptr, 0, geom(c), HR, vp, VQueue{}, (int)c->own_lo, (int)c->own_hi, ntx,        \
+            gauss_cur(c), nullptr, nullptr, 0, geom(c), HR, vp, VQueue{}, (int)c->own_lo, (int)c->own_hi, ntx,        \
             (int)((c->ny + TYV - 1) / TYV), res, nullptr)
         if (hm_ty() == 8) { if (c->fast_div) NL_LAUNCH_STATS(8, true, hessdv_fast(c)); else NL_LAUNCH_STATS(8, false, hessdv_exact(c)); }
         else { if (c->fast_div) NL_LAUNCH_STATS(16, true, hessdv_fast(c)); else NL_LAUNCH_STATS(16, false, hessdv_exact(c)); }
@@ -724,7 +736,7 @@ extern "C" int nl_vesselness_spec(nl_ctx *c, const double spacing[3], float fsq_
         const unsigned nblocks = (unsigned)(ntx * nty * nzc);
 #define NL_LAUNCH_SPEC(TYV, FASTV, HR)                                                                                    \
         hessian_g_kernel<2, TYV, FASTV><<<nblocks, HGCfg<TYV>::NT, HGCfg<TYV>::lds_bytes(), c->stream>>>(                 \
-            c->f[c->i_gauss], cm, pm, wpr, geom(c), HR, vp, vq, (int)z0, (int)z1, ntx, nty, res, d_cnt)
+            gauss_cur(c), cm, pm, wpr, geom(c), HR, vp, vq, (int)z0, (int)z1, ntx, nty, res, d_cnt)
         if (ty == 8) { if (c->fast_div) NL_LAUNCH_SPEC(8, true, hessdv_fast(c)); else NL_LAUNCH_SPEC(8, false, hessdv_exact(c)); }
         else { if (c->fast_div) NL_LAUNCH_SPEC(16, true, hessdv_fast(c)); else NL_LAUNCH_SPEC(16, false, hessdv_exact(c)); }
 #undef NL_LAUNCH_SPEC
@@ -833,7 +845,7 @@ extern "C" int nl_vesselness_step(nl_ctx *c, float gamma_sq, float alpha_sq, flo
         const int nty = (int)((c->ny + ty - 1) / ty);
 #define NL_LAUNCH_VESS(TYV, FASTV, HR)                                                                                    \
         hessian_g_kernel<1, TYV, FASTV><<<nblocks, HGCfg<TYV>::NT, HGCfg<TYV>::lds_bytes(), c->stream>>>(                 \
-            c->f[c->i_gauss], cm, pm, wpr, geom(c), HR, vp, vq, (int)za, (int)zb, ntx, nty, nullptr, d_cnt)
+            gauss_cur(c), cm, pm, wpr, geom(c), HR, vp, vq, (int)za, (int)zb, ntx, nty, nullptr, d_cnt)
         for (i64 za = z0; za < z1; za += planes_per_launch) {
             const i64 zb = za + planes_per_launch < z1 ? za + planes_per_launch : z1;
             const int nzc = (int)((zb - za + HM_ZCHUNK - 1) / HM_ZCHUNK);
@@ -930,12 +942,12 @@ extern "C" int nl_filter_store(nl_ctx *c, float *host, int64_t z0, int64_t z1, c
 }
 extern "C" int nl_gauss_store(nl_ctx *c, float *host, int64_t z0, int64_t z1, char *err, size_t errlen) {
     NL_ENTER(c);
-    return store_planes(c, c->f[c->i_gauss], host, 4, z0, z1, err, errlen);
+    return store_planes(c, gauss_cur(c), host, 4, z0, z1, err, errlen);
 }
 
 // ------------------------------------------------------------------------------ slab helpers ----
 static float *field_ptr(nl_ctx *c, int field) {
-    if (field == NL_FIELD_GAUSS) return c->f[c->i_gauss];
+    if (field == NL_FIELD_GAUSS) return gauss_cur(c);
     if (field == NL_FIELD_FRANGI) return c->f[c->i_vmax];
     return nullptr;
 }
@@ -1084,7 +1096,7 @@ extern "C" int nl_flat_sample_gather(nl_ctx *c, int field, int64_t offset, int64
     if (n) *n = count;
     if (count == 0 || (!out && cap == 0)) return NL_OK;   // size query
     if (!out || cap < count) return nl_fail(err, errlen, NL_EINVAL, "output capacity %lld < %lld samples", (i64)cap, count);
-    const float *src = (field == NL_FIELD_FRANGI) ? c->f[c->i_vmax] : c->f[c->i_gauss];
+    const float *src = (field == NL_FIELD_FRANGI) ? c->f[c->i_vmax] : gauss_cur(c);
     float *stage = nullptr;
     for (int k = 0; k < 3; ++k) if (k != c->i_gauss && c->f[k] != src) { stage = c->f[k]; break; }
     {

@@ -46,6 +46,8 @@ struct nl_ctx {
     void *h_small = nullptr;   // pinned mirror
     float *d_vq = nullptr;     // global queue of voxels to eigen-solve (32-byte entries, one region per wave)
     unsigned int *d_vq_count = nullptr;   // entries written per region
+    float *gauss_ext = nullptr;   // current Gaussian volume when it is NOT one of f[0..2]: the resident float32 input itself,
+                                  // until the first cascade step has written a volume of its own (saves the 8 B/voxel copy)
     int vq_chunks = 1;         // Z chunks (HM_ZCHUNK planes) one vesselness launch may cover
     int spec_ok = 0;           // the queue can hold a one-pass (MODE 2) vesselness of the whole slab
     int spec_valid = 0;        // a MODE 2 pass is waiting for nl_vesselness_resolve
