@@ -36,7 +36,10 @@ B_ALG_TOTAL = 301.0            # Filter 257 + Label 44 bytes/vox
 # algorithmic bytes per voxel of one launch of each kernel group (DESIGN.md "Kernels")
 B_ALG_KERNEL = {
     "load": 8.0,               # 4 r + 4 w
-    "gauss": 24.0,             # three axis passes x (4 r + 4 w)
+    "gauss_z": 8.0,            # one axis pass: 4 r + 4 w
+    "gauss_yx": 16.0,          # two axis passes of the model (4 r + 4 w each), one fused launch here
+    "gauss_y": 8.0,
+    "gauss_x": 8.0,
     "hessian_stats": 4.0,      # 4 r
     "vesselness": 22.0,        # Hessian/eigen/Frangi pass 16 + mask pass 6, one launch here
     "finish": 9.0,             # 4 r + 1 r + 4 w
@@ -45,7 +48,8 @@ B_ALG_KERNEL = {
 }
 
 
-PMC_KERNEL_OF_GROUP = {"vesselness": "hessian_g_kernel<2", "hessian_stats": "hessian_g_kernel<0"}
+PMC_KERNEL_OF_GROUP = {"vesselness": "hessian_g_kernel<2", "hessian_stats": "hessian_g_kernel<0",
+                       "gauss_yx": "gauss_yx_kernel<4", "gauss_z": "gauss_march_kernel<0, 4"}
 
 
 def pmc_traffic(group, shape):
@@ -72,7 +76,7 @@ def parse_args():
     ap.add_argument("--shape", type=int, nargs=3, default=None, help="per-GPU slab Z Y X (default 1024^3)")
     ap.add_argument("--seed", type=int, default=2345)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-shape", type=int, nargs=3, default=[64, 256, 256])
+    ap.add_argument("--cpu-shape", type=int, nargs=3, default=[96, 384, 384])
     ap.add_argument("--with-io", action="store_true", help="also report the PCIe-inclusive rate (untimed otherwise)")
     ap.add_argument("--no-zslab-check", action="store_true", help="N > 1: skip the RCCL Z-slab equality check")
     ap.add_argument("--zslab-timeout", type=float, default=240.0)
@@ -237,7 +241,7 @@ def main():
     # "vesselness" = the marching Hessian pass of a scale (statistics + masks + queue; one launch per scale),
     # "vesselness_resolve" = the dense eigen/Frangi kernel over its queue; "hessian_stats" only appears when a
     # scale falls back to the two-pass scheme
-    for name in ("load", "gauss", "sample", "hessian_stats", "vesselness", "vesselness_resolve", "finish", "mask_volume", "label"):
+    for name in ("load", "gauss_z", "gauss_yx", "gauss_y", "gauss_x", "sample", "hessian_stats", "vesselness", "vesselness_resolve", "finish", "mask_volume", "label"):
         ms, k = pipe.ctx.prof_get(name)
         if k:
             groups[name] = {"ms_total": ms, "launches": k, "ms_avg": ms / k}
@@ -254,8 +258,10 @@ def main():
         "pipeline": {
             "algorithmic_bytes_per_voxel": B_ALG_TOTAL,
             "kernel_ms_per_step": round(kernel_ms_per_step, 3),
-            "achieved": round(B_ALG_TOTAL * n_local / (kernel_ms_per_step * 1e-3) / 1e9, 1) if kernel_ms_per_step else None,
-            "frac": round(B_ALG_TOTAL * n_local / (kernel_ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if kernel_ms_per_step else None,
+            # over the wall time of a step (host round trips included): the resolve kernel overlaps the Gaussian of
+            # the next scale on a side stream, so the per-group times above add up to more than the step takes
+            "achieved": round(B_ALG_TOTAL * n_local / (ms_per_step * 1e-3) / 1e9, 1),
+            "frac": round(B_ALG_TOTAL * n_local / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
         },
         "groups_ms_per_step": {k: round(v["ms_total"] / max(1, args.steps), 3) for k, v in groups.items()},
     }

@@ -456,7 +456,6 @@ extern "C" int nl_gauss_step(nl_ctx *c, const double *wz, int rz, const double *
     // so "the next one" is always a legal destination
     const dim3 blk(256, 1, 1);
     const dim3 grid((unsigned)((c->nx + 255) / 256), (unsigned)c->ny, (unsigned)(z1 - z0));
-    ProfScope ps(c, "gauss");
     int src = c->i_gauss;
     const float *srcp = gauss_cur(c);       // the source of the next pass (the borrowed input before the first one)
     GaussW gw;
@@ -467,6 +466,7 @@ extern "C" int nl_gauss_step(nl_ctx *c, const double *wz, int rz, const double *
         if ((z0 - rz < 0 && c->gz0 > 0) || (z1 - 1 + rz >= c->nzl && c->gz0 + c->nzl < c->gnz))
             return nl_fail(err, errlen, NL_EINVAL, "Z pass of radius %d on planes [%lld,%lld) reaches outside the local slab", rz, (i64)z0, (i64)z1);
         const int dst = (src + 1) % 3;
+        ProfScope ps(c, "gauss_z");
         if (!launch_gauss_fast<0>(c, srcp, c->f[dst], v, z0, z1, gw))
             gauss_axis_kernel<0><<<grid, blk, 0, c->stream>>>(srcp, c->f[dst], v, z0, z1, gw);
         NL_CHECK_LAUNCH();
@@ -480,6 +480,7 @@ extern "C" int nl_gauss_step(nl_ctx *c, const double *wz, int rz, const double *
         GaussWS wsy, wsx;
         for (int k = 0; k <= GM_MAX_R; ++k) { wsy.w[k] = k <= ry ? gy.w[k] : 0.0; wsx.w[k] = k <= rx ? gx.w[k] : 0.0; }
         const int dst = (src + 1) % 3;
+        ProfScope ps(c, "gauss_yx");
         const dim3 g2((unsigned)((c->nx + GYX_COLS - 1) / GYX_COLS), (unsigned)((c->ny + GM_CHUNK - 1) / GM_CHUNK), (unsigned)(z1 - z0));
         switch (ry) {
 #define NL_YX(RR) case RR: gauss_yx_kernel<RR><<<g2, GYX_THREADS, 0, c->stream>>>(srcp, c->f[dst], v, z0, z1, wsy, wsx); break;
@@ -493,6 +494,7 @@ extern "C" int nl_gauss_step(nl_ctx *c, const double *wz, int rz, const double *
     if (wy && !fused_yx) {
         if ((rc = fill_gw(gw, wy, ry, err, errlen))) return rc;
         const int dst = (src + 1) % 3;
+        ProfScope ps(c, "gauss_y");
         if (!launch_gauss_fast<1>(c, srcp, c->f[dst], v, z0, z1, gw))
             gauss_axis_kernel<1><<<grid, blk, 0, c->stream>>>(srcp, c->f[dst], v, z0, z1, gw);
         NL_CHECK_LAUNCH();
@@ -501,6 +503,7 @@ extern "C" int nl_gauss_step(nl_ctx *c, const double *wz, int rz, const double *
     if (wx && !fused_yx) {
         if ((rc = fill_gw(gw, wx, rx, err, errlen))) return rc;
         const int dst = (src + 1) % 3;
+        ProfScope ps(c, "gauss_x");
         if (!launch_gauss_fast<2>(c, srcp, c->f[dst], v, z0, z1, gw))
             gauss_axis_kernel<2><<<grid, blk, 0, c->stream>>>(srcp, c->f[dst], v, z0, z1, gw);
         NL_CHECK_LAUNCH();
