@@ -248,6 +248,7 @@ def main():
     n_local = float(np.prod(shape))
     n_global = n_local * n_gpus
     kernel_ms_per_step = sum(g["ms_total"] for g in groups.values()) / max(1, args.steps)
+    ms_per_step = elapsed / args.steps * 1e3
     dom = max((g for g in groups if g in B_ALG_KERNEL), key=lambda g: groups[g]["ms_total"])
     dom_bytes = B_ALG_KERNEL[dom] * n_local
     dom_gbs = dom_bytes / (groups[dom]["ms_avg"] * 1e-3) / 1e9

@@ -912,7 +912,7 @@ extern "C" int nl_mask_volume(nl_ctx *c, float thr, char *err, size_t errlen) {
         const i64 m0 = c->own_lo - 2 > 0 ? c->own_lo - 2 : 0, m1 = c->own_hi + 2 < c->nzl ? c->own_hi + 2 : c->nzl;
         const i64 e0 = c->own_lo - 1 > 0 ? c->own_lo - 1 : 0, e1 = c->own_hi + 1 < c->nzl ? c->own_hi + 1 : c->nzl;
         unsigned long long *bM = (unsigned long long *)c->m[1], *bE = (unsigned long long *)c->m[2], *bD = (unsigned long long *)c->m[0];
-        rl_threshold_pack_kernel<<<grid1d((m1 - m0) * c->ny * wpr * 64, 256, 256 * 32), 256, 0, c->stream>>>(
+        rl_threshold_pack_kernel<<<grid1d((m1 - m0) * c->ny * 64, 256, 256 * 32), 256, 0, c->stream>>>(
             c->f[c->i_vmax] + m0 * c->ny * c->nx, bM + m0 * c->ny * wpr, 1, thr, (int)c->nx, (m1 - m0) * c->ny, wpr);
         NL_CHECK_LAUNCH();
         bits_morph6_kernel<0><<<(unsigned)(((e1 - e0) * c->ny * wpr + 255) / 256), 256, 0, c->stream>>>(bM, bE, v, wpr, e0, e1);
@@ -1328,7 +1328,7 @@ extern "C" int nl_label_run(nl_ctx *c, int has_thr, float thr, int64_t min_area,
     g.bitsA = (unsigned long long *)c->m[1]; g.bitsB = (unsigned long long *)c->m[2];
     g.paint_row0 = 0; g.paint_row1 = g.nrows; g.paint_out = (int *)c->f[label_out_index(c)];
     ProfScope ps(c, "label");
-    rl_threshold_pack_kernel<<<grid1d(g.nwords * 64, 256, 256 * 32), 256, 0, c->stream>>>(c->f[c->i_vmax], g.bitsA, has_thr, thr,
+    rl_threshold_pack_kernel<<<grid1d(g.nrows * 64, 256, 256 * 32), 256, 0, c->stream>>>(c->f[c->i_vmax], g.bitsA, has_thr, thr,
                                                                                           (int)c->nx, g.nrows, g.wpr);
     NL_CHECK_LAUNCH();
     bool overflow = false;
@@ -1368,7 +1368,7 @@ extern "C" int nl_label_pack(nl_ctx *c, int has_thr, float thr, char *err, size_
     const i64 own_rows = (c->own_hi - c->own_lo) * c->ny;
     const i64 row0 = (c->gz0 + c->own_lo) * c->ny;
     ProfScope ps(c, "label");
-    rl_threshold_pack_kernel<<<grid1d(own_rows * wpr * 64, 256, 256 * 32), 256, 0, c->stream>>>(
+    rl_threshold_pack_kernel<<<grid1d(own_rows * 64, 256, 256 * 32), 256, 0, c->stream>>>(
         c->f[c->i_vmax] + c->own_lo * c->ny * c->nx, c->gbits[0] + row0 * wpr, has_thr, thr, (int)c->nx, own_rows, wpr);
     NL_CHECK_LAUNCH();
     return NL_OK;
