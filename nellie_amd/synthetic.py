@@ -83,3 +83,19 @@ def make_volume(shape, seed: int, tubes: int | None = None, dtype=np.float32,
 
 ISO_01 = {"X": 0.1, "Y": 0.1, "Z": 0.1, "T": 1.0}
 ANISO_03 = {"X": 0.1, "Y": 0.1, "Z": 0.3, "T": 1.0}
+
+
+def make_image_2d(shape, seed, dtype=np.float32):
+    """Deterministic (Y, X) test image for the 2-D (no_z) path: N(100, 5) noise + a horizontal ridge, a diagonal
+    ridge and two blobs."""
+    rng = np.random.default_rng(seed)
+    ny, nx = shape
+    img = rng.normal(100.0, 5.0, shape)
+    yy, xx = np.mgrid[:ny, :nx]
+    img += 200.0 * np.exp(-((yy - 0.45 * ny) ** 2) / (2 * 2.5 ** 2))
+    img += 160.0 * np.exp(-((yy - 0.9 * xx - 0.1 * ny) ** 2) / (2 * 3.0 ** 2))
+    for cy, cx, r in ((0.2 * ny, 0.7 * nx, 3.0), (0.75 * ny, 0.3 * nx, 4.0)):
+        img += 180.0 * np.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / (2 * r ** 2))
+    if np.issubdtype(np.dtype(dtype), np.integer):
+        return np.clip(np.rint(img), 0, np.iinfo(dtype).max).astype(dtype)
+    return img.astype(dtype)

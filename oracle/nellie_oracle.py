@@ -622,6 +622,233 @@ def filter_frame(frame, dim_res, **kw):
 
 
 # =============================================================================
+# Filter, 2-D images (im_info.no_z): filtering.py:461-490, 675-690, 732-741, 772-796, 927-930
+# =============================================================================
+def default_sigmas_2d(dim_res, min_radius_um=0.25, max_radius_um=1.0):
+    """filtering.py:288-311; same arithmetic as 3-D (only X enters the pixel radii)."""
+    return default_sigmas(dim_res, min_radius_um, max_radius_um)
+
+
+def cascade_deltas_2d(sigmas):
+    """filtering.py:816-825 with sigma_vec = (s, s) (filtering.py:281-282)."""
+    out, prev = [], 0.0
+    for s in sigmas:
+        d = float(np.sqrt(max(0.0, float(s) ** 2 - float(prev) ** 2)))
+        out.append((d, d))
+        prev = s
+    return out
+
+
+def gaussian_kernel1d_order(sigma: float, order: int, radius: int) -> np.ndarray:
+    """scipy/ndimage/_filters.py `_gaussian_kernel1d` for any derivative order (float64)."""
+    exponent_range = np.arange(order + 1)
+    sigma2 = sigma * sigma
+    x = np.arange(-radius, radius + 1)
+    phi_x = np.exp(-0.5 / sigma2 * x ** 2)
+    phi_x = phi_x / phi_x.sum()
+    if order == 0:
+        return phi_x
+    q = np.zeros(order + 1)
+    q[0] = 1
+    D = np.diag(exponent_range[1:], 1)
+    P = np.diag(np.ones(order) / -sigma2, -1)
+    Q_deriv = D + P
+    for _ in range(order):
+        q = Q_deriv.dot(q)
+    q = (x[:, None] ** exponent_range).dot(q)
+    return q * phi_x
+
+
+def gaussian_filter_orders_f32(a, sigmas, orders, truncate):
+    """scipy gaussian_filter with a derivative order per axis: axes in order, float32 between the axes.
+    `gaussian_filter1d` correlates with the REVERSED kernel; orders 0 and 2 give symmetric kernels."""
+    out = a
+    for axis, (sd, order) in enumerate(zip(sigmas, orders)):
+        if sd > 1e-15:
+            r = gaussian_radius(sd, truncate)
+            w = gaussian_kernel1d_order(float(sd), order, r)[::-1]
+            out = correlate1d_reflect_f32(out, np.ascontiguousarray(w), axis)
+    return out
+
+
+def gaussian_laplace_f32(a, sigmas, truncate=4.0):
+    """scipy.ndimage.gaussian_laplace (generic_laplace): the second derivative along axis 0 goes to the output,
+    the ones along the other axes are added to it in float32.  Default truncate = 4.0."""
+    nd = a.ndim
+    out = None
+    for ax in range(nd):
+        orders = [0] * nd
+        orders[ax] = 2
+        t = gaussian_filter_orders_f32(a, sigmas, orders, truncate)
+        out = t if out is None else (out + t)
+    return out
+
+
+def hessian_components_2d(img, spacing):
+    """filtering.py:461-490: (hxx, hxy, hyy), 'x' = axis 0 (naming only)."""
+    g0 = gradient_axis(img, spacing[0], 0)
+    g1 = gradient_axis(img, spacing[1], 1)
+    return gradient_axis(g0, spacing[0], 0), gradient_axis(g0, spacing[1], 1), gradient_axis(g1, spacing[1], 1)
+
+
+def frobenius_2d(h3):
+    """filtering.py:488-489, 555-562."""
+    hxx, hxy, hyy = h3
+    frob_sq = hxx ** 2 + hyy ** 2 + F32(2.0) * (hxy ** 2)
+    max_abs = 0.0
+    for comp in h3:
+        if comp.size > 0:
+            max_abs = max(max_abs, float(np.max(np.abs(comp))))
+    if max_abs <= 0:
+        max_abs = 1.0
+    with np.errstate(invalid="ignore"):
+        frob = np.sqrt(frob_sq) / F32(max_abs)
+    return frob_sq, max_abs, frob
+
+
+def eig2_sorted_abs_f32(hxx, hxy, hyy):
+    """filtering.py:675-690: closed-form 2x2 eigenvalues in float32, smaller |.| first."""
+    with np.errstate(all="ignore"):
+        trace = hxx + hyy
+        diff = hxx - hyy
+        delta = np.sqrt(diff * diff + F32(4.0) * (hxy * hxy))
+        l1 = F32(0.5) * (trace - delta)
+        l2 = F32(0.5) * (trace + delta)
+    swap = np.abs(l1) > np.abs(l2)
+    return np.where(swap, l2, l1), np.where(swap, l1, l2)
+
+
+def frangi_response_2d(e1, e2, beta_sq, gamma_sq):
+    """filtering.py:732-741, 759-766 (2-D branch)."""
+    with np.errstate(all="ignore"):
+        rb_sq = (np.abs(e1) / (np.abs(e2) + 1e-12)) ** 2
+        s_sq = e1 ** 2 + e2 ** 2
+        v = np.exp(-(rb_sq / beta_sq)) * (1.0 - np.exp(-(s_sq / gamma_sq)))
+    v[e2 > 0] = 0.0
+    return np.nan_to_num(v, nan=0.0, posinf=0.0, neginf=0.0)
+
+
+def compute_vesselness_2d(frame, dim_res, sigmas=None, beta_sq=0.5, frob_thresh=None, frob_thresh_division=2,
+                          max_samples=int(1e6), mask=True, trace=None):
+    """filtering.py:806-853 on a (Y, X) image.  Returns (vesselness, masks, gauss): `gauss` is the image after
+    the last cascade step -- the reference blurs `frame` itself in place, and `_filter_log` then runs on it."""
+    frame = np.asarray(frame, dtype=np.float32)
+    spacing = (float(dim_res.get("Y") or 1.0), float(dim_res.get("X") or 1.0))
+    if sigmas is None:
+        sigmas = default_sigmas_2d(dim_res)
+    vesselness = np.zeros_like(frame, dtype=np.float32)
+    masks = np.ones_like(frame, dtype=bool)
+    gauss = frame.copy()
+    for sigma, delta in zip(sigmas, cascade_deltas_2d(sigmas)):
+        if any(s > 0 for s in delta):
+            gauss = gaussian_filter_f32(gauss, delta, 3.0)
+        gamma = calculate_gamma(gauss, max_samples)
+        gamma_sq = 2.0 * (float(gamma) ** 2)
+        h3 = hessian_components_2d(gauss, spacing)
+        if mask:
+            _, max_abs, frob = frobenius_2d(h3)
+            h_mask, thr = frob_mask(frob, frob_thresh, frob_thresh_division, max_samples)
+        else:
+            max_abs, thr = None, None
+            h_mask = np.ones_like(frame, dtype=bool)
+        rec = dict(sigma=float(sigma), delta=delta, gamma=gamma, gamma_sq=gamma_sq, max_abs=max_abs, frob_thr=thr,
+                   mask_count=int(h_mask.sum()))
+        if trace is not None:
+            rec["gauss"] = gauss.copy()
+            trace.append(rec)
+        if not np.any(h_mask):
+            continue
+        coords = np.where(h_mask)
+        e1, e2 = eig2_sorted_abs_f32(*[c[coords] for c in h3])
+        v = frangi_response_2d(e1, e2, beta_sq, gamma_sq).astype(np.float32, copy=False)
+        vessel_scale = np.zeros_like(frame, dtype=np.float32)
+        vessel_scale[coords] = v
+        vesselness = np.maximum(vesselness, vessel_scale)
+        masks &= h_mask
+    return vesselness, masks, gauss
+
+
+def filter_log_2d(frame, mask, sigmas):
+    """filtering.py:772-796: multi-scale -LoG * sigma^2, masked, maximum over scales, clipped at 0, scaled to
+    [0, 0.1]."""
+    frame = np.asarray(frame, dtype=np.float32)
+    lapofg = None
+    for i, s in enumerate(sigmas):
+        cur = -gaussian_laplace_f32(frame, (float(s), float(s))) * (float(s) ** 2)
+        cur = cur * mask
+        if i == 0:
+            lapofg = cur
+        else:
+            sel = cur > lapofg
+            lapofg[sel] = cur[sel]
+    lapofg[lapofg < 0] = 0.0
+    lapofg_max = np.max(lapofg)
+    lapofg = lapofg / (lapofg_max + 1e-12)
+    return lapofg / 10.0
+
+
+def remove_edges_2d(frangi_frame):
+    """filtering.py:974-985."""
+    frangi_frame = frangi_frame.copy()
+    rows = np.any(frangi_frame, axis=1)
+    cols = np.any(frangi_frame, axis=0)
+    if (not rows.any()) or (not cols.any()):
+        return frangi_frame
+    rmin, rmax = np.where(rows)[0][[0, -1]]
+    height = max(0, int(rmax) - int(rmin) + 1)
+    if height <= 0:
+        return frangi_frame
+    margin = min(15, height)
+    frangi_frame[rmin:rmin + margin, :] = 0
+    frangi_frame[rmax - margin + 1:rmax + 1, :] = 0
+    return frangi_frame
+
+
+def run_frame_2d(frame, dim_res, remove_edges_flag=False, mask=True, **kw):
+    """filtering.py:910-933 for a (Y, X) image: vesselness * masks, then the maximum with the blob response."""
+    sigmas = kw.get("sigmas")
+    if sigmas is None:
+        sigmas = default_sigmas_2d(dim_res)
+        kw = dict(kw, sigmas=sigmas)
+    vesselness, masks, gauss = compute_vesselness_2d(frame, dim_res, mask=mask, **kw)
+    out = vesselness * masks
+    blob = filter_log_2d(gauss, masks if mask else np.ones_like(gauss, bool), sigmas)
+    blob = np.maximum(blob, 0)
+    out = np.maximum(out, blob)
+    if remove_edges_flag:
+        out = remove_edges_2d(out)
+    return out
+
+
+def binary_opening4(m):
+    """scipy.ndimage.binary_opening of a 2-D mask: default 4-connected cross, one iteration, border_value 0."""
+    p = np.pad(m, 1, mode="constant", constant_values=False)
+    c = p[1:-1, 1:-1]
+    er = c & p[:-2, 1:-1] & p[2:, 1:-1] & p[1:-1, :-2] & p[1:-1, 2:]
+    p = np.pad(er, 1, mode="constant", constant_values=False)
+    c = p[1:-1, 1:-1]
+    return c | p[:-2, 1:-1] | p[2:, 1:-1] | p[1:-1, :-2] | p[1:-1, 2:]
+
+
+def mask_volume_2d(frangi_frame, max_samples=int(1e6), return_thr=False):
+    """filtering.py:952-967 on a (Y, X) image."""
+    positive = subsample_positive(frangi_frame, max_samples)
+    if positive.size == 0:
+        return (frangi_frame, None) if return_thr else frangi_frame
+    thr = percentile_linear_f32(positive, 1)
+    out = frangi_frame * binary_opening4(frangi_frame > thr)
+    return (out, thr) if return_thr else out
+
+
+def filter_frame_2d(frame, dim_res, **kw):
+    """filtering.py:1012-1020 for a (Y, X) image."""
+    fr = run_frame_2d(frame, dim_res, **kw)
+    if float(np.sum(fr)) > 0.0:
+        fr = mask_volume_2d(fr, kw.get("max_samples", int(1e6)))
+    return fr
+
+
+# =============================================================================
 # Label
 # =============================================================================
 def min_area_pixels(dim_res, min_radius_um=0.25):
@@ -753,6 +980,40 @@ def label_frame(frangi, dim_res, min_radius_um=0.25, max_samples=1_000_000, nbin
     else:
         thr = frangi_threshold(frangi, max_samples, nbins)
     _, labels = get_labels(frangi, thr, min_area_pixels(dim_res, min_radius_um))
+    return (labels, thr) if return_thr else labels
+
+
+def min_area_pixels_2d(dim_res, min_radius_um=0.25):
+    """labelling.py:95-97, 209-216 (no_z branch)."""
+    x_res = dim_res.get("X") or 1.0
+    y_res = dim_res.get("Y") or x_res
+    r = max(float(min_radius_um), float(x_res))
+    return max(1, int(np.ceil(np.pi * (r ** 2) / (float(x_res) * float(y_res)))))
+
+
+def get_labels_2d(frangi, frangi_thresh, min_area):
+    """labelling.py:467-509 on a (Y, X) image: no hole filling, 8-connected labels, 3x3 majority."""
+    if frangi_thresh is None:
+        mask = np.zeros_like(frangi, dtype=bool)
+    else:
+        mask = frangi > frangi_thresh
+    labels = _label(mask[None], 26)[0]                 # 26-connectivity inside one plane = 8-connectivity
+    areas = np.bincount(labels.ravel())
+    if labels.size == 0 or areas.size <= 1:
+        return mask, labels
+    areas[0] = 0
+    mask = (areas >= min_area)[labels]
+    p = np.pad(mask.astype(np.int32), 1, mode="symmetric")
+    s9 = p[:-2] + p[1:-1] + p[2:]
+    s9 = s9[:, :-2] + s9[:, 1:-1] + s9[:, 2:]
+    mask = s9 >= 5                                      # uniform_filter(size=3) > 0.5: 4/9 < 0.5 < 5/9
+    return mask, _label(mask[None], 26)[0]
+
+
+def label_frame_2d(frangi, dim_res, min_radius_um=0.25, max_samples=1_000_000, nbins=256, return_thr=False):
+    """labelling.py:538-556 on a (Y, X) image."""
+    thr = frangi_threshold(frangi, max_samples, nbins)
+    _, labels = get_labels_2d(frangi, thr, min_area_pixels_2d(dim_res, min_radius_um))
     return (labels, thr) if return_thr else labels
 
 

@@ -24,13 +24,14 @@ def load_golden(name):
     g = dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False))
     if "input" not in g and "input_shape" in g:
         import zlib
-        from nellie_amd.synthetic import make_volume
-        vol = make_volume(tuple(int(s) for s in g["input_shape"]), int(g["input_seed"]))
+        from nellie_amd.synthetic import make_image_2d, make_volume
+        shape = tuple(int(s) for s in g["input_shape"])
+        vol = (make_image_2d if len(shape) == 2 else make_volume)(shape, int(g["input_seed"]))
         assert np.uint32(zlib.crc32(vol.tobytes())) == g["input_crc"], "synthetic generator drifted"
         g["input"] = vol
     if "dim_res" in g:
         z, y, x = (float(v) for v in g["dim_res"])
-        g["dim_res_dict"] = {"X": x, "Y": y, "Z": z, "T": 1.0}
+        g["dim_res_dict"] = {"X": x, "Y": y, "Z": None if np.isnan(z) else z, "T": 1.0}
     g["kwargs"] = {}
     for k in list(g):
         if k.startswith("kw_"):
@@ -45,7 +46,8 @@ def load_golden(name):
     return g
 
 
-FILTER_CASES = [n for n in golden_names() if not n.startswith(("labelonly", "labelintensity", "removeedges"))]
+FILTER_CASES = [n for n in golden_names() if not n.startswith(("labelonly", "labelintensity", "removeedges", "twod"))]
+FILTER_2D_CASES = golden_names("twod")
 LABEL_INTENSITY_CASES = golden_names("labelintensity")
 LABEL_ONLY_CASES = golden_names("labelonly")
 

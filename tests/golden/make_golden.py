@@ -127,6 +127,111 @@ def run_filter_case(Filter, vol, dim_res, **kw):
     return out
 
 
+def im_info_2d(shape, dim_res):
+    from types import SimpleNamespace
+    y, x = shape
+    return SimpleNamespace(no_t=True, no_z=True, shape=(1, y, x), axes="TYX", dim_res=dict(dim_res))
+
+
+def image_2d(shape, seed, dtype=np.float32):
+    sys.path.insert(0, REPO)
+    from nellie_amd.synthetic import make_image_2d
+    return make_image_2d(shape, seed, dtype=dtype)
+
+
+def run_filter_case_2d(Filter, img, dim_res, **kw):
+    """Reference Filter on one (Y, X) frame (im_info.no_z), recording the per-scale intermediates."""
+    f = Filter(im_info_2d(img.shape, dim_res), device="cpu", **kw)
+    f._get_t()
+    f._set_default_sigmas()
+    f.im_memmap = img[None].copy()
+    rec = dict(gamma=[], max_abs=[], frob_thr=[], mask_count=[], gauss_crc=[])
+    orig_gamma, orig_frob, orig_hess = f._calculate_gamma, f._get_frob_mask, f._compute_hessian
+
+    def gamma_hook(g):
+        v = orig_gamma(g)
+        rec["gamma"].append(float(v))
+        rec["gauss_crc"].append(crc(g))
+        return v
+
+    def frob_hook(frob):
+        m = orig_frob(frob)
+        if not f.frob_thresh_division:
+            rec["frob_thr"].append(np.nan)
+        elif f.frob_thresh is not None:
+            rec["frob_thr"].append(float(f.frob_thresh))
+        else:
+            pos = f._subsample_for_thresholds(np.where(np.isinf(frob), 0, frob))
+            if pos.size == 0:
+                rec["frob_thr"].append(0.0)
+            else:
+                from nellie.utils.gpu_functions import triangle_threshold, otsu_threshold
+                rec["frob_thr"].append(float(min(triangle_threshold(pos), otsu_threshold(pos)[0])))
+        return m
+
+    def hess_hook(image, mask=True):
+        h_mask, comps = orig_hess(image, mask=mask)
+        ma = 0.0
+        for c in comps.values():
+            ma = max(ma, float(np.max(np.abs(c))))
+        rec["max_abs"].append(ma if ma > 0 else 1.0)
+        rec["mask_count"].append(int(h_mask.sum()))
+        return h_mask, comps
+
+    f._calculate_gamma, f._get_frob_mask, f._compute_hessian = gamma_hook, frob_hook, hess_hook
+    fr = f._run_frame(0)
+    if float(np.sum(fr)) > 0.0:
+        pos = f._subsample_for_thresholds(fr)
+        pthr = float(np.percentile(pos, 1)) if pos.size else np.nan
+        frangi = f._mask_volume(fr)
+    else:
+        pthr, frangi = np.nan, fr
+    return dict(sigmas=np.array(f.sigmas, dtype=np.float64), gamma=np.array(rec["gamma"]), max_abs=np.array(rec["max_abs"]),
+                frob_thr=np.array(rec["frob_thr"]), mask_count=np.array(rec["mask_count"], dtype=np.int64),
+                gauss_crc=np.array(rec["gauss_crc"], dtype=np.uint32), run_frame=fr.astype(np.float32),
+                percentile_thr=np.float64(pthr), frangi=np.asarray(frangi, dtype=np.float32))
+
+
+def run_label_case_2d(Label, img, frangi, dim_res, **kw):
+    lab = Label(im_info_2d(frangi.shape, dim_res), num_t=1, device="cpu", **kw)
+    ithr, fthr = lab._compute_frame_thresholds(img, frangi)
+    labels = lab._run_frame_full_volume(0, img, frangi, ithr, fthr)
+    return dict(label_thr=np.float64(np.nan if fthr is None else fthr), min_area_pixels=np.int64(lab.min_area_pixels),
+                labels=np.asarray(labels, dtype=np.int32))
+
+
+def twod_cases(Filter, Label):
+    """2-D images (im_info.no_z): filtering.py:461-490, 675-690, 732-741, 772-796, 927-930; labelling.py:191-216."""
+    iso = {"X": 0.1, "Y": 0.1, "Z": None, "T": 1.0}
+    aniso = {"X": 0.2, "Y": 0.15, "Z": None, "T": 1.0}
+
+    def case(name, img, dim_res, gen=None, **kw):
+        meta = dict(dim_res=np.array([np.nan, dim_res["Y"], dim_res["X"]], dtype=np.float64))
+        if gen is None:
+            meta["input"] = img
+        else:   # large input: regenerate with nellie_amd.synthetic.make_image_2d(shape, seed); CRC pins it
+            meta["input_shape"] = np.array(img.shape, dtype=np.int64)
+            meta["input_seed"] = np.int64(gen)
+            meta["input_crc"] = crc(img)
+        for k, val in kw.items():
+            meta["kw_" + k] = np.float64(np.nan if val is None else val)
+        try:
+            out = run_filter_case_2d(Filter, img, dim_res, **kw)
+        except Exception as exc:
+            save(name, error_type=np.array(type(exc).__name__), error_msg=np.array(str(exc)), **meta)
+            return
+        lab = run_label_case_2d(Label, img, out["frangi"], dim_res)
+        save(name, **meta, **out, **lab)
+
+    case("twod_iso_96x128_s20", image_2d((96, 128), 20), iso)
+    case("twod_aniso_61x77_s21", image_2d((61, 77), 21), aniso)
+    case("twod_u16_64x64_s22", image_2d((64, 64), 22, dtype=np.uint16), iso)
+    case("twod_removeedges_90x80_s23", image_2d((90, 80), 23), iso, remove_edges=True)
+    case("twod_frobfixed_72x72_s24", image_2d((72, 72), 24), iso, frob_thresh=0.3)
+    case("twod_big_1100x1000_s25", image_2d((1100, 1000), 25), iso, gen=25)       # > 1e6 pixels: strided threshold samples
+    case("twod_zeros_40x40", np.zeros((40, 40), np.float32), iso)
+
+
 def run_label_case(Label, vol, frangi, dim_res, **kw):
     lab = Label(im_info(frangi.shape, dim_res), num_t=1, device="cpu", **kw)
     ithr, fthr = lab._compute_frame_thresholds(vol, frangi)
@@ -178,6 +283,9 @@ def label_only_volume(shape, seed):
 def main():
     Filter, Label = _import_reference()
     sys.path.insert(0, REPO)
+    if "--only-2d" in sys.argv:          # add / refresh the 2-D cases without touching the 3-D files
+        twod_cases(Filter, Label)
+        return
     from nellie_amd.synthetic import make_volume, ISO_01, ANISO_03
 
     def full_case(name, vol, dim_res, gen=None, **kw):
@@ -250,6 +358,7 @@ def main():
     lv2 = label_only_volume((24, 48, 48), 12)
     lab2 = run_label_case(Label, lv2, lv2, ANISO_03)
     save("labelonly_aniso_24x48x48", frangi=lv2, dim_res=np.array([0.3, 0.1, 0.1]), **lab2)
+    twod_cases(Filter, Label)
 
 
 if __name__ == "__main__":

@@ -9,7 +9,7 @@ import zlib
 import numpy as np
 import pytest
 
-from conftest import FILTER_CASES, LABEL_INTENSITY_CASES, LABEL_ONLY_CASES, load_golden
+from conftest import FILTER_2D_CASES, FILTER_CASES, LABEL_INTENSITY_CASES, LABEL_ONLY_CASES, load_golden
 from oracle import nellie_oracle as orc
 
 
@@ -65,6 +65,45 @@ def test_label_matches_reference_given_reference_frangi(name):
         assert float(thr) == float(g["label_thr"])
     assert orc.min_area_pixels(g["dim_res_dict"]) == int(g["min_area_pixels"])
     assert labels.dtype == np.int32
+    assert np.array_equal(labels, g["labels"])
+
+
+@pytest.mark.parametrize("name", FILTER_2D_CASES)
+def test_filter_and_label_2d_match_reference(name):
+    """2-D images (im_info.no_z): per-scale intermediates, _run_frame (with the LoG blob response), _mask_volume and
+    Label, all bit-equal to the imported reference."""
+    g = load_golden(name)
+    dr = g["dim_res_dict"]
+    kw = dict(g["kwargs"])
+    rm = bool(kw.pop("remove_edges", False))
+    img = g["input"]
+    assert img.ndim == 2
+    sigmas = orc.default_sigmas_2d(dr)
+    assert np.array_equal(np.array(sigmas), g["sigmas"])
+    trace = []
+    orc.compute_vesselness_2d(img, dr, sigmas=sigmas, trace=trace, **kw)
+    assert len(trace) == len(g["gamma"])
+    for s, rec in enumerate(trace):
+        assert rec["gamma"] == g["gamma"][s]
+        assert np.uint32(zlib.crc32(rec["gauss"].tobytes())) == g["gauss_crc"][s], f"gauss scale {s}"
+        assert rec["max_abs"] == g["max_abs"][s]
+        if not np.isnan(g["frob_thr"][s]):
+            assert rec["frob_thr"] == g["frob_thr"][s]
+        assert rec["mask_count"] == g["mask_count"][s]
+    fr = orc.run_frame_2d(img, dr, remove_edges_flag=rm, **kw)
+    assert np.array_equal(fr, g["run_frame"])
+    if float(fr.sum()) > 0:
+        out, thr = orc.mask_volume_2d(fr, return_thr=True)
+        assert float(thr) == float(g["percentile_thr"])
+    else:
+        out = fr
+    assert out.dtype == np.float32 and np.array_equal(out, g["frangi"])
+    labels, lthr = orc.label_frame_2d(g["frangi"], dr, return_thr=True)
+    if np.isnan(g["label_thr"]):
+        assert lthr is None
+    else:
+        assert float(lthr) == float(g["label_thr"])
+    assert orc.min_area_pixels_2d(dr) == int(g["min_area_pixels"])
     assert np.array_equal(labels, g["labels"])
 
 
