@@ -180,6 +180,24 @@ int nl_vesselness_resolve(nl_ctx *ctx, float gamma_sq, float alpha_sq, float bet
    asynchronous; this returns the count later (and waits for the kernel). */
 int nl_vesselness_count(nl_ctx *ctx, int64_t *mask_count, char *err, size_t errlen);
 
+/* ---- 2-D images (im_info.no_z): a context of shape (1, ny, nx) switched to 2-D ------------------------------
+   nl_set_ndim(ctx, 2) makes nl_hessian_stats, NL_FIELD_FROB, nl_vesselness_step and nl_mask_volume follow the
+   reference's 2-D branches: Hessian (hxx, hxy, hyy) by np.gradient twice (filtering.py:461-490), closed-form
+   float32 eigenvalues (filtering.py:675-690), the two-eigenvalue Frangi response (filtering.py:732-741) and the
+   4-connected binary_opening.  nl_gauss_step is called with wz = NULL. */
+int nl_set_ndim(nl_ctx *ctx, int ndim, char *err, size_t errlen);
+
+/* One sigma of the multi-scale blob response (filtering.py:779-789): current = -gaussian_laplace(gauss, (s, s)) * s^2
+   [* masks], running element-wise maximum.  wy2/wy0/wx2/wx0: scipy's `_gaussian_kernel1d` of order 2 / 0 for the Y and
+   X axes, 2r+1 float64 weights each (truncate 4.0); s2 = float32(s**2); `gauss` is the current NL_FIELD_GAUSS
+   (the reference's in-place cascade leaves the LAST scale's Gaussian in `frame`, filtering.py:811, 927-928). */
+int nl_log2d_step(nl_ctx *ctx, const double *wy2, const double *wy0, const double *wx2, const double *wx0, int r,
+                  float s2, int first, int use_mask, char *err, size_t errlen);
+
+/* filtering.py:792-795 + 928-930: clip at 0, divide by (max + 1e-12) and by 10, NL_FIELD_FRANGI =
+   maximum(NL_FIELD_FRANGI, blob).  Call after nl_filter_finish.  n_positive = pixels > 0 afterwards. */
+int nl_log2d_finish(nl_ctx *ctx, int64_t *n_positive, char *err, size_t errlen);
+
 /* vesselness * masks (filtering.py:926) -> NL_FIELD_FRANGI on planes [z0, z1) (-1, -1: owned).
    n_positive = number of OWNED voxels > 0 (the `sum > 0` test of filtering.py:1016-1017). */
 int nl_filter_finish(nl_ctx *ctx, int64_t z0, int64_t z1, int64_t *n_positive, char *err, size_t errlen);

@@ -49,6 +49,7 @@ static RcclApi &rccl() {
 #include "gauss.inc"
 #include "sampling.inc"
 #include "hessian.inc"
+#include "filter2d.inc"
 #include "label_voxels.inc"
 #include "label_runs.inc"
 
@@ -202,6 +203,7 @@ extern "C" int nl_ctx_destroy(nl_ctx *c) {
     if (c->copy_in) hipStreamDestroy(c->copy_in);
     if (c->copy_out) hipStreamDestroy(c->copy_out);
     if (c->d_blk) hipFree(c->d_blk);
+    for (int k = 0; k < 4; ++k) if (c->d_2d[k]) hipFree(c->d_2d[k]);
     if (c->d_vq) hipFree(c->d_vq);
     if (c->d_vq_count) hipFree(c->d_vq_count);
     if (c->d_rows) hipFree(c->d_rows);
@@ -529,6 +531,7 @@ static int make_lattice(const nl_ctx *c, i64 sz, i64 sy, i64 sx, Lattice &L, cha
 
 static int make_field(nl_ctx *c, int field, FieldSrc &fs, char *err, size_t errlen) {
     fs.field = field; fs.hp = hessp(c); fs.max_abs = c->frob_max_abs; fs.max_finite = c->frob_max_finite;
+    fs.two_d = c->two_d;
     if (field == NL_FIELD_GAUSS) fs.p = gauss_cur(c);
     else if (field == NL_FIELD_FROB) {
         if (!c->have_spacing) return nl_fail(err, errlen, NL_ESTATE, "NL_FIELD_FROB before nl_hessian_stats");
@@ -616,7 +619,7 @@ extern "C" int nl_sample_hist(nl_ctx *c, int field, int64_t sz, int64_t sy, int6
 
 static int set_spacing(nl_ctx *c, const double spacing[3], char *err, size_t errlen) {
     if (!spacing) return nl_fail(err, errlen, NL_EINVAL, "spacing is NULL");
-    if (c->gnz < 2 || c->ny < 2 || c->nx < 2)
+    if ((!c->two_d && c->gnz < 2) || c->ny < 2 || c->nx < 2)
         return nl_fail(err, errlen, NL_EINVAL, "Shape of array too small to calculate a numerical gradient, at least (edge_order + 1) elements are required.");
     c->hz = (float)spacing[0]; c->hy = (float)spacing[1]; c->hx = (float)spacing[2];
     c->hz2 = (float)(2.0 * spacing[0]); c->hy2 = (float)(2.0 * spacing[1]); c->hx2 = (float)(2.0 * spacing[2]);
@@ -639,6 +642,22 @@ extern "C" int nl_hessian_stats(nl_ctx *c, const double spacing[3], float *max_a
     NL_ENTER(c);
     { int rcs = set_spacing(c, spacing, err, errlen); if (rcs) return rcs; }
     c->spec_valid = 0;
+    if (c->two_d) {
+        unsigned int *res2 = (unsigned int *)c->d_small;
+        NL_HIP(hipMemsetAsync(res2, 0, 16, c->stream));
+        {
+            ProfScope ps(c, "hessian_stats");
+            hessian2d_stats_kernel<<<grid1d(c->n), 256, 0, c->stream>>>(gauss_cur(c), geom(c), hessp(c), res2);
+            NL_CHECK_LAUNCH();
+        }
+        unsigned int *h2 = (unsigned int *)c->h_small;
+        NL_HIP(hipMemcpyAsync(h2, res2, 16, hipMemcpyDeviceToHost, c->stream));
+        NL_HIP(hipStreamSynchronize(c->stream));
+        if (max_abs) memcpy(max_abs, &h2[0], 4);
+        if (max_frob_sq) memcpy(max_frob_sq, &h2[1], 4);
+        if (any_inf) *any_inf = (int)h2[2];
+        return NL_OK;
+    }
     unsigned int *res = (unsigned int *)c->d_small;
     NL_HIP(hipMemsetAsync(res, 0, 16, c->stream));
     {
@@ -828,7 +847,18 @@ extern "C" int nl_vesselness_step(nl_ctx *c, float gamma_sq, float alpha_sq, flo
     VessP vp = make_vessp(c, gamma_sq, alpha_sq, beta_sq, use_thr, thr);
     vp.qcap = HM_REGION;
     c->spec_valid = 0;
-    {
+    if (c->two_d) {
+        ProfScope ps(c, "vesselness");
+        const int wpr = (int)((c->nx + 63) / 64);
+        const i64 slot_words = c->nzl * c->ny * wpr;
+        const int k_scale = c->mask_slots_used++;
+        vp.have_prev = k_scale > 0;
+        unsigned long long *cm = (unsigned long long *)c->m[0] + (i64)(k_scale & 1) * slot_words;
+        const unsigned long long *pm = (unsigned long long *)c->m[0] + (i64)((k_scale + 1) & 1) * slot_words;
+        if (vp.first) NL_HIP(hipMemsetAsync(c->f[c->i_vmax], 0, (size_t)c->n * 4, c->stream));
+        vesselness2d_kernel<<<grid1d(c->ny * wpr * 64), 256, 0, c->stream>>>(gauss_cur(c), c->f[c->i_vmax], cm, pm, wpr, geom(c), hessp(c), vp, d_cnt);
+        NL_CHECK_LAUNCH();
+    } else {
         ProfScope ps(c, "vesselness");
         const int ntx = (int)((c->nx + HM_TX - 1) / HM_TX);
         const int wpr = (int)((c->nx + 63) / 64);
@@ -869,6 +899,73 @@ extern "C" int nl_vesselness_step(nl_ctx *c, float gamma_sq, float alpha_sq, flo
         NL_HIP(hipStreamSynchronize(c->stream));
         *mask_count = (int64_t)(*(unsigned long long *)c->h_small);
     }
+    return NL_OK;
+}
+
+// ---- 2-D images (im_info.no_z) -----------------------------------------------------------------------------
+extern "C" int nl_set_ndim(nl_ctx *c, int ndim, char *err, size_t errlen) {
+    NL_ENTER(c);
+    if (ndim != 2 && ndim != 3) return nl_fail(err, errlen, NL_EINVAL, "ndim must be 2 or 3");
+    if (ndim == 2 && (c->nzl != 1 || c->gnz != 1)) return nl_fail(err, errlen, NL_EINVAL, "a 2-D context has exactly one plane");
+    c->two_d = ndim == 2;
+    return NL_OK;
+}
+
+// One sigma of filtering.py:779-789.  w?2 / w?0 = scipy's order-2 / order-0 Gaussian kernels (2r+1 float64 weights,
+// symmetric) for the Y and X axes; s2 = float32(sigma**2).
+extern "C" int nl_log2d_step(nl_ctx *c, const double *wy2, const double *wy0, const double *wx2, const double *wx0, int r,
+                             float s2, int first, int use_mask, char *err, size_t errlen) {
+    NL_ENTER(c);
+    if (!c->two_d) return nl_fail(err, errlen, NL_ESTATE, "nl_log2d_step on a 3-D context");
+    if (!wy2 || !wy0 || !wx2 || !wx0) return nl_fail(err, errlen, NL_EINVAL, "weights are NULL");
+    NL_JOIN_SIDE(c);
+    for (int k = 0; k < 4; ++k)
+        if (!c->d_2d[k]) NL_HIP(hipMalloc((void **)&c->d_2d[k], (size_t)c->n * 4));
+    GaussW gy2, gy0, gx2, gx0;
+    int rc;
+    if ((rc = fill_gw(gy2, wy2, r, err, errlen)) || (rc = fill_gw(gy0, wy0, r, err, errlen)) ||
+        (rc = fill_gw(gx2, wx2, r, err, errlen)) || (rc = fill_gw(gx0, wx0, r, err, errlen))) return rc;
+    const VolGeom v = geom(c);
+    const dim3 blk(256, 1, 1);
+    const dim3 grid((unsigned)((c->nx + 255) / 256), (unsigned)c->ny, 1);
+    ProfScope ps(c, "log2d");
+    const float *src = gauss_cur(c);
+    float *t = c->d_2d[0], *A = c->d_2d[1], *B = c->d_2d[2], *lap = c->d_2d[3];
+    // gaussian_laplace: second derivative along Y (then plain Gaussian along X), plus the one along X
+    gauss_axis_kernel<1><<<grid, blk, 0, c->stream>>>(src, t, v, 0, 1, gy2);
+    gauss_axis_kernel<2><<<grid, blk, 0, c->stream>>>(t, A, v, 0, 1, gx0);
+    gauss_axis_kernel<1><<<grid, blk, 0, c->stream>>>(src, t, v, 0, 1, gy0);
+    gauss_axis_kernel<2><<<grid, blk, 0, c->stream>>>(t, B, v, 0, 1, gx2);
+    const int wpr = (int)((c->nx + 63) / 64);
+    const i64 slot_words = c->nzl * c->ny * wpr;
+    const unsigned long long *mask = c->mask_slots_used > 0
+        ? (const unsigned long long *)c->m[0] + (i64)((c->mask_slots_used - 1) & 1) * slot_words : nullptr;
+    log2d_combine_kernel<<<grid1d(c->n), 256, 0, c->stream>>>(A, B, s2, use_mask ? mask : nullptr, wpr, v, first, lap);
+    NL_CHECK_LAUNCH();
+    return NL_OK;
+}
+
+// filtering.py:792-795 and 928-930: scale the blob response to [0, 0.1] and take the maximum with NL_FIELD_FRANGI
+// (call after nl_filter_finish).
+extern "C" int nl_log2d_finish(nl_ctx *c, int64_t *n_positive, char *err, size_t errlen) {
+    NL_ENTER(c);
+    if (!c->two_d || !c->d_2d[3]) return nl_fail(err, errlen, NL_ESTATE, "nl_log2d_finish before nl_log2d_step");
+    unsigned int *res = (unsigned int *)c->d_small;
+    unsigned long long *d_pos = (unsigned long long *)c->d_small + 2;
+    NL_HIP(hipMemsetAsync(res, 0, 32, c->stream));
+    ProfScope ps(c, "log2d");
+    log2d_clip_max_kernel<<<grid1d(c->n), 256, 0, c->stream>>>(c->d_2d[3], c->n, res);
+    NL_CHECK_LAUNCH();
+    NL_HIP(hipMemcpyAsync(c->h_small, res, 4, hipMemcpyDeviceToHost, c->stream));
+    NL_HIP(hipStreamSynchronize(c->stream));
+    float mx;
+    memcpy(&mx, c->h_small, 4);
+    const float denom = mx + 1e-12f;                      // float32 + weak python float
+    log2d_apply_kernel<<<grid1d(c->n), 256, 0, c->stream>>>(c->d_2d[3], denom, c->f[c->i_vmax], c->n, d_pos);
+    NL_CHECK_LAUNCH();
+    NL_HIP(hipMemcpyAsync(c->h_small, d_pos, 8, hipMemcpyDeviceToHost, c->stream));
+    NL_HIP(hipStreamSynchronize(c->stream));
+    if (n_positive) *n_positive = (int64_t)(*(unsigned long long *)c->h_small);
     return NL_OK;
 }
 
@@ -915,9 +1012,9 @@ extern "C" int nl_mask_volume(nl_ctx *c, float thr, char *err, size_t errlen) {
         rl_threshold_pack_kernel<<<grid1d((m1 - m0) * c->ny * 64, 256, 256 * 32), 256, 0, c->stream>>>(
             c->f[c->i_vmax] + m0 * c->ny * c->nx, bM + m0 * c->ny * wpr, 1, thr, (int)c->nx, (m1 - m0) * c->ny, wpr);
         NL_CHECK_LAUNCH();
-        bits_morph6_kernel<0><<<(unsigned)(((e1 - e0) * c->ny * wpr + 255) / 256), 256, 0, c->stream>>>(bM, bE, v, wpr, e0, e1);
+        bits_morph6_kernel<0><<<(unsigned)(((e1 - e0) * c->ny * wpr + 255) / 256), 256, 0, c->stream>>>(bM, bE, v, wpr, e0, e1, c->two_d);
         NL_CHECK_LAUNCH();
-        bits_morph6_kernel<1><<<(unsigned)(((c->own_hi - c->own_lo) * c->ny * wpr + 255) / 256), 256, 0, c->stream>>>(bE, bD, v, wpr, c->own_lo, c->own_hi);
+        bits_morph6_kernel<1><<<(unsigned)(((c->own_hi - c->own_lo) * c->ny * wpr + 255) / 256), 256, 0, c->stream>>>(bE, bD, v, wpr, c->own_lo, c->own_hi, c->two_d);
         NL_CHECK_LAUNCH();
         apply_bits_kernel<<<grid1d((c->own_hi - c->own_lo) * c->ny * ((c->nx + 3) / 4), 256, 256 * 32), 256, 0, c->stream>>>(
             c->f[c->i_vmax], bD, c->f[dst], v, wpr, c->own_lo, c->own_hi);

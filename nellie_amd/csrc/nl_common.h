@@ -46,6 +46,8 @@ struct nl_ctx {
     void *h_small = nullptr;   // pinned mirror
     float *d_vq = nullptr;     // global queue of voxels to eigen-solve (32-byte entries, one region per wave)
     unsigned int *d_vq_count = nullptr;   // entries written per region
+    int two_d = 0;                // the frame is a (Y, X) image (im_info.no_z): 2-D Hessian, eigenvalues, Frangi, opening
+    float *d_2d[4] = {nullptr, nullptr, nullptr, nullptr};   // 2-D only: LoG scratch (intermediate, two terms, running maximum)
     float *gauss_ext = nullptr;   // current Gaussian volume when it is NOT one of f[0..2]: the resident float32 input itself,
                                   // until the first cascade step has written a volume of its own (saves the 8 B/voxel copy)
     int vq_chunks = 1;         // Z chunks (HM_ZCHUNK planes) one vesselness launch may cover

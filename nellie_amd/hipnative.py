@@ -53,6 +53,9 @@ _PROTOS = {
                            C.POINTER(_int), C.POINTER(_int)],
     "nl_vesselness_resolve": [_p, _f32, _f32, _f32, _int, _f32, C.POINTER(_int), C.POINTER(_i64)],
     "nl_vesselness_count": [_p, C.POINTER(_i64)],
+    "nl_set_ndim": [_p, _int],
+    "nl_log2d_step": [_p, C.POINTER(_f64), C.POINTER(_f64), C.POINTER(_f64), C.POINTER(_f64), _int, _f32, _int, _int],
+    "nl_log2d_finish": [_p, C.POINTER(_i64)],
     "nl_filter_finish": [_p, _i64, _i64, C.POINTER(_i64)],
     "nl_planes_get": [_p, _int, _i64, _i64, _p],
     "nl_planes_put": [_p, _int, _i64, _i64, _p],
@@ -345,6 +348,21 @@ class Context:
         self._call("nl_vesselness_step", float(np.float32(gamma_sq)), float(np.float32(alpha_sq)),
                    float(np.float32(beta_sq)), use, float(np.float32(0.0 if thr is None else thr)),
                    int(z0), int(z1), C.byref(n) if want_count else None)
+        return int(n.value)
+
+    def set_ndim(self, ndim: int):
+        self._call("nl_set_ndim", int(ndim))
+
+    def log2d_step(self, wy2, wy0, wx2, wx0, s2, first, use_mask=True):
+        arrs = [np.ascontiguousarray(w, dtype=np.float64) for w in (wy2, wy0, wx2, wx0)]
+        r = (arrs[0].size - 1) // 2
+        assert all(a.size == 2 * r + 1 for a in arrs)
+        self._call("nl_log2d_step", *[a.ctypes.data_as(C.POINTER(_f64)) for a in arrs], r, float(np.float32(s2)),
+                   1 if first else 0, 1 if use_mask else 0)
+
+    def log2d_finish(self) -> int:
+        n = _i64(0)
+        self._call("nl_log2d_finish", C.byref(n))
         return int(n.value)
 
     def one_pass_available(self) -> bool:

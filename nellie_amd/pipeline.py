@@ -96,6 +96,29 @@ def gaussian_weights(sigma: float):
     return np.ascontiguousarray(phi_x[::-1])
 
 
+def gaussian_derivative_weights(sigma: float, order: int, truncate: float = 4.0):
+    """scipy.ndimage `_gaussian_kernel1d(sigma, order, radius)` reversed as `gaussian_filter1d` does, radius =
+    int(truncate*sd + 0.5) -- `gaussian_laplace` runs with scipy's default truncate = 4.0 (filtering.py:781)."""
+    sd = float(sigma)
+    radius = int(truncate * sd + 0.5)
+    exponent_range = np.arange(order + 1)
+    sigma2 = sd * sd
+    x = np.arange(-radius, radius + 1)
+    phi_x = np.exp(-0.5 / sigma2 * x ** 2)
+    phi_x = phi_x / phi_x.sum()
+    if order == 0:
+        return np.ascontiguousarray(phi_x[::-1])
+    q = np.zeros(order + 1)
+    q[0] = 1
+    D = np.diag(exponent_range[1:], 1)
+    P = np.diag(np.ones(order) / -sigma2, -1)
+    Q_deriv = D + P
+    for _ in range(order):
+        q = Q_deriv.dot(q)
+    q = (x[:, None] ** exponent_range).dot(q)
+    return np.ascontiguousarray((q * phi_x)[::-1])
+
+
 def cascade_deltas(sigmas, z_ratio):
     """filtering.py:814-825."""
     out = []
@@ -170,19 +193,34 @@ class FramePipeline:
 
     def __init__(self, shape, device: int = 0, ctx=None):
         self.shape = tuple(int(s) for s in shape)      # the GLOBAL frame shape (thresholds sample its lattice)
+        self.two_d = len(self.shape) == 2              # (Y, X) image, im_info.no_z: held as one plane
+        if self.two_d:
+            self.shape = (1,) + self.shape
         if len(self.shape) != 3:
-            raise ValueError("FramePipeline takes a (Z, Y, X) shape")
+            raise ValueError("FramePipeline takes a (Z, Y, X) or a (Y, X) shape")
         self.ctx = ctx if ctx is not None else hipnative.Context(self.shape, device=device)
+        if self.two_d:
+            self.ctx.set_ndim(2)
         self.trace = FrameTrace()
         # One walk over the Hessian per scale instead of two (statistics, then masks): the mask threshold is
         # predicted from the sample lattice and bracketed by a relative margin; a scale whose exact threshold
         # falls outside the bracket is redone the two-pass way, so results never depend on it.
-        self.one_pass = bool(getattr(self.ctx, "one_pass_available", lambda: False)())
+        self.one_pass = bool(getattr(self.ctx, "one_pass_available", lambda: False)()) and not self.two_d
         self.one_pass_margin = 1e-3
         self._one_pass_test_scale = 1.0      # tests: shifts the prediction to force a miss
 
     def close(self):
         self.ctx.close()
+
+    def _strides(self, max_samples):
+        """filtering.py:328-340 on the frame's own dimensionality (a 2-D image samples a 2-D lattice)."""
+        if self.two_d:
+            return (1,) + tuple(sample_strides(self.shape[1:], max_samples))
+        return sample_strides(self.shape, max_samples)
+
+    def _as_frame(self, a):
+        a = np.asarray(a)
+        return a[None] if (self.two_d and a.ndim == 2) else a
 
     # ---- hooks a Z-slab pipeline overrides (nellie_amd/sharded.py); identity on a single GPU -------------
     def _after_load(self, p):
@@ -212,7 +250,7 @@ class FramePipeline:
     # ------------------------------------------------------------------ Filter
     def load_input(self, frame):
         """Keep the raw frame resident in HBM; `filter(None, ...)` then starts from device memory."""
-        self.ctx.input_load(np.asarray(frame))
+        self.ctx.input_load(self._as_frame(frame))
 
     def _threshold_from_field(self, fld, strides):
         """min(triangle, otsu) over the positive lattice samples of a device field, or None if none."""
@@ -255,7 +293,7 @@ class FramePipeline:
         zr = z_ratio_of(p.dim_res)
         spacing = spacing_of(p.dim_res)
         sigmas = p.resolved_sigmas()
-        strides = sample_strides(self.shape, max_samples)
+        strides = self._strides(max_samples)
         alpha_sq = float(p.alpha_sq)
         beta_sq = float(p.beta_sq)
         pending = None       # trace entry whose h_mask count is still being produced on the side stream
@@ -267,6 +305,8 @@ class FramePipeline:
                 pending = None
 
         for sigma, delta in zip(sigmas, cascade_deltas(sigmas, zr)):
+            if self.two_d:
+                delta = (0.0, delta[1], delta[2])                 # sigma_vec = (s, s): no Z axis (filtering.py:281-282)
             if any(s > 0 for s in delta):
                 ws = [gaussian_weights(d) for d in delta]
                 z0, z1 = self._gauss_range(0 if ws[0] is None else (len(ws[0]) - 1) // 2)
@@ -329,14 +369,20 @@ class FramePipeline:
         settle()
         vz0, vz1 = self._vess_range()
         self.trace.n_positive = self._reduce_sum(ctx.filter_finish(vz0, vz1))
+        if self.two_d:
+            # filtering.py:927-930: blob response of the (by now fully blurred) frame, maximum with the vesselness
+            for i, s in enumerate(sigmas):
+                w2, w0 = gaussian_derivative_weights(s, 2), gaussian_derivative_weights(s, 0)
+                ctx.log2d_step(w2, w0, w2, w0, np.float32(float(s) ** 2), first=(i == 0), use_mask=mask)
+            self.trace.n_positive = ctx.log2d_finish()
         return self.trace.n_positive
 
     def _load(self, frame):
-        self.ctx.filter_load(np.asarray(frame))
+        self.ctx.filter_load(self._as_frame(frame))
 
     def mask_volume(self, p: FilterParams):
         """filtering.py:952-967 on the device-resident frame."""
-        strides = sample_strides(self.shape, int(p.max_threshold_samples))
+        strides = self._strides(int(p.max_threshold_samples))
         sample = self._gather(self.ctx.sample_gather(FIELD_FRANGI, strides))
         positive = sample[sample > 0]
         if positive.size == 0:
@@ -358,7 +404,7 @@ class FramePipeline:
 
     # ------------------------------------------------------------------ Label
     def upload_frangi(self, frangi):
-        self.ctx.label_load_frangi(np.asarray(frangi, dtype=np.float32))
+        self.ctx.label_load_frangi(self._as_frame(np.asarray(frangi, dtype=np.float32)))
 
     def frangi_threshold(self, max_samples=1_000_000, nbins=256):
         """labelling.py:385-455 on the device-resident Frangi frame (no mask arguments)."""

@@ -12,7 +12,6 @@ Deliberate differences from the reference (documented in DESIGN.md):
   * `device="cpu"` raises: this package has no CPU engine and no CPU fallback;
   * `low_memory` / `max_chunk_voxels` are accepted and ignored: the chunked mode of the reference
     changes the result (per-chunk thresholds); large volumes shard over Z across GPUs instead;
-  * 2-D (`no_z`) images are not implemented yet (NotImplementedError).
 """
 from __future__ import annotations
 
@@ -98,10 +97,12 @@ class Filter:
             max_threshold_samples=self.max_threshold_samples, sigmas=self.sigmas)
 
     def _get_pipeline(self, shape) -> FramePipeline:
-        if self._pipeline is None or self._pipeline.shape != tuple(shape):
+        key = tuple(int(s) for s in shape)
+        if self._pipeline is None or self._pipeline_key != key:
             if self._pipeline is not None:
                 self._pipeline.close()
-            self._pipeline = FramePipeline(shape, device=self.device_index)
+            self._pipeline = FramePipeline(key, device=self.device_index)     # (Z, Y, X), or (Y, X) for no_z images
+            self._pipeline_key = key
         return self._pipeline
 
     def close(self):
@@ -148,18 +149,15 @@ class Filter:
         return sample_strides(shape, max_samples)
 
     # ------------------------------------------------------------------ frames
-    def _check_3d(self):
-        if self.im_info.no_z:
-            raise NotImplementedError("the HIP Filter implements the 3-D path; 2-D (no_z) images are not supported yet")
-
     def _run_frame(self, t, mask=True):
         """filtering.py:910-933: vesselness * masks of frame t as a host float32 array."""
         logger.info(f"Running Frangi filter on t={t}.")
-        self._check_3d()
         frame_cpu = self.im_memmap[t, ...]
         pipe = self._get_pipeline(frame_cpu.shape)
         pipe.compute_vesselness(frame_cpu, self._params(), mask=mask)
         out = pipe.download_frangi()
+        if self.im_info.no_z:
+            out = out[0]
         if self.remove_edges:
             out = self._remove_edges(out)
         return out
@@ -171,7 +169,8 @@ class Filter:
         pipe.upload_frangi(frangi_frame)
         if pipe.mask_volume(self._params()) is None:
             return frangi_frame
-        return pipe.download_frangi()
+        out = pipe.download_frangi()
+        return out[0] if frangi_frame.ndim == 2 else out
 
     def _bbox(self, im):
         """filtering.py:227-236 (2-D slice form)."""
@@ -184,7 +183,18 @@ class Filter:
         return int(rmin), int(rmax), int(cmin), int(cmax)
 
     def _remove_edges(self, frangi_frame):
-        """filtering.py:969-1000 (3-D branch), on the host: off by default everywhere in the reference."""
+        """filtering.py:969-1000, on the host: off by default everywhere in the reference."""
+        if self.im_info.no_z:                                   # filtering.py:974-985
+            if frangi_frame.size == 0:
+                return frangi_frame
+            rmin, rmax, cmin, cmax = self._bbox(frangi_frame)
+            height = max(0, rmax - rmin + 1)
+            if height <= 0:
+                return frangi_frame
+            margin = min(15, height)
+            frangi_frame[rmin:rmin + margin, :] = 0
+            frangi_frame[rmax - margin + 1:rmax + 1, :] = 0
+            return frangi_frame
         num_z = frangi_frame.shape[0]
         margin = 15
         for z_idx in range(num_z):
@@ -202,7 +212,6 @@ class Filter:
 
     def _filter_frame(self, t, mask=True):
         """One frame end to end on the device (filtering.py:1012-1020), one download."""
-        self._check_3d()
         frame_cpu = self.im_memmap[t, ...]
         pipe = self._get_pipeline(frame_cpu.shape)
         p = self._params()
@@ -212,7 +221,8 @@ class Filter:
                 fr = self._mask_volume(fr)
             return fr
         pipe.filter(frame_cpu, p, mask=mask)
-        return pipe.download_frangi()
+        out = pipe.download_frangi()
+        return out[0] if self.im_info.no_z else out
 
     def _run_filter(self, mask=True):
         """filtering.py:1005-1031."""

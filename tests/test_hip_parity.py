@@ -12,7 +12,7 @@ import zlib
 import numpy as np
 import pytest
 
-from conftest import FILTER_CASES, LABEL_INTENSITY_CASES, LABEL_ONLY_CASES, load_golden
+from conftest import FILTER_2D_CASES, FILTER_CASES, LABEL_INTENSITY_CASES, LABEL_ONLY_CASES, load_golden
 from oracle import nellie_oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -198,6 +198,73 @@ def test_end_to_end_vs_oracle(shape, seed, aniso, pipes):
     match = float(np.mean(lab == ref_lab))
     print(f"end-to-end label match fraction {match:.6f}, labels {lab.max()} vs {ref_lab.max()}")
     assert match > 0.999
+
+
+@pytest.mark.parametrize("name", FILTER_2D_CASES)
+def test_filter_and_label_2d_golden(name, hip):
+    """2-D images (im_info.no_z) against the reference's own outputs: thresholds / statistics / mask counts equal,
+    Gaussian scale space bit-exact, Frangi + blob response within the Frangi tolerance, Label bit-exact."""
+    from nellie_amd import pipeline as pl
+    g = load_golden(name)
+    img, dr = g["input"], g["dim_res_dict"]
+    kw = dict(g["kwargs"])
+    rm = bool(kw.pop("remove_edges", False))
+    p = pl.FilterParams(dim_res=dr, **kw)
+    pipe = pl.FramePipeline(img.shape)
+    try:
+        assert pipe.two_d and np.array_equal(np.array(p.resolved_sigmas()), g["sigmas"])
+        pipe.compute_vesselness(img, p)
+        tr = pipe.trace
+        assert len(tr.scales) == len(g["gamma"])
+        for s, sc in enumerate(tr.scales):
+            assert sc.gamma == g["gamma"][s] and sc.max_abs == g["max_abs"][s]
+            if not np.isnan(g["frob_thr"][s]):
+                assert sc.frob_thr == g["frob_thr"][s]
+            assert sc.mask_count == (0 if sc.skipped else g["mask_count"][s])
+        run_frame = pipe.download_frangi()[0]
+        if rm:
+            run_frame = orc.remove_edges_2d(run_frame)
+            pipe.upload_frangi(run_frame)
+        assert_frangi_close(run_frame, g["run_frame"], "run_frame")
+        if float(run_frame.sum()) > 0:
+            thr = pipe.mask_volume(p)
+            assert abs(float(thr) - float(g["percentile_thr"])) <= 2e-4 * float(g["percentile_thr"]) + 1e-12
+            fr = pipe.download_frangi()[0]
+            assert_masked_close(fr[None], g["frangi"][None], g["run_frame"][None], g["percentile_thr"])
+        # Label on the reference's Frangi image: bit-exact
+        pipe.upload_frangi(g["frangi"])
+        thr = pipe.frangi_threshold()
+        if np.isnan(g["label_thr"]):
+            assert thr is None
+        else:
+            assert float(thr) == float(g["label_thr"])
+        assert pl.min_area_pixels_of(dr, no_z=True) == int(g["min_area_pixels"])
+        pipe.label(thr, int(g["min_area_pixels"]), fill_holes=False)
+        assert np.array_equal(pipe.download_labels()[0], g["labels"])
+    finally:
+        pipe.close()
+
+
+def test_stage_api_2d(hip):
+    """Filter / Label stage classes on a (T, Y, X) stack (im_info.no_z)."""
+    from fakes import ArrayImInfo
+    from nellie_amd.segmentation.filtering import Filter
+    from nellie_amd.segmentation.labelling import Label
+    from nellie_amd.synthetic import make_image_2d
+    dr = {"X": 0.1, "Y": 0.1, "Z": None, "T": 1.0}
+    stack = np.stack([make_image_2d((80, 96), 40 + t) for t in range(2)])
+    im_info = ArrayImInfo(stack, dr, no_z=True)
+    before = stack.copy()
+    Filter(im_info).run()
+    Label(im_info).run()
+    assert np.array_equal(im_info.store["im"], before), "input was modified"
+    for t in range(2):
+        ref_fr = orc.filter_frame_2d(stack[t], dr)
+        fr = np.asarray(im_info.store["frangi"][t])
+        assert fr.shape == ref_fr.shape
+        assert_frangi_close(fr, ref_fr, f"t={t}")
+        ref_lab = orc.label_frame_2d(fr, dr)
+        assert np.array_equal(np.asarray(im_info.store["labels"][t]), ref_lab)
 
 
 def test_ccl_random_masks_vs_oracle(pipes):
