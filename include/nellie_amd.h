@@ -63,6 +63,8 @@ extern "C" {
 #define NL_FIELD_GAUSS  0  /* current Gaussian scale-space volume */
 #define NL_FIELD_FROB   1  /* sqrt(frob_sq)/max_abs of the current scale, inf -> max finite (filtering.py:421-426, 562) */
 #define NL_FIELD_FRANGI 2  /* the Filter output (after nl_filter_finish / nl_mask_volume) or the uploaded Frangi image */
+#define NL_FIELD_VESSELNESS 3 /* vesselness * masks BEFORE nl_filter_finish: the running maximum seen through the
+                                 cumulative mask bits (what NL_FIELD_FRANGI would hold after nl_filter_finish) */
 
 typedef struct nl_ctx nl_ctx;
 
@@ -205,6 +207,14 @@ int nl_filter_finish(nl_ctx *ctx, int64_t z0, int64_t z1, int64_t *n_positive, c
 /* filtering.py:964-966: mask = frangi > thr; binary_opening (6-connected cross, one
    iteration, border 0); frangi *= mask. */
 int nl_mask_volume(nl_ctx *ctx, float thr, char *err, size_t errlen);
+
+/* nl_filter_finish + nl_mask_volume in one go for the common case (filtering.py:926 + 964-966), called INSTEAD of
+   nl_filter_finish after the last scale with the percentile threshold of the NL_FIELD_VESSELNESS samples:
+   the threshold pass reads the vesselness only where the cumulative mask has bits, the final pass reads it only where
+   the opened mask has bits and writes zeros elsewhere (12 instead of 27 bytes per voxel of traffic).
+   n_positive = OWNED voxels of vesselness * masks that are > 0 (what nl_filter_finish reports).  Requires at least
+   one evaluated scale. */
+int nl_mask_volume_fused(nl_ctx *ctx, float thr, int64_t *n_positive, char *err, size_t errlen);
 
 /* D2H of NL_FIELD_FRANGI local planes [z0, z1) (filtering.py:1023-1031). */
 int nl_filter_store(nl_ctx *ctx, float *host, int64_t z0, int64_t z1, char *err, size_t errlen);

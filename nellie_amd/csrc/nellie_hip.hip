@@ -531,13 +531,19 @@ static int make_lattice(const nl_ctx *c, i64 sz, i64 sy, i64 sx, Lattice &L, cha
 
 static int make_field(nl_ctx *c, int field, FieldSrc &fs, char *err, size_t errlen) {
     fs.field = field; fs.hp = hessp(c); fs.max_abs = c->frob_max_abs; fs.max_finite = c->frob_max_finite;
-    fs.two_d = c->two_d;
+    fs.two_d = c->two_d; fs.bits = nullptr; fs.wpr = 0;
     if (field == NL_FIELD_GAUSS) fs.p = gauss_cur(c);
     else if (field == NL_FIELD_FROB) {
         if (!c->have_spacing) return nl_fail(err, errlen, NL_ESTATE, "NL_FIELD_FROB before nl_hessian_stats");
         fs.p = gauss_cur(c);
     } else if (field == NL_FIELD_FRANGI) fs.p = c->f[c->i_vmax];
-    else return nl_fail(err, errlen, NL_EINVAL, "unknown field %d", field);
+    else if (field == NL_FIELD_VESSELNESS) {
+        if (c->mask_slots_used == 0) return nl_fail(err, errlen, NL_ESTATE, "NL_FIELD_VESSELNESS before any scale was evaluated");
+        NL_JOIN_SIDE(c);
+        fs.p = c->f[c->i_vmax];
+        fs.wpr = (int)((c->nx + 63) / 64);
+        fs.bits = (const unsigned long long *)c->m[0] + (i64)((c->mask_slots_used - 1) & 1) * (c->nzl * c->ny * fs.wpr);
+    } else return nl_fail(err, errlen, NL_EINVAL, "unknown field %d", field);
     return NL_OK;
 }
 
@@ -1024,6 +1030,48 @@ extern "C" int nl_mask_volume(nl_ctx *c, float thr, char *err, size_t errlen) {
     float *tmp = c->f[c->i_vmax];
     c->f[c->i_vmax] = c->f[dst];
     c->f[dst] = tmp;
+    return NL_OK;
+}
+
+extern "C" int nl_mask_volume_fused(nl_ctx *c, float thr, int64_t *n_positive, char *err, size_t errlen) {
+    NL_ENTER(c);
+    if (c->mask_slots_used == 0) return nl_fail(err, errlen, NL_ESTATE, "nl_mask_volume_fused before any scale was evaluated");
+    NL_JOIN_SIDE(c);
+    int dst = -1;
+    for (int k = 0; k < 3; ++k) if (k != c->i_gauss) { dst = k; break; }
+    unsigned long long *d_cnt = (unsigned long long *)c->d_small;
+    NL_HIP(hipMemsetAsync(d_cnt, 0, 8, c->stream));
+    {
+        ProfScope ps(c, "mask_volume");
+        const int wpr = (int)((c->nx + 63) / 64);
+        const VolGeom v = geom(c);
+        const i64 slot_words = c->nzl * c->ny * wpr;
+        const int last = (c->mask_slots_used - 1) & 1;
+        const unsigned long long *alive = (const unsigned long long *)c->m[0] + (i64)last * slot_words;
+        // the threshold bits may not overwrite the mask slot they are computed from: m[1] / m[2] hold them, the free
+        // slot of m[0] takes the opened mask
+        const i64 m0 = c->own_lo - 2 > 0 ? c->own_lo - 2 : 0, m1 = c->own_hi + 2 < c->nzl ? c->own_hi + 2 : c->nzl;
+        const i64 e0 = c->own_lo - 1 > 0 ? c->own_lo - 1 : 0, e1 = c->own_hi + 1 < c->nzl ? c->own_hi + 1 : c->nzl;
+        unsigned long long *bM = (unsigned long long *)c->m[1], *bE = (unsigned long long *)c->m[2];
+        unsigned long long *bD = (unsigned long long *)c->m[0] + (i64)(last ^ 1) * slot_words;
+        pack_masked_kernel<<<grid1d((m1 - m0) * c->ny * 64, 256, 256 * 32), 256, 0, c->stream>>>(
+            c->f[c->i_vmax], alive, bM, thr, (int)c->nx, m0 * c->ny, m1 * c->ny, wpr, c->own_lo * c->ny, c->own_hi * c->ny, d_cnt);
+        NL_CHECK_LAUNCH();
+        bits_morph6_kernel<0><<<(unsigned)(((e1 - e0) * c->ny * wpr + 255) / 256), 256, 0, c->stream>>>(bM, bE, v, wpr, e0, e1, c->two_d);
+        NL_CHECK_LAUNCH();
+        bits_morph6_kernel<1><<<(unsigned)(((c->own_hi - c->own_lo) * c->ny * wpr + 255) / 256), 256, 0, c->stream>>>(bE, bD, v, wpr, c->own_lo, c->own_hi, c->two_d);
+        NL_CHECK_LAUNCH();
+        apply_bits_pos_kernel<<<grid1d((c->own_hi - c->own_lo) * c->ny * ((c->nx + 3) / 4), 256, 256 * 32), 256, 0, c->stream>>>(
+            c->f[c->i_vmax], bD, c->f[dst], v, wpr, c->own_lo, c->own_hi);
+        NL_CHECK_LAUNCH();
+    }
+    float *tmp = c->f[c->i_vmax];
+    c->f[c->i_vmax] = c->f[dst];
+    c->f[dst] = tmp;
+    NL_HIP(hipMemcpyAsync(c->h_small, d_cnt, 8, hipMemcpyDeviceToHost, c->stream));
+    NL_HIP(hipStreamSynchronize(c->stream));
+    if (n_positive) *n_positive = (int64_t)(*(unsigned long long *)c->h_small);
+    c->frangi_ready = 1;
     return NL_OK;
 }
 

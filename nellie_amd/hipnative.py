@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libnellie_hip.so")
 
 NL_OK, NL_EINVAL, NL_ENODEV, NL_ENOMEM, NL_EHIP, NL_ESTATE, NL_ECOMM = range(7)
-FIELD_GAUSS, FIELD_FROB, FIELD_FRANGI = 0, 1, 2
+FIELD_GAUSS, FIELD_FROB, FIELD_FRANGI, FIELD_VESSELNESS = 0, 1, 2, 3
 
 DTYPE_CODES = {
     np.dtype(np.uint8): 0, np.dtype(np.int8): 1, np.dtype(np.uint16): 2, np.dtype(np.int16): 3,
@@ -54,6 +54,7 @@ _PROTOS = {
     "nl_vesselness_resolve": [_p, _f32, _f32, _f32, _int, _f32, C.POINTER(_int), C.POINTER(_i64)],
     "nl_vesselness_count": [_p, C.POINTER(_i64)],
     "nl_set_ndim": [_p, _int],
+    "nl_mask_volume_fused": [_p, _f32, C.POINTER(_i64)],
     "nl_log2d_step": [_p, C.POINTER(_f64), C.POINTER(_f64), C.POINTER(_f64), C.POINTER(_f64), _int, _f32, _int, _int],
     "nl_log2d_finish": [_p, C.POINTER(_i64)],
     "nl_filter_finish": [_p, _i64, _i64, C.POINTER(_i64)],
@@ -348,6 +349,11 @@ class Context:
         self._call("nl_vesselness_step", float(np.float32(gamma_sq)), float(np.float32(alpha_sq)),
                    float(np.float32(beta_sq)), use, float(np.float32(0.0 if thr is None else thr)),
                    int(z0), int(z1), C.byref(n) if want_count else None)
+        return int(n.value)
+
+    def mask_volume_fused(self, thr) -> int:
+        n = _i64(0)
+        self._call("nl_mask_volume_fused", float(np.float32(thr)), C.byref(n))
         return int(n.value)
 
     def set_ndim(self, ndim: int):

@@ -19,7 +19,7 @@ from typing import Optional
 import numpy as np
 
 from nellie_amd import hipnative
-from nellie_amd.hipnative import FIELD_FRANGI, FIELD_FROB, FIELD_GAUSS
+from nellie_amd.hipnative import FIELD_FRANGI, FIELD_FROB, FIELD_GAUSS, FIELD_VESSELNESS
 from nellie_amd.utils.gpu_functions import (histogram_edges, min_triangle_otsu, otsu_threshold,
                                             triangle_threshold)
 
@@ -278,8 +278,9 @@ class FramePipeline:
             return None
         return float(lo), float(hi)
 
-    def compute_vesselness(self, frame, p: FilterParams, mask: bool = True):
-        """filtering.py:806-853 + 926: leaves `vesselness * masks` on the device; returns #voxels > 0."""
+    def compute_vesselness(self, frame, p: FilterParams, mask: bool = True, finish: bool = True):
+        """filtering.py:806-853 + 926: leaves `vesselness * masks` on the device; returns #voxels > 0.
+        finish=False stops before the product is materialised (see filter()); returns None then."""
         ctx = self.ctx
         max_samples = int(p.max_threshold_samples) if p.max_threshold_samples is not None else 0
         if max_samples <= 0:
@@ -367,6 +368,8 @@ class FramePipeline:
                 settle()
                 pending = self.trace.scales[-1]      # its kernel overlaps the next scale's Gaussian; count read later
         settle()
+        if not finish:
+            return None
         vz0, vz1 = self._vess_range()
         self.trace.n_positive = self._reduce_sum(ctx.filter_finish(vz0, vz1))
         if self.two_d:
@@ -392,9 +395,28 @@ class FramePipeline:
         self.trace.percentile_thr = float(thr)
         return thr
 
+    _fused_epilogue = True      # a Z-slab pipeline keeps the two-step epilogue (ghost planes of the product)
+
     def filter(self, frame, p: FilterParams, mask: bool = True):
-        """filtering.py:1012-1018: _run_frame, then _mask_volume when the frame has signal."""
-        npos = self.compute_vesselness(frame, p, mask=mask)
+        """filtering.py:1012-1018: _run_frame, then _mask_volume when the frame has signal.
+        Common case in one go: the percentile threshold only needs lattice samples of `vesselness * masks`, which
+        can be read through the mask bits, so the product is never written just to be thresholded and rewritten
+        (nl_mask_volume_fused).  No positive sample, no evaluated scale, 2-D or a slab: the two plain steps."""
+        if self._fused_epilogue and not self.two_d:
+            self.compute_vesselness(frame, p, mask=mask, finish=False)
+            if any(not sc.skipped for sc in self.trace.scales):
+                strides = self._strides(int(p.max_threshold_samples))
+                sample = self.ctx.sample_gather(FIELD_VESSELNESS, strides)
+                positive = sample[sample > 0]
+                if positive.size > 0:
+                    thr = np.percentile(positive, 1)
+                    self.trace.percentile_thr = float(thr)
+                    self.trace.n_positive = self.ctx.mask_volume_fused(thr)
+                    return self.trace.n_positive
+            vz0, vz1 = self._vess_range()
+            npos = self.trace.n_positive = self._reduce_sum(self.ctx.filter_finish(vz0, vz1))
+        else:
+            npos = self.compute_vesselness(frame, p, mask=mask)
         if npos > 0:      # float(sum(frame)) > 0 for a non-negative frame
             self.mask_volume(p)
         return npos

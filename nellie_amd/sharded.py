@@ -114,6 +114,8 @@ class ShardedFramePipeline(FramePipeline):
         self._valid = (0, nzl)
 
     # ---- shrinking Z ranges -------------------------------------------------------------------------------
+    _fused_epilogue = False
+
     def _gauss_range(self, rz):
         v0, v1 = self._valid
         nzl = self.lshape[0]
