@@ -113,6 +113,15 @@ int nl_gauss_step(nl_ctx *ctx,
                   const double *wz, int rz, const double *wy, int ry, const double *wx, int rx,
                   int64_t z0, int64_t z1, char *err, size_t errlen);
 
+/* The same step enqueued AHEAD on the context's side stream: the cascade step of scale s+1 only reads the Gaussian of
+   scale s, so it can overlap the Hessian walk of scale s.  The result becomes NL_FIELD_GAUSS at nl_gauss_commit
+   (call it before anything of scale s+1).  In between, only the per-scale calls of Filter are allowed (sampling by
+   min/max + histogram, nl_hessian_stats, nl_vesselness_*); nl_sample_gather, nl_mask_volume* and Label use the free
+   Gaussian volumes as scratch. */
+int nl_gauss_step_ahead(nl_ctx *ctx, const double *wz, int rz, const double *wy, int ry, const double *wx, int rx,
+                        int64_t z0, int64_t z1, char *err, size_t errlen);
+int nl_gauss_commit(nl_ctx *ctx, char *err, size_t errlen);
+
 /* arr[::sz, ::sy, ::sx] of a field on the owned planes (strides are those of the GLOBAL
    lattice; filtering.py:342-346, 355-356).  `out` receives the samples in C order, `*n`
    their number; `cap` is the capacity of `out` in elements. */

@@ -200,6 +200,7 @@ extern "C" int nl_ctx_destroy(nl_ctx *c) {
     if (c->side) { hipStreamSynchronize(c->side); hipStreamDestroy(c->side); }
     if (c->ev_side) hipEventDestroy(c->ev_side);
     if (c->ev_main) hipEventDestroy(c->ev_main);
+    if (c->ev_ahead) hipEventDestroy(c->ev_ahead);
     if (c->copy_in) hipStreamDestroy(c->copy_in);
     if (c->copy_out) hipStreamDestroy(c->copy_out);
     if (c->d_blk) hipFree(c->d_blk);
@@ -275,7 +276,8 @@ extern "C" int nl_ctx_create(nl_ctx **out, int device, int64_t nzl, int64_t ny, 
     }
     if (ok && (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
                hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming) != hipSuccess ||
-               hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming) != hipSuccess)) {
+               hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming) != hipSuccess ||
+               hipEventCreateWithFlags(&c->ev_ahead, hipEventDisableTiming) != hipSuccess)) {
         rc = nl_fail(err, errlen, NL_EHIP, "stream/event creation failed"); ok = false;
     }
     if (ok && (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
@@ -349,6 +351,7 @@ extern "C" int nl_filter_load(nl_ctx *c, const void *host, int dtype, int64_t z0
     if (!host || z0 < 0 || z1 > c->nzl || z0 >= z1) return nl_fail(err, errlen, NL_EINVAL, "bad plane range [%lld,%lld)", (i64)z0, (i64)z1);
     c->i_gauss = 0; c->i_vmax = 3; c->i_labels = -1; c->frangi_ready = 0;
     c->gauss_ext = nullptr;
+    c->ahead_pending = 0;
     const i64 plane = c->ny * c->nx;
     int rc = upload_convert(c, host, dtype, c->f[0] + z0 * plane, (z1 - z0) * plane, err, errlen);
     if (rc) return rc;
@@ -383,6 +386,7 @@ extern "C" int nl_filter_begin(nl_ctx *c, char *err, size_t errlen) {
     c->i_gauss = 0; c->i_vmax = 3; c->i_labels = -1; c->frangi_ready = 0;
     c->mask_slots_used = 0;
     c->gauss_ext = nullptr;
+    c->ahead_pending = 0;
     if (c->input_dtype == NL_F32 && !getenv("NELLIE_COPY_INPUT")) {
         // float32 frames are used where they lie: the cascade never writes its source (ping-pong volumes), so the
         // first Gaussian pass reads the resident input directly (the reference's gauss = frame view, filtering.py:811)
@@ -452,6 +456,7 @@ static bool launch_gauss_fast(nl_ctx *c, const float *src, float *dst, const Vol
 extern "C" int nl_gauss_step(nl_ctx *c, const double *wz, int rz, const double *wy, int ry, const double *wx, int rx,
                              int64_t z0, int64_t z1, char *err, size_t errlen) {
     NL_ENTER(c);
+    if (c->ahead_pending) return nl_fail(err, errlen, NL_ESTATE, "nl_gauss_step while a step enqueued ahead is uncommitted");
     if (z0 < 0 || z1 > c->nzl || z0 >= z1) return nl_fail(err, errlen, NL_EINVAL, "bad plane range [%lld,%lld)", (i64)z0, (i64)z1);
     const VolGeom v = geom(c);
     // three ping-pong volumes f[0..2]: the source of a pass is dead once the pass has run,
@@ -513,6 +518,41 @@ extern "C" int nl_gauss_step(nl_ctx *c, const double *wz, int rz, const double *
     }
     c->i_gauss = src;
     if (srcp != c->gauss_ext) c->gauss_ext = nullptr;      // a cascade step ran: the Gaussian now lives in f[src]
+    return NL_OK;
+}
+
+// The cascade step of scale s+1 only reads the Gaussian of scale s -- like everything else scale s does -- so it can run
+// beside it.  nl_gauss_step_ahead enqueues the step on the side stream into the two free ping-pong volumes without
+// making it current; nl_gauss_commit (before anything of scale s+1) orders the main stream after it and switches.
+// Between the two calls no entry point that uses a free Gaussian volume as scratch may be called (nl_sample_gather,
+// nl_mask_volume*, Label); the per-scale calls of Filter do not.
+extern "C" int nl_gauss_step_ahead(nl_ctx *c, const double *wz, int rz, const double *wy, int ry, const double *wx, int rx,
+                                   int64_t z0, int64_t z1, char *err, size_t errlen) {
+    NL_ENTER(c);
+    if (c->ahead_pending) return nl_fail(err, errlen, NL_ESTATE, "a step enqueued ahead is already pending");
+    NL_HIP(hipEventRecord(c->ev_main, c->stream));
+    NL_HIP(hipStreamWaitEvent(c->side, c->ev_main, 0));
+    const int cur_idx = c->i_gauss;
+    float *cur_ext = c->gauss_ext;
+    hipStream_t main_stream = c->stream;
+    c->stream = c->side;                       // the launch helpers use c->stream
+    const int rc = nl_gauss_step(c, wz, rz, wy, ry, wx, rx, z0, z1, err, errlen);
+    c->stream = main_stream;
+    if (rc) { c->i_gauss = cur_idx; c->gauss_ext = cur_ext; return rc; }
+    c->ahead_gauss = c->i_gauss;
+    c->i_gauss = cur_idx; c->gauss_ext = cur_ext;
+    NL_HIP(hipEventRecord(c->ev_ahead, c->side));
+    c->ahead_pending = 1;
+    return NL_OK;
+}
+
+extern "C" int nl_gauss_commit(nl_ctx *c, char *err, size_t errlen) {
+    NL_ENTER(c);
+    if (!c->ahead_pending) return nl_fail(err, errlen, NL_ESTATE, "nl_gauss_commit without nl_gauss_step_ahead");
+    NL_HIP(hipStreamWaitEvent(c->stream, c->ev_ahead, 0));
+    c->i_gauss = c->ahead_gauss;
+    c->gauss_ext = nullptr;
+    c->ahead_pending = 0;
     return NL_OK;
 }
 

@@ -59,6 +59,8 @@ struct nl_ctx {
     unsigned long long spec_count = 0;   // owned voxels the pass already counted as h_mask
     hipStream_t side = nullptr;          // the resolve kernel of scale s runs here, beside the Gaussian of scale s+1
     hipEvent_t ev_side = nullptr, ev_main = nullptr;
+    hipEvent_t ev_ahead = nullptr;       // a cascade step enqueued ahead on `side` (nl_gauss_step_ahead)
+    int ahead_pending = 0, ahead_gauss = 0;
     int side_pending = 0;                // work on `side` the main stream has not been ordered after yet
     float last_fsq_min = 0;    // the exact mask threshold of the last scale (diagnostics)
     void *d_blk = nullptr;     // per-block partials for scans

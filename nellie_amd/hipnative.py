@@ -42,6 +42,8 @@ _PROTOS = {
     "nl_input_load": [_p, _p, _int, _i64, _i64],
     "nl_filter_begin": [_p],
     "nl_gauss_step": [_p, _p, _int, _p, _int, _p, _int, _i64, _i64],
+    "nl_gauss_step_ahead": [_p, _p, _int, _p, _int, _p, _int, _i64, _i64],
+    "nl_gauss_commit": [_p],
     "nl_sample_gather": [_p, _int, _i64, _i64, _i64, _p, _i64, C.POINTER(_i64)],
     "nl_sample_minmax": [_p, _int, _i64, _i64, _i64, C.POINTER(_f32), C.POINTER(_f32), C.POINTER(_i64)],
     "nl_sample_hist": [_p, _int, _i64, _i64, _i64, _p, _int, _p],
@@ -299,7 +301,11 @@ class Context:
     def filter_begin(self):
         self._call("nl_filter_begin")
 
-    def gauss_step(self, wz, wy, wx, z0=0, z1=None):
+    def gauss_commit(self):
+        self._call("nl_gauss_commit")
+
+    def gauss_step(self, wz, wy, wx, z0=0, z1=None, ahead=False):
+        """ahead=True: enqueue the step on the side stream; it becomes current at gauss_commit()."""
         z1 = self.shape[0] if z1 is None else z1
         args = []
         keep = []
@@ -310,7 +316,7 @@ class Context:
                 w = np.ascontiguousarray(w, dtype=np.float64)
                 keep.append(w)
                 args += [_ptr(w), (len(w) - 1) // 2]
-        self._call("nl_gauss_step", *args, z0, z1)
+        self._call("nl_gauss_step_ahead" if ahead else "nl_gauss_step", *args, z0, z1)
 
     def sample_gather(self, field, strides):
         sz, sy, sx = (int(s) for s in strides)

@@ -305,13 +305,28 @@ class FramePipeline:
                 pending.mask_count = self._reduce_sum(ctx.vesselness_count())
                 pending = None
 
-        for sigma, delta in zip(sigmas, cascade_deltas(sigmas, zr)):
-            if self.two_d:
-                delta = (0.0, delta[1], delta[2])                 # sigma_vec = (s, s): no Z axis (filtering.py:281-282)
-            if any(s > 0 for s in delta):
-                ws = [gaussian_weights(d) for d in delta]
-                z0, z1 = self._gauss_range(0 if ws[0] is None else (len(ws[0]) - 1) // 2)
-                ctx.gauss_step(*ws, z0=z0, z1=z1)
+        deltas = list(cascade_deltas(sigmas, zr))
+        if self.two_d:
+            deltas = [(0.0, d[1], d[2]) for d in deltas]          # sigma_vec = (s, s): no Z axis (filtering.py:281-282)
+        ahead = False        # the cascade step of the current scale was enqueued during the previous one
+
+        def cascade_step(k, run_ahead):
+            delta = deltas[k]
+            if not any(s > 0 for s in delta):
+                return False
+            ws = [gaussian_weights(d) for d in delta]
+            z0, z1 = self._gauss_range(0 if ws[0] is None else (len(ws[0]) - 1) // 2)
+            ctx.gauss_step(*ws, z0=z0, z1=z1, **({"ahead": True} if run_ahead else {}))
+            return True
+
+        for k, sigma in enumerate(sigmas):
+            if ahead:
+                ctx.gauss_commit()
+            else:
+                cascade_step(k, False)
+            # the next cascade step only reads the Gaussian of THIS scale: enqueue it now, on the side stream, so that
+            # it runs beside this scale's Hessian walk (filtering.py:814-835 has no such dependency either)
+            ahead = self._gauss_ahead and k + 1 < len(sigmas) and cascade_step(k + 1, True)
             # gamma (filtering.py:365-380, 839-840)
             gamma = self._threshold_from_field(FIELD_GAUSS, strides)
             if gamma is None or gamma <= 0:
@@ -396,6 +411,7 @@ class FramePipeline:
         return thr
 
     _fused_epilogue = True      # a Z-slab pipeline keeps the two-step epilogue (ghost planes of the product)
+    _gauss_ahead = True         # ... and its cascade steps in order (their plane ranges shrink step by step)
 
     def filter(self, frame, p: FilterParams, mask: bool = True):
         """filtering.py:1012-1018: _run_frame, then _mask_volume when the frame has signal.

@@ -115,6 +115,7 @@ class ShardedFramePipeline(FramePipeline):
 
     # ---- shrinking Z ranges -------------------------------------------------------------------------------
     _fused_epilogue = False
+    _gauss_ahead = False
 
     def _gauss_range(self, rz):
         v0, v1 = self._valid
