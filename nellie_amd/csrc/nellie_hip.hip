@@ -1417,7 +1417,8 @@ static int build_components(nl_ctx *c, const LabelGeo &g, const unsigned long lo
     rl_emit_kernel<<<(unsigned)((g.nrows + 255) / 256), 256, 0, c->stream>>>(bits, invert, row_off, rs.runs, rs.parent, g.nrows, g.wpr, (int)g.nx);
     NL_CHECK_LAUNCH();
     const unsigned gr = (unsigned)((rs.nruns + 255) / 256);
-    rl_union_kernel<CONN><<<gr, 256, 0, c->stream>>>(rs.runs, row_off, rs.parent, rs.nruns, (int)g.ny);
+    rl_union_kernel<CONN><<<gr, 256, 0, c->stream>>>(rs.runs, row_off, rs.parent, rs.nruns, (int)g.ny,
+                                                     CONN == 6 ? (int)g.nz : 0, (int)g.nx);
     NL_CHECK_LAUNCH();
     ccl_flatten_kernel<<<grid1d(rs.nruns), 256, 0, c->stream>>>(rs.parent, rs.nruns);
     NL_CHECK_LAUNCH();
