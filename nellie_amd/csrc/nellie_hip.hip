@@ -1055,7 +1055,7 @@ extern "C" int nl_mask_volume(nl_ctx *c, float thr, char *err, size_t errlen) {
         const i64 m0 = c->own_lo - 2 > 0 ? c->own_lo - 2 : 0, m1 = c->own_hi + 2 < c->nzl ? c->own_hi + 2 : c->nzl;
         const i64 e0 = c->own_lo - 1 > 0 ? c->own_lo - 1 : 0, e1 = c->own_hi + 1 < c->nzl ? c->own_hi + 1 : c->nzl;
         unsigned long long *bM = (unsigned long long *)c->m[1], *bE = (unsigned long long *)c->m[2], *bD = (unsigned long long *)c->m[0];
-        rl_threshold_pack_kernel<<<grid1d((m1 - m0) * c->ny * 64, 256, 256 * 32), 256, 0, c->stream>>>(
+        rl_threshold_pack_kernel<<<grid1d((m1 - m0) * c->ny * 64, 256, (i64)1 << 22), 256, 0, c->stream>>>(
             c->f[c->i_vmax] + m0 * c->ny * c->nx, bM + m0 * c->ny * wpr, 1, thr, (int)c->nx, (m1 - m0) * c->ny, wpr);
         NL_CHECK_LAUNCH();
         bits_morph6_kernel<0><<<(unsigned)(((e1 - e0) * c->ny * wpr + 255) / 256), 256, 0, c->stream>>>(bM, bE, v, wpr, e0, e1, c->two_d);
@@ -1094,14 +1094,14 @@ extern "C" int nl_mask_volume_fused(nl_ctx *c, float thr, int64_t *n_positive, c
         const i64 e0 = c->own_lo - 1 > 0 ? c->own_lo - 1 : 0, e1 = c->own_hi + 1 < c->nzl ? c->own_hi + 1 : c->nzl;
         unsigned long long *bM = (unsigned long long *)c->m[1], *bE = (unsigned long long *)c->m[2];
         unsigned long long *bD = (unsigned long long *)c->m[0] + (i64)(last ^ 1) * slot_words;
-        pack_masked_kernel<<<grid1d((m1 - m0) * c->ny * 64, 256, 256 * 32), 256, 0, c->stream>>>(
+        pack_masked_kernel<<<grid1d((m1 - m0) * c->ny * 64, 256, 256 * 32), 256, 0, c->stream>>>(    // one atomic per wave: small grid
             c->f[c->i_vmax], alive, bM, thr, (int)c->nx, m0 * c->ny, m1 * c->ny, wpr, c->own_lo * c->ny, c->own_hi * c->ny, d_cnt);
         NL_CHECK_LAUNCH();
         bits_morph6_kernel<0><<<(unsigned)(((e1 - e0) * c->ny * wpr + 255) / 256), 256, 0, c->stream>>>(bM, bE, v, wpr, e0, e1, c->two_d);
         NL_CHECK_LAUNCH();
         bits_morph6_kernel<1><<<(unsigned)(((c->own_hi - c->own_lo) * c->ny * wpr + 255) / 256), 256, 0, c->stream>>>(bE, bD, v, wpr, c->own_lo, c->own_hi, c->two_d);
         NL_CHECK_LAUNCH();
-        apply_bits_pos_kernel<<<grid1d((c->own_hi - c->own_lo) * c->ny * ((c->nx + 3) / 4), 256, 256 * 32), 256, 0, c->stream>>>(
+        apply_bits_pos_kernel<<<grid1d((c->own_hi - c->own_lo) * c->ny * 64, 256, (i64)1 << 22), 256, 0, c->stream>>>(
             c->f[c->i_vmax], bD, c->f[dst], v, wpr, c->own_lo, c->own_hi);
         NL_CHECK_LAUNCH();
     }
@@ -1483,7 +1483,7 @@ static int label_core(nl_ctx *c, const LabelGeo &g, int64_t min_area, int fill_h
         NL_CHECK_LAUNCH();
         NL_HIP(hipMemcpyAsync(c->h_small, d_total, 8, hipMemcpyDeviceToHost, c->stream));
     }
-    rl_paint_kernel<<<grid1d((g.paint_row1 - g.paint_row0) * 64, 256, 256 * 32), 256, 0, c->stream>>>(
+    rl_paint_kernel<<<grid1d((g.paint_row1 - g.paint_row0) * 64, 256, (i64)1 << 22), 256, 0, c->stream>>>(
         g.bitsA, rs.row_off, rs.parent, aux, g.paint_out, g.paint_row0, g.paint_row1, g.wpr, (int)g.nx);
     NL_CHECK_LAUNCH();
     NL_HIP(hipStreamSynchronize(c->stream));
@@ -1514,7 +1514,7 @@ extern "C" int nl_label_run(nl_ctx *c, int has_thr, float thr, int64_t min_area,
     g.bitsA = (unsigned long long *)c->m[1]; g.bitsB = (unsigned long long *)c->m[2];
     g.paint_row0 = 0; g.paint_row1 = g.nrows; g.paint_out = (int *)c->f[label_out_index(c)];
     ProfScope ps(c, "label");
-    rl_threshold_pack_kernel<<<grid1d(g.nrows * 64, 256, 256 * 32), 256, 0, c->stream>>>(c->f[c->i_vmax], g.bitsA, has_thr, thr,
+    rl_threshold_pack_kernel<<<grid1d(g.nrows * 64, 256, (i64)1 << 22), 256, 0, c->stream>>>(c->f[c->i_vmax], g.bitsA, has_thr, thr,
                                                                                           (int)c->nx, g.nrows, g.wpr);
     NL_CHECK_LAUNCH();
     bool overflow = false;
@@ -1554,7 +1554,7 @@ extern "C" int nl_label_pack(nl_ctx *c, int has_thr, float thr, char *err, size_
     const i64 own_rows = (c->own_hi - c->own_lo) * c->ny;
     const i64 row0 = (c->gz0 + c->own_lo) * c->ny;
     ProfScope ps(c, "label");
-    rl_threshold_pack_kernel<<<grid1d(own_rows * 64, 256, 256 * 32), 256, 0, c->stream>>>(
+    rl_threshold_pack_kernel<<<grid1d(own_rows * 64, 256, (i64)1 << 22), 256, 0, c->stream>>>(
         c->f[c->i_vmax] + c->own_lo * c->ny * c->nx, c->gbits[0] + row0 * wpr, has_thr, thr, (int)c->nx, own_rows, wpr);
     NL_CHECK_LAUNCH();
     return NL_OK;

@@ -16,6 +16,8 @@ from __future__ import annotations
 from dataclasses import dataclass, field
 from typing import Optional
 
+import os
+
 import numpy as np
 
 from nellie_amd import hipnative
@@ -411,7 +413,9 @@ class FramePipeline:
         return thr
 
     _fused_epilogue = True      # a Z-slab pipeline keeps the two-step epilogue (ghost planes of the product)
-    _gauss_ahead = True         # ... and its cascade steps in order (their plane ranges shrink step by step)
+    # Enqueue the cascade step of scale s+1 on the side stream beside the Hessian walk of scale s.  Exact either way.
+    # Off by default: at 1024^3 it buys ~1 % (two full-GPU kernels mostly take turns) and it blurs per-kernel timings.
+    _gauss_ahead = os.environ.get("NELLIE_GAUSS_AHEAD", "0") == "1"
 
     def filter(self, frame, p: FilterParams, mask: bool = True):
         """filtering.py:1012-1018: _run_frame, then _mask_volume when the frame has signal.

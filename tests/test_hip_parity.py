@@ -117,23 +117,24 @@ def test_one_pass_vesselness_equals_two_pass(shape, aniso, hip):
     vol = make_volume(shape, 99)
     p = FilterParams(dim_res=ANISO_03 if aniso else ISO_01)
     out = {}
-    for mode in ("two", "one", "miss"):
+    for mode in ("two", "one", "miss", "ahead"):
         pipe = FramePipeline(shape)
         assert pipe.ctx.one_pass_available()
         pipe.one_pass = mode != "two"
         if mode == "miss":
             pipe._one_pass_test_scale = 1.2
+        pipe._gauss_ahead = mode == "ahead"          # cascade step of scale s+1 beside the Hessian walk of scale s
         pipe.compute_vesselness(vol, p)
         out[mode] = (pipe.download_frangi(), pipe.trace)
         pipe.close()
     f2, t2 = out["two"]
-    for mode in ("one", "miss"):
+    for mode in ("one", "miss", "ahead"):
         f1, t1 = out[mode]
         assert np.array_equal(f1.view(np.uint32), f2.view(np.uint32)), mode
         assert t1.n_positive == t2.n_positive
         for a, b in zip(t1.scales, t2.scales):
             assert (a.gamma, a.max_abs, a.frob_thr, a.mask_count, a.skipped) == (b.gamma, b.max_abs, b.frob_thr, b.mask_count, b.skipped)
-            assert a.one_pass == (mode == "one" and not a.skipped)
+            assert a.one_pass == (mode in ("one", "ahead") and not a.skipped)
 
 
 @pytest.mark.parametrize("name", [n for n in FILTER_CASES if n.startswith(("iso", "aniso", "odd", "u16"))])
