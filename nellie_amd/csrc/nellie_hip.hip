@@ -205,6 +205,7 @@ extern "C" int nl_ctx_destroy(nl_ctx *c) {
     if (c->copy_out) hipStreamDestroy(c->copy_out);
     if (c->d_blk) hipFree(c->d_blk);
     for (int k = 0; k < 4; ++k) if (c->d_2d[k]) hipFree(c->d_2d[k]);
+    if (c->d_fsq_cache) hipFree(c->d_fsq_cache);
     if (c->d_vq) hipFree(c->d_vq);
     if (c->d_vq_count) hipFree(c->d_vq_count);
     if (c->d_rows) hipFree(c->d_rows);
@@ -352,6 +353,7 @@ extern "C" int nl_filter_load(nl_ctx *c, const void *host, int dtype, int64_t z0
     c->i_gauss = 0; c->i_vmax = 3; c->i_labels = -1; c->frangi_ready = 0;
     c->gauss_ext = nullptr;
     c->ahead_pending = 0;
+    c->fsq_cache_valid = 0;
     const i64 plane = c->ny * c->nx;
     int rc = upload_convert(c, host, dtype, c->f[0] + z0 * plane, (z1 - z0) * plane, err, errlen);
     if (rc) return rc;
@@ -387,6 +389,7 @@ extern "C" int nl_filter_begin(nl_ctx *c, char *err, size_t errlen) {
     c->mask_slots_used = 0;
     c->gauss_ext = nullptr;
     c->ahead_pending = 0;
+    c->fsq_cache_valid = 0;
     if (c->input_dtype == NL_F32 && !getenv("NELLIE_COPY_INPUT")) {
         // float32 frames are used where they lie: the cascade never writes its source (ping-pong volumes), so the
         // first Gaussian pass reads the resident input directly (the reference's gauss = frame view, filtering.py:811)
@@ -517,6 +520,7 @@ extern "C" int nl_gauss_step(nl_ctx *c, const double *wz, int rz, const double *
         src = dst; srcp = c->f[dst];
     }
     c->i_gauss = src;
+    c->fsq_cache_valid = 0;
     if (srcp != c->gauss_ext) c->gauss_ext = nullptr;      // a cascade step ran: the Gaussian now lives in f[src]
     return NL_OK;
 }
@@ -553,6 +557,7 @@ extern "C" int nl_gauss_commit(nl_ctx *c, char *err, size_t errlen) {
     c->i_gauss = c->ahead_gauss;
     c->gauss_ext = nullptr;
     c->ahead_pending = 0;
+    c->fsq_cache_valid = 0;
     return NL_OK;
 }
 
@@ -571,7 +576,7 @@ static int make_lattice(const nl_ctx *c, i64 sz, i64 sy, i64 sx, Lattice &L, cha
 
 static int make_field(nl_ctx *c, int field, FieldSrc &fs, char *err, size_t errlen) {
     fs.field = field; fs.hp = hessp(c); fs.max_abs = c->frob_max_abs; fs.max_finite = c->frob_max_finite;
-    fs.two_d = c->two_d; fs.bits = nullptr; fs.wpr = 0;
+    fs.two_d = c->two_d; fs.bits = nullptr; fs.wpr = 0; fs.fsq_cache = nullptr;
     if (field == NL_FIELD_GAUSS) fs.p = gauss_cur(c);
     else if (field == NL_FIELD_FROB) {
         if (!c->have_spacing) return nl_fail(err, errlen, NL_ESTATE, "NL_FIELD_FROB before nl_hessian_stats");
@@ -587,12 +592,36 @@ static int make_field(nl_ctx *c, int field, FieldSrc &fs, char *err, size_t errl
     return NL_OK;
 }
 
+// NL_FIELD_FROB is sampled up to four times per scale (threshold bracket and exact threshold, min/max and histogram
+// each) with different normalisations of the same frob_sq: evaluate the Hessian at the lattice points once.
+static int use_fsq_cache(nl_ctx *c, FieldSrc &fs, const Lattice &L, char *err, size_t errlen) {
+    if (fs.field != NL_FIELD_FROB) return NL_OK;
+    const i64 total = L.cz * L.cy * L.cx;
+    if (total == 0) return NL_OK;
+    if (!(c->fsq_cache_valid && c->fsq_cache_key[0] == L.sz && c->fsq_cache_key[1] == L.sy && c->fsq_cache_key[2] == L.sx)) {
+        if (total > c->fsq_cache_cap) {
+            if (c->d_fsq_cache) NL_HIP(hipFree(c->d_fsq_cache));
+            c->d_fsq_cache = nullptr; c->fsq_cache_cap = 0;
+            NL_HIP(hipMalloc((void **)&c->d_fsq_cache, (size_t)total * 4));
+            c->fsq_cache_cap = total;
+        }
+        ProfScope ps(c, "sample");
+        sample_fsq_kernel<<<(unsigned)((total + 255) / 256), 256, 0, c->stream>>>(fs, geom(c), L, c->d_fsq_cache);
+        NL_CHECK_LAUNCH();
+        c->fsq_cache_key[0] = L.sz; c->fsq_cache_key[1] = L.sy; c->fsq_cache_key[2] = L.sx;
+        c->fsq_cache_valid = 1;
+    }
+    fs.fsq_cache = c->d_fsq_cache;
+    return NL_OK;
+}
+
 extern "C" int nl_sample_gather(nl_ctx *c, int field, int64_t sz, int64_t sy, int64_t sx, float *out, int64_t cap,
                                 int64_t *n, char *err, size_t errlen) {
     NL_ENTER(c);
     Lattice L; FieldSrc fs; int rc;
     if ((rc = make_lattice(c, sz, sy, sx, L, err, errlen))) return rc;
     if ((rc = make_field(c, field, fs, err, errlen))) return rc;
+    if ((rc = use_fsq_cache(c, fs, L, err, errlen))) return rc;
     const i64 total = L.cz * L.cy * L.cx;
     if (n) *n = total;
     if (total == 0 || (!out && cap == 0)) return NL_OK;   // size query
@@ -616,6 +645,7 @@ extern "C" int nl_sample_minmax(nl_ctx *c, int field, int64_t sz, int64_t sy, in
     Lattice L; FieldSrc fs; int rc;
     if ((rc = make_lattice(c, sz, sy, sx, L, err, errlen))) return rc;
     if ((rc = make_field(c, field, fs, err, errlen))) return rc;
+    if ((rc = use_fsq_cache(c, fs, L, err, errlen))) return rc;
     const i64 total = L.cz * L.cy * L.cx;
     unsigned int *res = (unsigned int *)c->d_small;
     unsigned int *h = (unsigned int *)c->h_small;
@@ -644,6 +674,7 @@ extern "C" int nl_sample_hist(nl_ctx *c, int field, int64_t sz, int64_t sy, int6
     Lattice L; FieldSrc fs; int rc;
     if ((rc = make_lattice(c, sz, sy, sx, L, err, errlen))) return rc;
     if ((rc = make_field(c, field, fs, err, errlen))) return rc;
+    if ((rc = use_fsq_cache(c, fs, L, err, errlen))) return rc;
     const i64 total = L.cz * L.cy * L.cx;
     // d_small layout: [0, 32K) counts (u64 x nbins), [32K, 64K) edges (f32 x nbins+1)
     unsigned long long *d_counts = (unsigned long long *)c->d_small;
@@ -667,6 +698,7 @@ static int set_spacing(nl_ctx *c, const double spacing[3], char *err, size_t err
     if (!spacing) return nl_fail(err, errlen, NL_EINVAL, "spacing is NULL");
     if ((!c->two_d && c->gnz < 2) || c->ny < 2 || c->nx < 2)
         return nl_fail(err, errlen, NL_EINVAL, "Shape of array too small to calculate a numerical gradient, at least (edge_order + 1) elements are required.");
+    if (c->chk_spacing[0] != spacing[0] || c->chk_spacing[1] != spacing[1] || c->chk_spacing[2] != spacing[2]) c->fsq_cache_valid = 0;
     c->hz = (float)spacing[0]; c->hy = (float)spacing[1]; c->hx = (float)spacing[2];
     c->hz2 = (float)(2.0 * spacing[0]); c->hy2 = (float)(2.0 * spacing[1]); c->hx2 = (float)(2.0 * spacing[2]);
     if (!c->have_spacing || c->chk_spacing[0] != spacing[0] || c->chk_spacing[1] != spacing[1] || c->chk_spacing[2] != spacing[2]) {
@@ -954,6 +986,7 @@ extern "C" int nl_set_ndim(nl_ctx *c, int ndim, char *err, size_t errlen) {
     if (ndim != 2 && ndim != 3) return nl_fail(err, errlen, NL_EINVAL, "ndim must be 2 or 3");
     if (ndim == 2 && (c->nzl != 1 || c->gnz != 1)) return nl_fail(err, errlen, NL_EINVAL, "a 2-D context has exactly one plane");
     c->two_d = ndim == 2;
+    c->fsq_cache_valid = 0;
     return NL_OK;
 }
 
@@ -1150,6 +1183,7 @@ extern "C" int nl_planes_get(nl_ctx *c, int field, int64_t z0, int64_t z1, float
 extern "C" int nl_planes_put(nl_ctx *c, int field, int64_t z0, int64_t z1, const float *host, char *err, size_t errlen) {
     NL_ENTER(c);
     float *p = field_ptr(c, field);
+    c->fsq_cache_valid = 0;
     if (!p || !host || z0 < 0 || z1 > c->nzl || z0 >= z1) return nl_fail(err, errlen, NL_EINVAL, "nl_planes_put: bad field or plane range");
     const i64 plane = c->ny * c->nx;
     NL_HIP(hipMemcpyAsync(p + z0 * plane, host, (size_t)(z1 - z0) * plane * 4, hipMemcpyHostToDevice, c->stream));
@@ -1189,6 +1223,7 @@ extern "C" int nl_comm_init(nl_ctx *c, int world, int rank, const char *id128, c
 extern "C" int nl_halo_exchange(nl_ctx *c, int field, int64_t depth, char *err, size_t errlen) {
     NL_ENTER(c);
     if (!c->comm) return nl_fail(err, errlen, NL_ESTATE, "nl_halo_exchange before nl_comm_init");
+    c->fsq_cache_valid = 0;
     float *p = field_ptr(c, field);
     if (!p) return nl_fail(err, errlen, NL_EINVAL, "nl_halo_exchange: field %d has no volume", field);
     const i64 plane = c->ny * c->nx;

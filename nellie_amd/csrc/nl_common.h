@@ -48,6 +48,9 @@ struct nl_ctx {
     unsigned int *d_vq_count = nullptr;   // entries written per region
     int two_d = 0;                // the frame is a (Y, X) image (im_info.no_z): 2-D Hessian, eigenvalues, Frangi, opening
     float *d_2d[4] = {nullptr, nullptr, nullptr, nullptr};   // 2-D only: LoG scratch (intermediate, two terms, running maximum)
+    float *d_fsq_cache = nullptr;     // frob_sq at the lattice points of the current scale (NL_FIELD_FROB is sampled up to 4x)
+    i64 fsq_cache_cap = 0, fsq_cache_key[3] = {0, 0, 0};
+    int fsq_cache_valid = 0;
     float *gauss_ext = nullptr;   // current Gaussian volume when it is NOT one of f[0..2]: the resident float32 input itself,
                                   // until the first cascade step has written a volume of its own (saves the 8 B/voxel copy)
     int vq_chunks = 1;         // Z chunks (HM_ZCHUNK planes) one vesselness launch may cover
