@@ -254,9 +254,23 @@ class FramePipeline:
         """Keep the raw frame resident in HBM; `filter(None, ...)` then starts from device memory."""
         self.ctx.input_load(self._as_frame(frame))
 
-    def _threshold_from_field(self, fld, strides):
+    def _normalised_range(self, spec, max_abs):
+        """(min, max) of the positive NL_FIELD_FROB samples for the exact normalisation, derived from the range the
+        bracket round measured with max_abs := 1: x -> x / max_abs is monotone in float32, so min and max commute with
+        it.  None (measure it) unless the one-pass walk is still valid (no inf) and nothing underflows to 0."""
+        rng = getattr(self, "_raw_frob_range", None)
+        if not spec or rng is None:
+            return None
+        with np.errstate(all="ignore"):
+            mn, mx = rng[0] / np.float32(max_abs), rng[1] / np.float32(max_abs)
+        return (mn, mx) if (mn > 0 and np.isfinite(mx)) else None
+
+    def _threshold_from_field(self, fld, strides, known_range=None):
         """min(triangle, otsu) over the positive lattice samples of a device field, or None if none."""
-        mn, mx, npos = self._reduce_minmax(*self.ctx.sample_minmax(fld, strides))
+        if known_range is not None:
+            mn, mx, npos = known_range[0], known_range[1], 1
+        else:
+            mn, mx, npos = self._reduce_minmax(*self.ctx.sample_minmax(fld, strides))
         if npos == 0:
             return None
         edges = histogram_edges(mn, mx, 256)
@@ -269,9 +283,11 @@ class FramePipeline:
         (filtering.py:421-444), so the histogram threshold of sqrt(frob_sq) predicts sqrt(fsq_min) up to float32
         rounding -- unless the rounding moves the histogram argmax to another bin, which the bracket then misses."""
         self.ctx.set_frob_norm(1.0, 0.0)
+        self._raw_frob_range = None
         mn, mx, npos = self._reduce_minmax(*self.ctx.sample_minmax(FIELD_FROB, strides))
         if npos == 0 or not np.isfinite(mx):
             return None
+        self._raw_frob_range = (np.float32(mn), np.float32(mx))
         edges = histogram_edges(mn, mx, 256)
         counts = self._reduce_counts(self.ctx.sample_hist(FIELD_FROB, strides, edges))
         t = float(min_triangle_otsu(counts, edges)) * self._one_pass_test_scale / division
@@ -365,7 +381,7 @@ class FramePipeline:
                 nonempty = bool(max_frob > 0)
             else:
                 if p.frob_thresh is None:
-                    t = self._threshold_from_field(FIELD_FROB, strides)
+                    t = self._threshold_from_field(FIELD_FROB, strides, self._normalised_range(spec, max_abs))
                     thr = 0.0 if t is None else t                # filtering.py:433-439
                 else:
                     thr = float(p.frob_thresh)
