@@ -128,6 +128,12 @@ int nl_gauss_commit(nl_ctx *ctx, char *err, size_t errlen);
 int nl_sample_gather(nl_ctx *ctx, int field, int64_t sz, int64_t sy, int64_t sx,
                      float *out, int64_t cap, int64_t *n, char *err, size_t errlen);
 
+/* nl_sample_gather restricted to the positive samples, compacted on the device so that only they cross PCIe (every
+   consumer takes arr[arr > 0] first: filtering.py:357, 957-959).  Order unspecified; `cap` >= number of lattice
+   points; *n = number of positives written. */
+int nl_sample_gather_positive(nl_ctx *ctx, int field, int64_t sz, int64_t sy, int64_t sx,
+                              float *out, int64_t cap, int64_t *n, char *err, size_t errlen);
+
 /* min / max / count of the POSITIVE lattice samples (arr[arr > 0]; filtering.py:357 and the
    range=(min,max) of gpu_functions.py:31-35, 60-64).  npos == 0 leaves mn/mx untouched. */
 int nl_sample_minmax(nl_ctx *ctx, int field, int64_t sz, int64_t sy, int64_t sx,
@@ -267,6 +273,10 @@ int nl_label_intensity_mask(nl_ctx *ctx, const void *host_original, int dtype, d
 /* flat[offset::step] of a field (labelling.py:393, 412). */
 int nl_flat_sample_gather(nl_ctx *ctx, int field, int64_t offset, int64_t step,
                           float *out, int64_t cap, int64_t *n, char *err, size_t errlen);
+
+/* The same, positive samples only, compacted on the device (labelling.py:426-433); order unspecified. */
+int nl_flat_sample_gather_positive(nl_ctx *ctx, int field, int64_t offset, int64_t step, float *out, int64_t cap,
+                                   int64_t *n, char *err, size_t errlen);
 
 /* labelling.py:467-509 on the device:
      mask = has_thr ? frangi > thr : 0; binary_fill_holes (6-conn) if fill_holes;

@@ -639,6 +639,39 @@ extern "C" int nl_sample_gather(nl_ctx *c, int field, int64_t sz, int64_t sy, in
     return NL_OK;
 }
 
+// The positive samples of the same lattice, compacted on the device: only they cross PCIe (the consumers take
+// arr[arr > 0] first anyway: filtering.py:357, 957-959).  Order unspecified.  cap >= number of lattice points.
+extern "C" int nl_sample_gather_positive(nl_ctx *c, int field, int64_t sz, int64_t sy, int64_t sx, float *out, int64_t cap,
+                                         int64_t *n, char *err, size_t errlen) {
+    NL_ENTER(c);
+    Lattice L; FieldSrc fs; int rc;
+    if ((rc = make_lattice(c, sz, sy, sx, L, err, errlen))) return rc;
+    if ((rc = make_field(c, field, fs, err, errlen))) return rc;
+    if ((rc = use_fsq_cache(c, fs, L, err, errlen))) return rc;
+    const i64 total = L.cz * L.cy * L.cx;
+    if (n) *n = 0;
+    if (total == 0) return NL_OK;
+    if (!out || cap < total) return nl_fail(err, errlen, NL_EINVAL, "output capacity %lld < %lld lattice points", (i64)cap, total);
+    if (total > c->n) return nl_fail(err, errlen, NL_EINVAL, "lattice larger than the volume");
+    float *stage = c->f[(c->i_gauss + 1) % 3];
+    unsigned int *d_n = (unsigned int *)c->d_small;
+    NL_HIP(hipMemsetAsync(d_n, 0, 4, c->stream));
+    {
+        ProfScope ps(c, "sample");
+        sample_gather_pos_kernel<<<(unsigned)((total + 255) / 256), 256, 0, c->stream>>>(fs, geom(c), L, stage, d_n);
+        NL_CHECK_LAUNCH();
+    }
+    NL_HIP(hipMemcpyAsync(c->h_small, d_n, 4, hipMemcpyDeviceToHost, c->stream));
+    NL_HIP(hipStreamSynchronize(c->stream));
+    const i64 k = (i64)(*(unsigned int *)c->h_small);
+    if (k) {
+        NL_HIP(hipMemcpyAsync(out, stage, (size_t)k * 4, hipMemcpyDeviceToHost, c->stream));
+        NL_HIP(hipStreamSynchronize(c->stream));
+    }
+    if (n) *n = k;
+    return NL_OK;
+}
+
 extern "C" int nl_sample_minmax(nl_ctx *c, int field, int64_t sz, int64_t sy, int64_t sx, float *mn, float *mx,
                                 int64_t *npos, char *err, size_t errlen) {
     NL_ENTER(c);
@@ -1330,6 +1363,43 @@ extern "C" int nl_flat_sample_gather(nl_ctx *c, int field, int64_t offset, int64
     }
     NL_HIP(hipMemcpyAsync(out, stage, (size_t)count * 4, hipMemcpyDeviceToHost, c->stream));
     NL_HIP(hipStreamSynchronize(c->stream));
+    return NL_OK;
+}
+
+// nl_flat_sample_gather restricted to the positive samples, compacted on the device (labelling.py:426-433 takes
+// values[values > 0]); order unspecified.  cap >= the count nl_flat_sample_gather reports.
+extern "C" int nl_flat_sample_gather_positive(nl_ctx *c, int field, int64_t offset, int64_t step, float *out, int64_t cap,
+                                              int64_t *n, char *err, size_t errlen) {
+    NL_ENTER(c);
+    if (step < 1 || offset < 0) return nl_fail(err, errlen, NL_EINVAL, "bad offset/step");
+    if (field != NL_FIELD_FRANGI && field != NL_FIELD_GAUSS) return nl_fail(err, errlen, NL_EINVAL, "flat sampling supports GAUSS/FRANGI");
+    const i64 plane = c->ny * c->nx;
+    const i64 g_begin = (c->gz0 + c->own_lo) * plane, g_end = (c->gz0 + c->own_hi) * plane;
+    i64 k0 = 0;
+    if (g_begin > offset) k0 = (g_begin - offset + step - 1) / step;
+    i64 k1 = (g_end > offset) ? (g_end - offset + step - 1) / step : 0;
+    const i64 count = k1 > k0 ? k1 - k0 : 0;
+    if (n) *n = 0;
+    if (count == 0) return NL_OK;
+    if (!out || cap < count) return nl_fail(err, errlen, NL_EINVAL, "output capacity %lld < %lld samples", (i64)cap, count);
+    const float *src = (field == NL_FIELD_FRANGI) ? c->f[c->i_vmax] : gauss_cur(c);
+    float *stage = nullptr;
+    for (int k = 0; k < 3; ++k) if (k != c->i_gauss && c->f[k] != src) { stage = c->f[k]; break; }
+    unsigned int *d_n = (unsigned int *)c->d_small;
+    NL_HIP(hipMemsetAsync(d_n, 0, 4, c->stream));
+    {
+        ProfScope ps(c, "sample");
+        flat_gather_pos_kernel<<<(unsigned)((count + 255) / 256), 256, 0, c->stream>>>(src, -c->gz0 * plane, offset + k0 * step, step, count, stage, d_n);
+        NL_CHECK_LAUNCH();
+    }
+    NL_HIP(hipMemcpyAsync(c->h_small, d_n, 4, hipMemcpyDeviceToHost, c->stream));
+    NL_HIP(hipStreamSynchronize(c->stream));
+    const i64 k = (i64)(*(unsigned int *)c->h_small);
+    if (k) {
+        NL_HIP(hipMemcpyAsync(out, stage, (size_t)k * 4, hipMemcpyDeviceToHost, c->stream));
+        NL_HIP(hipStreamSynchronize(c->stream));
+    }
+    if (n) *n = k;
     return NL_OK;
 }
 

@@ -45,6 +45,7 @@ _PROTOS = {
     "nl_gauss_step_ahead": [_p, _p, _int, _p, _int, _p, _int, _i64, _i64],
     "nl_gauss_commit": [_p],
     "nl_sample_gather": [_p, _int, _i64, _i64, _i64, _p, _i64, C.POINTER(_i64)],
+    "nl_sample_gather_positive": [_p, _int, _i64, _i64, _i64, _p, _i64, C.POINTER(_i64)],
     "nl_sample_minmax": [_p, _int, _i64, _i64, _i64, C.POINTER(_f32), C.POINTER(_f32), C.POINTER(_i64)],
     "nl_sample_hist": [_p, _int, _i64, _i64, _i64, _p, _int, _p],
     "nl_hessian_stats": [_p, C.POINTER(_f64), C.POINTER(_f32), C.POINTER(_f32), C.POINTER(_int)],
@@ -72,6 +73,7 @@ _PROTOS = {
     "nl_label_load_frangi": [_p, _p, _i64, _i64],
     "nl_label_intensity_mask": [_p, _p, _int, _f64],
     "nl_flat_sample_gather": [_p, _int, _i64, _i64, _p, _i64, C.POINTER(_i64)],
+    "nl_flat_sample_gather_positive": [_p, _int, _i64, _i64, _p, _i64, C.POINTER(_i64)],
     "nl_label_run": [_p, _int, _f32, _i64, _int, C.POINTER(_i64)],
     "nl_label_store": [_p, _p, _i64, _i64],
     "nl_label_pack": [_p, _int, _f32],
@@ -327,6 +329,16 @@ class Context:
             self._call("nl_sample_gather", field, sz, sy, sx, _ptr(out), out.size, C.byref(n))
         return out
 
+    def sample_gather_positive(self, field, strides):
+        """The positive lattice samples (device-side compaction, unspecified order)."""
+        sz, sy, sx = (int(s) for s in strides)
+        n = _i64(0)
+        self._call("nl_sample_gather", field, sz, sy, sx, None, 0, C.byref(n))        # lattice size
+        out = np.empty(int(n.value), dtype=np.float32)
+        if out.size:
+            self._call("nl_sample_gather_positive", field, sz, sy, sx, _ptr(out), out.size, C.byref(n))
+        return out[:int(n.value)]
+
     def sample_minmax(self, field, strides):
         sz, sy, sx = (int(s) for s in strides)
         mn, mx, n = _f32(0), _f32(0), _i64(0)
@@ -499,6 +511,14 @@ class Context:
         if out.size:
             self._call("nl_flat_sample_gather", field, int(offset), int(step), _ptr(out), out.size, C.byref(n))
         return out
+
+    def flat_sample_gather_positive(self, field, offset, step):
+        n = _i64(0)
+        self._call("nl_flat_sample_gather", field, int(offset), int(step), None, 0, C.byref(n))
+        out = np.empty(int(n.value), dtype=np.float32)
+        if out.size:
+            self._call("nl_flat_sample_gather_positive", field, int(offset), int(step), _ptr(out), out.size, C.byref(n))
+        return out[:int(n.value)]
 
     def label_run(self, thr, min_area, fill_holes=True) -> int:
         n = _i64(0)

@@ -220,6 +220,22 @@ class FramePipeline:
             return (1,) + tuple(sample_strides(self.shape[1:], max_samples))
         return sample_strides(self.shape, max_samples)
 
+    def _positive_lattice_samples(self, fld, strides):
+        """arr[::sz, ::sy, ::sx][... > 0] of a device field (filtering.py:348-363), compacted on the device."""
+        f = getattr(self.ctx, "sample_gather_positive", None)
+        if f is not None:
+            return self._gather(f(fld, strides))
+        sample = self._gather(self.ctx.sample_gather(fld, strides))
+        return sample[sample > 0]
+
+    def _positive_flat_samples(self, fld, offset, step):
+        """flat[offset::step][... > 0] (labelling.py:418-433), compacted on the device."""
+        f = getattr(self.ctx, "flat_sample_gather_positive", None)
+        if f is not None:
+            return self._gather(f(fld, offset, step))
+        sample = self._gather(self.ctx.flat_sample_gather(fld, offset, step))
+        return sample[sample > 0]
+
     def _as_frame(self, a):
         a = np.asarray(a)
         return a[None] if (self.two_d and a.ndim == 2) else a
@@ -419,8 +435,7 @@ class FramePipeline:
     def mask_volume(self, p: FilterParams):
         """filtering.py:952-967 on the device-resident frame."""
         strides = self._strides(int(p.max_threshold_samples))
-        sample = self._gather(self.ctx.sample_gather(FIELD_FRANGI, strides))
-        positive = sample[sample > 0]
+        positive = self._positive_lattice_samples(FIELD_FRANGI, strides)
         if positive.size == 0:
             return None
         thr = np.percentile(positive, 1)
@@ -442,8 +457,7 @@ class FramePipeline:
             self.compute_vesselness(frame, p, mask=mask, finish=False)
             if any(not sc.skipped for sc in self.trace.scales):
                 strides = self._strides(int(p.max_threshold_samples))
-                sample = self.ctx.sample_gather(FIELD_VESSELNESS, strides)
-                positive = sample[sample > 0]
+                positive = self._positive_lattice_samples(FIELD_VESSELNESS, strides)
                 if positive.size > 0:
                     thr = np.percentile(positive, 1)
                     self.trace.percentile_thr = float(thr)
@@ -475,8 +489,7 @@ class FramePipeline:
         values = np.zeros(0, np.float32)
         found = False
         for offset in offsets:
-            sample = self._gather(self.ctx.flat_sample_gather(FIELD_FRANGI, offset, step))
-            values = sample[sample > 0]
+            values = self._positive_flat_samples(FIELD_FRANGI, offset, step)
             if values.size > 0 or step == 1:
                 found = True
                 break
