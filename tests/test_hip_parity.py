@@ -9,6 +9,8 @@ unattainable for 1-exp(-x) at small x).
 """
 import zlib
 
+import os
+
 import numpy as np
 import pytest
 
@@ -135,6 +137,32 @@ def test_one_pass_vesselness_equals_two_pass(shape, aniso, hip):
         for a, b in zip(t1.scales, t2.scales):
             assert (a.gamma, a.max_abs, a.frob_thr, a.mask_count, a.skipped) == (b.gamma, b.max_abs, b.frob_thr, b.mask_count, b.skipped)
             assert a.one_pass == (mode in ("one", "ahead") and not a.skipped)
+
+
+def test_two_pass_vesselness_in_several_launches(hip):
+    """The two-pass path launches the Hessian kernel per block of Z chunks when the eigen queue is small
+    (NELLIE_VQ_CAP is read once per process, hence the child processes): same bits as one launch."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, zlib, numpy as np; sys.path.insert(0, %r)\n"
+        "from nellie_amd import pipeline as pl\n"
+        "from nellie_amd.synthetic import ISO_01, make_volume\n"
+        "shape = (150, 40, 70); vol = make_volume(shape, 77)\n"
+        "pipe = pl.FramePipeline(shape); pipe.one_pass = False\n"
+        "pipe.compute_vesselness(vol, pl.FilterParams(dim_res=ISO_01))\n"
+        "print(zlib.crc32(pipe.download_frangi().tobytes()), [s.mask_count for s in pipe.trace.scales])\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for cap in ("", "200000"):          # default (one launch) / two Z chunks per launch at most
+        env = dict(os.environ)
+        env.pop("NELLIE_VQ_CAP", None)
+        if cap:
+            env["NELLIE_VQ_CAP"] = cap
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout.strip().splitlines()[-1])
+    assert outs[0] == outs[1]
 
 
 @pytest.mark.parametrize("name", [n for n in FILTER_CASES if n.startswith(("iso", "aniso", "odd", "u16"))])
