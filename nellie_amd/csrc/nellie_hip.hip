@@ -63,6 +63,16 @@ static inline unsigned int grid1d(i64 n, int block = 256, i64 cap = 256 * 32) {
     return (unsigned int)g;
 }
 
+// Zeroing a few counter words between kernels with a one-wave kernel of our own instead of the runtime's fill path
+// (~35 of these per frame).  `bytes` is a multiple of 4.
+__global__ void zero_words_kernel(unsigned int *p, int n) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0u;
+}
+static inline hipError_t zero_small(void *p, size_t bytes, hipStream_t st) {
+    zero_words_kernel<<<1, 256, 0, st>>>((unsigned int *)p, (int)(bytes / 4));
+    return hipGetLastError();
+}
+
 static float *gauss_cur(const nl_ctx *c) { return c->gauss_ext ? c->gauss_ext : c->f[c->i_gauss]; }
 static VolGeom geom(const nl_ctx *c) { return VolGeom{c->nzl, c->ny, c->nx, c->gz0, c->gnz}; }
 // tile height of the Hessian kernels (experiment knob; 8 -> 512-thread workgroups, 16 -> 1024)
@@ -83,7 +93,7 @@ static HessDv<false> hessdv_exact(const nl_ctx *c) {
 static int check_fast_div(nl_ctx *c, char *err, size_t errlen) {
     const float ds[6] = {c->hz, c->hy, c->hx, c->hz2, c->hy2, c->hx2};
     unsigned int *bad = (unsigned int *)c->d_small + 64;
-    NL_HIP(hipMemsetAsync(bad, 0, 6 * 4, c->stream));
+    NL_HIP(zero_small(bad, 6 * 4, c->stream));
     for (int k = 0; k < 6; ++k) {
         const Dv<true> dv = dv_fast(ds[k]);
         divcheck_kernel<<<(1u << 23) / 256, 256, 0, c->stream>>>(dv.d, dv.y, bad + k);
@@ -655,7 +665,7 @@ extern "C" int nl_sample_gather_positive(nl_ctx *c, int field, int64_t sz, int64
     if (total > c->n) return nl_fail(err, errlen, NL_EINVAL, "lattice larger than the volume");
     float *stage = c->f[(c->i_gauss + 1) % 3];
     unsigned int *d_n = (unsigned int *)c->d_small;
-    NL_HIP(hipMemsetAsync(d_n, 0, 4, c->stream));
+    NL_HIP(zero_small(d_n, 4, c->stream));
     {
         ProfScope ps(c, "sample");
         sample_gather_pos_kernel<<<(unsigned)((total + 255) / 256), 256, 0, c->stream>>>(fs, geom(c), L, stage, d_n);
@@ -712,7 +722,7 @@ extern "C" int nl_sample_hist(nl_ctx *c, int field, int64_t sz, int64_t sy, int6
     // d_small layout: [0, 32K) counts (u64 x nbins), [32K, 64K) edges (f32 x nbins+1)
     unsigned long long *d_counts = (unsigned long long *)c->d_small;
     float *d_edges = (float *)((char *)c->d_small + (1 << 15));
-    NL_HIP(hipMemsetAsync(d_counts, 0, (size_t)nbins * 8, c->stream));
+    NL_HIP(zero_small(d_counts, (size_t)nbins * 8, c->stream));
     memcpy((char *)c->h_small + (1 << 15), edges, (size_t)(nbins + 1) * 4);
     NL_HIP(hipMemcpyAsync(d_edges, (char *)c->h_small + (1 << 15), (size_t)(nbins + 1) * 4, hipMemcpyHostToDevice, c->stream));
     if (total > 0) {
@@ -755,7 +765,7 @@ extern "C" int nl_hessian_stats(nl_ctx *c, const double spacing[3], float *max_a
     c->spec_valid = 0;
     if (c->two_d) {
         unsigned int *res2 = (unsigned int *)c->d_small;
-        NL_HIP(hipMemsetAsync(res2, 0, 16, c->stream));
+        NL_HIP(zero_small(res2, 16, c->stream));
         {
             ProfScope ps(c, "hessian_stats");
             hessian2d_stats_kernel<<<grid1d(c->n), 256, 0, c->stream>>>(gauss_cur(c), geom(c), hessp(c), res2);
@@ -770,7 +780,7 @@ extern "C" int nl_hessian_stats(nl_ctx *c, const double spacing[3], float *max_a
         return NL_OK;
     }
     unsigned int *res = (unsigned int *)c->d_small;
-    NL_HIP(hipMemsetAsync(res, 0, 16, c->stream));
+    NL_HIP(zero_small(res, 16, c->stream));
     {
         ProfScope ps(c, "hessian_stats");
         const int ntx = (int)((c->nx + HM_TX - 1) / HM_TX), nty = (int)((c->ny + 15) / 16);
@@ -849,7 +859,7 @@ extern "C" int nl_vesselness_spec(nl_ctx *c, const double spacing[3], float fsq_
     { int rcs = set_spacing(c, spacing, err, errlen); if (rcs) return rcs; }
     unsigned long long *d_cnt = (unsigned long long *)c->d_small;
     unsigned int *res = (unsigned int *)c->d_small + 16;
-    NL_HIP(hipMemsetAsync(c->d_small, 0, 128, c->stream));
+    NL_HIP(zero_small(c->d_small, 128, c->stream));
     VessP vp{};
     vp.cnt_lo = (int)c->own_lo; vp.cnt_hi = (int)c->own_hi;
     vp.have_prev = c->mask_slots_used > 0;
@@ -918,7 +928,7 @@ extern "C" int nl_vesselness_resolve(nl_ctx *c, float gamma_sq, float alpha_sq, 
     unsigned long long *d_cnt = (unsigned long long *)((char *)c->d_small + (48 << 10));
     NL_HIP(hipEventRecord(c->ev_main, c->stream));
     NL_HIP(hipStreamWaitEvent(c->side, c->ev_main, 0));
-    NL_HIP(hipMemsetAsync(d_cnt, 0, 8, c->side));
+    NL_HIP(zero_small(d_cnt, 8, c->side));
     vp.qcap = HM_SPEC_CAP;
     vp.idx_lo = (c->own_lo - z0) * plane; vp.idx_hi = (c->own_hi - z0) * plane;
     {
@@ -954,7 +964,7 @@ extern "C" int nl_vesselness_step(nl_ctx *c, float gamma_sq, float alpha_sq, flo
     if (!c->have_spacing) return nl_fail(err, errlen, NL_ESTATE, "nl_vesselness_step before nl_hessian_stats");
     NL_JOIN_SIDE(c);
     unsigned long long *d_cnt = (unsigned long long *)c->d_small;
-    NL_HIP(hipMemsetAsync(d_cnt, 0, 8, c->stream));
+    NL_HIP(zero_small(d_cnt, 8, c->stream));
     VessP vp = make_vessp(c, gamma_sq, alpha_sq, beta_sq, use_thr, thr);
     vp.qcap = HM_REGION;
     c->spec_valid = 0;
@@ -1064,7 +1074,7 @@ extern "C" int nl_log2d_finish(nl_ctx *c, int64_t *n_positive, char *err, size_t
     if (!c->two_d || !c->d_2d[3]) return nl_fail(err, errlen, NL_ESTATE, "nl_log2d_finish before nl_log2d_step");
     unsigned int *res = (unsigned int *)c->d_small;
     unsigned long long *d_pos = (unsigned long long *)c->d_small + 2;
-    NL_HIP(hipMemsetAsync(res, 0, 32, c->stream));
+    NL_HIP(zero_small(res, 32, c->stream));
     ProfScope ps(c, "log2d");
     log2d_clip_max_kernel<<<grid1d(c->n), 256, 0, c->stream>>>(c->d_2d[3], c->n, res);
     NL_CHECK_LAUNCH();
@@ -1087,7 +1097,7 @@ extern "C" int nl_filter_finish(nl_ctx *c, int64_t z0, int64_t z1, int64_t *n_po
     if (z0 < 0 || z1 > c->nzl || z0 >= z1) return nl_fail(err, errlen, NL_EINVAL, "bad plane range [%lld,%lld)", (i64)z0, (i64)z1);
     NL_JOIN_SIDE(c);
     unsigned long long *d_cnt = (unsigned long long *)c->d_small;
-    NL_HIP(hipMemsetAsync(d_cnt, 0, 8, c->stream));
+    NL_HIP(zero_small(d_cnt, 8, c->stream));
     const i64 plane = c->ny * c->nx;
     if (c->mask_slots_used == 0)       // every scale was skipped: vesselness was never written
         NL_HIP(hipMemsetAsync(c->f[c->i_vmax] + z0 * plane, 0, (size_t)(z1 - z0) * plane * 4, c->stream));
@@ -1146,7 +1156,7 @@ extern "C" int nl_mask_volume_fused(nl_ctx *c, float thr, int64_t *n_positive, c
     int dst = -1;
     for (int k = 0; k < 3; ++k) if (k != c->i_gauss) { dst = k; break; }
     unsigned long long *d_cnt = (unsigned long long *)c->d_small;
-    NL_HIP(hipMemsetAsync(d_cnt, 0, 8, c->stream));
+    NL_HIP(zero_small(d_cnt, 8, c->stream));
     {
         ProfScope ps(c, "mask_volume");
         const int wpr = (int)((c->nx + 63) / 64);
@@ -1386,7 +1396,7 @@ extern "C" int nl_flat_sample_gather_positive(nl_ctx *c, int field, int64_t offs
     float *stage = nullptr;
     for (int k = 0; k < 3; ++k) if (k != c->i_gauss && c->f[k] != src) { stage = c->f[k]; break; }
     unsigned int *d_n = (unsigned int *)c->d_small;
-    NL_HIP(hipMemsetAsync(d_n, 0, 4, c->stream));
+    NL_HIP(zero_small(d_n, 4, c->stream));
     {
         ProfScope ps(c, "sample");
         flat_gather_pos_kernel<<<(unsigned)((count + 255) / 256), 256, 0, c->stream>>>(src, -c->gz0 * plane, offset + k0 * step, step, count, stage, d_n);
@@ -1508,7 +1518,7 @@ template <int CONN>
 static int build_components(nl_ctx *c, const LabelGeo &g, const unsigned long long *bits, int invert, RunSet &rs, i64 cap,
                             bool *overflow, char *err, size_t errlen) {
     unsigned int *counts = g.rows, *row_off = g.rows + (g.nrows + 2);
-    NL_HIP(hipMemsetAsync(counts + g.nrows, 0, 4, c->stream));
+    NL_HIP(zero_small(counts + g.nrows, 4, c->stream));
     rl_count_kernel<<<(unsigned)((g.nrows + 255) / 256), 256, 0, c->stream>>>(bits, invert, counts, g.nrows, g.wpr, (int)g.nx);
     NL_CHECK_LAUNCH();
     int rc = scan_excl_u32(c, counts, row_off, g.nrows + 1, err, errlen);
