@@ -897,6 +897,7 @@ extern "C" int nl_vesselness_spec(nl_ctx *c, const double spacing[3], float fsq_
     if (overflow) *overflow = (int)h[3];
     c->spec_lo = fsq_lo; c->spec_hi = fsq_hi; c->spec_z0 = z0; c->spec_z1 = z1;
     c->spec_valid = (h[2] == 0 && h[3] == 0) ? 1 : 0;
+    c->last_spec_overflow = (int)h[3];
     return NL_OK;
 }
 
@@ -1833,6 +1834,7 @@ extern "C" int nl_ctx_info(nl_ctx *c, const char *key, double *value) {
     else if (!strcmp(key, "hessian_tile_rows")) *value = hm_ty();
     else if (!strcmp(key, "vesselness_one_pass")) *value = c->spec_ok;
     else if (!strcmp(key, "last_fsq_min")) *value = c->last_fsq_min;
+    else if (!strcmp(key, "last_spec_overflow")) *value = c->last_spec_overflow;
     else if (!strcmp(key, "device_bytes")) *value = (double)nl_ctx_bytes(c->nzl, c->ny, c->nx);
     else return NL_EINVAL;
     return NL_OK;

@@ -65,6 +65,7 @@ struct nl_ctx {
     hipEvent_t ev_ahead = nullptr;       // a cascade step enqueued ahead on `side` (nl_gauss_step_ahead)
     int ahead_pending = 0, ahead_gauss = 0;
     int side_pending = 0;                // work on `side` the main stream has not been ordered after yet
+    int last_spec_overflow = 0;          // the last one-pass walk overflowed a queue region (diagnostics)
     float last_fsq_min = 0;    // the exact mask threshold of the last scale (diagnostics)
     void *d_blk = nullptr;     // per-block partials for scans
     unsigned int *d_rows = nullptr;   // per-row run counts and offsets (Label on runs)

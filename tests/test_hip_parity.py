@@ -139,6 +139,31 @@ def test_one_pass_vesselness_equals_two_pass(shape, aniso, hip):
             assert a.one_pass == (mode in ("one", "ahead") and not a.skipped)
 
 
+def test_one_pass_queue_overflow_falls_back(hip):
+    """A dense texture masks > 50 % of every 64x64-voxel wave region: the one-pass walk reports the overflow of its
+    queue regions and the scale is redone the two-pass way -- same bits."""
+    from nellie_amd.pipeline import FilterParams, FramePipeline
+    from nellie_amd.synthetic import ISO_01
+    shape = (64, 64, 128)
+    z, y, x = np.mgrid[:shape[0], :shape[1], :shape[2]]
+    vol = np.random.default_rng(3).normal(100, 1, shape).astype(np.float32)
+    vol += (50.0 * (np.sin(x * 0.9) * np.sin(y * 0.9) * np.sin(z * 0.9))).astype(np.float32)
+    out = {}
+    for mode in (False, True):
+        pipe = FramePipeline(shape)
+        pipe.one_pass = mode
+        overflow = []
+        spec = pipe.ctx.vesselness_spec
+        pipe.ctx.vesselness_spec = lambda *a, **k: (lambda r: (overflow.append(bool(r[3])), r)[1])(spec(*a, **k))
+        pipe.compute_vesselness(vol, FilterParams(dim_res=ISO_01))
+        out[mode] = (pipe.download_frangi(), [s.mask_count for s in pipe.trace.scales], [s.one_pass for s in pipe.trace.scales], overflow)
+        pipe.close()
+    assert any(out[True][3]), "the texture was meant to overflow a queue region"
+    assert [h for h, o in zip(out[True][2], out[True][3]) if o] == [False] * sum(out[True][3])
+    assert out[True][1] == out[False][1]
+    assert np.array_equal(out[True][0].view(np.uint32), out[False][0].view(np.uint32))
+
+
 def test_two_pass_vesselness_in_several_launches(hip):
     """The two-pass path launches the Hessian kernel per block of Z chunks when the eigen queue is small
     (NELLIE_VQ_CAP is read once per process, hence the child processes): same bits as one launch."""
