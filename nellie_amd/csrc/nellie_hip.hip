@@ -1520,7 +1520,8 @@ static int build_components(nl_ctx *c, const LabelGeo &g, const unsigned long lo
                             bool *overflow, char *err, size_t errlen) {
     unsigned int *counts = g.rows, *row_off = g.rows + (g.nrows + 2);
     NL_HIP(zero_small(counts + g.nrows, 4, c->stream));
-    rl_count_kernel<<<(unsigned)((g.nrows + 255) / 256), 256, 0, c->stream>>>(bits, invert, counts, g.nrows, g.wpr, (int)g.nx);
+    if (g.wpr <= 64) rl_count_wave_kernel<<<(unsigned)((g.nrows + 3) / 4), 256, 0, c->stream>>>(bits, invert, counts, g.nrows, g.wpr, (int)g.nx);
+    else rl_count_kernel<<<(unsigned)((g.nrows + 255) / 256), 256, 0, c->stream>>>(bits, invert, counts, g.nrows, g.wpr, (int)g.nx);
     NL_CHECK_LAUNCH();
     int rc = scan_excl_u32(c, counts, row_off, g.nrows + 1, err, errlen);
     if (rc) return rc;
