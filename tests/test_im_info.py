@@ -75,3 +75,28 @@ def test_rejects_what_cannot_be_mapped(tmp_path):
         ome_tiff.read_layout(str(p))
     with pytest.raises(ValueError):
         ome_tiff.create(str(tmp_path / "c.ome.tif"), (1, 1, 2, 2), np.complex64)
+
+
+def test_files_read_back_with_an_independent_tiff_reader(tmp_path):
+    """Pillow's TIFF reader (libtiff-style parser, shares no code with ours) sees every plane, the pixel type, the
+    pixel data and the OME-XML ImageDescription of the BigTIFF files this package writes."""
+    PIL = pytest.importorskip("PIL")
+    from PIL import Image, ImageSequence
+    import xml.etree.ElementTree as ET
+    from nellie_amd.im_info import ome_tiff
+    rng = np.random.default_rng(0)
+    for dtype, mode in ((np.float32, "F"), (np.int32, "I"), (np.uint16, "I;16")):
+        a = (rng.random((2, 3, 20, 24)) * 1000).astype(dtype)
+        path = str(tmp_path / f"t_{np.dtype(dtype).name}.ome.tif")
+        ome_tiff.create(path, a.shape, dtype, dim_res={"X": 0.1, "Y": 0.2, "Z": 0.3, "T": 1.5}, description="d", data=a)
+        with Image.open(path) as im:
+            assert im.format == "TIFF" and im.n_frames == 6 and im.size == (24, 20) and im.mode == mode
+            got = np.stack([np.array(fr) for fr in ImageSequence.Iterator(im)]).reshape(a.shape)
+            assert got.dtype == np.dtype(dtype) and np.array_equal(got, a)
+            im.seek(0)
+            xml = im.tag_v2[270]
+        root = ET.fromstring(xml)                                  # well-formed
+        px = [e for e in root.iter() if e.tag.endswith("Pixels")][0]
+        assert (px.get("SizeX"), px.get("SizeY"), px.get("SizeZ"), px.get("SizeT")) == ("24", "20", "3", "2")
+        assert float(px.get("PhysicalSizeX")) == 0.1 and float(px.get("PhysicalSizeY")) == 0.2
+        assert float(px.get("PhysicalSizeZ")) == 0.3 and float(px.get("TimeIncrement")) == 1.5
