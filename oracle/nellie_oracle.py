@@ -25,6 +25,11 @@ its published algorithm:
                               the float64 trigonometric closed form rounded to float32.
   * numpy.percentile          method='linear'.
   * scipy.ndimage.binary_opening / binary_fill_holes / label / uniform_filter.
+  * scipy.ndimage.gaussian_laplace (2-D images only: `_gaussian_kernel1d` of order 2, truncate 4.0,
+                              one second-derivative pass per axis, summed in float32).
+
+Both dimensionalities of the stage are covered: (Z, Y, X) volumes and (Y, X) images (im_info.no_z: 2x2
+closed-form eigenvalues, two-eigenvalue Frangi, the multi-scale LoG blob response, 4-connected opening).
 
 Pinning (parity is PINNED): the reference's own tests hold no vector for Filter
 and two toy cases for Label (tests/test_labelling.py:25-77).  The oracle is
