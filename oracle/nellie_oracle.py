@@ -1022,6 +1022,110 @@ def label_frame_2d(frangi, dim_res, min_radius_um=0.25, max_samples=1_000_000, n
     return (labels, thr) if return_thr else labels
 
 
+# =============================================================================
+# Markers (nellie/segmentation/mocap_marking.py) -- the stage after Label
+# =============================================================================
+def marker_sigmas(dim_res, min_radius_um=0.20, max_radius_um=1, num_sigma=5):
+    """mocap_marking.py:121-134, 329-362."""
+    x_res = dim_res.get("X") or 1.0
+    min_r = max(min_radius_um, float(x_res)) / float(x_res)
+    max_r = max_radius_um / float(x_res)
+    sigma_min, sigma_max = min_r / 2.0, max_r / 3.0
+    rng = sigma_max - sigma_min
+    if rng <= 0:
+        return [sigma_min], max_r
+    step = max(0.2, rng / max(num_sigma, 1))
+    sig = list(np.arange(sigma_min, sigma_max, step))
+    return (sig if len(sig) else [sigma_min]), max_r
+
+
+def distance_transform_edt_exact(mask):
+    """scipy.ndimage.distance_transform_edt(mask) (unit sampling): Euclidean distance of every True voxel to the
+    nearest False voxel, sqrt of the exact integer squared distance in float64; 0 on False voxels.  Separable
+    min-plus passes; a volume without any False voxel is outside what the stage feeds it."""
+    m = np.asarray(mask, dtype=bool)
+    big = np.int64(1) << 40
+    d2 = np.where(m, big, np.int64(0))
+    for axis in range(m.ndim):
+        n = m.shape[axis]
+        a = np.moveaxis(d2, axis, 0)
+        out = np.full_like(a, big)
+        k = np.arange(n, dtype=np.int64)
+        for i in range(n):                                  # out[i] = min_j a[j] + (i-j)^2
+            w = ((k - i) ** 2).reshape((n,) + (1,) * (a.ndim - 1))
+            out[i] = np.min(a + w, axis=0)
+        d2 = np.moveaxis(out, 0, axis)
+    return np.sqrt(d2.astype(np.float64))
+
+
+def marker_distance_and_border(mask, max_radius_px):
+    """mocap_marking.py:419-450."""
+    border = binary_dilation6(mask) ^ mask if mask.ndim == 3 else None
+    dist = distance_transform_edt_exact(mask).astype(np.float32)
+    np.minimum(dist, max_radius_px * 2.0, out=dist)
+    return dist, border
+
+
+def maximum_filter_nearest(a, size):
+    """scipy.ndimage.maximum_filter(a, size=size, mode='nearest'): separable running maximum, edge replicated."""
+    r = size // 2
+    out = a
+    for axis in range(a.ndim):
+        p = np.pad(out, [(r, r) if ax == axis else (0, 0) for ax in range(a.ndim)], mode="edge")
+        n = out.shape[axis]
+        acc = None
+        for k in range(size):
+            sl = [slice(None)] * a.ndim
+            sl[axis] = slice(k, k + n)
+            acc = p[tuple(sl)] if acc is None else np.maximum(acc, p[tuple(sl)])
+        out = acc
+    return out
+
+
+def marker_local_max_peaks(use_im, mask, distance_im, sigmas, z_ratio_):
+    """mocap_marking.py:452-511: multi-scale -LoG * sigma^2, local maxima, best response across scales."""
+    valid = mask & (distance_im > 0)
+    best = np.zeros_like(use_im, dtype=np.float32)
+    peak = np.zeros(use_im.shape, dtype=bool)
+    for s in sigmas:
+        sv = float(s)
+        vec = (sv / z_ratio_, sv, sv) if use_im.ndim == 3 else (sv, sv)
+        log_resp = -gaussian_laplace_f32(use_im, vec)
+        log_resp = (log_resp * (sv ** 2)).astype(np.float32, copy=False)
+        log_resp[log_resp < 0] = 0
+        local_max = log_resp == maximum_filter_nearest(log_resp, 3)
+        local_max &= valid
+        better = local_max & (log_resp > best)
+        peak[better] = True
+        best[better] = log_resp[better]
+    return np.argwhere(peak)
+
+
+def marker_remove_close_peaks(coords, intensity_im, peak_min_distance=2):
+    """mocap_marking.py:569-606."""
+    if coords.size == 0:
+        return coords
+    score = np.zeros_like(intensity_im, dtype=np.float32)
+    score[tuple(coords.T)] = intensity_im[tuple(coords.T)]
+    mx = maximum_filter_nearest(score, 2 * int(peak_min_distance) + 1)
+    return np.argwhere((score == mx) & (score > 0))
+
+
+def markers_frame(intensity, labels, dim_res, min_radius_um=0.20, max_radius_um=1, num_sigma=5, peak_min_distance=2):
+    """mocap_marking.py:648-703 (use_im='distance'), 3-D: (marker uint8, distance float32, border uint8)."""
+    mask = np.asarray(labels) > 0
+    if not mask.any():
+        return (np.zeros(mask.shape, np.uint8), np.zeros(mask.shape, np.float32), np.zeros(mask.shape, np.uint8))
+    sigmas, max_r = marker_sigmas(dim_res, min_radius_um, max_radius_um, num_sigma)
+    dist, border = marker_distance_and_border(mask, max_r)
+    coords = marker_local_max_peaks(dist, mask, dist, sigmas, z_ratio(dim_res))
+    coords = marker_remove_close_peaks(coords, np.asarray(intensity), peak_min_distance)
+    marker = np.zeros(mask.shape, np.uint8)
+    if coords.size:
+        marker[tuple(coords.T)] = 1
+    return marker, dist, border.astype(np.uint8)
+
+
 def segment_frame(frame, dim_res):
     """Filter then Label on one 3-D frame: (im_preprocessed float32, im_instance_label int32)."""
     fr = filter_frame(frame, dim_res)

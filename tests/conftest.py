@@ -46,7 +46,8 @@ def load_golden(name):
     return g
 
 
-FILTER_CASES = [n for n in golden_names() if not n.startswith(("labelonly", "labelintensity", "removeedges", "twod"))]
+FILTER_CASES = [n for n in golden_names() if not n.startswith(("labelonly", "labelintensity", "removeedges", "twod", "markers"))]
+MARKERS_CASES = golden_names("markers")
 FILTER_2D_CASES = golden_names("twod")
 LABEL_INTENSITY_CASES = golden_names("labelintensity")
 LABEL_ONLY_CASES = golden_names("labelonly")

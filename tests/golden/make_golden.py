@@ -232,6 +232,48 @@ def twod_cases(Filter, Label):
     case("twod_zeros_40x40", np.zeros((40, 40), np.float32), iso)
 
 
+def markers_cases():
+    """Markers stage (nellie/segmentation/mocap_marking.py:648-703, use_im='distance'): the reference's marker,
+    distance and border images for given intensity + instance-label volumes."""
+    from nellie.segmentation.mocap_marking import Markers
+    sys.path.insert(0, REPO)
+    from nellie_amd.synthetic import make_volume, ISO_01, ANISO_03
+    import oracle.nellie_oracle as orc            # only to produce realistic label volumes to feed the reference
+
+    def case(name, vol, lab, dim_res, gen=None, **kw):
+        m = Markers(im_info(vol.shape, dim_res), device="cpu", **kw)
+        m._set_default_sigmas()
+        m.im_memmap, m.label_memmap, m.im_frangi_memmap, m.num_t = vol[None], lab[None], None, 1
+        marker, dist, border = m._run_frame_impl(0)
+        meta = dict(dim_res=np.array([dim_res["Z"], dim_res["Y"], dim_res["X"]], dtype=np.float64))
+        for k, val in kw.items():
+            meta["kw_" + k] = np.float64(val)
+        if gen is None:
+            meta["input"] = vol
+        else:   # regenerate with nellie_amd.synthetic.make_volume(shape, seed); CRC pins it
+            meta["input_shape"] = np.array(vol.shape, dtype=np.int64)
+            meta["input_seed"] = np.int64(gen)
+            meta["input_crc"] = crc(vol)
+        save(name, labels_in=lab.astype(np.int32), sigmas=np.array(m.sigmas, dtype=np.float64),
+             marker=np.asarray(marker, np.uint8), distance=np.asarray(dist, np.float32), border=np.asarray(border, np.uint8), **meta)
+
+    for name, shape, dr, seed in (("markers_iso_24x48x48_s1", (24, 48, 48), ISO_01, 1),
+                                  ("markers_aniso_20x40x44_s3", (20, 40, 44), ANISO_03, 3),
+                                  ("markers_iso_40x96x80_s9", (40, 96, 80), ISO_01, 9)):
+        vol = make_volume(shape, seed)
+        lab = orc.label_frame(orc.filter_frame(vol, dr), dr)
+        case(name, vol, lab, dr, gen=seed)
+    # thick blobs (distances beyond the clamp of 2 * max_radius_px), objects on the faces, a cavity
+    lv = label_only_volume((24, 48, 48), 11)
+    lab = orc.label_frame(lv, ISO_01)
+    case("markers_blobs_24x48x48", lv, lab, ISO_01)
+    big = np.zeros((40, 64, 64), np.float32); big[4:36, 6:58, 8:60] = 5.0; big[18:22, 30:34, 30:34] = 0.0
+    case("markers_slab_40x64x64", big + make_volume((40, 64, 64), 2) * 0.01, (big > 0).astype(np.int32), ISO_01)
+    case("markers_pmd3_24x48x48_s1", make_volume((24, 48, 48), 1),
+         orc.label_frame(orc.filter_frame(make_volume((24, 48, 48), 1), ISO_01), ISO_01), ISO_01, peak_min_distance=3)
+    case("markers_empty_12x20x20", make_volume((12, 20, 20), 4), np.zeros((12, 20, 20), np.int32), ISO_01)
+
+
 def run_label_case(Label, vol, frangi, dim_res, **kw):
     lab = Label(im_info(frangi.shape, dim_res), num_t=1, device="cpu", **kw)
     ithr, fthr = lab._compute_frame_thresholds(vol, frangi)
@@ -285,6 +327,9 @@ def main():
     sys.path.insert(0, REPO)
     if "--only-2d" in sys.argv:          # add / refresh the 2-D cases without touching the 3-D files
         twod_cases(Filter, Label)
+        return
+    if "--only-markers" in sys.argv:
+        markers_cases()
         return
     from nellie_amd.synthetic import make_volume, ISO_01, ANISO_03
 
@@ -359,6 +404,7 @@ def main():
     lab2 = run_label_case(Label, lv2, lv2, ANISO_03)
     save("labelonly_aniso_24x48x48", frangi=lv2, dim_res=np.array([0.3, 0.1, 0.1]), **lab2)
     twod_cases(Filter, Label)
+    markers_cases()
 
 
 if __name__ == "__main__":

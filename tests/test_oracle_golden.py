@@ -9,7 +9,7 @@ import zlib
 import numpy as np
 import pytest
 
-from conftest import FILTER_2D_CASES, FILTER_CASES, LABEL_INTENSITY_CASES, LABEL_ONLY_CASES, load_golden
+from conftest import FILTER_2D_CASES, FILTER_CASES, LABEL_INTENSITY_CASES, LABEL_ONLY_CASES, MARKERS_CASES, load_golden
 from oracle import nellie_oracle as orc
 
 
@@ -105,6 +105,21 @@ def test_filter_and_label_2d_match_reference(name):
         assert float(lthr) == float(g["label_thr"])
     assert orc.min_area_pixels_2d(dr) == int(g["min_area_pixels"])
     assert np.array_equal(labels, g["labels"])
+
+
+@pytest.mark.parametrize("name", MARKERS_CASES)
+def test_markers_match_reference(name):
+    """Markers stage (mocap_marking.py): marker, distance and border images bit-equal to the imported reference."""
+    g = load_golden(name)
+    dr = g["dim_res_dict"]
+    kw = {k: (int(v) if k == "peak_min_distance" else v) for k, v in g["kwargs"].items()}
+    sig, _ = orc.marker_sigmas(dr)
+    assert np.array_equal(np.array(sig), g["sigmas"])
+    marker, dist, border = orc.markers_frame(g["input"], g["labels_in"], dr, **kw)
+    assert marker.dtype == np.uint8 and dist.dtype == np.float32 and border.dtype == np.uint8
+    assert np.array_equal(dist, g["distance"])
+    assert np.array_equal(border, g["border"])
+    assert np.array_equal(marker, g["marker"])
 
 
 @pytest.mark.parametrize("name", LABEL_ONLY_CASES)
