@@ -337,6 +337,29 @@ int nl_prof_enable(nl_ctx *ctx, int on);
 int nl_prof_get(nl_ctx *ctx, const char *name, double *ms, int64_t *launches);
 int nl_prof_reset(nl_ctx *ctx);
 
+/* ---- Markers stage (nellie/segmentation/mocap_marking.py:648-703, use_im = 'distance', 3-D volumes) -----------------
+   The stage after Label: distance transform of the labelled objects, their border shell, multi-scale LoG peaks of
+   the distance image, intensity-based non-maximum suppression.  All three products are bit-exact.
+   nl_markers_begin : mask = labels > 0 (mocap_marking.py:658-659); labels = NULL uses the labels nl_label_run left on
+                      the device, intensity = NULL the resident input of nl_input_load (any dtype, cast to float32 as
+                      `score_img[...] = intensity_im[...]` does, :595-596).
+   nl_markers_distance : border = binary_dilation(mask) ^ mask; distance = float32(distance_transform_edt(mask)) clamped
+                      at `clamp` = float32(2 * max_radius_px) (:440-448).  Exact: only background within floor(clamp)
+                      voxels can matter.  n_mask (may be NULL) = object voxels.
+   nl_markers_log_step : one sigma of :488-508 -- response = float32(-gaussian_laplace(distance, (s/z_ratio, s, s)) * s^2)
+                      clamped at 0; a valid voxel (mask & distance > 0) whose response equals the maximum of its 3x3x3
+                      neighbourhood (mode 'nearest') and beats every earlier scale becomes a peak.  Weights: scipy's
+                      `_gaussian_kernel1d` of order 2 / 0, truncate 4.0, 2r+1 float64 values each, s2 = float32(s**2).
+   nl_markers_finish : :569-606 -- a peak survives if its float32 intensity is positive and equals the maximum over the
+                      peaks within +-peak_min_distance.
+   nl_markers_store  : marker (uint8 0/1), distance (float32), border (uint8 0/1); NULL pointers are skipped. */
+int nl_markers_begin(nl_ctx *ctx, const int32_t *labels_host, const void *intensity_host, int dtype, char *err, size_t errlen);
+int nl_markers_distance(nl_ctx *ctx, float clamp, int64_t *n_mask, char *err, size_t errlen);
+int nl_markers_log_step(nl_ctx *ctx, const double *wz2, const double *wz0, int rz, const double *wy2, const double *wy0,
+                        const double *wx2, const double *wx0, int ryx, float s2, char *err, size_t errlen);
+int nl_markers_finish(nl_ctx *ctx, int peak_min_distance, int64_t *n_markers, char *err, size_t errlen);
+int nl_markers_store(nl_ctx *ctx, uint8_t *marker, float *distance, uint8_t *border, char *err, size_t errlen);
+
 #ifdef __cplusplus
 }
 #endif

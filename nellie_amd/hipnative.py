@@ -57,6 +57,12 @@ _PROTOS = {
     "nl_vesselness_resolve": [_p, _f32, _f32, _f32, _int, _f32, C.POINTER(_int), C.POINTER(_i64)],
     "nl_vesselness_count": [_p, C.POINTER(_i64)],
     "nl_set_ndim": [_p, _int],
+    "nl_markers_begin": [_p, _p, _p, _int],
+    "nl_markers_distance": [_p, _f32, C.POINTER(_i64)],
+    "nl_markers_log_step": [_p, C.POINTER(_f64), C.POINTER(_f64), _int, C.POINTER(_f64), C.POINTER(_f64), C.POINTER(_f64),
+                            C.POINTER(_f64), _int, _f32],
+    "nl_markers_finish": [_p, _int, C.POINTER(_i64)],
+    "nl_markers_store": [_p, _p, _p, _p],
     "nl_mask_volume_fused": [_p, _f32, C.POINTER(_i64)],
     "nl_log2d_step": [_p, C.POINTER(_f64), C.POINTER(_f64), C.POINTER(_f64), C.POINTER(_f64), _int, _f32, _int, _int],
     "nl_log2d_finish": [_p, C.POINTER(_i64)],
@@ -373,6 +379,46 @@ class Context:
         n = _i64(0)
         self._call("nl_mask_volume_fused", float(np.float32(thr)), C.byref(n))
         return int(n.value)
+
+    # ---------------------------------------------------------------- Markers stage
+    def markers_begin(self, labels=None, intensity=None):
+        """labels: int32 (Z, Y, X) host array or None (device labels of label_run); intensity: host array of any
+        supported dtype or None (the resident input)."""
+        lab_p, int_p, code = None, None, 0
+        keep = []
+        if labels is not None:
+            a = np.ascontiguousarray(labels, dtype=np.int32)
+            assert a.shape == self.shape
+            keep.append(a); lab_p = _ptr(a)
+        if intensity is not None:
+            b = np.ascontiguousarray(intensity)
+            assert b.shape == self.shape
+            keep.append(b); int_p = _ptr(b); code = DTYPE_CODES[b.dtype]
+        self._call("nl_markers_begin", lab_p, int_p, code)
+
+    def markers_distance(self, clamp) -> int:
+        n = _i64(0)
+        self._call("nl_markers_distance", float(np.float32(clamp)), C.byref(n))
+        return int(n.value)
+
+    def markers_log_step(self, wz2, wz0, wy2, wy0, wx2, wx0, s2):
+        arrs = [np.ascontiguousarray(w, dtype=np.float64) for w in (wz2, wz0, wy2, wy0, wx2, wx0)]
+        rz, ryx = (arrs[0].size - 1) // 2, (arrs[2].size - 1) // 2
+        assert arrs[1].size == arrs[0].size and all(a.size == arrs[2].size for a in arrs[2:])
+        ptr = [a.ctypes.data_as(C.POINTER(_f64)) for a in arrs]
+        self._call("nl_markers_log_step", ptr[0], ptr[1], rz, ptr[2], ptr[3], ptr[4], ptr[5], ryx, float(np.float32(s2)))
+
+    def markers_finish(self, peak_min_distance) -> int:
+        n = _i64(0)
+        self._call("nl_markers_finish", int(peak_min_distance), C.byref(n))
+        return int(n.value)
+
+    def markers_store(self, marker=True, distance=True, border=True):
+        m = np.empty(self.shape, np.uint8) if marker else None
+        d = np.empty(self.shape, np.float32) if distance else None
+        b = np.empty(self.shape, np.uint8) if border else None
+        self._call("nl_markers_store", None if m is None else _ptr(m), None if d is None else _ptr(d), None if b is None else _ptr(b))
+        return m, d, b
 
     def set_ndim(self, ndim: int):
         self._call("nl_set_ndim", int(ndim))

@@ -121,6 +121,20 @@ def gaussian_derivative_weights(sigma: float, order: int, truncate: float = 4.0)
     return np.ascontiguousarray((q * phi_x)[::-1])
 
 
+def marker_sigmas(dim_res, min_radius_um=0.20, max_radius_um=1, num_sigma=5):
+    """mocap_marking.py:121-134, 329-362: (sigmas, max_radius_px)."""
+    x_res = dim_res.get("X") or 1.0
+    min_r = max(min_radius_um, float(x_res)) / float(x_res)
+    max_r = max_radius_um / float(x_res)
+    sigma_min, sigma_max = min_r / 2.0, max_r / 3.0
+    rng = sigma_max - sigma_min
+    if rng <= 0:
+        return [sigma_min], max_r
+    step = max(0.2, rng / max(num_sigma, 1))
+    sig = list(np.arange(sigma_min, sigma_max, step))
+    return (sig if len(sig) else [sigma_min]), max_r
+
+
 def cascade_deltas(sigmas, z_ratio):
     """filtering.py:814-825."""
     out = []
@@ -508,6 +522,30 @@ class FramePipeline:
         self.trace.label_thr = None if frangi_thresh is None else float(frangi_thresh)
         self.trace.n_labels = self.ctx.label_run(frangi_thresh, int(min_area), fill_holes)
         return self.trace.n_labels
+
+    # ------------------------------------------------------------------ Markers (the stage after Label)
+    def markers(self, dim_res, labels=None, intensity=None, min_radius_um=0.20, max_radius_um=1, num_sigma=5,
+                peak_min_distance=2):
+        """mocap_marking.py:648-703 (use_im='distance') on the device; returns the number of markers.  labels /
+        intensity default to what Label and load_input left on the device.  Products: download_markers()."""
+        if self.two_d:
+            raise NotImplementedError("the HIP Markers stage implements the 3-D path")
+        sigmas, max_r_px = marker_sigmas(dim_res, min_radius_um, max_radius_um, num_sigma)
+        zr = z_ratio_of(dim_res)
+        ctx = self.ctx
+        ctx.markers_begin(labels, intensity)
+        n_mask = ctx.markers_distance(np.float32(max_r_px * 2.0))
+        if n_mask > 0:                                  # empty mask: no markers, zero distance and border (:662-667)
+            for s in sigmas:
+                sv = float(s)
+                wz2, wz0 = gaussian_derivative_weights(sv / zr, 2), gaussian_derivative_weights(sv / zr, 0)
+                w2, w0 = gaussian_derivative_weights(sv, 2), gaussian_derivative_weights(sv, 0)
+                ctx.markers_log_step(wz2, wz0, w2, w0, w2, w0, np.float32(sv ** 2))
+        return ctx.markers_finish(int(peak_min_distance))
+
+    def download_markers(self):
+        """(marker uint8, distance float32, border uint8)."""
+        return self.ctx.markers_store()
 
     def download_labels(self, out=None):
         return self.ctx.label_store(out=out)

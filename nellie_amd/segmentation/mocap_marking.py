@@ -1,0 +1,140 @@
+"""
+`Markers`: drop-in for nellie.segmentation.mocap_marking.Markers (reference mocap_marking.py:21-836) on the MI355X
+HIP engine -- the stage after Label: distance transform of the labelled objects, their border shell, and the
+motion-capture markers (multi-scale LoG peaks of the distance image, intensity-based non-maximum suppression).
+
+Same constructor keywords, same `.run()`, same on-disk products (`im_marker` uint8, `im_distance` float32,
+`im_border` uint8 in `im_info.pipeline_paths`).  All three are bit-identical to the reference's numpy path.
+
+Differences (documented in DESIGN.md): 3-D volumes with `use_im='distance'` (the default) only -- 2-D images and
+`use_im='frangi'` raise NotImplementedError; `low_memory` / `max_chunk_voxels` are accepted and ignored; there is no
+CPU engine behind this class (`device="cpu"` raises).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from nellie_amd.pipeline import FramePipeline, marker_sigmas
+from nellie_amd.utils import adaptive_run
+from nellie_amd.utils.base_logger import logger
+
+
+class Markers:
+    def __init__(self, im_info, num_t=None, min_radius_um=0.20, max_radius_um=1, use_im="distance", num_sigma=5,
+                 viewer=None, prefer_gpu=True, peak_min_distance=2, device="auto", low_memory=False,
+                 max_chunk_voxels=int(1e6)):
+        self.im_info = im_info
+        self.num_t = num_t
+        if self.im_info.no_t:
+            self.num_t = 1
+        elif num_t is None:
+            self.num_t = im_info.shape[im_info.axes.index("T")]
+        x_res = self.im_info.dim_res.get("X") or 1.0
+        z_res = self.im_info.dim_res.get("Z") or x_res
+        self.z_ratio = float(z_res) / float(x_res) if not self.im_info.no_z else 1.0
+        self.min_radius_um = max(min_radius_um, float(x_res))        # mocap_marking.py:128-132
+        self.max_radius_um = max_radius_um
+        self.min_radius_px = self.min_radius_um / float(x_res)
+        self.max_radius_px = self.max_radius_um / float(x_res)
+        self.use_im = use_im
+        self.num_sigma = num_sigma
+        self.sigmas = []
+        self.shape = ()
+        self.im_memmap = self.im_frangi_memmap = self.label_memmap = None
+        self.im_marker_memmap = self.im_distance_memmap = self.im_border_memmap = None
+        self.debug = None
+        self.viewer = viewer
+        dev = str(device or "auto").lower()
+        if dev not in ("auto", "cpu", "gpu", "cuda"):
+            raise ValueError(f"Unsupported device '{device}'. Use 'auto', 'cpu', or 'gpu'.")
+        if dev == "cpu" or (dev == "auto" and not prefer_gpu):
+            raise RuntimeError("nellie_amd provides the MI355X HIP backend only: device='cpu' is not available "
+                               "(no CPU fallback exists in this package; use the reference implementation on CPU)")
+        if not adaptive_run.gpu_available():
+            raise RuntimeError("GPU backend requested but no HIP device / libnellie_hip.so is available.")
+        self.device = device or "auto"
+        self.device_type = "hip"
+        self.device_index = 0
+        self.use_gpu = True
+        self.peak_min_distance = peak_min_distance
+        self.low_memory = bool(low_memory)
+        self.max_chunk_voxels = int(max_chunk_voxels)
+        self.truncate = 4.0
+        self._pipeline = None
+        self._pipeline_key = None
+
+    # ------------------------------------------------------------------ setup (mocap_marking.py:329-417)
+    def _set_default_sigmas(self):
+        logger.debug("Setting sigma values.")
+        self.sigmas, _ = marker_sigmas(self.im_info.dim_res, self.min_radius_um, self.max_radius_um, self.num_sigma)
+
+    def _get_t(self):
+        if self.num_t is None:
+            self.num_t = 1 if self.im_info.no_t else self.im_info.shape[self.im_info.axes.index("T")]
+
+    def _allocate_memory(self):
+        logger.debug("Allocating memory for mocap marking.")
+        self.label_memmap = self.im_info.get_memmap(self.im_info.pipeline_paths["im_instance_label"])
+        self.im_memmap = self.im_info.get_memmap(self.im_info.im_path)
+        self.shape = self.label_memmap.shape
+        alloc = self.im_info.allocate_memory
+        self.im_marker_memmap = alloc(self.im_info.pipeline_paths["im_marker"], dtype="uint8",
+                                      description="mocap marker image", return_memmap=True)
+        self.im_distance_memmap = alloc(self.im_info.pipeline_paths["im_distance"], dtype="float32",
+                                        description="distance transform image", return_memmap=True)
+        self.im_border_memmap = alloc(self.im_info.pipeline_paths["im_border"], dtype="uint8",
+                                      description="border image", return_memmap=True)
+
+    def _get_pipeline(self, shape) -> FramePipeline:
+        key = tuple(int(s) for s in shape)
+        if self._pipeline is None or self._pipeline_key != key:
+            self.close()
+            self._pipeline = FramePipeline(key, device=self.device_index)
+            self._pipeline_key = key
+        return self._pipeline
+
+    def close(self):
+        if self._pipeline is not None:
+            self._pipeline.close()
+            self._pipeline = None
+
+    # ------------------------------------------------------------------ frames (mocap_marking.py:648-703)
+    def _run_frame(self, t):
+        logger.info(f"Running motion capture marking, volume {t}/{self.num_t - 1}")
+        intensity = np.asarray(self.im_memmap[t])
+        labels = np.asarray(self.label_memmap[t])
+        pipe = self._get_pipeline(labels.shape)
+        pipe.markers(self.im_info.dim_res, labels=labels, intensity=intensity, min_radius_um=self.min_radius_um,
+                     max_radius_um=self.max_radius_um, num_sigma=self.num_sigma, peak_min_distance=self.peak_min_distance)
+        return pipe.download_markers()
+
+    def _run_mocap_marking(self):
+        for t in range(self.num_t):
+            if self.viewer is not None:
+                self.viewer.status = f"Mocap marking. Frame: {t + 1} of {self.num_t}."
+            marker, distance, border = self._run_frame(t)
+            if self.im_info.no_t or self.num_t == 1 and self.im_marker_memmap.ndim == marker.ndim:
+                self.im_marker_memmap[...] = marker
+                self.im_distance_memmap[...] = distance
+                self.im_border_memmap[...] = border
+            else:
+                self.im_marker_memmap[t] = marker
+                self.im_distance_memmap[t] = distance
+                self.im_border_memmap[t] = border
+            for mm in (self.im_marker_memmap, self.im_distance_memmap, self.im_border_memmap):
+                if hasattr(mm, "flush"):
+                    mm.flush()
+
+    def run(self):
+        if self.im_info.no_z:
+            raise NotImplementedError("the HIP Markers stage implements the 3-D path; 2-D (no_z) images are not supported yet")
+        if self.use_im != "distance":
+            raise NotImplementedError("the HIP Markers stage implements use_im='distance' (the reference's default)")
+        logger.info("Running Markers (HIP).")
+        self._get_t()
+        self._allocate_memory()
+        self._set_default_sigmas()
+        try:
+            self._run_mocap_marking()
+        finally:
+            self.close()

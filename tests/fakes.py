@@ -22,7 +22,8 @@ class ArrayImInfo:
         self.shape = v.shape
         self.dim_res = dict(dim_res)
         self.im_path = "im"
-        self.pipeline_paths = {"im_preprocessed": "frangi", "im_instance_label": "labels"}
+        self.pipeline_paths = {"im_preprocessed": "frangi", "im_instance_label": "labels", "im_marker": "marker",
+                               "im_distance": "distance", "im_border": "border"}
         self.store = {"im": _mem(v)}
         self.im = self.store["im"]
 

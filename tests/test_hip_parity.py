@@ -14,7 +14,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import FILTER_2D_CASES, FILTER_CASES, LABEL_INTENSITY_CASES, LABEL_ONLY_CASES, load_golden
+from conftest import FILTER_2D_CASES, MARKERS_CASES, FILTER_CASES, LABEL_INTENSITY_CASES, LABEL_ONLY_CASES, load_golden
 from oracle import nellie_oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -319,6 +319,56 @@ def test_stage_api_2d(hip):
         assert_frangi_close(fr, ref_fr, f"t={t}")
         ref_lab = orc.label_frame_2d(fr, dr)
         assert np.array_equal(np.asarray(im_info.store["labels"][t]), ref_lab)
+
+
+@pytest.mark.parametrize("name", MARKERS_CASES)
+def test_markers_golden_bitexact(name, hip):
+    """Markers stage against the reference's own outputs: marker, distance and border images bit for bit."""
+    from nellie_amd import pipeline as pl
+    g = load_golden(name)
+    dr = g["dim_res_dict"]
+    kw = {k: (int(v) if k == "peak_min_distance" else v) for k, v in g["kwargs"].items()}
+    vol, lab = g["input"], g["labels_in"]
+    pipe = pl.FramePipeline(vol.shape)
+    try:
+        sig, _ = pl.marker_sigmas(dr)
+        assert np.array_equal(np.array(sig), g["sigmas"])
+        n = pipe.markers(dr, labels=lab, intensity=vol, **kw)
+        marker, dist, border = pipe.download_markers()
+        assert np.array_equal(dist, g["distance"])
+        assert np.array_equal(border, g["border"])
+        assert np.array_equal(marker, g["marker"]) and n == int(g["marker"].sum())
+        # the same from device-resident labels and input (Filter -> Label -> Markers without leaving the GPU)
+        pipe.load_input(vol)
+        pipe.upload_frangi(np.where(lab > 0, 1.0, 0.0).astype(np.float32))
+        pipe.label(np.float32(0.5), 1, fill_holes=False)
+        if np.array_equal(pipe.download_labels() > 0, lab > 0):          # same object mask (ids do not matter)
+            pipe.markers(dr, **kw)
+            m2, d2, b2 = pipe.download_markers()
+            assert np.array_equal(m2, g["marker"]) and np.array_equal(d2, g["distance"]) and np.array_equal(b2, g["border"])
+    finally:
+        pipe.close()
+
+
+def test_stage_api_markers(hip):
+    """Filter -> Label -> Markers through the drop-in stage classes; products equal the oracle's on the same labels."""
+    from fakes import ArrayImInfo
+    from nellie_amd.segmentation.filtering import Filter
+    from nellie_amd.segmentation.labelling import Label
+    from nellie_amd.segmentation.mocap_marking import Markers
+    from nellie_amd.synthetic import ISO_01, make_volume
+    vols = np.stack([make_volume((24, 48, 48), 50 + t) for t in range(2)])
+    im_info = ArrayImInfo(vols, ISO_01)
+    Filter(im_info).run()
+    Label(im_info).run()
+    Markers(im_info).run()
+    for t in range(2):
+        lab = np.asarray(im_info.store["labels"][t])
+        marker, dist, border = orc.markers_frame(vols[t], lab, ISO_01)
+        assert np.array_equal(np.asarray(im_info.store["distance"][t]), dist)
+        assert np.array_equal(np.asarray(im_info.store["border"][t]), border)
+        assert np.array_equal(np.asarray(im_info.store["marker"][t]), marker)
+        assert im_info.store["marker"].dtype == np.uint8 and im_info.store["distance"].dtype == np.float32
 
 
 def test_ccl_random_masks_vs_oracle(pipes):
