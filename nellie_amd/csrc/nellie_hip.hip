@@ -1380,23 +1380,19 @@ extern "C" int nl_markers_distance(nl_ctx *c, float clamp, int64_t *n_mask, char
     mk_border_kernel<<<(unsigned)((nw + 255) / 256), 256, 0, c->stream>>>(mask, border, v, wpr);
     NL_CHECK_LAUNCH();
     NL_HIP(hipMemsetAsync(c->f[0], 0, (size_t)c->n * 4, c->stream));            // distance = 0 on the background
-    const unsigned gb = (unsigned)((c->n + 255) / 256);
-    mk_edt_x_kernel<<<gb, 256, 0, c->stream>>>(mask, (int *)c->f[1], v, wpr, W);
-    mk_edt_axis_kernel<1, 0><<<gb, 256, 0, c->stream>>>(mask, (const int *)c->f[1], (int *)c->f[2], nullptr, clamp, v, wpr, W);
-    mk_edt_axis_kernel<0, 1><<<gb, 256, 0, c->stream>>>(mask, (const int *)c->f[2], nullptr, c->f[0], clamp, v, wpr, W);
+    unsigned long long *d_cnt = (unsigned long long *)c->d_small;
+    NL_HIP(zero_small(d_cnt, 8, c->stream));
+    const unsigned gw_ = grid1d(nw * 64, 256, (i64)1 << 20);
+    mk_edt_x_kernel<<<grid1d(nw * 64, 256, 256 * 32), 256, 0, c->stream>>>(mask, (int *)c->f[1], v, wpr, W, d_cnt);
+    mk_edt_axis_kernel<1, 0><<<gw_, 256, 0, c->stream>>>(mask, (const int *)c->f[1], (int *)c->f[2], nullptr, clamp, v, wpr, W);
+    mk_edt_axis_kernel<0, 1><<<gw_, 256, 0, c->stream>>>(mask, (const int *)c->f[2], nullptr, c->f[0], clamp, v, wpr, W);
     NL_CHECK_LAUNCH();
     // best response = 0, no peaks yet (mocap_marking.py:483-484)
     NL_HIP(hipMemsetAsync(c->f[3], 0, (size_t)c->n * 4, c->stream));
     NL_HIP(hipMemsetAsync(c->m[0], 0, (size_t)nw * 8 * 2, c->stream));
-    if (n_mask) {
-        // number of object voxels: popcount of the mask words (host side, the words are 1/32 of a float plane)
-        std::vector<unsigned long long> h((size_t)nw);
-        NL_HIP(hipMemcpyAsync(h.data(), mask, (size_t)nw * 8, hipMemcpyDeviceToHost, c->stream));
-        NL_HIP(hipStreamSynchronize(c->stream));
-        int64_t k = 0;
-        for (unsigned long long w : h) k += __builtin_popcountll(w);
-        *n_mask = k;
-    }
+    NL_HIP(hipMemcpyAsync(c->h_small, d_cnt, 8, hipMemcpyDeviceToHost, c->stream));
+    NL_HIP(hipStreamSynchronize(c->stream));
+    if (n_mask) *n_mask = (int64_t)(*(unsigned long long *)c->h_small);
     c->i_gauss = 0; c->gauss_ext = nullptr;
     c->mk_state = 2; c->mk_first_scale = 1;
     return NL_OK;
@@ -1456,7 +1452,7 @@ extern "C" int nl_markers_log_step(nl_ctx *c, const double *wz2, const double *w
 extern "C" int nl_markers_finish(nl_ctx *c, int peak_min_distance, int64_t *n_markers, char *err, size_t errlen) {
     NL_ENTER(c);
     if (c->mk_state < 2) return nl_fail(err, errlen, NL_ESTATE, "nl_markers_finish before nl_markers_distance");
-    if (peak_min_distance < 0 || peak_min_distance > 64) return nl_fail(err, errlen, NL_EINVAL, "peak_min_distance %d out of range", peak_min_distance);
+    if (peak_min_distance < 0 || peak_min_distance > 31) return nl_fail(err, errlen, NL_EINVAL, "peak_min_distance %d out of range", peak_min_distance);
     const int wpr = (int)((c->nx + 63) / 64);
     const i64 nw = c->nzl * c->ny * wpr;
     unsigned long long *d_cnt = (unsigned long long *)c->d_small;
