@@ -447,7 +447,7 @@ static void launch_gauss_x(nl_ctx *c, const float *src, float *dst, const VolGeo
     GaussWS ws;
     for (int k = 0; k <= GM_MAX_R; ++k) ws.w[k] = k <= R ? gw.w[k] : 0.0;
     const dim3 grid((unsigned)((c->nx + GX_SEG - 1) / GX_SEG), (unsigned)c->ny, (unsigned)(z1 - z0));
-    gauss_x_kernel<R><<<grid, 256, 0, c->stream>>>(src, dst, v, z0, z1, ws, (c->nx % 4 == 0) ? 1 : 0);
+    gauss_x_kernel<R><<<grid, 256, 0, c->stream>>>(src, dst, v, z0, z1, ws, (c->nx % 4 == 0) ? 1 : 0, 0);
 }
 // returns false when the radius has no specialised kernel
 template <int AXIS>
@@ -1421,8 +1421,26 @@ extern "C" int nl_markers_log_step(nl_ctx *c, const double *wz2, const double *w
     auto zpass = [&](const GaussW &gz) {
         if (!launch_gauss_fast<0>(c, dist, tz, v, z0, z1, gz)) gauss_axis_kernel<0><<<grid, blk, 0, c->stream>>>(dist, tz, v, z0, z1, gz);
     };
+    // large radii: the fused Y+X kernel turns compute-bound (one output per thread reads 2R+1 LDS values); a marching Y
+    // pass plus the stand-alone X kernel (four outputs per thread) through one more scratch volume is faster there
+    static int split_from = -1;
+    if (split_from < 0) { const char *e = getenv("NELLIE_MK_SPLIT_R"); split_from = e ? atoi(e) : 8; }
+    float *tmp2 = mk_intensity(c) + c->n;
+    const bool can_split = vq_alloc_entries(c->nzl, c->ny, c->nx) * 32 >= c->n * 8;
     auto yx = [&](const GaussW &gy, const GaussW &gx, bool acc) {
         const GaussWS wy = ws_of(gy), wx = ws_of(gx);
+        if (can_split && ryx >= split_from) {
+            const dim3 gym((unsigned)((c->nx + 63) / 64), (unsigned)((c->nzl + 3) / 4), (unsigned)((c->ny + GM_CHUNK - 1) / GM_CHUNK));
+            const dim3 gxk((unsigned)((c->nx + GX_SEG - 1) / GX_SEG), (unsigned)c->ny, (unsigned)c->nzl);
+            const int vec4 = (c->nx % 4 == 0) ? 1 : 0;
+            switch (ryx) {
+#define NL_MKS(RR) case RR: gauss_march_kernel<1, RR><<<gym, 256, 0, c->stream>>>(tz, tmp2, v, z0, z1, wy);                      \
+                            gauss_x_kernel<RR><<<gxk, 256, 0, c->stream>>>(tmp2, lap, v, z0, z1, wx, vec4, acc ? 1 : 0); break;
+                NL_MKS(1) NL_MKS(2) NL_MKS(3) NL_MKS(4) NL_MKS(5) NL_MKS(6) NL_MKS(7) NL_MKS(8) NL_MKS(9) NL_MKS(10) NL_MKS(11) NL_MKS(12)
+#undef NL_MKS
+            }
+            return;
+        }
         switch (ryx) {
 #define NL_MKYX(RR) case RR: if (acc) gauss_yx_kernel<RR, true><<<g2, GYX_THREADS, 0, c->stream>>>(tz, lap, v, z0, z1, wy, wx); \
                              else gauss_yx_kernel<RR, false><<<g2, GYX_THREADS, 0, c->stream>>>(tz, lap, v, z0, z1, wy, wx); break;
