@@ -1,7 +1,9 @@
 """
 `run()`: the hot-path half of nellie.run.run (reference nellie/run.py:18-130) -- Filter then Label on the
 MI355X engine, same keyword names, same `timeit` prints.  The later stages (Network, Markers, tracking,
-Hierarchy) are Nellie's own and consume the two files this writes.
+Hierarchy) are Nellie's own and consume the two files this writes; `markers=True` also runs this package's
+Markers stage (reference run.py:88-89; it does not depend on Network) and writes im_marker / im_distance /
+im_border.
 """
 from __future__ import annotations
 
@@ -37,7 +39,7 @@ def run_streamed(im_info, viewer=None, device_index=0):
 
 
 def run(im_info, remove_edges=False, otsu_thresh_intensity=False, threshold=None, timeit=False, device="auto",
-        low_memory=False):
+        low_memory=False, markers=False):
     t0 = time.perf_counter() if timeit else None
     preprocessing = Filter(im_info, remove_edges=remove_edges, device=device, low_memory=low_memory)
     preprocessing.run()
@@ -50,5 +52,11 @@ def run(im_info, remove_edges=False, otsu_thresh_intensity=False, threshold=None
     if timeit:
         t2 = time.perf_counter()
         print(f"[timeit] Label: {t2 - t1:.3f}s")
-        print(f"[timeit] Total: {t2 - t0:.3f}s")
+    if markers and not im_info.no_z:
+        from nellie_amd.segmentation.mocap_marking import Markers
+        Markers(im_info, device=device, low_memory=low_memory).run()
+        if timeit:
+            print(f"[timeit] Markers: {time.perf_counter() - t2:.3f}s")
+    if timeit:
+        print(f"[timeit] Total: {time.perf_counter() - t0:.3f}s")
     return im_info

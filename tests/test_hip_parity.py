@@ -466,16 +466,22 @@ def test_run_on_disk_layout(hip, tmp_path):
     from nellie_amd.synthetic import ISO_01, make_volume
     vols = np.stack([make_volume((24, 48, 48), 40 + t) for t in range(2)])
     im_info = ImInfo(vols, dim_res=ISO_01, output_dir=str(tmp_path), name="stack")
-    run(im_info, device="gpu")
+    run(im_info, device="gpu", markers=True)
     fr_path, lab_path = im_info.pipeline_paths["im_preprocessed"], im_info.pipeline_paths["im_instance_label"]
     assert os.path.dirname(fr_path).endswith(os.path.join("nellie_output", "nellie_necessities"))
     fr = im_info.get_memmap(fr_path, read_mode="r")
     lab = im_info.get_memmap(lab_path, read_mode="r")
     assert fr.dtype == np.float32 and lab.dtype == np.int32 and fr.shape == vols.shape == lab.shape
     assert np.array_equal(im_info.get_memmap(im_info.im_path, read_mode="r"), vols), "input file was modified"
+    mk = im_info.get_memmap(im_info.pipeline_paths["im_marker"], read_mode="r")
+    di = im_info.get_memmap(im_info.pipeline_paths["im_distance"], read_mode="r")
+    bo = im_info.get_memmap(im_info.pipeline_paths["im_border"], read_mode="r")
+    assert mk.dtype == np.uint8 and di.dtype == np.float32 and bo.dtype == np.uint8 and mk.shape == vols.shape
     for t in range(2):
         assert_frangi_close(np.asarray(fr[t]), orc.filter_frame(vols[t], ISO_01), f"t={t}")
         assert np.array_equal(np.asarray(lab[t]), orc.label_frame(np.asarray(fr[t]), ISO_01))
+        m, d, b = orc.markers_frame(vols[t], np.asarray(lab[t]), ISO_01)
+        assert np.array_equal(np.asarray(mk[t]), m) and np.array_equal(np.asarray(di[t]), d) and np.array_equal(np.asarray(bo[t]), b)
 
 
 def test_streamed_stack_equals_per_stage_run(hip, tmp_path):
