@@ -360,6 +360,18 @@ int nl_markers_log_step(nl_ctx *ctx, const double *wz2, const double *wz0, int r
 int nl_markers_finish(nl_ctx *ctx, int peak_min_distance, int64_t *n_markers, char *err, size_t errlen);
 int nl_markers_store(nl_ctx *ctx, uint8_t *marker, float *distance, uint8_t *border, char *err, size_t errlen);
 
+/* ---- Network stage, the two dense per-voxel steps (nellie/segmentation/networking.py; 3-D volumes and 2-D images) ----
+   The skeletonisation itself (skimage, networking.py:394-409) and the per-object relabelling stay on the host.
+   nl_skel_pixel_class  : `_get_pixel_class_impl` (networking.py:672-683) -- skel_mask = skel > 0;
+                          class = min(4, convolve(skel_mask, ones(3,3,3), mode="constant", cval=0)) * skel_mask, uint8:
+                          1 isolated, 2 tip, 3 edge, 4 junction.  n_skel (may be NULL) = skeleton voxels.
+   nl_skel_branch_labels: `_get_branch_skel_labels` (networking.py:758-800) -- label((pc > 0) & (pc != 4),
+                          structure = ones(3,3,3)): int32 ids 1..K in raster order of each component's first voxel.
+                          pixel_class = NULL uses the classes the previous nl_skel_pixel_class left on the device.
+   A context of shape (1, ny, nx) gives the reference's 2-D branch (ones(3,3)). */
+int nl_skel_pixel_class(nl_ctx *ctx, const int32_t *skel, uint8_t *pixel_class, int64_t *n_skel, char *err, size_t errlen);
+int nl_skel_branch_labels(nl_ctx *ctx, const uint8_t *pixel_class, int32_t *labels, int64_t *n_labels, char *err, size_t errlen);
+
 #ifdef __cplusplus
 }
 #endif

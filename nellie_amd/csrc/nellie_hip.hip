@@ -53,6 +53,7 @@ static RcclApi &rccl() {
 #include "markers.inc"
 #include "label_voxels.inc"
 #include "label_runs.inc"
+#include "network.inc"
 
 // =================================================================================================
 // host side: context, launch helpers, C-ABI
@@ -1746,6 +1747,30 @@ static int build_components(nl_ctx *c, const LabelGeo &g, const unsigned long lo
     return NL_OK;
 }
 
+// ids 1..K in raster order of each component's first voxel (scipy.ndimage.label numbering), painted as int32
+static int number_and_paint(nl_ctx *c, const LabelGeo &g, const RunSet &rs, int *aux, int64_t *n_labels, char *err, size_t errlen) {
+    unsigned long long total = 0;
+    if (rs.nruns) {
+        const i64 nblk = (rs.nruns + SCAN_CHUNK - 1) / SCAN_CHUNK;
+        unsigned int *blk = (unsigned int *)c->d_blk;
+        unsigned long long *d_total = (unsigned long long *)c->d_small;
+        root_count_kernel<<<(unsigned)nblk, 256, 0, c->stream>>>(rs.parent, rs.nruns, blk);
+        NL_CHECK_LAUNCH();
+        blk_scan_kernel<<<1, 1024, 0, c->stream>>>(blk, nblk, d_total);
+        NL_CHECK_LAUNCH();
+        root_assign_kernel<<<(unsigned)nblk, 256, 0, c->stream>>>(rs.parent, rs.nruns, blk, aux);
+        NL_CHECK_LAUNCH();
+        NL_HIP(hipMemcpyAsync(c->h_small, d_total, 8, hipMemcpyDeviceToHost, c->stream));
+    }
+    rl_paint_kernel<<<grid1d((g.paint_row1 - g.paint_row0) * 64, 256, (i64)1 << 22), 256, 0, c->stream>>>(
+        g.bitsA, rs.row_off, rs.parent, aux, g.paint_out, g.paint_row0, g.paint_row1, g.wpr, (int)g.nx);
+    NL_CHECK_LAUNCH();
+    NL_HIP(hipStreamSynchronize(c->stream));
+    if (rs.nruns) total = *(unsigned long long *)c->h_small;
+    if (n_labels) *n_labels = (int64_t)total;
+    return NL_OK;
+}
+
 // labelling.py:484-509 on a bit-packed mask (bitsA holds `frame > thr` on entry).  *overflow: more runs than scratch.
 static int label_core(nl_ctx *c, const LabelGeo &g, int64_t min_area, int fill_holes, int64_t *n_labels, bool *overflow,
                       char *err, size_t errlen) {
@@ -1791,25 +1816,7 @@ static int label_core(nl_ctx *c, const LabelGeo &g, int64_t min_area, int fill_h
     NL_CHECK_LAUNCH();
     if ((rc = build_components<26>(c, g, g.bitsA, 0, rs, cap, overflow, err, errlen))) return rc;
     if (*overflow) return NL_OK;
-    unsigned long long total = 0;
-    if (rs.nruns) {
-        const i64 nblk = (rs.nruns + SCAN_CHUNK - 1) / SCAN_CHUNK;
-        unsigned int *blk = (unsigned int *)c->d_blk;
-        unsigned long long *d_total = (unsigned long long *)c->d_small;
-        root_count_kernel<<<(unsigned)nblk, 256, 0, c->stream>>>(rs.parent, rs.nruns, blk);
-        NL_CHECK_LAUNCH();
-        blk_scan_kernel<<<1, 1024, 0, c->stream>>>(blk, nblk, d_total);
-        NL_CHECK_LAUNCH();
-        root_assign_kernel<<<(unsigned)nblk, 256, 0, c->stream>>>(rs.parent, rs.nruns, blk, aux);
-        NL_CHECK_LAUNCH();
-        NL_HIP(hipMemcpyAsync(c->h_small, d_total, 8, hipMemcpyDeviceToHost, c->stream));
-    }
-    rl_paint_kernel<<<grid1d((g.paint_row1 - g.paint_row0) * 64, 256, (i64)1 << 22), 256, 0, c->stream>>>(
-        g.bitsA, rs.row_off, rs.parent, aux, g.paint_out, g.paint_row0, g.paint_row1, g.wpr, (int)g.nx);
-    NL_CHECK_LAUNCH();
-    NL_HIP(hipStreamSynchronize(c->stream));
-    if (rs.nruns) total = *(unsigned long long *)c->h_small;
-    if (n_labels) *n_labels = (int64_t)total;
+    if ((rc = number_and_paint(c, g, rs, aux, n_labels, err, errlen))) return rc;
     c->i_labels = free_idx[2];
     return NL_OK;
 }
@@ -1944,6 +1951,78 @@ extern "C" int nl_label_store(nl_ctx *c, int32_t *host, int64_t z0, int64_t z1, 
 // 3-D+T stacks (BASELINE config 5): frame t+1 travels host -> HBM on a copy stream while frame t computes, and the
 // outputs of frame t-1 travel back on a second copy stream.  Host buffers must be pinned (nl_pinned_alloc) for the
 // copies to be asynchronous.
+// ------------------------------------------------------------------ Network (pixel class, branch labels) -------
+// networking.py:672-683: skeleton voxels classified by their 3x3x3 (2-D: 3x3) occupancy.
+extern "C" int nl_skel_pixel_class(nl_ctx *c, const int32_t *skel_host, uint8_t *pixel_class_host, int64_t *n_skel,
+                                   char *err, size_t errlen) {
+    NL_ENTER(c);
+    NL_JOIN_SIDE(c);
+    if (!skel_host) return nl_fail(err, errlen, NL_EINVAL, "nl_skel_pixel_class: skel is NULL");
+    if (c->own_lo != 0 || c->own_hi != c->nzl || c->gnz != c->nzl) return nl_fail(err, errlen, NL_EINVAL, "the Network kernels run on a whole volume");
+    const int wpr = (int)((c->nx + 63) / 64);
+    const i64 nrows = c->nzl * c->ny, nw = nrows * wpr;
+    ProfScope ps(c, "network");
+    NL_HIP(hipMemcpyAsync(c->f[3], skel_host, (size_t)c->n * 4, hipMemcpyHostToDevice, c->stream));
+    unsigned long long *skel = (unsigned long long *)c->m[1], *branch = (unsigned long long *)c->m[2];
+    mk_pack_labels_kernel<<<grid1d(nw * 64, 256, (i64)1 << 20), 256, 0, c->stream>>>((const int *)c->f[3], skel, (int)c->nx, nrows, wpr);
+    NL_CHECK_LAUNCH();
+    uint8_t *pc = (uint8_t *)c->f[2];
+    NL_HIP(hipMemsetAsync(pc, 0, (size_t)c->n, c->stream));
+    unsigned long long *d_cnt = (unsigned long long *)c->d_small;
+    NL_HIP(zero_small(d_cnt, 8, c->stream));
+    nw_pixel_class_kernel<<<(unsigned)((nw + 255) / 256), 256, 0, c->stream>>>(skel, pc, branch, geom(c), wpr, d_cnt);
+    NL_CHECK_LAUNCH();
+    NL_HIP(hipMemcpyAsync(c->h_small, d_cnt, 8, hipMemcpyDeviceToHost, c->stream));
+    if (pixel_class_host) NL_HIP(hipMemcpyAsync(pixel_class_host, pc, (size_t)c->n, hipMemcpyDeviceToHost, c->stream));
+    NL_HIP(hipStreamSynchronize(c->stream));
+    if (n_skel) *n_skel = (int64_t)(*(unsigned long long *)c->h_small);
+    c->i_labels = -1; c->frangi_ready = 0; c->gauss_ext = nullptr; c->fsq_cache_valid = 0; c->mk_state = 0;
+    c->nw_state = 1;
+    return NL_OK;
+}
+
+// networking.py:758-800: label(pixel_class > 0 & pixel_class != 4, structure = ones(3,3,3)) -> int32 ids in raster order.
+// pixel_class_host = NULL uses the classes nl_skel_pixel_class left on the device.
+extern "C" int nl_skel_branch_labels(nl_ctx *c, const uint8_t *pixel_class_host, int32_t *labels_host, int64_t *n_labels,
+                                     char *err, size_t errlen) {
+    NL_ENTER(c);
+    NL_JOIN_SIDE(c);
+    if (c->own_lo != 0 || c->own_hi != c->nzl || c->gnz != c->nzl) return nl_fail(err, errlen, NL_EINVAL, "the Network kernels run on a whole volume");
+    if (c->nx > 65535) return nl_fail(err, errlen, NL_EINVAL, "rows longer than 65535 voxels are not supported here");
+    LabelGeo g;
+    g.nz = c->nzl; g.ny = c->ny; g.nx = c->nx;
+    g.nrows = c->nzl * c->ny; g.wpr = (int)((c->nx + 63) / 64); g.nwords = g.nrows * g.wpr;
+    g.rows = c->d_rows;
+    g.bitsA = (unsigned long long *)c->m[2]; g.bitsB = (unsigned long long *)c->m[1];
+    g.paint_row0 = 0; g.paint_row1 = g.nrows; g.paint_out = (int *)c->f[3];
+    ProfScope ps(c, "network");
+    if (pixel_class_host) {
+        uint8_t *pc = (uint8_t *)c->f[2];
+        NL_HIP(hipMemcpyAsync(pc, pixel_class_host, (size_t)c->n, hipMemcpyHostToDevice, c->stream));
+        nw_pack_branch_kernel<<<grid1d(g.nwords * 64, 256, (i64)1 << 20), 256, 0, c->stream>>>(pc, g.bitsA, (int)c->nx, g.nrows, g.wpr);
+        NL_CHECK_LAUNCH();
+        c->i_labels = -1; c->frangi_ready = 0; c->gauss_ext = nullptr; c->fsq_cache_valid = 0; c->mk_state = 0;
+    } else if (c->nw_state < 1) {
+        return nl_fail(err, errlen, NL_ESTATE, "nl_skel_branch_labels(pixel_class = NULL) before nl_skel_pixel_class");
+    }
+    const i64 cap = c->n / 2;
+    RunSet rs;
+    rs.runs = (RunRec *)c->f[0];
+    rs.parent = (int *)c->f[1];
+    int *aux = rs.parent + cap;
+    bool overflow = false;
+    int rc = build_components<26>(c, g, g.bitsA, 0, rs, cap, &overflow, err, errlen);
+    if (rc) return rc;
+    if (overflow) return nl_fail(err, errlen, NL_ENOMEM, "more branch runs than scratch [out of memory]");
+    if ((rc = number_and_paint(c, g, rs, aux, n_labels, err, errlen))) return rc;
+    if (labels_host) {
+        NL_HIP(hipMemcpyAsync(labels_host, g.paint_out, (size_t)c->n * 4, hipMemcpyDeviceToHost, c->stream));
+        NL_HIP(hipStreamSynchronize(c->stream));
+    }
+    c->nw_state = 0;
+    return NL_OK;
+}
+
 extern "C" int nl_pinned_alloc(void **ptr, int64_t bytes, char *err, size_t errlen) {
     if (!ptr || bytes < 1) return nl_fail(err, errlen, NL_EINVAL, "bad pinned allocation request");
     hipError_t e = hipHostMalloc(ptr, (size_t)bytes, hipHostMallocDefault);

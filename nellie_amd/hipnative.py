@@ -63,6 +63,8 @@ _PROTOS = {
                             C.POINTER(_f64), _int, _f32],
     "nl_markers_finish": [_p, _int, C.POINTER(_i64)],
     "nl_markers_store": [_p, _p, _p, _p],
+    "nl_skel_pixel_class": [_p, _p, _p, C.POINTER(_i64)],
+    "nl_skel_branch_labels": [_p, _p, _p, C.POINTER(_i64)],
     "nl_mask_volume_fused": [_p, _f32, C.POINTER(_i64)],
     "nl_log2d_step": [_p, C.POINTER(_f64), C.POINTER(_f64), C.POINTER(_f64), C.POINTER(_f64), _int, _f32, _int, _int],
     "nl_log2d_finish": [_p, C.POINTER(_i64)],
@@ -419,6 +421,29 @@ class Context:
         b = np.empty(self.shape, np.uint8) if border else None
         self._call("nl_markers_store", None if m is None else _ptr(m), None if d is None else _ptr(d), None if b is None else _ptr(b))
         return m, d, b
+
+    def skel_pixel_class(self, skel, download=True):
+        """networking.py:672-683.  Returns (uint8 pixel classes or None, number of skeleton voxels)."""
+        skel = np.ascontiguousarray(skel, dtype=np.int32)
+        if skel.size != int(np.prod(self.shape)):
+            raise ValueError(f"skeleton shape {skel.shape} does not match the context shape {tuple(self.shape)}")
+        out = np.empty(skel.shape, np.uint8) if download else None
+        n = _i64(0)
+        self._call("nl_skel_pixel_class", _ptr(skel), None if out is None else _ptr(out), C.byref(n))
+        return out, int(n.value)
+
+    def skel_branch_labels(self, pixel_class=None):
+        """networking.py:758-800.  pixel_class=None: the classes of the previous skel_pixel_class on this context.
+        Returns (int32 branch labels, number of branches)."""
+        pc = None
+        if pixel_class is not None:
+            pc = np.ascontiguousarray(pixel_class, dtype=np.uint8)
+            if pc.size != int(np.prod(self.shape)):
+                raise ValueError(f"pixel_class shape {pc.shape} does not match the context shape {tuple(self.shape)}")
+        out = np.empty(self.shape if pc is None else pc.shape, np.int32)
+        n = _i64(0)
+        self._call("nl_skel_branch_labels", None if pc is None else _ptr(pc), _ptr(out), C.byref(n))
+        return out, int(n.value)
 
     def set_ndim(self, ndim: int):
         self._call("nl_set_ndim", int(ndim))

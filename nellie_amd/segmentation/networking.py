@@ -1,0 +1,109 @@
+"""
+The two dense per-voxel steps of nellie.segmentation.networking.Network on the MI355X HIP engine:
+
+  `_get_pixel_class`         (reference networking.py:634-683): skeleton voxels classified by the number of skeleton
+                             voxels in their 3x3x3 (2-D: 3x3) neighbourhood -- 1 isolated, 2 tip, 3 edge, 4 junction;
+  `_get_branch_skel_labels`  (reference networking.py:758-800): 26- (2-D: 8-) connected labels of the skeleton with the
+                             junction voxels removed, int32 ids in scipy's raster order.
+
+Both are bit-identical to the reference's numpy path.  The rest of Network -- skimage's skeletonisation
+(networking.py:394-409), `_add_missing_skeleton_labels`, the per-object `_relabel_objects` -- is host code that stays
+with the reference; `HipNetworkKernels` is written as a mixin so that
+
+    class Network(HipNetworkKernels, nellie.segmentation.networking.Network): pass
+
+replaces exactly these two methods (same names, same arguments, numpy arrays in and out).  There is no CPU engine
+behind them: `force_cpu=True` and a missing HIP device raise.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from nellie_amd import hipnative
+from nellie_amd.utils import adaptive_run
+
+
+def _ctx_shape(shape):
+    shape = tuple(int(s) for s in shape)
+    if len(shape) == 2:
+        return (1,) + shape
+    if len(shape) == 3:
+        return shape
+    raise ValueError(f"expected a 2-D image or a 3-D volume, got shape {shape}")
+
+
+class HipNetworkKernels:
+    """Mixin / helper holding one HIP context per frame shape."""
+
+    _hip_ctx = None
+    _hip_ctx_key = None
+    device_index = 0
+
+    def _hip_context(self, shape):
+        if not adaptive_run.gpu_available():
+            raise RuntimeError("GPU backend requested but no HIP device / libnellie_hip.so is available.")
+        key = (_ctx_shape(shape), int(getattr(self, "device_index", 0) or 0))
+        if self._hip_ctx is None or self._hip_ctx_key != key:
+            self.close()
+            self._hip_ctx = hipnative.Context(key[0], device=key[1])
+            self._hip_ctx_key = key
+        return self._hip_ctx
+
+    def close(self):
+        if self._hip_ctx is not None:
+            self._hip_ctx.close()
+        self._hip_ctx = None
+        self._hip_ctx_key = None
+
+    @staticmethod
+    def _no_cpu(force_cpu):
+        if force_cpu:
+            raise RuntimeError("nellie_amd provides the MI355X HIP backend only: force_cpu=True is not available "
+                               "(use the reference implementation on CPU)")
+
+    def _get_pixel_class(self, skel, force_cpu: bool = False):
+        """uint8 classes: 0 background, 1 isolated, 2 tips, 3 edges, 4 junctions (clipped) -- networking.py:634-683."""
+        self._no_cpu(force_cpu)
+        skel = np.asarray(skel)
+        ctx = self._hip_context(skel.shape)
+        # skel_mask = skel > 0: any integer / float dtype reduces to its sign here
+        if skel.dtype != np.int32:
+            skel = (skel > 0).astype(np.int32)
+        out, self.n_skeleton_voxels = ctx.skel_pixel_class(skel)
+        self._pixel_class_resident = out
+        return out
+
+    def _get_branch_skel_labels(self, pixel_class, force_cpu: bool = False):
+        """int32 connected components of (pixel_class > 0) & (pixel_class != 4) -- networking.py:758-800."""
+        self._no_cpu(force_cpu)
+        pc = np.asarray(pixel_class)
+        ctx = self._hip_context(pc.shape)
+        resident = getattr(self, "_pixel_class_resident", None)
+        self._pixel_class_resident = None
+        if resident is pixel_class:               # the array the previous call returned: its bits are still on the device
+            labels, self.n_branches = ctx.skel_branch_labels(None)
+            return labels.reshape(pc.shape)
+        if pc.dtype != np.uint8:
+            pc = np.where(pc == 4, 4, (pc > 0).astype(np.uint8)).astype(np.uint8)
+        labels, self.n_branches = ctx.skel_branch_labels(pc)
+        return labels
+
+
+def pixel_class(skel, device=0):
+    """Function form of `Network._get_pixel_class` (networking.py:672-683)."""
+    k = HipNetworkKernels()
+    k.device_index = device
+    try:
+        return k._get_pixel_class(skel)
+    finally:
+        k.close()
+
+
+def branch_skel_labels(pixel_class_im, device=0):
+    """Function form of `Network._get_branch_skel_labels` (networking.py:758-800)."""
+    k = HipNetworkKernels()
+    k.device_index = device
+    try:
+        return k._get_branch_skel_labels(pixel_class_im)
+    finally:
+        k.close()

@@ -99,3 +99,37 @@ def make_image_2d(shape, seed, dtype=np.float32):
     if np.issubdtype(np.dtype(dtype), np.integer):
         return np.clip(np.rint(img), 0, np.iinfo(dtype).max).astype(dtype)
     return img.astype(dtype)
+
+
+def make_skeleton(shape, seed, n_walks=None, branch_prob=0.04):
+    """A synthetic skeleton-like int32 label image: one-voxel-wide random walks (26-/8-connected steps with momentum)
+    that fork now and then, so that tips, edges, junction clusters and isolated voxels all occur.  Deterministic."""
+    rng = np.random.default_rng(seed)
+    shape = tuple(int(s) for s in shape)
+    nd = len(shape)
+    out = np.zeros(shape, np.int32)
+    n = int(np.prod(shape))
+    if n_walks is None:
+        n_walks = max(3, n // 2500)
+    hi = np.array(shape) - 1
+    for lab in range(1, n_walks + 1):
+        stack = [(np.array([rng.integers(0, s) for s in shape]), rng.integers(-1, 2, nd))]
+        budget = int(rng.integers(20, 250))
+        while stack and budget > 0:
+            pos, step = stack.pop()
+            length = int(rng.integers(3, 25))
+            for _ in range(length):
+                if not step.any():
+                    step = rng.integers(-1, 2, nd)
+                    continue
+                out[tuple(pos)] = lab
+                budget -= 1
+                if rng.random() < 0.3:
+                    step = np.clip(step + rng.integers(-1, 2, nd), -1, 1)
+                if rng.random() < branch_prob:
+                    stack.append((pos.copy(), rng.integers(-1, 2, nd)))
+                pos = np.clip(pos + step, 0, hi)
+    # a few isolated voxels
+    for _ in range(max(1, n_walks // 3)):
+        out[tuple(rng.integers(0, s) for s in shape)] = n_walks + 1
+    return out

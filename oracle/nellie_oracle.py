@@ -28,6 +28,9 @@ its published algorithm:
   * scipy.ndimage.gaussian_laplace (2-D images only: `_gaussian_kernel1d` of order 2, truncate 4.0,
                               one second-derivative pass per axis, summed in float32).
 
+Also restated: the Markers stage (mocap_marking.py) and the two dense steps of the Network stage
+(networking.py: pixel classes, branch labels).
+
 Both dimensionalities of the stage are covered: (Z, Y, X) volumes and (Y, X) images (im_info.no_z: 2x2
 closed-form eigenvalues, two-eigenvalue Frangi, the multi-scale LoG blob response, 4-connected opening).
 
@@ -1124,6 +1127,34 @@ def markers_frame(intensity, labels, dim_res, min_radius_um=0.20, max_radius_um=
     if coords.size:
         marker[tuple(coords.T)] = 1
     return marker, dist, border.astype(np.uint8)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Network stage: the two dense per-voxel steps (nellie/segmentation/networking.py)
+# ---------------------------------------------------------------------------------------------------------------
+def network_pixel_class(skel):
+    """networking.py:672-683 (`_get_pixel_class_impl`): occupancy of the 3x3x3 (2-D: 3x3) neighbourhood, centre included,
+    zero outside the image (`mode="constant", cval=0`), kept on skeleton voxels, clipped at 4; uint8.
+    Restated as a sum of shifted copies of the zero-padded mask (exact: integer counts <= 27)."""
+    m = (np.asarray(skel) > 0).astype(np.uint8)
+    pad = np.pad(m, 1)
+    total = np.zeros(m.shape, dtype=np.uint8)
+    for off in np.ndindex(*[3] * m.ndim):
+        total += pad[tuple(slice(o, o + n) for o, n in zip(off, m.shape))]
+    total *= m
+    total[total > 4] = 4
+    return total
+
+
+def network_branch_skel_labels(pixel_class):
+    """networking.py:758-800 (`_get_branch_skel_labels`): label((pc > 0) & (pc != 4), structure=ones(3,...)),
+    int32 ids in raster order of each component's first voxel (26-connected; 8-connected for a 2-D image)."""
+    pc = np.asarray(pixel_class)
+    nj = (pc > 0) & (pc != 4)
+    if nj.ndim == 2:
+        return label26(nj[None])[0]
+    return label26(nj)
+
 
 
 def segment_frame(frame, dim_res):

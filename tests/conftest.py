@@ -46,8 +46,9 @@ def load_golden(name):
     return g
 
 
-FILTER_CASES = [n for n in golden_names() if not n.startswith(("labelonly", "labelintensity", "removeedges", "twod", "markers"))]
+FILTER_CASES = [n for n in golden_names() if not n.startswith(("labelonly", "labelintensity", "removeedges", "twod", "markers", "network"))]
 MARKERS_CASES = golden_names("markers")
+NETWORK_CASES = golden_names("network")
 FILTER_2D_CASES = golden_names("twod")
 LABEL_INTENSITY_CASES = golden_names("labelintensity")
 LABEL_ONLY_CASES = golden_names("labelonly")

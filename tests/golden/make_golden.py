@@ -274,6 +274,35 @@ def markers_cases():
     case("markers_empty_12x20x20", make_volume((12, 20, 20), 4), np.zeros((12, 20, 20), np.int32), ISO_01)
 
 
+def network_cases():
+    """Network stage, the two dense steps (nellie/segmentation/networking.py:672-683 and :758-800): the reference's
+    pixel classes and branch labels for given skeleton label images (3-D and 2-D)."""
+    from nellie.segmentation.networking import Network
+    sys.path.insert(0, REPO)
+    from nellie_amd.synthetic import make_skeleton, make_volume, ISO_01
+    import oracle.nellie_oracle as orc            # only to produce a realistic label volume to feed the reference
+
+    def case(name, skel):
+        info = im_info(skel.shape, ISO_01) if skel.ndim == 3 else im_info_2d(skel.shape, ISO_01)
+        net = Network(info, device="cpu")
+        pc = net._get_pixel_class(skel, force_cpu=True)
+        bl = net._get_branch_skel_labels(pc, force_cpu=True)
+        save(name, skel=skel.astype(np.int32), pixel_class=np.asarray(pc), pixel_class_dtype=np.array(str(np.asarray(pc).dtype)),
+             branch_labels=np.asarray(bl), branch_labels_dtype=np.array(str(np.asarray(bl).dtype)))
+
+    case("network_walks_24x48x48_s1", make_skeleton((24, 48, 48), 1))
+    case("network_walks_17x33x29_s2", make_skeleton((17, 33, 29), 2))
+    case("network_walks_12x40x130_s3", make_skeleton((12, 40, 130), 3))        # rows longer than two 64-bit words
+    case("network_walks2d_64x70_s4", make_skeleton((64, 70), 4, n_walks=8))
+    case("network_walks2d_50x129_s5", make_skeleton((50, 129), 5, n_walks=10))
+    # a thick object (every voxel a junction), objects on the faces, single voxels
+    lab = orc.label_frame(orc.filter_frame(make_volume((24, 48, 48), 1), ISO_01), ISO_01)
+    case("network_thick_24x48x48", lab)
+    z = np.zeros((6, 9, 9), np.int32); z[0, 0, 0] = 1; z[5, 8, 8] = 2; z[2, 4, 3:7] = 3; z[3, 0:3, 0] = 4
+    case("network_corners_6x9x9", z)
+    case("network_empty_5x6x7", np.zeros((5, 6, 7), np.int32))
+
+
 def run_label_case(Label, vol, frangi, dim_res, **kw):
     lab = Label(im_info(frangi.shape, dim_res), num_t=1, device="cpu", **kw)
     ithr, fthr = lab._compute_frame_thresholds(vol, frangi)
@@ -330,6 +359,9 @@ def main():
         return
     if "--only-markers" in sys.argv:
         markers_cases()
+        return
+    if "--only-network" in sys.argv:
+        network_cases()
         return
     from nellie_amd.synthetic import make_volume, ISO_01, ANISO_03
 

@@ -523,3 +523,43 @@ def test_label_intensity_threshold_golden(name, hip):
     kw = dict(otsu_thresh_intensity=True) if int(g["otsu"]) else dict(threshold=float(g["threshold"]))
     Label(im_info, **kw).run()
     assert np.array_equal(np.asarray(im_info.store["labels"][0]), g["labels"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", __import__("conftest").NETWORK_CASES)
+def test_network_steps_golden_bitexact(name, hip):
+    """Network's two dense steps against the reference's own outputs, through the mixin a maintainer would use."""
+    from nellie_amd.segmentation.networking import HipNetworkKernels, pixel_class, branch_skel_labels
+    g = load_golden(name)
+    k = HipNetworkKernels()
+    try:
+        pc = k._get_pixel_class(g["skel"])
+        assert pc.dtype == np.uint8 and pc.shape == g["skel"].shape and np.array_equal(pc, g["pixel_class"])
+        assert k.n_skeleton_voxels == int((g["skel"] > 0).sum())
+        bl = k._get_branch_skel_labels(pc)                       # device-resident classes
+        assert bl.dtype == np.int32 and np.array_equal(bl, g["branch_labels"])
+        assert k.n_branches == int(g["branch_labels"].max())
+        bl2 = k._get_branch_skel_labels(g["pixel_class"].copy())   # classes handed over by the host (e.g. after _clean_junctions)
+        assert np.array_equal(bl2, g["branch_labels"])
+    finally:
+        k.close()
+    assert np.array_equal(pixel_class((g["skel"] > 0).astype(np.uint16)), g["pixel_class"])
+    assert np.array_equal(branch_skel_labels(g["pixel_class"]), g["branch_labels"])
+
+
+@pytest.mark.gpu
+def test_network_steps_large_vs_oracle(hip):
+    """A 96x200x330 skeleton image (rows of 6 words, ~30k skeleton voxels): both steps equal the oracle's."""
+    from nellie_amd.synthetic import make_skeleton
+    from nellie_amd.segmentation.networking import HipNetworkKernels
+    skel = make_skeleton((96, 200, 330), 21, n_walks=400)
+    k = HipNetworkKernels()
+    try:
+        pc = k._get_pixel_class(skel)
+        ref = orc.network_pixel_class(skel)
+        assert np.array_equal(pc, ref)
+        assert np.array_equal(k._get_branch_skel_labels(pc), orc.network_branch_skel_labels(ref))
+        with pytest.raises(RuntimeError):
+            k._get_pixel_class(skel, force_cpu=True)
+    finally:
+        k.close()

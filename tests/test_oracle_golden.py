@@ -156,3 +156,13 @@ def test_label_with_intensity_threshold_matches_reference(name):
     labels, thr = orc.label_frame(g["frangi"], g["dim_res_dict"], return_thr=True, original=g["input"], **kw)
     assert float(thr) == float(g["label_thr"])
     assert np.array_equal(labels, g["labels"])
+
+
+@pytest.mark.parametrize("name", __import__("conftest").NETWORK_CASES)
+def test_network_steps_match_reference(name):
+    """Network's pixel classes and branch labels (networking.py:672-683, 758-800) against the reference's outputs."""
+    g = load_golden(name)
+    pc = orc.network_pixel_class(g["skel"])
+    assert str(pc.dtype) == str(g["pixel_class_dtype"]) and np.array_equal(pc, g["pixel_class"])
+    bl = orc.network_branch_skel_labels(pc)
+    assert str(bl.dtype) == str(g["branch_labels_dtype"]) and np.array_equal(bl, g["branch_labels"])
