@@ -9,6 +9,7 @@ and ~96 GB there, so parity at full size is shown through size-independent prope
     (majority filter), labels are 1..K without gaps, K equals the returned count, and label ids increase with the
     raster index of each object's first voxel (scipy.ndimage.label's numbering, labelling.py:507).
 """
+import os
 import threading
 
 import numpy as np
@@ -68,20 +69,20 @@ def test_properties_at_1024_cube(full_run):
     assert all(0.01 < sc.mask_count / fr.size < 0.9 for sc in full_run["trace"].scales)
 
 
-def test_two_slabs_equal_one_volume_at_1024_cube(full_run):
+def run_slabs(vol, shape, world, seed_dim_res=None):
+    """The volume as `world` Z-slabs, one context and one thread per slab on this GPU (ghost planes and reductions
+    through the host): [(o0, o1, frangi, labels, thr, n)] per rank."""
     from nellie_amd.pipeline import FilterParams, min_area_pixels_of
     from nellie_amd.sharded import ShardedFramePipeline, slab_range
     from nellie_amd.synthetic import ISO_01
-    world = 2
     group = ThreadGroup(world)
     out, errs = [None] * world, []
-    vol = full_run["vol"]
 
     def worker(rank):
         try:
             p = FilterParams(dim_res=ISO_01)
-            o0, o1 = slab_range(SHAPE[0], world, rank)
-            pipe = ShardedFramePipeline(SHAPE, rank, world, lambda ctx: ThreadComm(group, rank), p)
+            o0, o1 = slab_range(shape[0], world, rank)
+            pipe = ShardedFramePipeline(shape, rank, world, lambda ctx: ThreadComm(group, rank), p)
             pipe.filter(vol[o0:o1], p)
             thr = pipe.frangi_threshold()
             n = pipe.label(thr, min_area_pixels_of(ISO_01))
@@ -98,10 +99,52 @@ def test_two_slabs_equal_one_volume_at_1024_cube(full_run):
         t.join()
     if errs:
         raise errs[0]
-    for o0, o1, fr, lab, thr, n in out:
+    return out
+
+
+def test_two_slabs_equal_one_volume_at_1024_cube(full_run):
+    for o0, o1, fr, lab, thr, n in run_slabs(full_run["vol"], SHAPE, 2):
         assert thr == full_run["thr"], (thr, full_run["thr"])
         assert n == full_run["n"], (n, full_run["n"])
         ref = full_run["frangi"][o0:o1]
         assert np.array_equal(fr, ref), f"slab [{o0},{o1}): {int((fr != ref).sum())} Frangi voxels differ, first at {np.argwhere(fr != ref)[:4].tolist()}"
         ref = full_run["labels"][o0:o1]
         assert np.array_equal(lab, ref), f"slab [{o0},{o1}): {int((lab != ref).sum())} label voxels differ, first at {np.argwhere(lab != ref)[:4].tolist()}"
+
+
+@pytest.mark.skipif(os.environ.get("NELLIE_TEST_C4", "0") != "1", reason="opt-in (NELLIE_TEST_C4=1): ~170 GB of HBM, ~60 GB of host RAM, minutes")
+def test_c4_volume_partition_invariance(hip):
+    """BASELINE.json's 8-GPU configuration -- ONE (1024, 2048, 2048) volume, 4.29e9 voxels -- on a single MI355X: the
+    eight 128-plane slabs of the 8-GPU decomposition (eight contexts on this device, 288 GB of HBM hold them all) and
+    the four 256-plane slabs of a 4-GPU decomposition must give the same Frangi image and the same labels, bit for bit."""
+    import json
+    import time
+    free, _ = hip.device_mem_info(0)
+    if free < 200e9:
+        pytest.skip("needs ~170 GB of free HBM")
+    from nellie_amd.synthetic import make_volume
+    shape = (1024, 2048, 2048)
+    vol = make_volume(shape, 3456)
+    t0 = time.perf_counter()
+    a = run_slabs(vol, shape, 8)
+    t8 = time.perf_counter() - t0
+    fr8 = np.concatenate([r[2] for r in a]); lab8 = np.concatenate([r[3] for r in a])
+    thr8, n8 = a[0][4], a[0][5]
+    assert all(r[4] == thr8 and r[5] == n8 for r in a)
+    del a
+    t0 = time.perf_counter()
+    b = run_slabs(vol, shape, 4)
+    t4 = time.perf_counter() - t0
+    assert all(r[4] == thr8 and r[5] == n8 for r in b), ([r[4] for r in b], thr8, [r[5] for r in b], n8)
+    for o0, o1, fr, lab, _, _ in b:
+        assert np.array_equal(fr, fr8[o0:o1]), f"planes [{o0},{o1}): {int((fr != fr8[o0:o1]).sum())} Frangi voxels differ"
+        assert np.array_equal(lab, lab8[o0:o1]), f"planes [{o0},{o1}): {int((lab != lab8[o0:o1]).sum())} label voxels differ"
+    assert fr8.min() >= 0.0 and np.isfinite(fr8.max()) and n8 >= 10 and int(lab8.max()) == n8
+    report = {"shape": list(shape), "voxels": int(np.prod(shape)), "labels": int(n8), "frangi_threshold": float(thr8),
+              "survival_fraction": float(np.count_nonzero(fr8) / fr8.size), "labelled_fraction": float(np.count_nonzero(lab8) / lab8.size),
+              "wall_s_8_slabs_one_gpu_incl_host_io": round(t8, 2), "wall_s_4_slabs_one_gpu_incl_host_io": round(t4, 2),
+              "equal_bit_for_bit": True}
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/c4_partition_invariance.json", "w") as f:
+        json.dump(report, f)
+    print(json.dumps(report))
