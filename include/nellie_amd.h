@@ -350,11 +350,17 @@ int nl_prof_reset(nl_ctx *ctx);
                       clamped at 0; a valid voxel (mask & distance > 0) whose response equals the maximum of its 3x3x3
                       neighbourhood (mode 'nearest') and beats every earlier scale becomes a peak.  Weights: scipy's
                       `_gaussian_kernel1d` of order 2 / 0, truncate 4.0, 2r+1 float64 values each, s2 = float32(s**2).
+                      2-D image (context of shape (1, ny, nx)): wz2 = wz0 = NULL, sigma_vec = (s, s) (:323-324) -- the two
+                      in-plane terms only; distance transform, border, 3x3 maxima and the suppression window are the
+                      nz = 1 cases of the 3-D kernels.
    nl_markers_finish : :569-606 -- a peak survives if its float32 intensity is positive and equals the maximum over the
                       peaks within +-peak_min_distance.
    nl_markers_store  : marker (uint8 0/1), distance (float32), border (uint8 0/1); NULL pointers are skipped. */
 int nl_markers_begin(nl_ctx *ctx, const int32_t *labels_host, const void *intensity_host, int dtype, char *err, size_t errlen);
 int nl_markers_distance(nl_ctx *ctx, float clamp, int64_t *n_mask, char *err, size_t errlen);
+/* use_im = 'frangi' (mocap_marking.py:675-679): the LoG of nl_markers_log_step runs on this float32 image (whole
+   volume, host) instead of the distance image; NULL switches back.  Call between nl_markers_begin and the first step. */
+int nl_markers_use_image(nl_ctx *ctx, const float *image, char *err, size_t errlen);
 int nl_markers_log_step(nl_ctx *ctx, const double *wz2, const double *wz0, int rz, const double *wy2, const double *wy0,
                         const double *wx2, const double *wx0, int ryx, float s2, char *err, size_t errlen);
 int nl_markers_finish(nl_ctx *ctx, int peak_min_distance, int64_t *n_markers, char *err, size_t errlen);

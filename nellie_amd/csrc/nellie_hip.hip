@@ -1320,7 +1320,6 @@ static float *mk_intensity(nl_ctx *c) { return c->d_vq; }
 extern "C" int nl_markers_begin(nl_ctx *c, const int *labels_host, const void *intensity_host, int dtype, char *err, size_t errlen) {
     NL_ENTER(c);
     NL_JOIN_SIDE(c);
-    if (c->two_d) return nl_fail(err, errlen, NL_EINVAL, "the Markers stage is implemented for 3-D volumes");
     if (c->own_lo != 0 || c->own_hi != c->nzl || c->gnz != c->nzl) return nl_fail(err, errlen, NL_EINVAL, "the Markers stage runs on a whole volume (no Z slabs yet)");
     const int wpr = (int)((c->nx + 63) / 64);
     const i64 nrows = c->nzl * c->ny;
@@ -1363,7 +1362,20 @@ extern "C" int nl_markers_begin(nl_ctx *c, const int *labels_host, const void *i
         NL_CHECK_LAUNCH();
     }
     c->i_labels = -1; c->frangi_ready = 0; c->gauss_ext = nullptr; c->fsq_cache_valid = 0;
-    c->mk_state = 1; c->mk_first_scale = 1;
+    c->mk_state = 1; c->mk_first_scale = 1; c->mk_use = nullptr;
+    return NL_OK;
+}
+
+// use_im = 'frangi' (mocap_marking.py:675-679): the LoG runs on this float32 image instead of the distance image
+extern "C" int nl_markers_use_image(nl_ctx *c, const float *host, char *err, size_t errlen) {
+    NL_ENTER(c);
+    if (c->mk_state < 1) return nl_fail(err, errlen, NL_ESTATE, "nl_markers_use_image before nl_markers_begin");
+    if (!host) { c->mk_use = nullptr; return NL_OK; }
+    if (vq_alloc_entries(c->nzl, c->ny, c->nx) * 32 < c->n * 8) return nl_fail(err, errlen, NL_ENOMEM, "scratch too small for the LoG source image [out of memory]");
+    float *dst = mk_intensity(c) + c->n;
+    NL_HIP(hipMemcpyAsync(dst, host, (size_t)c->n * 4, hipMemcpyHostToDevice, c->stream));
+    NL_HIP(hipStreamSynchronize(c->stream));
+    c->mk_use = dst;
     return NL_OK;
 }
 
@@ -1406,11 +1418,13 @@ extern "C" int nl_markers_log_step(nl_ctx *c, const double *wz2, const double *w
                                    const double *wx2, const double *wx0, int ryx, float s2, char *err, size_t errlen) {
     NL_ENTER(c);
     if (c->mk_state < 2) return nl_fail(err, errlen, NL_ESTATE, "nl_markers_log_step before nl_markers_distance");
-    if (!wz2 || !wz0 || !wy2 || !wy0 || !wx2 || !wx0) return nl_fail(err, errlen, NL_EINVAL, "weights are NULL");
-    if (rz < 1 || ryx < 1 || ryx > GM_MAX_R || ryx > c->ny) return nl_fail(err, errlen, NL_EINVAL, "LoG radii (%d, %d) outside the supported range [1, %d]", rz, ryx, GM_MAX_R);
+    const bool flat = !wz2 && !wz0;                    // 2-D image: sigma_vec = (s, s), no Z terms (mocap_marking.py:323-324)
+    if (flat && c->nzl != 1) return nl_fail(err, errlen, NL_EINVAL, "Z weights are NULL on a 3-D context");
+    if ((!flat && (!wz2 || !wz0)) || !wy2 || !wy0 || !wx2 || !wx0) return nl_fail(err, errlen, NL_EINVAL, "weights are NULL");
+    if ((!flat && rz < 1) || ryx < 1 || ryx > GM_MAX_R || ryx > c->ny) return nl_fail(err, errlen, NL_EINVAL, "LoG radii (%d, %d) outside the supported range [1, %d]", rz, ryx, GM_MAX_R);
     GaussW gz2, gz0, gy2, gy0, gx2, gx0;
     int rc;
-    if ((rc = fill_gw(gz2, wz2, rz, err, errlen)) || (rc = fill_gw(gz0, wz0, rz, err, errlen)) || (rc = fill_gw(gy2, wy2, ryx, err, errlen)) ||
+    if ((!flat && ((rc = fill_gw(gz2, wz2, rz, err, errlen)) || (rc = fill_gw(gz0, wz0, rz, err, errlen)))) || (rc = fill_gw(gy2, wy2, ryx, err, errlen)) ||
         (rc = fill_gw(gy0, wy0, ryx, err, errlen)) || (rc = fill_gw(gx2, wx2, ryx, err, errlen)) || (rc = fill_gw(gx0, wx0, ryx, err, errlen))) return rc;
     const VolGeom v = geom(c);
     const i64 z0 = 0, z1 = c->nzl;
@@ -1418,16 +1432,18 @@ extern "C" int nl_markers_log_step(nl_ctx *c, const double *wz2, const double *w
     const dim3 grid((unsigned)((c->nx + 255) / 256), (unsigned)c->ny, (unsigned)c->nzl);
     const dim3 g2((unsigned)((c->nx + GYX_COLS - 1) / GYX_COLS), (unsigned)((c->ny + GM_CHUNK - 1) / GM_CHUNK), (unsigned)c->nzl);
     float *dist = c->f[0], *tz = c->f[1], *lap = c->f[2];
+    const float *use = c->mk_use ? c->mk_use : dist;            // the image the LoG runs on
     auto ws_of = [](const GaussW &g) { GaussWS w; for (int k = 0; k <= GM_MAX_R; ++k) w.w[k] = k <= g.r ? g.w[k] : 0.0; return w; };
     auto zpass = [&](const GaussW &gz) {
-        if (!launch_gauss_fast<0>(c, dist, tz, v, z0, z1, gz)) gauss_axis_kernel<0><<<grid, blk, 0, c->stream>>>(dist, tz, v, z0, z1, gz);
+        if (!launch_gauss_fast<0>(c, use, tz, v, z0, z1, gz)) gauss_axis_kernel<0><<<grid, blk, 0, c->stream>>>(use, tz, v, z0, z1, gz);
     };
     // large radii: the fused Y+X kernel turns compute-bound (one output per thread reads 2R+1 LDS values); a marching Y
     // pass plus the stand-alone X kernel (four outputs per thread) through one more scratch volume is faster there
     static int split_from = -1;
     if (split_from < 0) { const char *e = getenv("NELLIE_MK_SPLIT_R"); split_from = e ? atoi(e) : 8; }
     float *tmp2 = mk_intensity(c) + c->n;
-    const bool can_split = vq_alloc_entries(c->nzl, c->ny, c->nx) * 32 >= c->n * 8;
+    const bool can_split = !c->mk_use && vq_alloc_entries(c->nzl, c->ny, c->nx) * 32 >= c->n * 8;     // mk_use lives in tmp2's place
+    const float *yx_src = flat ? use : tz;
     auto yx = [&](const GaussW &gy, const GaussW &gx, bool acc) {
         const GaussWS wy = ws_of(gy), wx = ws_of(gx);
         if (can_split && ryx >= split_from) {
@@ -1435,7 +1451,7 @@ extern "C" int nl_markers_log_step(nl_ctx *c, const double *wz2, const double *w
             const dim3 gxk((unsigned)((c->nx + GX_SEG - 1) / GX_SEG), (unsigned)c->ny, (unsigned)c->nzl);
             const int vec4 = (c->nx % 4 == 0) ? 1 : 0;
             switch (ryx) {
-#define NL_MKS(RR) case RR: gauss_march_kernel<1, RR><<<gym, 256, 0, c->stream>>>(tz, tmp2, v, z0, z1, wy);                      \
+#define NL_MKS(RR) case RR: gauss_march_kernel<1, RR><<<gym, 256, 0, c->stream>>>(yx_src, tmp2, v, z0, z1, wy);                      \
                             gauss_x_kernel<RR><<<gxk, 256, 0, c->stream>>>(tmp2, lap, v, z0, z1, wx, vec4, acc ? 1 : 0); break;
                 NL_MKS(1) NL_MKS(2) NL_MKS(3) NL_MKS(4) NL_MKS(5) NL_MKS(6) NL_MKS(7) NL_MKS(8) NL_MKS(9) NL_MKS(10) NL_MKS(11) NL_MKS(12)
 #undef NL_MKS
@@ -1443,8 +1459,8 @@ extern "C" int nl_markers_log_step(nl_ctx *c, const double *wz2, const double *w
             return;
         }
         switch (ryx) {
-#define NL_MKYX(RR) case RR: if (acc) gauss_yx_kernel<RR, true><<<g2, GYX_THREADS, 0, c->stream>>>(tz, lap, v, z0, z1, wy, wx); \
-                             else gauss_yx_kernel<RR, false><<<g2, GYX_THREADS, 0, c->stream>>>(tz, lap, v, z0, z1, wy, wx); break;
+#define NL_MKYX(RR) case RR: if (acc) gauss_yx_kernel<RR, true><<<g2, GYX_THREADS, 0, c->stream>>>(yx_src, lap, v, z0, z1, wy, wx); \
+                             else gauss_yx_kernel<RR, false><<<g2, GYX_THREADS, 0, c->stream>>>(yx_src, lap, v, z0, z1, wy, wx); break;
             NL_MKYX(1) NL_MKYX(2) NL_MKYX(3) NL_MKYX(4) NL_MKYX(5) NL_MKYX(6) NL_MKYX(7) NL_MKYX(8) NL_MKYX(9) NL_MKYX(10) NL_MKYX(11) NL_MKYX(12)
 #undef NL_MKYX
         }
@@ -1452,8 +1468,12 @@ extern "C" int nl_markers_log_step(nl_ctx *c, const double *wz2, const double *w
     {
         ProfScope ps(c, "markers_log");
         // generic_laplace: output = d2/dz2 term; output += d2/dy2 term; output += d2/dx2 term (float32 adds, in this order)
-        zpass(gz2); yx(gy0, gx0, false);
-        zpass(gz0); yx(gy2, gx0, true); yx(gy0, gx2, true);
+        if (flat) {
+            yx(gy2, gx0, false); yx(gy0, gx2, true);
+        } else {
+            zpass(gz2); yx(gy0, gx0, false);
+            zpass(gz0); yx(gy2, gx0, true); yx(gy0, gx2, true);
+        }
         NL_CHECK_LAUNCH();
     }
     {

@@ -47,6 +47,7 @@ struct nl_ctx {
     float *d_vq = nullptr;     // global queue of voxels to eigen-solve (32-byte entries, one region per wave)
     unsigned int *d_vq_count = nullptr;   // entries written per region
     int nw_state = 0;             // Network: 1 after nl_skel_pixel_class (classes + branch bits resident)
+    float *mk_use = nullptr;      // Markers: LoG source when use_im = 'frangi' (inside d_vq), else the distance image
     int mk_state = 0;             // Markers: 0 idle, 1 begun, 2 distance done, 3 finished
     int mk_first_scale = 1;
     int two_d = 0;                // the frame is a (Y, X) image (im_info.no_z): 2-D Hessian, eigenvalues, Frangi, opening

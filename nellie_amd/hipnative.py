@@ -62,6 +62,7 @@ _PROTOS = {
     "nl_markers_log_step": [_p, C.POINTER(_f64), C.POINTER(_f64), _int, C.POINTER(_f64), C.POINTER(_f64), C.POINTER(_f64),
                             C.POINTER(_f64), _int, _f32],
     "nl_markers_finish": [_p, _int, C.POINTER(_i64)],
+    "nl_markers_use_image": [_p, _p],
     "nl_markers_store": [_p, _p, _p, _p],
     "nl_skel_pixel_class": [_p, _p, _p, C.POINTER(_i64)],
     "nl_skel_branch_labels": [_p, _p, _p, C.POINTER(_i64)],
@@ -404,11 +405,29 @@ class Context:
         return int(n.value)
 
     def markers_log_step(self, wz2, wz0, wy2, wy0, wx2, wx0, s2):
-        arrs = [np.ascontiguousarray(w, dtype=np.float64) for w in (wz2, wz0, wy2, wy0, wx2, wx0)]
-        rz, ryx = (arrs[0].size - 1) // 2, (arrs[2].size - 1) // 2
-        assert arrs[1].size == arrs[0].size and all(a.size == arrs[2].size for a in arrs[2:])
+        """One sigma of mocap_marking.py:488-508.  wz2 = wz0 = None: 2-D image (no Z terms)."""
+        flat = wz2 is None and wz0 is None
+        arrs = [np.ascontiguousarray(w, dtype=np.float64) for w in (wy2, wy0, wx2, wx0)]
+        ryx = (arrs[0].size - 1) // 2
+        assert all(a.size == arrs[0].size for a in arrs)
         ptr = [a.ctypes.data_as(C.POINTER(_f64)) for a in arrs]
-        self._call("nl_markers_log_step", ptr[0], ptr[1], rz, ptr[2], ptr[3], ptr[4], ptr[5], ryx, float(np.float32(s2)))
+        if flat:
+            self._call("nl_markers_log_step", None, None, 0, ptr[0], ptr[1], ptr[2], ptr[3], ryx, float(np.float32(s2)))
+            return
+        z2, z0 = np.ascontiguousarray(wz2, dtype=np.float64), np.ascontiguousarray(wz0, dtype=np.float64)
+        assert z2.size == z0.size
+        self._call("nl_markers_log_step", z2.ctypes.data_as(C.POINTER(_f64)), z0.ctypes.data_as(C.POINTER(_f64)), (z2.size - 1) // 2,
+                   ptr[0], ptr[1], ptr[2], ptr[3], ryx, float(np.float32(s2)))
+
+    def markers_use_image(self, image=None):
+        """use_im='frangi' (mocap_marking.py:675-679): the float32 image the LoG runs on; None = the distance image."""
+        if image is None:
+            self._call("nl_markers_use_image", None)
+            return
+        im = np.ascontiguousarray(image, dtype=np.float32)
+        if im.size != int(np.prod(self.shape)):
+            raise ValueError(f"image shape {im.shape} does not match the context shape {tuple(self.shape)}")
+        self._call("nl_markers_use_image", _ptr(im))
 
     def markers_finish(self, peak_min_distance) -> int:
         n = _i64(0)

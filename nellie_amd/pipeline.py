@@ -525,22 +525,27 @@ class FramePipeline:
 
     # ------------------------------------------------------------------ Markers (the stage after Label)
     def markers(self, dim_res, labels=None, intensity=None, min_radius_um=0.20, max_radius_um=1, num_sigma=5,
-                peak_min_distance=2):
-        """mocap_marking.py:648-703 (use_im='distance') on the device; returns the number of markers.  labels /
-        intensity default to what Label and load_input left on the device.  Products: download_markers()."""
-        if self.two_d:
-            raise NotImplementedError("the HIP Markers stage implements the 3-D path")
+                peak_min_distance=2, use_image=None):
+        """mocap_marking.py:648-703 on the device; returns the number of markers.  labels / intensity default to what
+        Label and load_input left on the device.  use_image: the float32 image the LoG runs on (use_im='frangi',
+        :675-679); None = the distance image (use_im='distance').  2-D pipelines follow the reference's `no_z`
+        branch (sigma_vec = (s, s), :323-324).  Products: download_markers()."""
         sigmas, max_r_px = marker_sigmas(dim_res, min_radius_um, max_radius_um, num_sigma)
-        zr = z_ratio_of(dim_res)
         ctx = self.ctx
-        ctx.markers_begin(labels, intensity)
+        ctx.markers_begin(None if labels is None else self._as_frame(labels), None if intensity is None else self._as_frame(intensity))
         n_mask = ctx.markers_distance(np.float32(max_r_px * 2.0))
         if n_mask > 0:                                  # empty mask: no markers, zero distance and border (:662-667)
+            if use_image is not None:
+                ctx.markers_use_image(self._as_frame(use_image))
+            zr = None if self.two_d else z_ratio_of(dim_res)
             for s in sigmas:
                 sv = float(s)
-                wz2, wz0 = gaussian_derivative_weights(sv / zr, 2), gaussian_derivative_weights(sv / zr, 0)
                 w2, w0 = gaussian_derivative_weights(sv, 2), gaussian_derivative_weights(sv, 0)
-                ctx.markers_log_step(wz2, wz0, w2, w0, w2, w0, np.float32(sv ** 2))
+                if self.two_d:
+                    ctx.markers_log_step(None, None, w2, w0, w2, w0, np.float32(sv ** 2))
+                else:
+                    wz2, wz0 = gaussian_derivative_weights(sv / zr, 2), gaussian_derivative_weights(sv / zr, 0)
+                    ctx.markers_log_step(wz2, wz0, w2, w0, w2, w0, np.float32(sv ** 2))
         return ctx.markers_finish(int(peak_min_distance))
 
     def download_markers(self):

@@ -52,7 +52,7 @@ def run(im_info, remove_edges=False, otsu_thresh_intensity=False, threshold=None
     if timeit:
         t2 = time.perf_counter()
         print(f"[timeit] Label: {t2 - t1:.3f}s")
-    if markers and not im_info.no_z:
+    if markers:
         from nellie_amd.segmentation.mocap_marking import Markers
         Markers(im_info, device=device, low_memory=low_memory).run()
         if timeit:

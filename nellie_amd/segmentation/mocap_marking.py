@@ -6,9 +6,10 @@ motion-capture markers (multi-scale LoG peaks of the distance image, intensity-b
 Same constructor keywords, same `.run()`, same on-disk products (`im_marker` uint8, `im_distance` float32,
 `im_border` uint8 in `im_info.pipeline_paths`).  All three are bit-identical to the reference's numpy path.
 
-Differences (documented in DESIGN.md): 3-D volumes with `use_im='distance'` (the default) only -- 2-D images and
-`use_im='frangi'` raise NotImplementedError; `low_memory` / `max_chunk_voxels` are accepted and ignored; there is no
-CPU engine behind this class (`device="cpu"` raises).
+3-D volumes and 2-D (`no_z`) images, `use_im='distance'` (the default) and `use_im='frangi'`.
+Differences (documented in DESIGN.md): `low_memory` / `max_chunk_voxels` are accepted and ignored (the reference's
+chunked path gives the same results as its full-frame path); there is no CPU engine behind this class
+(`device="cpu"` raises).
 """
 from __future__ import annotations
 
@@ -76,6 +77,8 @@ class Markers:
         logger.debug("Allocating memory for mocap marking.")
         self.label_memmap = self.im_info.get_memmap(self.im_info.pipeline_paths["im_instance_label"])
         self.im_memmap = self.im_info.get_memmap(self.im_info.im_path)
+        if self.use_im == "frangi":
+            self.im_frangi_memmap = self.im_info.get_memmap(self.im_info.pipeline_paths["im_preprocessed"])
         self.shape = self.label_memmap.shape
         alloc = self.im_info.allocate_memory
         self.im_marker_memmap = alloc(self.im_info.pipeline_paths["im_marker"], dtype="uint8",
@@ -99,14 +102,39 @@ class Markers:
             self._pipeline = None
 
     # ------------------------------------------------------------------ frames (mocap_marking.py:648-703)
-    def _run_frame(self, t):
+    def _run_frame_impl(self, t, low_memory=False, chunk_voxels=None):
+        """(marker uint8, distance float32, border uint8) of frame t.  `low_memory` / `chunk_voxels` select the
+        reference's chunked CPU path, whose results equal the full-frame ones (tests/test_mocap_marking.py:34-58);
+        here the frame is always processed whole on the device."""
         logger.info(f"Running motion capture marking, volume {t}/{self.num_t - 1}")
         intensity = np.asarray(self.im_memmap[t])
         labels = np.asarray(self.label_memmap[t])
+        use_image = None
+        if self.use_im == "frangi":                                   # mocap_marking.py:675-679
+            if self.im_frangi_memmap is None:
+                raise RuntimeError("Frangi image requested for peak detection but not available.")
+            use_image = np.asarray(self.im_frangi_memmap[t], dtype=np.float32)
+        elif self.use_im != "distance":
+            raise ValueError(f"Unknown use_im value: {self.use_im}")
         pipe = self._get_pipeline(labels.shape)
         pipe.markers(self.im_info.dim_res, labels=labels, intensity=intensity, min_radius_um=self.min_radius_um,
-                     max_radius_um=self.max_radius_um, num_sigma=self.num_sigma, peak_min_distance=self.peak_min_distance)
-        return pipe.download_markers()
+                     max_radius_um=self.max_radius_um, num_sigma=self.num_sigma, peak_min_distance=self.peak_min_distance,
+                     use_image=use_image)
+        return tuple(a.reshape(labels.shape) for a in pipe.download_markers())
+
+    def _run_frame(self, t):
+        return self._run_frame_impl(t)
+
+    def _distance_im(self, mask):
+        """mocap_marking.py:419-450: (float32 distance to the background clamped at 2 * max_radius_px, bool border shell)."""
+        mask = np.asarray(mask).astype(bool)
+        pipe = self._get_pipeline(mask.shape)
+        ctx = pipe.ctx
+        ctx.markers_begin(pipe._as_frame(mask.astype(np.int32)), pipe._as_frame(np.zeros(mask.shape, np.float32)))
+        ctx.markers_distance(np.float32(self.max_radius_px * 2.0))
+        ctx.markers_finish(0)
+        _, dist, border = ctx.markers_store(marker=False)
+        return dist.reshape(mask.shape), border.reshape(mask.shape).astype(bool)
 
     def _run_mocap_marking(self):
         for t in range(self.num_t):
@@ -126,10 +154,6 @@ class Markers:
                     mm.flush()
 
     def run(self):
-        if self.im_info.no_z:
-            raise NotImplementedError("the HIP Markers stage implements the 3-D path; 2-D (no_z) images are not supported yet")
-        if self.use_im != "distance":
-            raise NotImplementedError("the HIP Markers stage implements use_im='distance' (the reference's default)")
         logger.info("Running Markers (HIP).")
         self._get_t()
         self._allocate_memory()

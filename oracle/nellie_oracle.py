@@ -1063,7 +1063,11 @@ def distance_transform_edt_exact(mask):
 
 def marker_distance_and_border(mask, max_radius_px):
     """mocap_marking.py:419-450."""
-    border = binary_dilation6(mask) ^ mask if mask.ndim == 3 else None
+    if mask.ndim == 3:
+        border = binary_dilation6(mask) ^ mask
+    else:                                           # 2-D: the default structuring element is the 4-connected cross
+        p = np.pad(mask, 1, mode="constant", constant_values=False)
+        border = (p[1:-1, 1:-1] | p[:-2, 1:-1] | p[2:, 1:-1] | p[1:-1, :-2] | p[1:-1, 2:]) ^ mask
     dist = distance_transform_edt_exact(mask).astype(np.float32)
     np.minimum(dist, max_radius_px * 2.0, out=dist)
     return dist, border
@@ -1114,14 +1118,17 @@ def marker_remove_close_peaks(coords, intensity_im, peak_min_distance=2):
     return np.argwhere((score == mx) & (score > 0))
 
 
-def markers_frame(intensity, labels, dim_res, min_radius_um=0.20, max_radius_um=1, num_sigma=5, peak_min_distance=2):
-    """mocap_marking.py:648-703 (use_im='distance'), 3-D: (marker uint8, distance float32, border uint8)."""
+def markers_frame(intensity, labels, dim_res, min_radius_um=0.20, max_radius_um=1, num_sigma=5, peak_min_distance=2,
+                  frangi=None):
+    """mocap_marking.py:648-703, 3-D volumes and 2-D images: (marker uint8, distance float32, border uint8).
+    frangi=None: use_im='distance'; a float32 image: use_im='frangi' (:675-679, the LoG runs on it)."""
     mask = np.asarray(labels) > 0
     if not mask.any():
         return (np.zeros(mask.shape, np.uint8), np.zeros(mask.shape, np.float32), np.zeros(mask.shape, np.uint8))
     sigmas, max_r = marker_sigmas(dim_res, min_radius_um, max_radius_um, num_sigma)
     dist, border = marker_distance_and_border(mask, max_r)
-    coords = marker_local_max_peaks(dist, mask, dist, sigmas, z_ratio(dim_res))
+    base = dist if frangi is None else np.asarray(frangi)
+    coords = marker_local_max_peaks(base, mask, dist, sigmas, z_ratio(dim_res) if mask.ndim == 3 else None)
     coords = marker_remove_close_peaks(coords, np.asarray(intensity), peak_min_distance)
     marker = np.zeros(mask.shape, np.uint8)
     if coords.size:

@@ -274,6 +274,55 @@ def markers_cases():
     case("markers_empty_12x20x20", make_volume((12, 20, 20), 4), np.zeros((12, 20, 20), np.int32), ISO_01)
 
 
+def markers_cases_more():
+    """Markers stage, the remaining branches: 2-D images (`no_z`, mocap_marking.py:323-324) and use_im='frangi'
+    (:675-679).  File names start with `markers2d_` / `markersfr_` so the 3-D distance cases stay untouched."""
+    from nellie.segmentation.mocap_marking import Markers
+    sys.path.insert(0, REPO)
+    from nellie_amd.synthetic import make_volume, make_image_2d, ISO_01, ANISO_03
+    import oracle.nellie_oracle as orc            # only to produce realistic label / Frangi images to feed the reference
+
+    def case(name, vol, lab, dim_res, frangi=None, **kw):
+        info = im_info(vol.shape, dim_res) if vol.ndim == 3 else im_info_2d(vol.shape, dim_res)
+        m = Markers(info, device="cpu", use_im="distance" if frangi is None else "frangi", **kw)
+        m._set_default_sigmas()
+        m.im_memmap, m.label_memmap, m.num_t = vol[None], lab[None], 1
+        m.im_frangi_memmap = None if frangi is None else frangi[None]
+        marker, dist, border = m._run_frame_impl(0)
+        z = dim_res.get("Z")
+        meta = dict(dim_res=np.array([np.nan if z is None else z, dim_res["Y"], dim_res["X"]], dtype=np.float64), input=vol)
+        for k, val in kw.items():
+            meta["kw_" + k] = np.float64(val)
+        if frangi is not None:
+            meta["frangi_in"] = frangi.astype(np.float32)
+        save(name, labels_in=lab.astype(np.int32), sigmas=np.array(m.sigmas, dtype=np.float64),
+             marker=np.asarray(marker, np.uint8), distance=np.asarray(dist, np.float32), border=np.asarray(border, np.uint8), **meta)
+
+    iso2 = {"X": 0.1, "Y": 0.1, "Z": None, "T": 1.0}
+    for name, shape, seed in (("markers2d_iso_96x80_s1", (96, 80), 1), ("markers2d_iso_130x200_s2", (130, 200), 2)):
+        img = make_image_2d(shape, seed)
+        lab = orc.label_frame_2d(orc.filter_frame_2d(img, iso2), iso2)
+        case(name, img, lab, iso2)
+    img = make_image_2d((96, 80), 1)
+    lab = orc.label_frame_2d(orc.filter_frame_2d(img, iso2), iso2)
+    case("markers2d_pmd3_96x80_s1", img, lab, iso2, peak_min_distance=3)
+    coarse = {"X": 0.2, "Y": 0.2, "Z": None, "T": 1.0}          # the reference's own test geometry (tests/test_mocap_marking.py)
+    inten = np.zeros((9, 9), np.float32); inten[4, 4] = 10.0
+    sq = np.zeros((9, 9), np.int32); sq[2:7, 2:7] = 1
+    case("markers2d_reftest_9x9", inten, sq, coarse, num_sigma=3)
+    blob = np.zeros((70, 90), np.int32); blob[5:60, 8:80] = 1; blob[30:34, 40:44] = 0
+    case("markers2d_blob_70x90", make_image_2d((70, 90), 3), blob, iso2)
+    case("markers2d_empty_20x20", make_image_2d((20, 20), 4), np.zeros((20, 20), np.int32), iso2)
+    # use_im='frangi'
+    for name, shape, dr, seed in (("markersfr_iso_24x48x48_s1", (24, 48, 48), ISO_01, 1), ("markersfr_aniso_20x40x44_s3", (20, 40, 44), ANISO_03, 3)):
+        vol = make_volume(shape, seed)
+        fr = orc.filter_frame(vol, dr)
+        case(name, vol, orc.label_frame(fr, dr), dr, frangi=fr)
+    img = make_image_2d((96, 80), 1)
+    fr = orc.filter_frame_2d(img, iso2)
+    case("markersfr2d_iso_96x80_s1", img, orc.label_frame_2d(fr, iso2), iso2, frangi=fr)
+
+
 def network_cases():
     """Network stage, the two dense steps (nellie/segmentation/networking.py:672-683 and :758-800): the reference's
     pixel classes and branch labels for given skeleton label images (3-D and 2-D)."""
@@ -360,6 +409,9 @@ def main():
     if "--only-markers" in sys.argv:
         markers_cases()
         return
+    if "--only-markers-more" in sys.argv:
+        markers_cases_more()
+        return
     if "--only-network" in sys.argv:
         network_cases()
         return
@@ -437,6 +489,8 @@ def main():
     save("labelonly_aniso_24x48x48", frangi=lv2, dim_res=np.array([0.3, 0.1, 0.1]), **lab2)
     twod_cases(Filter, Label)
     markers_cases()
+    markers_cases_more()
+    network_cases()
 
 
 if __name__ == "__main__":

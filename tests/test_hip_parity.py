@@ -323,29 +323,31 @@ def test_stage_api_2d(hip):
 
 @pytest.mark.parametrize("name", MARKERS_CASES)
 def test_markers_golden_bitexact(name, hip):
-    """Markers stage against the reference's own outputs: marker, distance and border images bit for bit."""
+    """Markers stage against the reference's own outputs: marker, distance and border images bit for bit -- 3-D and
+    2-D images, use_im='distance' and use_im='frangi'."""
     from nellie_amd import pipeline as pl
     g = load_golden(name)
     dr = g["dim_res_dict"]
-    kw = {k: (int(v) if k == "peak_min_distance" else v) for k, v in g["kwargs"].items()}
-    vol, lab = g["input"], g["labels_in"]
+    kw = {k: (int(v) if k in ("peak_min_distance", "num_sigma") else v) for k, v in g["kwargs"].items()}
+    vol, lab, fr = g["input"], g["labels_in"], g.get("frangi_in")
     pipe = pl.FramePipeline(vol.shape)
     try:
-        sig, _ = pl.marker_sigmas(dr)
+        sig, _ = pl.marker_sigmas(dr, num_sigma=kw.get("num_sigma", 5))
         assert np.array_equal(np.array(sig), g["sigmas"])
-        n = pipe.markers(dr, labels=lab, intensity=vol, **kw)
-        marker, dist, border = pipe.download_markers()
+        n = pipe.markers(dr, labels=lab, intensity=vol, use_image=fr, **kw)
+        marker, dist, border = (a.reshape(vol.shape) for a in pipe.download_markers())
         assert np.array_equal(dist, g["distance"])
         assert np.array_equal(border, g["border"])
         assert np.array_equal(marker, g["marker"]) and n == int(g["marker"].sum())
-        # the same from device-resident labels and input (Filter -> Label -> Markers without leaving the GPU)
-        pipe.load_input(vol)
-        pipe.upload_frangi(np.where(lab > 0, 1.0, 0.0).astype(np.float32))
-        pipe.label(np.float32(0.5), 1, fill_holes=False)
-        if np.array_equal(pipe.download_labels() > 0, lab > 0):          # same object mask (ids do not matter)
-            pipe.markers(dr, **kw)
-            m2, d2, b2 = pipe.download_markers()
-            assert np.array_equal(m2, g["marker"]) and np.array_equal(d2, g["distance"]) and np.array_equal(b2, g["border"])
+        if vol.ndim == 3 and fr is None:
+            # the same from device-resident labels and input (Filter -> Label -> Markers without leaving the GPU)
+            pipe.load_input(vol)
+            pipe.upload_frangi(np.where(lab > 0, 1.0, 0.0).astype(np.float32))
+            pipe.label(np.float32(0.5), 1, fill_holes=False)
+            if np.array_equal(pipe.download_labels() > 0, lab > 0):          # same object mask (ids do not matter)
+                pipe.markers(dr, **kw)
+                m2, d2, b2 = pipe.download_markers()
+                assert np.array_equal(m2, g["marker"]) and np.array_equal(d2, g["distance"]) and np.array_equal(b2, g["border"])
     finally:
         pipe.close()
 
@@ -369,6 +371,65 @@ def test_stage_api_markers(hip):
         assert np.array_equal(np.asarray(im_info.store["border"][t]), border)
         assert np.array_equal(np.asarray(im_info.store["marker"][t]), marker)
         assert im_info.store["marker"].dtype == np.uint8 and im_info.store["distance"].dtype == np.float32
+
+
+def test_stage_api_markers_2d_and_frangi(hip):
+    """Markers on a 2-D (no_z) stack and with use_im='frangi': products equal the oracle's on the same labels / Frangi."""
+    from fakes import ArrayImInfo
+    from nellie_amd.segmentation.filtering import Filter
+    from nellie_amd.segmentation.labelling import Label
+    from nellie_amd.segmentation.mocap_marking import Markers
+    from nellie_amd.synthetic import ISO_01, make_image_2d, make_volume
+    iso2 = {"X": 0.1, "Y": 0.1, "Z": None, "T": 1.0}
+    imgs = np.stack([make_image_2d((96, 80), 60 + t) for t in range(2)])
+    info2 = ArrayImInfo(imgs, iso2, no_z=True)
+    Filter(info2).run(); Label(info2).run(); Markers(info2).run()
+    for t in range(2):
+        marker, dist, border = orc.markers_frame(imgs[t], np.asarray(info2.store["labels"][t]), iso2)
+        assert np.array_equal(np.asarray(info2.store["distance"][t]), dist)
+        assert np.array_equal(np.asarray(info2.store["border"][t]), border)
+        assert np.array_equal(np.asarray(info2.store["marker"][t]), marker)
+    vols = np.stack([make_volume((24, 48, 48), 70)])
+    info3 = ArrayImInfo(vols, ISO_01)
+    Filter(info3).run(); Label(info3).run(); Markers(info3, use_im="frangi").run()
+    marker, dist, border = orc.markers_frame(vols[0], np.asarray(info3.store["labels"][0]), ISO_01,
+                                             frangi=np.asarray(info3.store["frangi"][0]))
+    assert np.array_equal(np.asarray(info3.store["marker"][0]), marker) and marker.sum() > 0
+    assert np.array_equal(np.asarray(info3.store["distance"][0]), dist)
+    with pytest.raises(ValueError):
+        m = Markers(info3, use_im="nonsense"); m._get_t(); m._allocate_memory(); m._set_default_sigmas(); m._run_frame(0)
+
+
+def test_reference_mocap_tests_on_the_hip_class(hip):
+    """The reference's own tests for this stage (tests/test_mocap_marking.py:34-71) run against the HIP class: the
+    `low_memory` call equals the full-frame call, and the border shell never overlaps the mask."""
+    from types import SimpleNamespace
+    from nellie_amd.segmentation.mocap_marking import Markers
+    info = SimpleNamespace(no_t=True, no_z=True, shape=(1, 9, 9), axes="TYX", dim_res={"X": 0.2, "Y": 0.2, "Z": None, "T": 1.0})
+    intensity = np.zeros((1, 9, 9), dtype=np.float32); intensity[0, 4, 4] = 10.0
+    labels = np.zeros((1, 9, 9), dtype=np.uint8); labels[0, 2:7, 2:7] = 1
+
+    def setup(**kw):
+        m = Markers(info, num_t=1, **kw)
+        m.im_memmap, m.label_memmap, m.shape = intensity, labels, labels.shape
+        m._set_default_sigmas()
+        return m
+
+    full = setup(num_sigma=3, low_memory=False)
+    low = setup(num_sigma=3, low_memory=True, max_chunk_voxels=20)
+    try:
+        a = full._run_frame_impl(0, low_memory=False)
+        b = low._run_frame_impl(0, low_memory=True, chunk_voxels=20)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+        g = load_golden("markers2d_reftest_9x9")                  # the reference's outputs for exactly this input
+        assert np.array_equal(a[0], g["marker"]) and np.array_equal(a[1], g["distance"]) and np.array_equal(a[2], g["border"])
+        mask = np.zeros((7, 7), dtype=bool); mask[2:5, 2:5] = True
+        dist, border = full._distance_im(mask)
+        assert border.shape == mask.shape and border.dtype == bool and not np.any(border & mask) and border.sum() == 12
+        assert dist.dtype == np.float32 and dist[3, 3] == 2.0 and dist[0, 0] == 0.0
+    finally:
+        full.close(); low.close()
 
 
 def test_ccl_random_masks_vs_oracle(pipes):

@@ -112,10 +112,10 @@ def test_markers_match_reference(name):
     """Markers stage (mocap_marking.py): marker, distance and border images bit-equal to the imported reference."""
     g = load_golden(name)
     dr = g["dim_res_dict"]
-    kw = {k: (int(v) if k == "peak_min_distance" else v) for k, v in g["kwargs"].items()}
-    sig, _ = orc.marker_sigmas(dr)
+    kw = {k: (int(v) if k in ("peak_min_distance", "num_sigma") else v) for k, v in g["kwargs"].items()}
+    sig, _ = orc.marker_sigmas(dr, num_sigma=kw.get("num_sigma", 5))
     assert np.array_equal(np.array(sig), g["sigmas"])
-    marker, dist, border = orc.markers_frame(g["input"], g["labels_in"], dr, **kw)
+    marker, dist, border = orc.markers_frame(g["input"], g["labels_in"], dr, frangi=g.get("frangi_in"), **kw)
     assert marker.dtype == np.uint8 and dist.dtype == np.float32 and border.dtype == np.uint8
     assert np.array_equal(dist, g["distance"])
     assert np.array_equal(border, g["border"])
