@@ -75,6 +75,12 @@ static inline hipError_t zero_small(void *p, size_t bytes, hipStream_t st) {
     return hipGetLastError();
 }
 
+// fused Y+X Gaussian: tiled / register-blocked X pass (default) or the row-at-a-time kernel (NELLIE_GYX_TILE=0)
+static bool gyx_tiled() {
+    static int on = -1;
+    if (on < 0) { const char *e = getenv("NELLIE_GYX_TILE"); on = (e && !atoi(e)) ? 0 : 1; }
+    return on != 0;
+}
 static float *gauss_cur(const nl_ctx *c) { return c->gauss_ext ? c->gauss_ext : c->f[c->i_gauss]; }
 static VolGeom geom(const nl_ctx *c) { return VolGeom{c->nzl, c->ny, c->nx, c->gz0, c->gnz}; }
 // tile height of the Hessian kernels (experiment knob; 8 -> 512-thread workgroups, 16 -> 1024)
@@ -505,10 +511,19 @@ extern "C" int nl_gauss_step(nl_ctx *c, const double *wz, int rz, const double *
         const int dst = (src + 1) % 3;
         ProfScope ps(c, "gauss_yx");
         const dim3 g2((unsigned)((c->nx + GYX_COLS - 1) / GYX_COLS), (unsigned)((c->ny + GM_CHUNK - 1) / GM_CHUNK), (unsigned)(z1 - z0));
-        switch (ry) {
-#define NL_YX(RR) case RR: gauss_yx_kernel<RR, false><<<g2, GYX_THREADS, 0, c->stream>>>(srcp, c->f[dst], v, z0, z1, wsy, wsx); break;
-            NL_YX(1) NL_YX(2) NL_YX(3) NL_YX(4) NL_YX(5) NL_YX(6) NL_YX(7) NL_YX(8) NL_YX(9) NL_YX(10) NL_YX(11) NL_YX(12)
+        const int vec4 = (c->nx % 4 == 0) ? 1 : 0;
+        if (gyx_tiled()) {
+            switch (ry) {
+#define NL_YX(RR) case RR: gauss_yx_tile_kernel<RR, false><<<g2, GYX_THREADS, 0, c->stream>>>(srcp, c->f[dst], v, z0, z1, wsy, wsx, vec4); break;
+                NL_YX(1) NL_YX(2) NL_YX(3) NL_YX(4) NL_YX(5) NL_YX(6) NL_YX(7) NL_YX(8) NL_YX(9) NL_YX(10) NL_YX(11) NL_YX(12)
 #undef NL_YX
+            }
+        } else {
+            switch (ry) {
+#define NL_YX(RR) case RR: gauss_yx_kernel<RR, false><<<g2, GYX_THREADS, 0, c->stream>>>(srcp, c->f[dst], v, z0, z1, wsy, wsx); break;
+                NL_YX(1) NL_YX(2) NL_YX(3) NL_YX(4) NL_YX(5) NL_YX(6) NL_YX(7) NL_YX(8) NL_YX(9) NL_YX(10) NL_YX(11) NL_YX(12)
+#undef NL_YX
+            }
         }
         NL_CHECK_LAUNCH();
         src = dst; srcp = c->f[dst];
@@ -1440,7 +1455,7 @@ extern "C" int nl_markers_log_step(nl_ctx *c, const double *wz2, const double *w
     // large radii: the fused Y+X kernel turns compute-bound (one output per thread reads 2R+1 LDS values); a marching Y
     // pass plus the stand-alone X kernel (four outputs per thread) through one more scratch volume is faster there
     static int split_from = -1;
-    if (split_from < 0) { const char *e = getenv("NELLIE_MK_SPLIT_R"); split_from = e ? atoi(e) : 8; }
+    if (split_from < 0) { const char *e = getenv("NELLIE_MK_SPLIT_R"); split_from = e ? atoi(e) : (gyx_tiled() ? 99 : 8); }
     float *tmp2 = mk_intensity(c) + c->n;
     const bool can_split = !c->mk_use && vq_alloc_entries(c->nzl, c->ny, c->nx) * 32 >= c->n * 8;     // mk_use lives in tmp2's place
     const float *yx_src = flat ? use : tz;
@@ -1455,6 +1470,16 @@ extern "C" int nl_markers_log_step(nl_ctx *c, const double *wz2, const double *w
                             gauss_x_kernel<RR><<<gxk, 256, 0, c->stream>>>(tmp2, lap, v, z0, z1, wx, vec4, acc ? 1 : 0); break;
                 NL_MKS(1) NL_MKS(2) NL_MKS(3) NL_MKS(4) NL_MKS(5) NL_MKS(6) NL_MKS(7) NL_MKS(8) NL_MKS(9) NL_MKS(10) NL_MKS(11) NL_MKS(12)
 #undef NL_MKS
+            }
+            return;
+        }
+        if (gyx_tiled()) {
+            const int vec4 = (c->nx % 4 == 0) ? 1 : 0;
+            switch (ryx) {
+#define NL_MKYT(RR) case RR: if (acc) gauss_yx_tile_kernel<RR, true><<<g2, GYX_THREADS, 0, c->stream>>>(yx_src, lap, v, z0, z1, wy, wx, vec4); \
+                             else gauss_yx_tile_kernel<RR, false><<<g2, GYX_THREADS, 0, c->stream>>>(yx_src, lap, v, z0, z1, wy, wx, vec4); break;
+                NL_MKYT(1) NL_MKYT(2) NL_MKYT(3) NL_MKYT(4) NL_MKYT(5) NL_MKYT(6) NL_MKYT(7) NL_MKYT(8) NL_MKYT(9) NL_MKYT(10) NL_MKYT(11) NL_MKYT(12)
+#undef NL_MKYT
             }
             return;
         }
