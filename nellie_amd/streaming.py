@@ -9,7 +9,9 @@ stays resident in HBM from upload to label download.  Results are the same array
 """
 from __future__ import annotations
 
+import os
 import threading
+import time
 from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
@@ -32,12 +34,29 @@ class StreamedSegmenter:
         self.in_buf = [hipnative.PinnedArray(self.shape, dtype) for _ in range(2)]
         self.fr_buf = [hipnative.PinnedArray(self.shape, np.float32) for _ in range(2)]
         self.lab_buf = [hipnative.PinnedArray(self.shape, np.int32) for _ in range(2)]
-        self.io = ThreadPoolExecutor(max_workers=2)
+        self.io = ThreadPoolExecutor(max_workers=3)
+        self.copy_threads = max(1, min(8, (os.cpu_count() or 2) // 2))
+        self.copiers = ThreadPoolExecutor(max_workers=self.copy_threads)
         self.stats = []
+        self.timing = {"wait_upload": 0.0, "compute": 0.0, "wait_download": 0.0, "frames": 0}   # main-thread seconds
         self._reg_in = None
+
+    def _copy(self, dst, src):
+        """dst[...] = src, split over the copy threads along the first axis (numpy releases the GIL inside the
+        copy; one thread moves ~20 GB/s, eight > 100 GB/s, and first-touch page faults of a fresh destination --
+        a new memmap, an untouched array -- are taken in parallel too)."""
+        n = dst.shape[0]
+        k = min(self.copy_threads, n)
+        if k <= 1 or dst.nbytes < (8 << 20):
+            np.copyto(dst, src, casting="unsafe")
+            return
+        bounds = [n * i // k for i in range(k + 1)]
+        list(self.copiers.map(lambda i: np.copyto(dst[bounds[i]:bounds[i + 1]], src[bounds[i]:bounds[i + 1]], casting="unsafe"),
+                              range(k)))
 
     def close(self):
         self.io.shutdown(wait=True)
+        self.copiers.shutdown(wait=True)
         self.pipe.close()
         for b in self.in_buf + self.fr_buf + self.lab_buf:
             b.free()
@@ -48,36 +67,38 @@ class StreamedSegmenter:
         if self._reg_in is not None and self._reg_in.ok:
             self.pipe.ctx.input_load_async(slot, frames[t])
             return
-        np.copyto(self.in_buf[slot].array, frames[t], casting="unsafe")
+        self._copy(self.in_buf[slot].array, frames[t])
         self.pipe.ctx.input_load_async(slot, self.in_buf[slot])
 
     def run(self, frames, out_frangi, out_labels, status=None, flush=True):
         """frames: (T, Z, Y, X) array / memmap; out_*: writable (T, Z, Y, X) float32 / int32 arrays (memmaps).
-        In-memory arrays are page-locked in place (hipHostRegister) so that no host-side staging copy is needed."""
+        An in-memory input stack is page-locked in place (hipHostRegister: its pages hold data, so this costs
+        ~0.1 ms/GiB) and uploaded without a staging copy.  Outputs always land in page-locked staging buffers and are
+        copied out by the copy threads: locking a fresh, never-touched output array in place costs 170 ms/GiB on
+        this host (single-threaded page population), three times the parallel copy including its page faults."""
         ctx = self.pipe.ctx
         num_t = len(frames)
         plain = lambda a: isinstance(a, np.ndarray) and not isinstance(a, np.memmap)   # noqa: E731
         self._reg_in = hipnative.RegisteredArray(frames) if plain(frames) and frames.dtype == self.in_buf[0].dtype else None
-        reg_fr = hipnative.RegisteredArray(out_frangi) if plain(out_frangi) and out_frangi.dtype == np.float32 else None
-        reg_lab = hipnative.RegisteredArray(out_labels) if plain(out_labels) and out_labels.dtype == np.int32 else None
-        direct_out = bool(reg_fr and reg_fr.ok and reg_lab and reg_lab.ok)
         try:
-            return self._run(ctx, frames, out_frangi, out_labels, num_t, status, flush, direct_out)
+            return self._run(ctx, frames, out_frangi, out_labels, num_t, status, flush, False)
         finally:
-            for r in (self._reg_in, reg_fr, reg_lab):
-                if r is not None:
-                    r.release()
+            if self._reg_in is not None:
+                self._reg_in.release()
             self._reg_in = None
 
     def _run(self, ctx, frames, out_frangi, out_labels, num_t, status, flush, direct_out):
         load = self.io.submit(self._stage_in, frames, 0, 0)
-        pending = None                                        # (t, slot, future that waits + writes)
+        landed = None                                         # event: the D2H of the previous frame has finished
+        copied = [None, None]                                 # per staging slot: future of the copy into the caller's arrays
         for t in range(num_t):
             slot = t & 1
             if status is not None:
                 status(t, num_t)
+            t_a = time.perf_counter()
             load.result()
             ctx.input_select(slot)
+            t_b = time.perf_counter()
             # while frame t computes, frame t+1 is read and uploaded into the other slot (its previous user,
             # frame t-1, has finished computing: every frame ends with a synchronising label count)
             if t + 1 < num_t:
@@ -86,24 +107,31 @@ class StreamedSegmenter:
             thr = self.pipe.frangi_threshold(*self.sampling)
             n = self.pipe.label(thr, self.min_area)
             self.stats.append((self.pipe.trace.n_positive, n))
-            if pending is not None:
-                pending.result()                              # frame t-1 landed on the host and in the memmaps
+            t_c = time.perf_counter()
+            if landed is not None:
+                landed.wait()                                 # the device-side staging copy of frame t-1 has been read out
+            if copied[slot] is not None:
+                copied[slot].result()                         # frame t-2 left this slot's page-locked buffers
+            t_d = time.perf_counter()
+            tm = self.timing
+            tm["wait_upload"] += t_b - t_a; tm["compute"] += t_c - t_b; tm["wait_download"] += t_d - t_c; tm["frames"] += 1
             ctx.outputs_stage(True)
-            if direct_out:
-                ctx.outputs_fetch_async(out_frangi[t], out_labels[t])
-            else:
-                ctx.outputs_fetch_async(self.fr_buf[slot], self.lab_buf[slot])
+            ctx.outputs_fetch_async(self.fr_buf[slot], self.lab_buf[slot])
+            landed = threading.Event()
 
-            def drain(tt=t, ss=slot):
-                ctx.outputs_wait()
-                if direct_out:
-                    return
-                out_frangi[tt] = self.fr_buf[ss].array
-                out_labels[tt] = self.lab_buf[ss].array
+            def drain(tt=t, ss=slot, ev=landed):
+                try:
+                    ctx.outputs_wait()
+                finally:
+                    ev.set()
+                self._copy(out_frangi[tt], self.fr_buf[ss].array)
+                self._copy(out_labels[tt], self.lab_buf[ss].array)
                 if flush and hasattr(out_frangi, "flush"):
                     out_frangi.flush()
                     out_labels.flush()
-            pending = self.io.submit(drain)
-        if pending is not None:
-            pending.result()
+            copied[slot] = self.io.submit(drain)
+        for f in copied:
+            if f is not None:
+                f.result()
         return self.stats
+
