@@ -1189,7 +1189,7 @@ extern "C" int nl_mask_volume_fused(nl_ctx *c, float thr, int64_t *n_positive, c
         const i64 e0 = c->own_lo - 1 > 0 ? c->own_lo - 1 : 0, e1 = c->own_hi + 1 < c->nzl ? c->own_hi + 1 : c->nzl;
         unsigned long long *bM = (unsigned long long *)c->m[1], *bE = (unsigned long long *)c->m[2];
         unsigned long long *bD = (unsigned long long *)c->m[0] + (i64)(last ^ 1) * slot_words;
-        pack_masked_kernel<<<grid1d((m1 - m0) * c->ny * 64, 256, 256 * 32), 256, 0, c->stream>>>(    // one atomic per wave: small grid
+        pack_masked_kernel<<<grid1d((m1 - m0) * c->ny * 64, 256, 256 * 16), 256, 0, c->stream>>>(    // one atomic per workgroup: small grid
             c->f[c->i_vmax], alive, bM, thr, (int)c->nx, m0 * c->ny, m1 * c->ny, wpr, c->own_lo * c->ny, c->own_hi * c->ny, d_cnt);
         NL_CHECK_LAUNCH();
         bits_morph6_kernel<0><<<(unsigned)(((e1 - e0) * c->ny * wpr + 255) / 256), 256, 0, c->stream>>>(bM, bE, v, wpr, e0, e1, c->two_d);
