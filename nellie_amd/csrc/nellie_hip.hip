@@ -318,7 +318,13 @@ extern "C" int nl_sync(nl_ctx *c, char *err, size_t errlen) {
 
 #define NL_ENTER(c)                                                    \
     if (!(c)) return nl_fail(err, errlen, NL_EINVAL, "ctx is NULL");   \
+    ++(c)->epoch;                                                      \
     NL_HIP(hipSetDevice((c)->device));
+
+// nl_mask_volume_fused leaves the support of the Frangi frame (the opened mask, 1 bit/voxel) behind; nl_label_run may
+// use it to skip the 98 % of the frame that is zero -- but only if nothing else ran in between.  Every entry point
+// bumps `epoch`; the few that read the frame without touching it or the mask planes carry the validity forward.
+#define NL_KEEP_SUPPORT(c) if ((c)->support_epoch + 1 == (c)->epoch.load()) (c)->support_epoch = (c)->epoch.load();
 
 // Orders the main stream after whatever is still running on the side stream (the resolve kernel of the previous
 // scale).  Called by every entry point that touches the vesselness volume, the mask planes or the queue.
@@ -1151,7 +1157,7 @@ extern "C" int nl_mask_volume(nl_ctx *c, float thr, char *err, size_t errlen) {
         const i64 e0 = c->own_lo - 1 > 0 ? c->own_lo - 1 : 0, e1 = c->own_hi + 1 < c->nzl ? c->own_hi + 1 : c->nzl;
         unsigned long long *bM = (unsigned long long *)c->m[1], *bE = (unsigned long long *)c->m[2], *bD = (unsigned long long *)c->m[0];
         rl_threshold_pack_kernel<<<grid1d((m1 - m0) * c->ny * 64, 256, (i64)1 << 22), 256, 0, c->stream>>>(
-            c->f[c->i_vmax] + m0 * c->ny * c->nx, bM + m0 * c->ny * wpr, 1, thr, (int)c->nx, (m1 - m0) * c->ny, wpr);
+            c->f[c->i_vmax] + m0 * c->ny * c->nx, nullptr, bM + m0 * c->ny * wpr, 1, thr, (int)c->nx, (m1 - m0) * c->ny, wpr);
         NL_CHECK_LAUNCH();
         bits_morph6_kernel<0><<<(unsigned)(((e1 - e0) * c->ny * wpr + 255) / 256), 256, 0, c->stream>>>(bM, bE, v, wpr, e0, e1, c->two_d);
         NL_CHECK_LAUNCH();
@@ -1207,6 +1213,10 @@ extern "C" int nl_mask_volume_fused(nl_ctx *c, float thr, int64_t *n_positive, c
     NL_HIP(hipStreamSynchronize(c->stream));
     if (n_positive) *n_positive = (int64_t)(*(unsigned long long *)c->h_small);
     c->frangi_ready = 1;
+    // valid as long as only NL_KEEP_SUPPORT entry points follow (whole volumes only: slabs label through nl_label_pack)
+    const bool whole = c->own_lo == 0 && c->own_hi == c->nzl && c->gnz == c->nzl;
+    c->d_support = whole ? (const unsigned long long *)c->m[0] + (i64)(((c->mask_slots_used - 1) & 1) ^ 1) * (c->nzl * c->ny * (i64)((c->nx + 63) / 64)) : nullptr;
+    c->support_epoch = c->epoch.load();
     return NL_OK;
 }
 
@@ -1221,6 +1231,7 @@ static int store_planes(nl_ctx *c, const void *dev_base, void *host, size_t elem
 
 extern "C" int nl_filter_store(nl_ctx *c, float *host, int64_t z0, int64_t z1, char *err, size_t errlen) {
     NL_ENTER(c);
+    NL_KEEP_SUPPORT(c);
     return store_planes(c, c->f[c->i_vmax], host, 4, z0, z1, err, errlen);
 }
 extern "C" int nl_gauss_store(nl_ctx *c, float *host, int64_t z0, int64_t z1, char *err, size_t errlen) {
@@ -1601,6 +1612,7 @@ extern "C" int nl_label_intensity_mask(nl_ctx *c, const void *host_original, int
 extern "C" int nl_flat_sample_gather(nl_ctx *c, int field, int64_t offset, int64_t step, float *out, int64_t cap, int64_t *n,
                                      char *err, size_t errlen) {
     NL_ENTER(c);
+    NL_KEEP_SUPPORT(c);
     if (step < 1 || offset < 0) return nl_fail(err, errlen, NL_EINVAL, "bad offset/step");
     if (field != NL_FIELD_FRANGI && field != NL_FIELD_GAUSS) return nl_fail(err, errlen, NL_EINVAL, "flat sampling supports GAUSS/FRANGI");
     // flat index runs over the GLOBAL volume; this rank contributes indices inside its owned planes
@@ -1632,6 +1644,7 @@ extern "C" int nl_flat_sample_gather(nl_ctx *c, int field, int64_t offset, int64
 extern "C" int nl_flat_sample_gather_positive(nl_ctx *c, int field, int64_t offset, int64_t step, float *out, int64_t cap,
                                               int64_t *n, char *err, size_t errlen) {
     NL_ENTER(c);
+    NL_KEEP_SUPPORT(c);
     if (step < 1 || offset < 0) return nl_fail(err, errlen, NL_EINVAL, "bad offset/step");
     if (field != NL_FIELD_FRANGI && field != NL_FIELD_GAUSS) return nl_fail(err, errlen, NL_EINVAL, "flat sampling supports GAUSS/FRANGI");
     const i64 plane = c->ny * c->nx;
@@ -1887,7 +1900,10 @@ extern "C" int nl_label_run(nl_ctx *c, int has_thr, float thr, int64_t min_area,
     g.bitsA = (unsigned long long *)c->m[1]; g.bitsB = (unsigned long long *)c->m[2];
     g.paint_row0 = 0; g.paint_row1 = g.nrows; g.paint_out = (int *)c->f[label_out_index(c)];
     ProfScope ps(c, "label");
-    rl_threshold_pack_kernel<<<grid1d(g.nrows * 64, 256, (i64)1 << 22), 256, 0, c->stream>>>(c->f[c->i_vmax], g.bitsA, has_thr, thr,
+    const unsigned long long *support = (c->support_epoch + 1 == c->epoch.load() && c->d_support && has_thr && thr >= 0.0f) ? c->d_support : nullptr;
+    c->last_label_sparse = support ? 1 : 0;
+    // dense: a pure streaming read wants one wave per row; sparse: most rows end after one load, several rows per wave
+    rl_threshold_pack_kernel<<<grid1d(g.nrows * 64, 256, support ? (i64)256 * 64 : (i64)1 << 22), 256, 0, c->stream>>>(c->f[c->i_vmax], support, g.bitsA, has_thr, thr,
                                                                                           (int)c->nx, g.nrows, g.wpr);
     NL_CHECK_LAUNCH();
     bool overflow = false;
@@ -1928,7 +1944,7 @@ extern "C" int nl_label_pack(nl_ctx *c, int has_thr, float thr, char *err, size_
     const i64 row0 = (c->gz0 + c->own_lo) * c->ny;
     ProfScope ps(c, "label");
     rl_threshold_pack_kernel<<<grid1d(own_rows * 64, 256, (i64)1 << 22), 256, 0, c->stream>>>(
-        c->f[c->i_vmax] + c->own_lo * c->ny * c->nx, c->gbits[0] + row0 * wpr, has_thr, thr, (int)c->nx, own_rows, wpr);
+        c->f[c->i_vmax] + c->own_lo * c->ny * c->nx, nullptr, c->gbits[0] + row0 * wpr, has_thr, thr, (int)c->nx, own_rows, wpr);
     NL_CHECK_LAUNCH();
     return NL_OK;
 }
@@ -2164,6 +2180,7 @@ extern "C" int nl_ctx_info(nl_ctx *c, const char *key, double *value) {
     else if (!strcmp(key, "vesselness_one_pass")) *value = c->spec_ok;
     else if (!strcmp(key, "last_fsq_min")) *value = c->last_fsq_min;
     else if (!strcmp(key, "last_spec_overflow")) *value = c->last_spec_overflow;
+    else if (!strcmp(key, "last_label_sparse")) *value = c->last_label_sparse;
     else if (!strcmp(key, "device_bytes")) *value = (double)nl_ctx_bytes(c->nzl, c->ny, c->nx);
     else return NL_EINVAL;
     return NL_OK;

@@ -1,5 +1,6 @@
 // Internal declarations shared by the translation units of libnellie_hip.so (gfx950 only).
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdint.h>
@@ -48,6 +49,10 @@ struct nl_ctx {
     unsigned int *d_vq_count = nullptr;   // entries written per region
     int nw_state = 0;             // Network: 1 after nl_skel_pixel_class (classes + branch bits resident)
     float *mk_use = nullptr;      // Markers: LoG source when use_im = 'frangi' (inside d_vq), else the distance image
+    std::atomic<unsigned long long> epoch{0};      // C-ABI calls made on this context (see NL_KEEP_SUPPORT)
+    unsigned long long support_epoch = ~0ull - 8;   // epoch at which d_support described the Frangi frame
+    const unsigned long long *d_support = nullptr;
+    int last_label_sparse = 0;
     int mk_state = 0;             // Markers: 0 idle, 1 begun, 2 distance done, 3 finished
     int mk_first_scale = 1;
     int two_d = 0;                // the frame is a (Y, X) image (im_info.no_z): 2-D Hessian, eigenvalues, Frangi, opening

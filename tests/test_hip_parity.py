@@ -432,6 +432,35 @@ def test_reference_mocap_tests_on_the_hip_class(hip):
         full.close(); low.close()
 
 
+def test_label_sparse_support_equals_dense(pipes):
+    """Label right after Filter reads the Frangi frame only inside the opened mask the fused epilogue left behind;
+    the same frame uploaded from the host (no support known) must give the same labels -- and an entry point that
+    changes the frame in between must switch the shortcut off."""
+    from nellie_amd import pipeline as pl
+    from nellie_amd.synthetic import ISO_01, make_volume
+    shape = (40, 96, 130)
+    vol = make_volume(shape, 77)
+    pipe = pipes(shape)
+    p = pl.FilterParams(dim_res=ISO_01)
+    pipe.filter(vol, p)
+    fr = pipe.download_frangi()                      # read-only: the support stays valid
+    thr = pipe.frangi_threshold()
+    n1 = pipe.label(thr, pl.min_area_pixels_of(ISO_01))
+    lab1 = pipe.download_labels()
+    pipe.upload_frangi(fr)
+    n2 = pipe.label(thr, pl.min_area_pixels_of(ISO_01))
+    assert n1 == n2 and n1 > 0 and np.array_equal(lab1, pipe.download_labels())
+    _, ref = orc.get_labels(fr, np.float32(thr), pl.min_area_pixels_of(ISO_01))
+    assert np.array_equal(lab1, ref)
+    # a different frame uploaded after Filter: the stale support must not be used
+    pipe.filter(vol, p)
+    other = np.roll(fr, 7, axis=2)
+    pipe.upload_frangi(other)
+    pipe.label(thr, pl.min_area_pixels_of(ISO_01))
+    _, ref2 = orc.get_labels(other, np.float32(thr), pl.min_area_pixels_of(ISO_01))
+    assert np.array_equal(pipe.download_labels(), ref2)
+
+
 def test_ccl_random_masks_vs_oracle(pipes):
     """Random dense masks stress the union-find far harder than Frangi output does."""
     rng = np.random.default_rng(5)
