@@ -79,7 +79,9 @@ def parse_args():
     ap.add_argument("--cpu-shape", type=int, nargs=3, default=[96, 384, 384])
     ap.add_argument("--with-io", action="store_true", help="also report the PCIe-inclusive rate (untimed otherwise)")
     ap.add_argument("--no-zslab-check", action="store_true", help="N > 1: skip the RCCL Z-slab equality check")
-    ap.add_argument("--zslab-timeout", type=float, default=240.0)
+    ap.add_argument("--zslab-timeout", type=float, default=150.0)
+    ap.add_argument("--zslab-child", action="store_true", help="internal: run only the Z-slab check (spawned by the bench)")
+    ap.add_argument("--zslab-force", action="store_true", help="testing: run the check even with --share-device")
     ap.add_argument("--share-device", action="store_true",
                     help="testing only: every rank uses device 0 (exercise the multi-process control flow on a 1-GPU box)")
     return ap.parse_args()
@@ -174,6 +176,9 @@ def zslab_check(dist, rank, world, local_rank, gshape=None):
 
 def main():
     args = parse_args()
+    if args.zslab_child:
+        zslab_child_main(args)
+        return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -317,36 +322,78 @@ def main():
         print(json.dumps(out), flush=True)
         return
 
-    # N > 1: optionally prove the Z-slab decomposition on the real GPUs (RCCL), guarded so that a communication
-    # problem can never cost the measured line: a watchdog thread prints the line without the check and leaves
-    # if the check has not come back in time (the main thread may be blocked inside a collective).
-    import threading
-    lock = threading.Lock()
-    state = {"printed": False}
-
-    def emit(extra):
-        with lock:
-            if rank == 0 and not state["printed"]:
-                state["printed"] = True
-                line = dict(out)
-                if extra is not None:
-                    line["zslab"] = extra
-                print(json.dumps(line), flush=True)
-
+    # N > 1: optionally prove the Z-slab decomposition on the real GPUs (RCCL).  It runs in a CHILD process per rank
+    # (own rendezvous on another port, own HIP contexts), so that nothing in the communication path -- a hang inside a
+    # collective, a crash inside the library -- can cost the measured line: the parent waits with a timeout, kills its
+    # child if need be, and rank 0 prints the line either way.
     zslab = None
-    if not args.no_zslab_check and not args.share_device:
-        def watchdog():
-            time.sleep(args.zslab_timeout)
-            emit({"error": f"no answer within {args.zslab_timeout} s"})
-            os._exit(0)
-        threading.Thread(target=watchdog, daemon=True).start()
-        try:
-            zslab = zslab_check(dist, rank, world, local_rank)
-        except Exception as exc:  # noqa: BLE001
-            zslab = {"error": f"{type(exc).__name__}: {exc}"[:300]}
-    emit(zslab)
+    if not args.no_zslab_check and (not args.share_device or args.zslab_force):
+        dist.barrier()                                     # rank 0 comes here late (CPU baseline): start the children together
+        zslab = run_zslab_child(args, rank)
+    if rank == 0:
+        if zslab is not None:
+            out["zslab"] = zslab
+        print(json.dumps(out), flush=True)
     sys.stdout.flush()
     os._exit(0)      # skip collective teardown: nothing after the JSON line may hang the job
+
+
+def run_zslab_child(args, rank):
+    import signal
+    import subprocess
+    env = dict(os.environ)
+    env["MASTER_PORT"] = str((int(env.get("MASTER_PORT", "29500")) - 1024 + 101) % 60000 + 1024)
+    env.pop("TORCHELASTIC_USE_AGENT_STORE", None)          # the children rendezvous among themselves (rank 0 hosts the store)
+    cmd = [sys.executable, os.path.abspath(__file__), "--zslab-child", "--gpus", str(args.gpus)]
+    if args.share_device:
+        cmd.append("--share-device")
+    try:
+        proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, start_new_session=True, text=True)
+    except OSError as exc:
+        return {"error": f"could not start the check: {exc}"[:300]}
+    try:
+        so, se = proc.communicate(timeout=args.zslab_timeout)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)             # exactly the process group started above
+        except OSError:
+            pass
+        try:
+            proc.communicate(timeout=10)
+        except Exception:  # noqa: BLE001
+            pass
+        return {"error": f"no answer within {args.zslab_timeout} s (child killed)"}
+    if rank != 0:
+        return None
+    for line in reversed(so.strip().splitlines()):
+        if line.startswith("{"):
+            try:
+                return json.loads(line)
+            except ValueError:
+                break
+    return {"error": f"child exit code {proc.returncode}: {se.strip()[-300:]}"}
+
+
+def zslab_child_main(args):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = 0 if args.share_device else int(os.environ.get("LOCAL_RANK", "0"))
+    import datetime
+    import torch.distributed as dist
+    dist.init_process_group(backend="gloo", init_method="env://", timeout=datetime.timedelta(seconds=120))
+    fake = os.environ.get("NELLIE_ZSLAB_FAKE", "")      # tests of the isolation: "crash" (rank 1 aborts), "hang"
+    if fake == "crash" and rank == world - 1:
+        os.abort()
+    if fake == "hang":
+        time.sleep(1e6)
+    try:
+        res = zslab_check(dist, rank, world, local_rank)
+    except Exception as exc:  # noqa: BLE001
+        res = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    sys.stdout.flush()
+    os._exit(0)
 
 
 if __name__ == "__main__":
