@@ -293,7 +293,14 @@ extern "C" int nl_ctx_create(nl_ctx **out, int device, int64_t nzl, int64_t ny, 
     if (ok && hipHostMalloc(&c->h_small, 1 << 16, hipHostMallocDefault) != hipSuccess) {
         rc = nl_fail(err, errlen, NL_ENOMEM, "hipHostMalloc failed [out of memory]"); ok = false;
     }
-    if (ok && (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
+    // side stream: the compute-bound resolve kernel runs beside the memory-bound Gaussian of the next scale; NELLIE_SIDE_PRIO
+    // (-1 high, 0 normal, 1 low) chooses which of the two the dispatcher serves first
+    int side_prio = -1;
+    { const char *e = getenv("NELLIE_SIDE_PRIO"); if (e) side_prio = atoi(e); }
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);      // lo = numerically largest = lowest priority
+    const int side_p = side_prio < 0 ? prio_hi : (side_prio > 0 ? prio_lo : (prio_lo + prio_hi) / 2);
+    if (ok && (hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, side_p) != hipSuccess ||
                hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming) != hipSuccess ||
                hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming) != hipSuccess ||
                hipEventCreateWithFlags(&c->ev_ahead, hipEventDisableTiming) != hipSuccess)) {
@@ -971,6 +978,9 @@ extern "C" int nl_vesselness_resolve(nl_ctx *c, float gamma_sq, float alpha_sq, 
         NL_CHECK_LAUNCH();
     }
     NL_HIP(hipEventRecord(c->ev_side, c->side));
+    static int serial = -1;                            // measurement knob: the main stream waits, the kernel runs alone
+    if (serial < 0) serial = getenv("NELLIE_RESOLVE_SERIAL") ? 1 : 0;
+    if (serial) NL_HIP(hipStreamWaitEvent(c->stream, c->ev_side, 0));
     c->side_pending = 1;
     c->spec_valid = 0;
     *hit = 1;
