@@ -527,7 +527,7 @@ extern "C" int nl_gauss_step(nl_ctx *c, const double *wz, int rz, const double *
         const int vec4 = (c->nx % 4 == 0) ? 1 : 0;
         if (gyx_tiled()) {
             switch (ry) {
-#define NL_YX(RR) case RR: gauss_yx_tile_kernel<RR, false><<<g2, GYX_THREADS, 0, c->stream>>>(srcp, c->f[dst], v, z0, z1, wsy, wsx, vec4); break;
+#define NL_YX(RR) case RR: gauss_yx_tile_kernel<RR, false><<<g2.x * g2.y * g2.z, GYX_THREADS, 0, c->stream>>>(srcp, c->f[dst], v, z0, z1, wsy, wsx, vec4, (int)g2.x, (int)g2.y); break;
                 NL_YX(1) NL_YX(2) NL_YX(3) NL_YX(4) NL_YX(5) NL_YX(6) NL_YX(7) NL_YX(8) NL_YX(9) NL_YX(10) NL_YX(11) NL_YX(12)
 #undef NL_YX
             }
@@ -1497,8 +1497,8 @@ extern "C" int nl_markers_log_step(nl_ctx *c, const double *wz2, const double *w
         if (gyx_tiled()) {
             const int vec4 = (c->nx % 4 == 0) ? 1 : 0;
             switch (ryx) {
-#define NL_MKYT(RR) case RR: if (acc) gauss_yx_tile_kernel<RR, true><<<g2, GYX_THREADS, 0, c->stream>>>(yx_src, lap, v, z0, z1, wy, wx, vec4); \
-                             else gauss_yx_tile_kernel<RR, false><<<g2, GYX_THREADS, 0, c->stream>>>(yx_src, lap, v, z0, z1, wy, wx, vec4); break;
+#define NL_MKYT(RR) case RR: if (acc) gauss_yx_tile_kernel<RR, true><<<g2.x * g2.y * g2.z, GYX_THREADS, 0, c->stream>>>(yx_src, lap, v, z0, z1, wy, wx, vec4, (int)g2.x, (int)g2.y); \
+                             else gauss_yx_tile_kernel<RR, false><<<g2.x * g2.y * g2.z, GYX_THREADS, 0, c->stream>>>(yx_src, lap, v, z0, z1, wy, wx, vec4, (int)g2.x, (int)g2.y); break;
                 NL_MKYT(1) NL_MKYT(2) NL_MKYT(3) NL_MKYT(4) NL_MKYT(5) NL_MKYT(6) NL_MKYT(7) NL_MKYT(8) NL_MKYT(9) NL_MKYT(10) NL_MKYT(11) NL_MKYT(12)
 #undef NL_MKYT
             }
