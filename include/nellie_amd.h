@@ -145,6 +145,14 @@ int nl_sample_minmax(nl_ctx *ctx, int field, int64_t sz, int64_t sy, int64_t sx,
 int nl_sample_hist(nl_ctx *ctx, int field, int64_t sz, int64_t sy, int64_t sx,
                    const float *edges, int nbins, int64_t *counts, char *err, size_t errlen);
 
+/* nl_sample_minmax followed by nl_sample_hist without a host round trip in between: numpy's float32 bin edges for
+   range = (min, max) of the positive samples (`_get_outer_edges` / `np.linspace`, numpy/lib/_histograms_impl.py) are
+   formed on the device.  *valid: 0 = no positive sample (counts are zero), 1 = ok, 2 = the range is not finite (numpy
+   raises ValueError there; counts are zero).  `edges` (may be NULL) receives the nbins + 1 edges the device used;
+   they equal np.linspace(np.float32(min), np.float32(max), nbins + 1, dtype=float32) bit for bit. */
+int nl_sample_range_hist(nl_ctx *ctx, int field, int64_t sz, int64_t sy, int64_t sx, int nbins, float *mn, float *mx,
+                         int64_t *n_positive, int64_t *counts, float *edges, int *valid, char *err, size_t errlen);
+
 /* Hessian by double finite differences of the current Gaussian volume (xp.gradient twice,
    filtering.py:518-536) on the owned planes; returns
      max_abs          = max over the six components of max|h|         (filtering.py:556-561; NOT yet mapped 0 -> 1)

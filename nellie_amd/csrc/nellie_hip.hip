@@ -759,12 +759,57 @@ extern "C" int nl_sample_hist(nl_ctx *c, int field, int64_t sz, int64_t sy, int6
     if (total > 0) {
         ProfScope ps(c, "sample");
         const size_t sh = (size_t)(nbins + 2) * 4 + (size_t)nbins * 4;
-        sample_hist_kernel<<<grid1d(total, 256, 1024), 256, sh, c->stream>>>(fs, geom(c), L, d_edges, nbins, d_counts);
+        sample_hist_kernel<<<grid1d(total, 256, 1024), 256, sh, c->stream>>>(fs, geom(c), L, d_edges, nbins, d_counts, nullptr);
         NL_CHECK_LAUNCH();
     }
     NL_HIP(hipMemcpyAsync(c->h_small, d_counts, (size_t)nbins * 8, hipMemcpyDeviceToHost, c->stream));
     NL_HIP(hipStreamSynchronize(c->stream));
     memcpy(counts, c->h_small, (size_t)nbins * 8);
+    return NL_OK;
+}
+
+// nl_sample_minmax + nl_sample_hist in one go: the bin edges numpy would build from the range are formed on the
+// device, so the two passes need no host round trip in between.  *valid: 0 no positive sample, 1 ok, 2 range not finite
+// (the caller raises numpy's ValueError then).  edges (may be NULL) receives the nbins + 1 device-built edges.
+extern "C" int nl_sample_range_hist(nl_ctx *c, int field, int64_t sz, int64_t sy, int64_t sx, int nbins, float *mn, float *mx,
+                                    int64_t *npos, int64_t *counts, float *edges, int *valid, char *err, size_t errlen) {
+    NL_ENTER(c);
+    if (!counts || !valid || nbins < 1 || nbins > 2048) return nl_fail(err, errlen, NL_EINVAL, "bad histogram arguments (nbins=%d)", nbins);
+    Lattice L; FieldSrc fs; int rc;
+    if ((rc = make_lattice(c, sz, sy, sx, L, err, errlen))) return rc;
+    if ((rc = make_field(c, field, fs, err, errlen))) return rc;
+    if ((rc = use_fsq_cache(c, fs, L, err, errlen))) return rc;
+    const i64 total = L.cz * L.cy * L.cx;
+    // d_small layout (contiguous, one transfer back): counts (u64 x nbins) | edges (f32 x nbins+1, padded) | range, count, flag
+    const size_t off_edges = (size_t)nbins * 8, off_res = off_edges + (((size_t)(nbins + 1) * 4 + 15) & ~(size_t)15);
+    const size_t bytes = off_res + 32;
+    unsigned long long *d_counts = (unsigned long long *)c->d_small;
+    float *d_edges = (float *)((char *)c->d_small + off_edges);
+    unsigned int *res = (unsigned int *)((char *)c->d_small + off_res);
+    unsigned int *h = (unsigned int *)c->h_small;
+    h[0] = 0xffffffffu; h[1] = 0; h[2] = 0; h[3] = 0; h[4] = 0;
+    NL_HIP(hipMemcpyAsync(res, h, 20, hipMemcpyHostToDevice, c->stream));
+    NL_HIP(zero_small(d_counts, (size_t)nbins * 8, c->stream));
+    if (total > 0) {
+        ProfScope ps(c, "sample");
+        sample_minmax_kernel<<<grid1d(total, 256, 1024), 256, 0, c->stream>>>(fs, geom(c), L, res);
+        sample_edges_kernel<<<1, 64, 0, c->stream>>>(res, nbins, d_edges, res + 4);
+        const size_t sh = (size_t)(nbins + 2) * 4 + (size_t)nbins * 4;
+        sample_hist_kernel<<<grid1d(total, 256, 1024), 256, sh, c->stream>>>(fs, geom(c), L, d_edges, nbins, d_counts, res + 4);
+        NL_CHECK_LAUNCH();
+    }
+    NL_HIP(hipMemcpyAsync(c->h_small, c->d_small, bytes, hipMemcpyDeviceToHost, c->stream));
+    NL_HIP(hipStreamSynchronize(c->stream));
+    const unsigned int *hr = (const unsigned int *)((const char *)c->h_small + off_res);
+    const unsigned long long cnt = *(const unsigned long long *)(hr + 2);
+    if (npos) *npos = (int64_t)cnt;
+    *valid = (int)hr[4];
+    if (cnt) {
+        if (mn) memcpy(mn, &hr[0], 4);
+        if (mx) memcpy(mx, &hr[1], 4);
+    }
+    memcpy(counts, c->h_small, (size_t)nbins * 8);
+    if (edges) memcpy(edges, (const char *)c->h_small + off_edges, (size_t)(nbins + 1) * 4);
     return NL_OK;
 }
 

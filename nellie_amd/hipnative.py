@@ -48,6 +48,7 @@ _PROTOS = {
     "nl_sample_gather_positive": [_p, _int, _i64, _i64, _i64, _p, _i64, C.POINTER(_i64)],
     "nl_sample_minmax": [_p, _int, _i64, _i64, _i64, C.POINTER(_f32), C.POINTER(_f32), C.POINTER(_i64)],
     "nl_sample_hist": [_p, _int, _i64, _i64, _i64, _p, _int, _p],
+    "nl_sample_range_hist": [_p, _int, _i64, _i64, _i64, _int, C.POINTER(_f32), C.POINTER(_f32), C.POINTER(_i64), _p, _p, C.POINTER(_int)],
     "nl_hessian_stats": [_p, C.POINTER(_f64), C.POINTER(_f32), C.POINTER(_f32), C.POINTER(_int)],
     "nl_set_frob_norm": [_p, _f32, _f32],
     "nl_vesselness_step": [_p, _f32, _f32, _f32, _int, _f32, _i64, _i64, C.POINTER(_i64)],
@@ -360,6 +361,17 @@ class Context:
         counts = np.zeros(e.size - 1, dtype=np.int64)
         self._call("nl_sample_hist", field, sz, sy, sx, _ptr(e), e.size - 1, _ptr(counts))
         return counts
+
+    def sample_range_hist(self, field, strides, nbins=256):
+        """sample_minmax + sample_hist in one call (the device forms numpy's float32 bin edges itself).
+        Returns (min, max, n_positive, counts, edges, valid): valid 0 = no positive sample, 1 = ok, 2 = range not finite."""
+        mn, mx, n, valid = _f32(0), _f32(0), _i64(0), _int(0)
+        counts = np.zeros(nbins, np.int64)
+        edges = np.zeros(nbins + 1, np.float32)
+        sz, sy, sx = (int(s) for s in strides)
+        self._call("nl_sample_range_hist", int(field), sz, sy, sx, int(nbins), C.byref(mn), C.byref(mx), C.byref(n),
+                   _ptr(counts), _ptr(edges), C.byref(valid))
+        return np.float32(mn.value), np.float32(mx.value), int(n.value), counts, edges, int(valid.value)
 
     def hessian_stats(self, spacing):
         sp = (_f64 * 3)(*[float(s) for s in spacing])

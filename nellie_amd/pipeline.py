@@ -223,6 +223,10 @@ class FramePipeline:
         # falls outside the bracket is redone the two-pass way, so results never depend on it.
         self.one_pass = bool(getattr(self.ctx, "one_pass_available", lambda: False)()) and not self.two_d
         self.one_pass_margin = 1e-3
+        # range + histogram of a threshold in one device round trip (a Z-slab pipeline reduces the range across ranks
+        # between the two passes and keeps them apart)
+        self._chain_hist = hasattr(self.ctx, "sample_range_hist") and os.environ.get("NELLIE_CHAIN_HIST", "1") != "0"
+        self.check_device_edges = os.environ.get("NELLIE_CHECK_EDGES", "0") == "1"
         self._one_pass_test_scale = 1.0      # tests: shifts the prediction to force a miss
 
     def close(self):
@@ -299,6 +303,11 @@ class FramePipeline:
         """min(triangle, otsu) over the positive lattice samples of a device field, or None if none."""
         if known_range is not None:
             mn, mx, npos = known_range[0], known_range[1], 1
+        elif self._chain_hist:
+            mn, mx, counts, npos = self._range_hist(fld, strides)
+            if npos == 0:
+                return None
+            return float(min_triangle_otsu(counts, histogram_edges(mn, mx, 256)))
         else:
             mn, mx, npos = self._reduce_minmax(*self.ctx.sample_minmax(fld, strides))
         if npos == 0:
@@ -307,6 +316,15 @@ class FramePipeline:
         counts = self._reduce_counts(self.ctx.sample_hist(fld, strides, edges))
         return float(min_triangle_otsu(counts, edges))
 
+    def _range_hist(self, fld, strides):
+        """Range and 256-bin histogram of the positive lattice samples in one device round trip (single GPU: no
+        cross-rank reduction sits between the two passes).  The device builds numpy's float32 edges itself; the host
+        builds them again for the threshold arithmetic (and raises numpy's errors for degenerate ranges)."""
+        mn, mx, npos, counts, dev_edges, valid = self.ctx.sample_range_hist(fld, strides, 256)
+        if npos and valid == 1 and self.check_device_edges:
+            assert np.array_equal(dev_edges, histogram_edges(mn, mx, 256)), "device-built histogram edges differ from numpy's"
+        return mn, mx, counts, npos
+
     def _fsq_bracket(self, strides, division):
         """Predicted [lo, hi] for the un-normalised frob_sq threshold of the current scale, or None.
         Normalising by 1 instead of the (unknown) global max |H| rescales samples and threshold alike
@@ -314,12 +332,19 @@ class FramePipeline:
         rounding -- unless the rounding moves the histogram argmax to another bin, which the bracket then misses."""
         self.ctx.set_frob_norm(1.0, 0.0)
         self._raw_frob_range = None
-        mn, mx, npos = self._reduce_minmax(*self.ctx.sample_minmax(FIELD_FROB, strides))
-        if npos == 0 or not np.isfinite(mx):
-            return None
-        self._raw_frob_range = (np.float32(mn), np.float32(mx))
-        edges = histogram_edges(mn, mx, 256)
-        counts = self._reduce_counts(self.ctx.sample_hist(FIELD_FROB, strides, edges))
+        if self._chain_hist:
+            mn, mx, counts, npos = self._range_hist(FIELD_FROB, strides)
+            if npos == 0 or not np.isfinite(mx):
+                return None
+            self._raw_frob_range = (np.float32(mn), np.float32(mx))
+            edges = histogram_edges(mn, mx, 256)
+        else:
+            mn, mx, npos = self._reduce_minmax(*self.ctx.sample_minmax(FIELD_FROB, strides))
+            if npos == 0 or not np.isfinite(mx):
+                return None
+            self._raw_frob_range = (np.float32(mn), np.float32(mx))
+            edges = histogram_edges(mn, mx, 256)
+            counts = self._reduce_counts(self.ctx.sample_hist(FIELD_FROB, strides, edges))
         t = float(min_triangle_otsu(counts, edges)) * self._one_pass_test_scale / division
         lo, hi = np.float32(t * t * (1.0 - self.one_pass_margin)), np.float32(t * t * (1.0 + self.one_pass_margin))
         if not (np.isfinite(lo) and np.isfinite(hi) and hi > 0):

@@ -91,6 +91,7 @@ class ShardedFramePipeline(FramePipeline):
         make = ctx_factory or (lambda shp, dev, g0, gn, own: hipnative.Context(shp, device=dev, gz0=g0, gnz=gn, own=own))
         ctx = make(lshape, device, gz0, int(gshape[0]), (own_lo, own_hi))
         super().__init__(gshape, device=device, ctx=ctx)
+        self._chain_hist = False           # the sample range is reduced across the ranks before the histogram pass
         self.comm = comm_factory(ctx)
         self.params = params
         self._valid = (0, lshape[0])
