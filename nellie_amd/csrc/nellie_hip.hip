@@ -1556,14 +1556,32 @@ extern "C" int nl_markers_log_step(nl_ctx *c, const double *wz2, const double *w
 #undef NL_MKYX
         }
     };
+    // the two in-plane terms in one walk over their common input
+    static int dual = -1;
+    if (dual < 0) { const char *e = getenv("NELLIE_MK_DUAL"); dual = (e && !atoi(e)) ? 0 : 1; }
+    auto yx_dual = [&](bool acc) {
+        const GaussWS wya = ws_of(gy2), wxa = ws_of(gx0), wyb = ws_of(gy0), wxb = ws_of(gx2);
+        const int vec4 = (c->nx % 4 == 0) ? 1 : 0;
+        const unsigned nb = g2.x * g2.y * g2.z;
+        switch (ryx) {
+#define NL_MKD(RR) case RR: if (acc) gauss_yx_dual_kernel<RR, true><<<nb, GYX_THREADS, 0, c->stream>>>(yx_src, lap, v, z0, z1, wya, wxa, wyb, wxb, vec4, (int)g2.x, (int)g2.y); \
+                            else gauss_yx_dual_kernel<RR, false><<<nb, GYX_THREADS, 0, c->stream>>>(yx_src, lap, v, z0, z1, wya, wxa, wyb, wxb, vec4, (int)g2.x, (int)g2.y); break;
+            NL_MKD(1) NL_MKD(2) NL_MKD(3) NL_MKD(4) NL_MKD(5) NL_MKD(6) NL_MKD(7) NL_MKD(8) NL_MKD(9) NL_MKD(10) NL_MKD(11) NL_MKD(12)
+#undef NL_MKD
+        }
+    };
+    const bool use_dual = dual && gyx_tiled();
     {
         ProfScope ps(c, "markers_log");
         // generic_laplace: output = d2/dz2 term; output += d2/dy2 term; output += d2/dx2 term (float32 adds, in this order)
         if (flat) {
-            yx(gy2, gx0, false); yx(gy0, gx2, true);
+            if (use_dual) yx_dual(false);
+            else { yx(gy2, gx0, false); yx(gy0, gx2, true); }
         } else {
             zpass(gz2); yx(gy0, gx0, false);
-            zpass(gz0); yx(gy2, gx0, true); yx(gy0, gx2, true);
+            zpass(gz0);
+            if (use_dual) yx_dual(true);
+            else { yx(gy2, gx0, true); yx(gy0, gx2, true); }
         }
         NL_CHECK_LAUNCH();
     }
