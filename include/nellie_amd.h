@@ -227,6 +227,12 @@ int nl_log2d_finish(nl_ctx *ctx, int64_t *n_positive, char *err, size_t errlen);
    n_positive = number of OWNED voxels > 0 (the `sum > 0` test of filtering.py:1016-1017). */
 int nl_filter_finish(nl_ctx *ctx, int64_t z0, int64_t z1, int64_t *n_positive, char *err, size_t errlen);
 
+/* `_remove_edges` (filtering.py:969-1000, called at :931-932 when remove_edges=True) on the frame nl_filter_finish left
+   on the device: in every Z plane (a 2-D image is one plane) the rows that hold a non-zero value span [rmin, rmax];
+   min(margin, rmax - rmin + 1) rows at each end of the span are zeroed (margin = 15 in the reference).
+   *n_positive = values > 0 that remain on the owned planes (`float(sum(frame)) > 0`, filtering.py:1014). */
+int nl_remove_edges(nl_ctx *ctx, int margin, int64_t *n_positive, char *err, size_t errlen);
+
 /* filtering.py:964-966: mask = frangi > thr; binary_opening (6-connected cross, one
    iteration, border 0); frangi *= mask. */
 int nl_mask_volume(nl_ctx *ctx, float thr, char *err, size_t errlen);

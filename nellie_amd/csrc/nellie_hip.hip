@@ -1198,6 +1198,26 @@ extern "C" int nl_filter_finish(nl_ctx *c, int64_t z0, int64_t z1, int64_t *n_po
     return NL_OK;
 }
 
+// filtering.py:931-932, 969-1000: `_remove_edges` on the resident `vesselness * masks` frame (after nl_filter_finish),
+// owned planes; *n_positive = values > 0 left on them.
+extern "C" int nl_remove_edges(nl_ctx *c, int margin, int64_t *n_positive, char *err, size_t errlen) {
+    NL_ENTER(c);
+    NL_JOIN_SIDE(c);
+    if (!c->frangi_ready) return nl_fail(err, errlen, NL_ESTATE, "nl_remove_edges before a Frangi frame exists");
+    if (margin < 0) return nl_fail(err, errlen, NL_EINVAL, "margin %d is negative", margin);
+    unsigned long long *d_cnt = (unsigned long long *)c->d_small;
+    NL_HIP(zero_small(d_cnt, 8, c->stream));
+    {
+        ProfScope ps(c, "finish");
+        remove_edges_kernel<<<(unsigned)(c->own_hi - c->own_lo), 256, 0, c->stream>>>(c->f[c->i_vmax], geom(c), c->own_lo, margin, d_cnt);
+        NL_CHECK_LAUNCH();
+    }
+    NL_HIP(hipMemcpyAsync(c->h_small, d_cnt, 8, hipMemcpyDeviceToHost, c->stream));
+    NL_HIP(hipStreamSynchronize(c->stream));
+    if (n_positive) *n_positive = (int64_t)(*(unsigned long long *)c->h_small);
+    return NL_OK;
+}
+
 extern "C" int nl_mask_volume(nl_ctx *c, float thr, char *err, size_t errlen) {
     NL_ENTER(c);
     // result goes to a free gauss volume, which then becomes the Frangi volume

@@ -71,6 +71,7 @@ _PROTOS = {
     "nl_log2d_step": [_p, C.POINTER(_f64), C.POINTER(_f64), C.POINTER(_f64), C.POINTER(_f64), _int, _f32, _int, _int],
     "nl_log2d_finish": [_p, C.POINTER(_i64)],
     "nl_filter_finish": [_p, _i64, _i64, C.POINTER(_i64)],
+    "nl_remove_edges": [_p, _int, C.POINTER(_i64)],
     "nl_planes_get": [_p, _int, _i64, _i64, _p],
     "nl_planes_put": [_p, _int, _i64, _i64, _p],
     "nl_comm_unique_id": [C.c_char_p],
@@ -528,6 +529,12 @@ class Context:
         return int(n.value)
 
     # ---------------------------------------------------------------- Z-slabs
+    def remove_edges(self, margin=15) -> int:
+        """filtering.py:969-1000 on the resident frame; returns the number of values > 0 left."""
+        n = _i64(0)
+        self._call("nl_remove_edges", int(margin), C.byref(n))
+        return int(n.value)
+
     def planes_get(self, field, z0, z1):
         out = np.empty((z1 - z0, self.shape[1], self.shape[2]), dtype=np.float32)
         self._call("nl_planes_get", int(field), int(z0), int(z1), _ptr(out))

@@ -487,11 +487,17 @@ class FramePipeline:
     # Off by default: at 1024^3 it buys ~1 % (two full-GPU kernels mostly take turns) and it blurs per-kernel timings.
     _gauss_ahead = os.environ.get("NELLIE_GAUSS_AHEAD", "0") == "1"
 
-    def filter(self, frame, p: FilterParams, mask: bool = True):
+    def filter(self, frame, p: FilterParams, mask: bool = True, remove_edges: bool = False):
         """filtering.py:1012-1018: _run_frame, then _mask_volume when the frame has signal.
         Common case in one go: the percentile threshold only needs lattice samples of `vesselness * masks`, which
         can be read through the mask bits, so the product is never written just to be thresholded and rewritten
         (nl_mask_volume_fused).  No positive sample, no evaluated scale, 2-D or a slab: the two plain steps."""
+        if remove_edges:                     # filtering.py:931-932: between the product and _mask_volume
+            self.compute_vesselness(frame, p, mask=mask)
+            npos = self.trace.n_positive = self._reduce_sum(self.ctx.remove_edges(15))
+            if npos > 0:
+                self.mask_volume(p)
+            return npos
         if self._fused_epilogue and not self.two_d:
             self.compute_vesselness(frame, p, mask=mask, finish=False)
             if any(not sc.skipped for sc in self.trace.scales):

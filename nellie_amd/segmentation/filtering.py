@@ -150,17 +150,16 @@ class Filter:
 
     # ------------------------------------------------------------------ frames
     def _run_frame(self, t, mask=True):
-        """filtering.py:910-933: vesselness * masks of frame t as a host float32 array."""
+        """filtering.py:910-933: vesselness * masks of frame t (2-D: maximum with the LoG blob response; remove_edges
+        if requested) as a host float32 array."""
         logger.info(f"Running Frangi filter on t={t}.")
         frame_cpu = self.im_memmap[t, ...]
         pipe = self._get_pipeline(frame_cpu.shape)
         pipe.compute_vesselness(frame_cpu, self._params(), mask=mask)
-        out = pipe.download_frangi()
-        if self.im_info.no_z:
-            out = out[0]
         if self.remove_edges:
-            out = self._remove_edges(out)
-        return out
+            pipe.ctx.remove_edges(self.edge_margin)
+        out = pipe.download_frangi()
+        return out[0] if self.im_info.no_z else out
 
     def _mask_volume(self, frangi_frame):
         """filtering.py:952-967 for a host frame (device does the work)."""
@@ -172,55 +171,45 @@ class Filter:
         out = pipe.download_frangi()
         return out[0] if frangi_frame.ndim == 2 else out
 
+    edge_margin = 15                                            # filtering.py:978, 988
+
     def _bbox(self, im):
-        """filtering.py:227-236 (2-D slice form)."""
-        rows = np.any(im, axis=1)
-        cols = np.any(im, axis=0)
-        if (not rows.any()) or (not cols.any()):
-            return 0, 0, 0, 0
-        rmin, rmax = np.where(rows)[0][[0, -1]]
-        cmin, cmax = np.where(cols)[0][[0, -1]]
-        return int(rmin), int(rmax), int(cmin), int(cmax)
+        """filtering.py:227-250: inclusive index range of the non-zero values along every axis, axis by axis
+        (rows, columns[, planes] in the reference's order); all zeros when the image is empty."""
+        im = np.asarray(im)
+        if im.ndim not in (2, 3):
+            logger.warning("Image not 2D or 3D... Cannot get bounding box.")
+            return None
+        nz = im != 0
+        out = []
+        for axis in ((0, 1) if im.ndim == 2 else (0, 1, 2)):
+            flags = nz.any(axis=tuple(a for a in range(im.ndim) if a != axis))
+            if not flags.any():
+                return (0,) * (2 * im.ndim)
+            out += [int(flags.argmax()), int(flags.size - 1 - flags[::-1].argmax())]
+        return tuple(out)
 
     def _remove_edges(self, frangi_frame):
-        """filtering.py:969-1000, on the host: off by default everywhere in the reference."""
-        if self.im_info.no_z:                                   # filtering.py:974-985
-            if frangi_frame.size == 0:
-                return frangi_frame
-            rmin, rmax, cmin, cmax = self._bbox(frangi_frame)
-            height = max(0, rmax - rmin + 1)
-            if height <= 0:
-                return frangi_frame
-            margin = min(15, height)
-            frangi_frame[rmin:rmin + margin, :] = 0
-            frangi_frame[rmax - margin + 1:rmax + 1, :] = 0
+        """filtering.py:969-1000 for a host frame: the device zeroes min(15, height) rows at both ends of the row span
+        of every Z plane (of the image, in 2-D); like the reference, the frame is changed in place when it can be."""
+        frame = np.asarray(frangi_frame)
+        if frame.size == 0:
             return frangi_frame
-        num_z = frangi_frame.shape[0]
-        margin = 15
-        for z_idx in range(num_z):
-            slice_im = frangi_frame[z_idx, ...]
-            if slice_im.size == 0:
-                continue
-            rmin, rmax, cmin, cmax = self._bbox(slice_im)
-            height = max(0, rmax - rmin + 1)
-            if height <= 0:
-                continue
-            use_margin = min(margin, height)
-            frangi_frame[z_idx, rmin:rmin + use_margin, :] = 0
-            frangi_frame[z_idx, rmax - use_margin + 1:rmax + 1, :] = 0
-        return frangi_frame
+        pipe = self._get_pipeline(frame.shape)
+        pipe.upload_frangi(frame.astype(np.float32, copy=False))
+        pipe.ctx.remove_edges(self.edge_margin)
+        out = pipe.download_frangi()
+        out = out[0] if frame.ndim == 2 else out
+        if isinstance(frangi_frame, np.ndarray) and frangi_frame.flags.writeable and frangi_frame.dtype == np.float32:
+            frangi_frame[...] = out
+            return frangi_frame
+        return out
 
     def _filter_frame(self, t, mask=True):
         """One frame end to end on the device (filtering.py:1012-1020), one download."""
         frame_cpu = self.im_memmap[t, ...]
         pipe = self._get_pipeline(frame_cpu.shape)
-        p = self._params()
-        if self.remove_edges:
-            fr = self._run_frame(t, mask=mask)
-            if float(np.sum(fr)) > 0.0:
-                fr = self._mask_volume(fr)
-            return fr
-        pipe.filter(frame_cpu, p, mask=mask)
+        pipe.filter(frame_cpu, self._params(), mask=mask, remove_edges=bool(self.remove_edges))
         out = pipe.download_frangi()
         return out[0] if self.im_info.no_z else out
 

@@ -602,6 +602,43 @@ def test_remove_edges_golden(hip):
     assert_masked_close(np.asarray(im_info.store["frangi"][0]), g["frangi"], g["run_frame"], g["percentile_thr"])
 
 
+def test_remove_edges_device_vs_oracle(hip):
+    """nl_remove_edges against the oracle's restatement of filtering.py:969-1000: random sparse frames (3-D, 2-D),
+    spans shorter than the margin (overlapping stretches), empty planes, a single non-zero row, negative values."""
+    from types import SimpleNamespace
+    from nellie_amd.segmentation.filtering import Filter
+    rng = np.random.default_rng(3)
+    iso = {"X": 0.1, "Y": 0.1, "Z": 0.1, "T": 1.0}
+    vol = np.zeros((9, 70, 45), np.float32)
+    vol[0, 20:60] = (rng.random((40, 45)) < 0.2) * rng.random((40, 45))       # ordinary plane
+    vol[1, 30:38, 5] = 1.0                                                   # span of 8 rows < margin: all zeroed
+    vol[2, 10:35, 7] = 2.0                                                   # span of 25: the two stretches overlap
+    vol[3, 33, 40] = 5.0                                                     # one row
+    vol[5, 0, 0] = 1.0; vol[5, 69, 44] = 1.0                                 # first and last row
+    vol[6, 12:50, 3] = -1.0                                                  # non-zero but not positive
+    vol[7] = rng.random((70, 45)).astype(np.float32)                         # dense
+    f3 = Filter(SimpleNamespace(no_t=True, no_z=False, shape=vol.shape, axes="ZYX", dim_res=iso, im_path="im", pipeline_paths={}),
+                remove_edges=True)
+    try:
+        out = f3._remove_edges(vol.copy())
+        assert np.array_equal(out, orc.remove_edges(vol))
+        pipe = f3._get_pipeline(vol.shape)
+        pipe.upload_frangi(vol)
+        assert pipe.ctx.remove_edges(15) == int((orc.remove_edges(vol) > 0).sum())      # the count that gates _mask_volume
+        assert f3._bbox(vol[0]) == (20, 59, int(np.flatnonzero(vol[0].any(0))[0]), int(np.flatnonzero(vol[0].any(0))[-1]))
+        assert f3._bbox(np.zeros((4, 5))) == (0, 0, 0, 0) and f3._bbox(np.zeros((2, 3, 4))) == (0,) * 6
+    finally:
+        f3.close()
+    img = vol[0].copy()
+    f2 = Filter(SimpleNamespace(no_t=True, no_z=True, shape=img.shape, axes="YX", dim_res={"X": 0.1, "Y": 0.1, "Z": None, "T": 1.0},
+                                im_path="im", pipeline_paths={}), remove_edges=True)
+    try:
+        assert np.array_equal(f2._remove_edges(img.copy()), orc.remove_edges_2d(img))
+        assert np.array_equal(f2._remove_edges(vol[1].copy()), orc.remove_edges_2d(vol[1]))
+    finally:
+        f2.close()
+
+
 @pytest.mark.parametrize("name", LABEL_INTENSITY_CASES)
 def test_label_intensity_threshold_golden(name, hip):
     """Label(otsu_thresh_intensity=True) / Label(threshold=...) behind the stage API (labelling.py:511-532, 550-552)."""
