@@ -81,6 +81,12 @@ static bool gyx_tiled() {
     if (on < 0) { const char *e = getenv("NELLIE_GYX_TILE"); on = (e && !atoi(e)) ? 0 : 1; }
     return on != 0;
 }
+// grid of the queue kernels: NELLIE_RESOLVE_GRID caps it (waves then walk several regions each)
+static unsigned resolve_grid(unsigned blocks) {
+    static long cap = -1;
+    if (cap < 0) { const char *e = getenv("NELLIE_RESOLVE_GRID"); cap = e ? atol(e) : 16384; }
+    return (cap > 0 && (unsigned)cap < blocks) ? (unsigned)cap : blocks;
+}
 static float *gauss_cur(const nl_ctx *c) { return c->gauss_ext ? c->gauss_ext : c->f[c->i_gauss]; }
 static VolGeom geom(const nl_ctx *c) { return VolGeom{c->nzl, c->ny, c->nx, c->gz0, c->gnz}; }
 // tile height of the Hessian kernels (experiment knob; 8 -> 512-thread workgroups, 16 -> 1024)
@@ -1018,7 +1024,7 @@ extern "C" int nl_vesselness_resolve(nl_ctx *c, float gamma_sq, float alpha_sq, 
         const unsigned long long *pm = (unsigned long long *)c->m[0] + (i64)((k_scale + 1) & 1) * slot_words;
         if (vp.first)
             NL_HIP(hipMemsetAsync(c->f[c->i_vmax] + z0 * plane, 0, (size_t)(z1 - z0) * plane * 4, c->side));
-        vesselness_queue_kernel<true><<<(c->spec_nregions + 3) / 4, 256, 0, c->side>>>(
+        vesselness_queue_kernel<true><<<resolve_grid((c->spec_nregions + 3) / 4), 256, 0, c->side>>>(
             (const float4 *)c->d_vq, c->d_vq_count, c->spec_nregions, c->f[c->i_vmax], z0 * plane, vp, cm, pm, wpr, (int)c->ny, (int)c->nx, z0, d_cnt);
         NL_CHECK_LAUNCH();
     }
@@ -1088,7 +1094,7 @@ extern "C" int nl_vesselness_step(nl_ctx *c, float gamma_sq, float alpha_sq, flo
             else { if (c->fast_div) NL_LAUNCH_VESS(16, true, hessdv_fast(c)); else NL_LAUNCH_VESS(16, false, hessdv_exact(c)); }
             NL_CHECK_LAUNCH();
             const unsigned nregions = nblocks * (unsigned)ty;
-            vesselness_queue_kernel<false><<<(nregions + 3) / 4, 256, 0, c->stream>>>(vq.ent, vq.count, nregions, c->f[c->i_vmax], za * plane, vp,
+            vesselness_queue_kernel<false><<<resolve_grid((nregions + 3) / 4), 256, 0, c->stream>>>(vq.ent, vq.count, nregions, c->f[c->i_vmax], za * plane, vp,
                                                                                       nullptr, nullptr, wpr, (int)c->ny, (int)c->nx, za, nullptr);
             NL_CHECK_LAUNCH();
         }
