@@ -1864,7 +1864,7 @@ static int scan_excl_u32(nl_ctx *c, const unsigned int *in, unsigned int *out, i
     return NL_OK;
 }
 
-struct RunSet { RunRec *runs; int *parent; unsigned int *row_off; i64 nruns; };
+struct RunSet { RunRec *runs; int *parent; unsigned int *row_off; i64 nruns; int *proot = nullptr; int *link = nullptr; };
 
 // Geometry the run-level Label works on: the whole (global) volume as rows of bit-packed words.
 struct LabelGeo {
@@ -1874,6 +1874,7 @@ struct LabelGeo {
     unsigned long long *bitsA, *bitsB;
     i64 paint_row0, paint_row1;   // rows this context paints ...
     int *paint_out;               // ... into this int32 buffer (row paint_row0 first)
+    int *link_scratch = nullptr;  // >= one int per possible run, free until the paint (enables the two-level union-find)
 };
 
 // runs of `bits` (or of its complement) + union-find over them, flattened
@@ -1896,8 +1897,20 @@ static int build_components(nl_ctx *c, const LabelGeo &g, const unsigned long lo
     rl_emit_kernel<<<(unsigned)((g.nrows + 255) / 256), 256, 0, c->stream>>>(bits, invert, row_off, rs.runs, rs.parent, g.nrows, g.wpr, (int)g.nx);
     NL_CHECK_LAUNCH();
     const unsigned gr = (unsigned)((rs.nruns + 255) / 256);
-    rl_union_kernel<CONN><<<gr, 256, 0, c->stream>>>(rs.runs, row_off, rs.parent, rs.nruns, (int)g.ny,
-                                                     CONN == 6 ? (int)g.nz : 0, (int)g.nx);
+    // two levels (see label_runs.inc): planes in LDS, then component pairs across planes; NELLIE_UF_PLANES=0: one level
+    static int two_level = -1;
+    if (two_level < 0) { const char *e = getenv("NELLIE_UF_PLANES"); two_level = (e && !atoi(e)) ? 0 : 1; }
+    if (two_level && g.nz <= 8192 && rs.proot && rs.link) {
+        uint8_t *plane_done = (uint8_t *)c->d_small + (52 << 10);
+        NL_HIP(hipMemsetAsync(rs.link, 0xff, (size_t)rs.nruns * 4, c->stream));
+        rl_union_plane_kernel<CONN><<<(unsigned)g.nz, 256, 0, c->stream>>>(rs.runs, row_off, rs.parent, rs.proot, (int)g.ny,
+                                                                         CONN == 6 ? (int)g.nz : 0, (int)g.nx, plane_done);
+        rl_union_cross_kernel<CONN><<<gr, 256, 0, c->stream>>>(rs.runs, row_off, rs.parent, rs.proot, rs.link, rs.nruns, (int)g.ny,
+                                                               CONN == 6 ? (int)g.nz : 0, (int)g.nx, plane_done);
+    } else {
+        rl_union_kernel<CONN><<<gr, 256, 0, c->stream>>>(rs.runs, row_off, rs.parent, rs.nruns, (int)g.ny,
+                                                         CONN == 6 ? (int)g.nz : 0, (int)g.nx);
+    }
     NL_CHECK_LAUNCH();
     ccl_flatten_kernel<<<grid1d(rs.nruns), 256, 0, c->stream>>>(rs.parent, rs.nruns);
     NL_CHECK_LAUNCH();
@@ -1938,6 +1951,8 @@ static int label_core(nl_ctx *c, const LabelGeo &g, int64_t min_area, int fill_h
     rs.runs = (RunRec *)c->f[free_idx[0]];                    // 8 B x cap  = 4N bytes
     rs.parent = (int *)c->f[free_idx[1]];                     // 4 B x cap  = 2N bytes
     int *aux = rs.parent + cap;                               // 4 B x cap  = 2N bytes (areas, then new ids)
+    rs.proot = aux;                                           // in-plane roots during the unions (aux is idle until the areas)
+    rs.link = g.link_scratch;
     uint8_t *flag = c->m[0];
     const VolGeom vg{g.nz, g.ny, g.nx, 0, g.nz};             // boundary rules of the whole volume
     int rc;
@@ -1998,6 +2013,7 @@ extern "C" int nl_label_run(nl_ctx *c, int has_thr, float thr, int64_t min_area,
     g.rows = c->d_rows;
     g.bitsA = (unsigned long long *)c->m[1]; g.bitsB = (unsigned long long *)c->m[2];
     g.paint_row0 = 0; g.paint_row1 = g.nrows; g.paint_out = (int *)c->f[label_out_index(c)];
+    g.link_scratch = g.paint_out;                 // the whole label volume (4N bytes) is idle until the paint
     ProfScope ps(c, "label");
     const unsigned long long *support = (c->support_epoch + 1 == c->epoch.load() && c->d_support && has_thr && thr >= 0.0f) ? c->d_support : nullptr;
     c->last_label_sparse = support ? 1 : 0;
