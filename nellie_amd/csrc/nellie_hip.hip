@@ -1883,7 +1883,12 @@ static int build_components(nl_ctx *c, const LabelGeo &g, const unsigned long lo
                             bool *overflow, char *err, size_t errlen) {
     unsigned int *counts = g.rows, *row_off = g.rows + (g.nrows + 2);
     NL_HIP(zero_small(counts + g.nrows, 4, c->stream));
-    if (g.wpr <= 64) rl_count_wave_kernel<<<(unsigned)((g.nrows + 3) / 4), 256, 0, c->stream>>>(bits, invert, counts, g.nrows, g.wpr, (int)g.nx);
+    if (g.wpr <= 64) {
+        int P = 1;
+        while (P < g.wpr) P <<= 1;
+        const i64 groups = (g.nrows + 64 / P - 1) / (64 / P);
+        rl_count_wave_kernel<<<grid1d(groups * 64, 256, 16384), 256, 0, c->stream>>>(bits, invert, counts, g.nrows, g.wpr, (int)g.nx, P);
+    }
     else rl_count_kernel<<<(unsigned)((g.nrows + 255) / 256), 256, 0, c->stream>>>(bits, invert, counts, g.nrows, g.wpr, (int)g.nx);
     NL_CHECK_LAUNCH();
     int rc = scan_excl_u32(c, counts, row_off, g.nrows + 1, err, errlen);
@@ -1894,7 +1899,10 @@ static int build_components(nl_ctx *c, const LabelGeo &g, const unsigned long lo
     rs.row_off = row_off;
     *overflow = rs.nruns > cap;
     if (*overflow || rs.nruns == 0) return NL_OK;
-    rl_emit_kernel<<<(unsigned)((g.nrows + 255) / 256), 256, 0, c->stream>>>(bits, invert, row_off, rs.runs, rs.parent, g.nrows, g.wpr, (int)g.nx);
+    if (g.wpr <= 30)
+        rl_emit_kernel<true><<<(unsigned)((g.nrows + 255) / 256), 256, (size_t)256 * (g.wpr + 1) * 8, c->stream>>>(bits, invert, row_off, rs.runs, rs.parent, g.nrows, g.wpr, (int)g.nx);
+    else
+        rl_emit_kernel<false><<<(unsigned)((g.nrows + 255) / 256), 256, 0, c->stream>>>(bits, invert, row_off, rs.runs, rs.parent, g.nrows, g.wpr, (int)g.nx);
     NL_CHECK_LAUNCH();
     const unsigned gr = (unsigned)((rs.nruns + 255) / 256);
     // two levels (see label_runs.inc): planes in LDS, then component pairs across planes; NELLIE_UF_PLANES=0: one level
