@@ -1502,8 +1502,8 @@ extern "C" int nl_markers_distance(nl_ctx *c, float clamp, int64_t *n_mask, char
     NL_HIP(hipMemsetAsync(c->f[0], 0, (size_t)c->n * 4, c->stream));            // distance = 0 on the background
     unsigned long long *d_cnt = (unsigned long long *)c->d_small;
     NL_HIP(zero_small(d_cnt, 8, c->stream));
-    const unsigned gw_ = grid1d(nw * 64, 256, (i64)1 << 20);
-    mk_edt_x_kernel<<<grid1d(nw * 64, 256, 256 * 32), 256, 0, c->stream>>>(mask, (int *)c->f[1], v, wpr, W, d_cnt);
+    const unsigned gw_ = grid1d(nw, 256, (i64)1 << 20);               // a wave scans 64 mask words per trip
+    mk_edt_x_kernel<<<grid1d(nw, 256, 256 * 32), 256, 0, c->stream>>>(mask, (int *)c->f[1], v, wpr, W, d_cnt);
     mk_edt_axis_kernel<1, 0><<<gw_, 256, 0, c->stream>>>(mask, (const int *)c->f[1], (int *)c->f[2], nullptr, clamp, v, wpr, W);
     mk_edt_axis_kernel<0, 1><<<gw_, 256, 0, c->stream>>>(mask, (const int *)c->f[2], nullptr, c->f[0], clamp, v, wpr, W);
     NL_CHECK_LAUNCH();
@@ -1615,7 +1615,7 @@ extern "C" int nl_markers_log_step(nl_ctx *c, const double *wz2, const double *w
         ProfScope ps(c, "markers_peaks");
         const int wpr = (int)((c->nx + 63) / 64);
         const i64 nw = c->nzl * c->ny * wpr;
-        mk_peak_kernel<<<grid1d(nw * 64, 256, (i64)1 << 20), 256, 0, c->stream>>>(lap, s2, (const unsigned long long *)c->m[1], dist, c->f[3],
+        mk_peak_kernel<<<grid1d(nw, 256, (i64)1 << 20), 256, 0, c->stream>>>(lap, s2, (const unsigned long long *)c->m[1], dist, c->f[3],
                                                                                  (unsigned long long *)c->m[0], v, wpr);
         NL_CHECK_LAUNCH();
     }
@@ -1633,7 +1633,7 @@ extern "C" int nl_markers_finish(nl_ctx *c, int peak_min_distance, int64_t *n_ma
     NL_HIP(zero_small(d_cnt, 8, c->stream));
     {
         ProfScope ps(c, "markers_nms");
-        mk_nms_kernel<<<grid1d(nw * 64, 256, 256 * 32), 256, 0, c->stream>>>((const unsigned long long *)c->m[0], mk_intensity(c), peak_min_distance,
+        mk_nms_kernel<<<grid1d(nw, 256, 256 * 32), 256, 0, c->stream>>>((const unsigned long long *)c->m[0], mk_intensity(c), peak_min_distance,
                                                                              (unsigned long long *)c->m[0] + nw, geom(c), wpr, d_cnt);
         NL_CHECK_LAUNCH();
     }
