@@ -474,6 +474,39 @@ def test_ccl_random_masks_vs_oracle(pipes):
             assert np.array_equal(pipe.download_labels(), ref), (shape, p, min_area)
 
 
+def test_ccl_two_level_paths_vs_oracle(pipes):
+    """The union-find's two levels on the inputs that leave the common path: planes with more runs than the in-plane LDS
+    array (they fall to the global pass, next to sparse planes that do not), rows wider than the LDS-staged run emission
+    handles (> 30 words), and a single plane (nz = 1)."""
+    rng = np.random.default_rng(11)
+    cases = []
+    dense = (rng.random((5, 300, 410)) < 0.5)
+    dense[1] = rng.random((300, 410)) < 0.01                      # a sparse plane between planes of ~30 000 runs
+    dense[3] &= rng.random((300, 410)) < 0.3
+    cases.append(dense)
+    cases.append(rng.random((3, 40, 2100)) < 0.4)                  # 33 words per row
+    cases.append(rng.random((1, 200, 333)) < 0.55)                 # one plane
+    for m in cases:
+        fr = m.astype(np.float32) * rng.uniform(0.5, 1.0, m.shape).astype(np.float32)
+        pipe = pipes(m.shape)
+        for min_area, fill in ((1, True), (4, False)):
+            pipe.upload_frangi(fr)
+            pipe.ctx.label_run(np.float32(0.25), min_area, fill)
+            if fill:
+                _, ref = orc.get_labels(fr, np.float32(0.25), min_area)
+            else:
+                mk = orc._label(orc.majority3(_area_filter(orc._label(fr > 0.25, 26), min_area)), 26)
+                ref = mk
+            assert np.array_equal(pipe.download_labels(), ref), (m.shape, min_area, fill)
+
+
+def _area_filter(lab, min_area):
+    counts = np.bincount(lab.ravel())
+    keep = counts >= min_area
+    keep[0] = False
+    return keep[lab]
+
+
 def test_stage_api_filter_then_label(hip):
     """The drop-in classes behind the reference's stage API, T = 2 frames, uint16 input."""
     from fakes import ArrayImInfo
