@@ -17,8 +17,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libnellie_hip.so")
 SOURCES = ["nellie_hip.hip"]
-HEADERS = ["nl_common.h", "device_math.inc", "convert.inc", "gauss.inc", "sampling.inc", "hessian.inc",
-           "label_voxels.inc", "label_runs.inc", os.path.join("..", "..", "include", "nellie_amd.h")]
+# every include of the translation unit: a stale library after editing one of them would silently test old kernels
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith((".inc", ".h"))) + [os.path.join("..", "..", "include", "nellie_amd.h")]
 
 
 def hipcc_path() -> str:
