@@ -40,6 +40,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not needs_build():
         return LIB
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+           "-fno-slp-vectorize",      # packed-float32 pairs cost the Hessian walk 27 register moves per voxel-plane (-1.1 ms/step)
            "-fPIC", "-shared", "-Wno-unused-value",
            "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
     cmd += ["-ldl"]          # RCCL is dlopen()ed on first use (nl_comm_*), never linked
