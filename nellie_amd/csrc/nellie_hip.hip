@@ -49,6 +49,7 @@ static RcclApi &rccl() {
 #include "gauss.inc"
 #include "sampling.inc"
 #include "hessian.inc"
+#include "hessian_pair.inc"
 #include "filter2d.inc"
 #include "markers.inc"
 #include "label_voxels.inc"
@@ -95,6 +96,15 @@ static int hm_ty() {
     if (v < 0) { const char *e = getenv("NELLIE_HM_TY"); v = (e && atoi(e) == 16) ? 16 : 8; }
     return v;
 }
+// Hessian walk: two voxels per thread (hessian_pair.inc), tile 2*RS rows; NELLIE_HV_RS = 8 (default) / 4, 0 = the
+// one-voxel kernel of hessian.inc
+static int hv_rs_env() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("NELLIE_HV_RS"); v = e ? atoi(e) : 8; if (v != 0 && v != 4 && v != 8) v = 8; }
+    return v;
+}
+// the pair kernel addresses the planes of a Z chunk through one buffer resource (32-bit byte offsets)
+static int hv_rs(const nl_ctx *c) { return ((i64)(HM_ZCHUNK + 4) * c->ny * c->nx * 4 < ((i64)1 << 32)) ? hv_rs_env() : 0; }
 static Dv<true> dv_fast(float d) { return Dv<true>{d, (float)(1.0 / (double)d)}; }
 static Dv<false> dv_exact(float d) { return Dv<false>{1.0 / (double)d}; }
 static HessDv<true> hessdv_fast(const nl_ctx *c) {
@@ -873,9 +883,17 @@ extern "C" int nl_hessian_stats(nl_ctx *c, const double spacing[3], float *max_a
                                           HGCfg<TYV>::lds_bytes(), c->stream>>>(                                          \
             gauss_cur(c), nullptr, nullptr, 0, geom(c), HR, vp, VQueue{}, (int)c->own_lo, (int)c->own_hi, ntx,        \
             (int)((c->ny + TYV - 1) / TYV), res, nullptr)
-        if (hm_ty() == 8) { if (c->fast_div) NL_LAUNCH_STATS(8, true, hessdv_fast(c)); else NL_LAUNCH_STATS(8, false, hessdv_exact(c)); }
+#define NL_LAUNCH_STATS_V(RSV, FASTV, HR)                                                                                 \
+        hessian_v_kernel<0, RSV, FASTV><<<(unsigned)(ntx * (int)((c->ny + 2 * RSV - 1) / (2 * RSV)) * nzc), HVCfg<RSV>::NT, \
+                                          HVCfg<RSV>::lds_bytes(), c->stream>>>(                                          \
+            gauss_cur(c), nullptr, nullptr, 0, geom(c), HR, vp, VQueue{}, (int)c->own_lo, (int)c->own_hi, ntx,        \
+            (int)((c->ny + 2 * RSV - 1) / (2 * RSV)), res, nullptr)
+        if (hv_rs(c) == 8) { if (c->fast_div) NL_LAUNCH_STATS_V(8, true, hessdv_fast(c)); else NL_LAUNCH_STATS_V(8, false, hessdv_exact(c)); }
+        else if (hv_rs(c) == 4) { if (c->fast_div) NL_LAUNCH_STATS_V(4, true, hessdv_fast(c)); else NL_LAUNCH_STATS_V(4, false, hessdv_exact(c)); }
+        else if (hm_ty() == 8) { if (c->fast_div) NL_LAUNCH_STATS(8, true, hessdv_fast(c)); else NL_LAUNCH_STATS(8, false, hessdv_exact(c)); }
         else { if (c->fast_div) NL_LAUNCH_STATS(16, true, hessdv_fast(c)); else NL_LAUNCH_STATS(16, false, hessdv_exact(c)); }
 #undef NL_LAUNCH_STATS
+#undef NL_LAUNCH_STATS_V
         NL_CHECK_LAUNCH();
     }
     unsigned int *h = (unsigned int *)c->h_small;
@@ -955,18 +973,27 @@ extern "C" int nl_vesselness_spec(nl_ctx *c, const double spacing[3], float fsq_
         unsigned long long *cm = (unsigned long long *)c->m[0] + (i64)(k_scale & 1) * slot_words;
         const unsigned long long *pm = (unsigned long long *)c->m[0] + (i64)((k_scale + 1) & 1) * slot_words;
         const VQueue vq{(float4 *)c->d_vq, c->d_vq_count};
-        const int ty = hm_ty();
+        const int rs = hv_rs(c);
+        const int ty = rs ? 2 * rs : hm_ty();
         const int nty = (int)((c->ny + ty - 1) / ty);
         const int nzc = (int)((z1 - z0 + HM_ZCHUNK - 1) / HM_ZCHUNK);
         const unsigned nblocks = (unsigned)(ntx * nty * nzc);
+        if (rs) vp.qcap = 2 * HM_SPEC_CAP;              // a wave owns two row segments
+#define NL_LAUNCH_SPEC_V(RSV, FASTV, HR)                                                                                  \
+        hessian_v_kernel<2, RSV, FASTV><<<nblocks, HVCfg<RSV>::NT, HVCfg<RSV>::lds_bytes(), c->stream>>>(                 \
+            gauss_cur(c), cm, pm, wpr, geom(c), HR, vp, vq, (int)z0, (int)z1, ntx, nty, res, d_cnt)
 #define NL_LAUNCH_SPEC(TYV, FASTV, HR)                                                                                    \
         hessian_g_kernel<2, TYV, FASTV><<<nblocks, HGCfg<TYV>::NT, HGCfg<TYV>::lds_bytes(), c->stream>>>(                 \
             gauss_cur(c), cm, pm, wpr, geom(c), HR, vp, vq, (int)z0, (int)z1, ntx, nty, res, d_cnt)
-        if (ty == 8) { if (c->fast_div) NL_LAUNCH_SPEC(8, true, hessdv_fast(c)); else NL_LAUNCH_SPEC(8, false, hessdv_exact(c)); }
+        if (rs == 8) { if (c->fast_div) NL_LAUNCH_SPEC_V(8, true, hessdv_fast(c)); else NL_LAUNCH_SPEC_V(8, false, hessdv_exact(c)); }
+        else if (rs == 4) { if (c->fast_div) NL_LAUNCH_SPEC_V(4, true, hessdv_fast(c)); else NL_LAUNCH_SPEC_V(4, false, hessdv_exact(c)); }
+        else if (ty == 8) { if (c->fast_div) NL_LAUNCH_SPEC(8, true, hessdv_fast(c)); else NL_LAUNCH_SPEC(8, false, hessdv_exact(c)); }
         else { if (c->fast_div) NL_LAUNCH_SPEC(16, true, hessdv_fast(c)); else NL_LAUNCH_SPEC(16, false, hessdv_exact(c)); }
 #undef NL_LAUNCH_SPEC
+#undef NL_LAUNCH_SPEC_V
         NL_CHECK_LAUNCH();
-        c->spec_nregions = nblocks * (unsigned)ty;
+        c->spec_nregions = nblocks * (unsigned)(rs ? rs : ty);
+        c->spec_qcap = vp.qcap;
     }
     unsigned int *h = (unsigned int *)c->h_small;
     NL_HIP(hipMemcpyAsync(h, c->d_small, 128, hipMemcpyDeviceToHost, c->stream));      // [0] count, [16..19] statistics
@@ -1012,7 +1039,7 @@ extern "C" int nl_vesselness_resolve(nl_ctx *c, float gamma_sq, float alpha_sq, 
     NL_HIP(hipEventRecord(c->ev_main, c->stream));
     NL_HIP(hipStreamWaitEvent(c->side, c->ev_main, 0));
     NL_HIP(zero_small(d_cnt, 8, c->side));
-    vp.qcap = HM_SPEC_CAP;
+    vp.qcap = c->spec_qcap;
     vp.idx_lo = (c->own_lo - z0) * plane; vp.idx_hi = (c->own_hi - z0) * plane;
     {
         ProfScope ps(c, "vesselness_resolve", c->side);
@@ -1081,8 +1108,13 @@ extern "C" int nl_vesselness_step(nl_ctx *c, float gamma_sq, float alpha_sq, flo
         const VQueue vq{(float4 *)c->d_vq, c->d_vq_count};
         if (vp.first)      // vesselness = zeros (filtering.py:807); only voxels alive in every mask are ever read again
             NL_HIP(hipMemsetAsync(c->f[c->i_vmax] + z0 * plane, 0, (size_t)(z1 - z0) * plane * 4, c->stream));
-        const int ty = hm_ty();
+        const int rs = hv_rs(c);
+        const int ty = rs ? 2 * rs : hm_ty();
         const int nty = (int)((c->ny + ty - 1) / ty);
+        if (rs) vp.qcap = 2 * HM_REGION;
+#define NL_LAUNCH_VESS_V(RSV, FASTV, HR)                                                                                  \
+        hessian_v_kernel<1, RSV, FASTV><<<nblocks, HVCfg<RSV>::NT, HVCfg<RSV>::lds_bytes(), c->stream>>>(                 \
+            gauss_cur(c), cm, pm, wpr, geom(c), HR, vp, vq, (int)za, (int)zb, ntx, nty, nullptr, d_cnt)
 #define NL_LAUNCH_VESS(TYV, FASTV, HR)                                                                                    \
         hessian_g_kernel<1, TYV, FASTV><<<nblocks, HGCfg<TYV>::NT, HGCfg<TYV>::lds_bytes(), c->stream>>>(                 \
             gauss_cur(c), cm, pm, wpr, geom(c), HR, vp, vq, (int)za, (int)zb, ntx, nty, nullptr, d_cnt)
@@ -1090,15 +1122,18 @@ extern "C" int nl_vesselness_step(nl_ctx *c, float gamma_sq, float alpha_sq, flo
             const i64 zb = za + planes_per_launch < z1 ? za + planes_per_launch : z1;
             const int nzc = (int)((zb - za + HM_ZCHUNK - 1) / HM_ZCHUNK);
             const unsigned nblocks = (unsigned)(ntx * nty * nzc);
-            if (ty == 8) { if (c->fast_div) NL_LAUNCH_VESS(8, true, hessdv_fast(c)); else NL_LAUNCH_VESS(8, false, hessdv_exact(c)); }
+            if (rs == 8) { if (c->fast_div) NL_LAUNCH_VESS_V(8, true, hessdv_fast(c)); else NL_LAUNCH_VESS_V(8, false, hessdv_exact(c)); }
+            else if (rs == 4) { if (c->fast_div) NL_LAUNCH_VESS_V(4, true, hessdv_fast(c)); else NL_LAUNCH_VESS_V(4, false, hessdv_exact(c)); }
+            else if (ty == 8) { if (c->fast_div) NL_LAUNCH_VESS(8, true, hessdv_fast(c)); else NL_LAUNCH_VESS(8, false, hessdv_exact(c)); }
             else { if (c->fast_div) NL_LAUNCH_VESS(16, true, hessdv_fast(c)); else NL_LAUNCH_VESS(16, false, hessdv_exact(c)); }
             NL_CHECK_LAUNCH();
-            const unsigned nregions = nblocks * (unsigned)ty;
+            const unsigned nregions = nblocks * (unsigned)(rs ? rs : ty);
             vesselness_queue_kernel<false><<<resolve_grid((nregions + 3) / 4), 256, 0, c->stream>>>(vq.ent, vq.count, nregions, c->f[c->i_vmax], za * plane, vp,
                                                                                       nullptr, nullptr, wpr, (int)c->ny, (int)c->nx, za, nullptr);
             NL_CHECK_LAUNCH();
         }
 #undef NL_LAUNCH_VESS
+#undef NL_LAUNCH_VESS_V
         NL_CHECK_LAUNCH();
     }
     if (mask_count) {
@@ -1215,7 +1250,10 @@ extern "C" int nl_remove_edges(nl_ctx *c, int margin, int64_t *n_positive, char 
     NL_HIP(zero_small(d_cnt, 8, c->stream));
     {
         ProfScope ps(c, "finish");
-        remove_edges_kernel<<<(unsigned)(c->own_hi - c->own_lo), 256, 0, c->stream>>>(c->f[c->i_vmax], geom(c), c->own_lo, margin, d_cnt);
+        // the same planes nl_filter_finish materialises: nl_mask_volume thresholds and opens own +- 2, so the ghost planes
+        // of a Z slab must lose their edge rows too (each plane is trimmed on its own: no cross-plane dependency)
+        const i64 r0 = c->own_lo - 2 > 0 ? c->own_lo - 2 : 0, r1 = c->own_hi + 2 < c->nzl ? c->own_hi + 2 : c->nzl;
+        remove_edges_kernel<<<(unsigned)(r1 - r0), 256, 0, c->stream>>>(c->f[c->i_vmax], geom(c), r0, margin, c->own_lo, c->own_hi, d_cnt);
         NL_CHECK_LAUNCH();
     }
     NL_HIP(hipMemcpyAsync(c->h_small, d_cnt, 8, hipMemcpyDeviceToHost, c->stream));
@@ -2299,7 +2337,7 @@ extern "C" int nl_outputs_wait(nl_ctx *c, char *err, size_t errlen) {
 extern "C" int nl_ctx_info(nl_ctx *c, const char *key, double *value) {
     if (!c || !key || !value) return NL_EINVAL;
     if (!strcmp(key, "fast_div")) *value = c->fast_div;
-    else if (!strcmp(key, "hessian_tile_rows")) *value = hm_ty();
+    else if (!strcmp(key, "hessian_tile_rows")) *value = hv_rs(c) ? 2 * hv_rs(c) : hm_ty();
     else if (!strcmp(key, "vesselness_one_pass")) *value = c->spec_ok;
     else if (!strcmp(key, "last_fsq_min")) *value = c->last_fsq_min;
     else if (!strcmp(key, "last_spec_overflow")) *value = c->last_spec_overflow;

@@ -68,6 +68,7 @@ struct nl_ctx {
     float spec_lo = 0, spec_hi = 0;
     i64 spec_z0 = 0, spec_z1 = 0;
     unsigned int spec_nregions = 0;
+    int spec_qcap = 0;                   // entries per queue region of that pass
     unsigned long long spec_count = 0;   // owned voxels the pass already counted as h_mask
     hipStream_t side = nullptr;          // the resolve kernel of scale s runs here, beside the Gaussian of scale s+1
     hipEvent_t ev_side = nullptr, ev_main = nullptr;

@@ -418,6 +418,9 @@ class FramePipeline:
                     ma, mf, inf_, ovf = ctx.vesselness_spec(spacing, bracket[0], bracket[1], z0=vz0, z1=vz1)
                     stats = self._reduce_stats(ma, mf, inf_)
                     spec = not stats[2] and self._reduce_sum(int(ovf)) == 0
+                    if stats[2]:
+                        stats = None     # a +inf frob_sq turned up: the one-pass walk only flags it (the largest finite
+                                         # value comes from the statistics pass below), and the scale goes the two-pass way
             if stats is None:
                 stats = self._reduce_stats(*ctx.hessian_stats(spacing))
             max_abs32, max_fsq32, any_inf = stats
