@@ -153,6 +153,15 @@ int nl_sample_hist(nl_ctx *ctx, int field, int64_t sz, int64_t sy, int64_t sx,
 int nl_sample_range_hist(nl_ctx *ctx, int field, int64_t sz, int64_t sy, int64_t sx, int nbins, float *mn, float *mx,
                          int64_t *n_positive, int64_t *counts, float *edges, int *valid, char *err, size_t errlen);
 
+/* The two histogram thresholds of nellie/utils/gpu_functions.py on a finished histogram (host arithmetic, no device
+   work; callable without a context): `counts[nbins]` int64 as numpy.histogram returns them, `edges[nbins + 1]`
+   float32 bin edges.  *otsu = centre of the bin maximising the between-class variance (gpu_functions.py:36-50),
+   *triangle = the triangle-method bin centre (:64-94), both float32 values widened to double, computed with numpy's
+   float64 operation order so that they carry numpy's bits.  *status: 0 ok, 1 = the triangle construction is degenerate
+   (numpy raises "attempt to get argmax of an empty sequence" there; *triangle is 0, *otsu is valid). */
+int nl_hist_thresholds(const int64_t *counts, const float *edges, int nbins, double *triangle, double *otsu, int *status,
+                       char *err, size_t errlen);
+
 /* Hessian by double finite differences of the current Gaussian volume (xp.gradient twice,
    filtering.py:518-536) on the owned planes; returns
      max_abs          = max over the six components of max|h|         (filtering.py:556-561; NOT yet mapped 0 -> 1)

@@ -55,6 +55,7 @@ static RcclApi &rccl() {
 #include "label_voxels.inc"
 #include "label_runs.inc"
 #include "network.inc"
+#include "thresholds.inc"
 
 // =================================================================================================
 // host side: context, launch helpers, C-ABI
@@ -100,8 +101,12 @@ static int hm_ty() {
 // one-voxel kernel of hessian.inc
 static int hv_rs_env() {
     static int v = -1;
-    if (v < 0) { const char *e = getenv("NELLIE_HV_RS"); v = e ? atoi(e) : 8; if (v != 0 && v != 4 && v != 8) v = 8; }
+    if (v < 0) { const char *e = getenv("NELLIE_HV_RS"); v = e ? atoi(e) : 8; if (v != 0 && v != 8 && v != 16) v = 8; }
     return v;
+}
+// dynamic LDS beyond 64 KiB has to be allowed per kernel (the RS = 16 tile of the pair kernel takes 121 KiB)
+template <typename K> static void allow_lds(K kernel, int bytes) {
+    if (bytes > (64 << 10)) (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 // the pair kernel addresses the planes of a Z chunk through one buffer resource (32-bit byte offsets)
 static int hv_rs(const nl_ctx *c) { return ((i64)(HM_ZCHUNK + 4) * c->ny * c->nx * 4 < ((i64)1 << 32)) ? hv_rs_env() : 0; }
@@ -180,7 +185,7 @@ extern "C" int nl_device_name(int device, char *name, size_t namelen, char *err,
 // Global eigen queue: every wave of the vesselness kernel owns HM_REGION entries (32 bytes each), so one launch
 // needs (padded plane) x (Z chunks x HM_ZCHUNK) entries.  A launch covers as many Z chunks as fit 2^28 entries
 // (8 GiB); smaller volumes go in one launch.  NELLIE_VQ_CAP (entries) is a test knob to force several launches.
-static int64_t vq_padded_plane(int64_t ny, int64_t nx) { return ((nx + HM_TX - 1) / HM_TX) * HM_TX * (((ny + 15) / 16) * 16); }
+static int64_t vq_padded_plane(int64_t ny, int64_t nx) { return ((nx + HM_TX - 1) / HM_TX) * HM_TX * (((ny + 31) / 32) * 32); }
 static int64_t vq_chunks(int64_t nzl, int64_t ny, int64_t nx) {
     static int64_t lim = 0;
     if (!lim) { const char *e = getenv("NELLIE_VQ_CAP"); lim = (e && atoll(e) > 0) ? atoll(e) : ((int64_t)1 << 28); }
@@ -829,6 +834,14 @@ extern "C" int nl_sample_range_hist(nl_ctx *c, int field, int64_t sz, int64_t sy
     return NL_OK;
 }
 
+extern "C" int nl_hist_thresholds(const int64_t *counts, const float *edges, int nbins, double *triangle, double *otsu, int *status,
+                                  char *err, size_t errlen) {
+    if (!counts || !edges || !triangle || !otsu || !status || nbins < 1 || nbins > (1 << 20))
+        return nl_fail(err, errlen, NL_EINVAL, "bad histogram arguments (nbins=%d)", nbins);
+    hist_thresholds_host(counts, edges, nbins, triangle, otsu, status);
+    return NL_OK;
+}
+
 static int set_spacing(nl_ctx *c, const double spacing[3], char *err, size_t errlen) {
     if (!spacing) return nl_fail(err, errlen, NL_EINVAL, "spacing is NULL");
     if ((!c->two_d && c->gnz < 2) || c->ny < 2 || c->nx < 2)
@@ -884,12 +897,13 @@ extern "C" int nl_hessian_stats(nl_ctx *c, const double spacing[3], float *max_a
             gauss_cur(c), nullptr, nullptr, 0, geom(c), HR, vp, VQueue{}, (int)c->own_lo, (int)c->own_hi, ntx,        \
             (int)((c->ny + TYV - 1) / TYV), res, nullptr)
 #define NL_LAUNCH_STATS_V(RSV, FASTV, HR)                                                                                 \
+        allow_lds(hessian_v_kernel<0, RSV, FASTV>, HVCfg<RSV>::lds_bytes());                                              \
         hessian_v_kernel<0, RSV, FASTV><<<(unsigned)(ntx * (int)((c->ny + 2 * RSV - 1) / (2 * RSV)) * nzc), HVCfg<RSV>::NT, \
                                           HVCfg<RSV>::lds_bytes(), c->stream>>>(                                          \
             gauss_cur(c), nullptr, nullptr, 0, geom(c), HR, vp, VQueue{}, (int)c->own_lo, (int)c->own_hi, ntx,        \
             (int)((c->ny + 2 * RSV - 1) / (2 * RSV)), res, nullptr)
-        if (hv_rs(c) == 8) { if (c->fast_div) NL_LAUNCH_STATS_V(8, true, hessdv_fast(c)); else NL_LAUNCH_STATS_V(8, false, hessdv_exact(c)); }
-        else if (hv_rs(c) == 4) { if (c->fast_div) NL_LAUNCH_STATS_V(4, true, hessdv_fast(c)); else NL_LAUNCH_STATS_V(4, false, hessdv_exact(c)); }
+        if (hv_rs(c) == 16) { if (c->fast_div) { NL_LAUNCH_STATS_V(16, true, hessdv_fast(c)); } else { NL_LAUNCH_STATS_V(16, false, hessdv_exact(c)); } }
+        else if (hv_rs(c) == 8) { if (c->fast_div) { NL_LAUNCH_STATS_V(8, true, hessdv_fast(c)); } else { NL_LAUNCH_STATS_V(8, false, hessdv_exact(c)); } }
         else if (hm_ty() == 8) { if (c->fast_div) NL_LAUNCH_STATS(8, true, hessdv_fast(c)); else NL_LAUNCH_STATS(8, false, hessdv_exact(c)); }
         else { if (c->fast_div) NL_LAUNCH_STATS(16, true, hessdv_fast(c)); else NL_LAUNCH_STATS(16, false, hessdv_exact(c)); }
 #undef NL_LAUNCH_STATS
@@ -980,13 +994,14 @@ extern "C" int nl_vesselness_spec(nl_ctx *c, const double spacing[3], float fsq_
         const unsigned nblocks = (unsigned)(ntx * nty * nzc);
         if (rs) vp.qcap = 2 * HM_SPEC_CAP;              // a wave owns two row segments
 #define NL_LAUNCH_SPEC_V(RSV, FASTV, HR)                                                                                  \
+        allow_lds(hessian_v_kernel<2, RSV, FASTV>, HVCfg<RSV>::lds_bytes());                                              \
         hessian_v_kernel<2, RSV, FASTV><<<nblocks, HVCfg<RSV>::NT, HVCfg<RSV>::lds_bytes(), c->stream>>>(                 \
             gauss_cur(c), cm, pm, wpr, geom(c), HR, vp, vq, (int)z0, (int)z1, ntx, nty, res, d_cnt)
 #define NL_LAUNCH_SPEC(TYV, FASTV, HR)                                                                                    \
         hessian_g_kernel<2, TYV, FASTV><<<nblocks, HGCfg<TYV>::NT, HGCfg<TYV>::lds_bytes(), c->stream>>>(                 \
             gauss_cur(c), cm, pm, wpr, geom(c), HR, vp, vq, (int)z0, (int)z1, ntx, nty, res, d_cnt)
-        if (rs == 8) { if (c->fast_div) NL_LAUNCH_SPEC_V(8, true, hessdv_fast(c)); else NL_LAUNCH_SPEC_V(8, false, hessdv_exact(c)); }
-        else if (rs == 4) { if (c->fast_div) NL_LAUNCH_SPEC_V(4, true, hessdv_fast(c)); else NL_LAUNCH_SPEC_V(4, false, hessdv_exact(c)); }
+        if (rs == 16) { if (c->fast_div) { NL_LAUNCH_SPEC_V(16, true, hessdv_fast(c)); } else { NL_LAUNCH_SPEC_V(16, false, hessdv_exact(c)); } }
+        else if (rs == 8) { if (c->fast_div) { NL_LAUNCH_SPEC_V(8, true, hessdv_fast(c)); } else { NL_LAUNCH_SPEC_V(8, false, hessdv_exact(c)); } }
         else if (ty == 8) { if (c->fast_div) NL_LAUNCH_SPEC(8, true, hessdv_fast(c)); else NL_LAUNCH_SPEC(8, false, hessdv_exact(c)); }
         else { if (c->fast_div) NL_LAUNCH_SPEC(16, true, hessdv_fast(c)); else NL_LAUNCH_SPEC(16, false, hessdv_exact(c)); }
 #undef NL_LAUNCH_SPEC
@@ -1056,8 +1071,12 @@ extern "C" int nl_vesselness_resolve(nl_ctx *c, float gamma_sq, float alpha_sq, 
         NL_CHECK_LAUNCH();
     }
     NL_HIP(hipEventRecord(c->ev_side, c->side));
-    static int serial = -1;                            // measurement knob: the main stream waits, the kernel runs alone
-    if (serial < 0) serial = getenv("NELLIE_RESOLVE_SERIAL") ? 1 : 0;
+    // The kernel runs on the side stream, but the main stream waits for it by default: since the two-voxel walk and the
+    // cheaper resolve kernel, running it beside the next scale's Gaussian buys nothing (48.8 vs 49.0 ms/step at 1024^3:
+    // the Z pass slows from 1.77 to 2.55 ms per launch while it shares the GPU) and it blurs every per-kernel figure.
+    // NELLIE_RESOLVE_OVERLAP=1 lets the two overlap again.
+    static int serial = -1;
+    if (serial < 0) { const char *e = getenv("NELLIE_RESOLVE_OVERLAP"); serial = (e && atoi(e)) ? 0 : 1; }
     if (serial) NL_HIP(hipStreamWaitEvent(c->stream, c->ev_side, 0));
     c->side_pending = 1;
     c->spec_valid = 0;
@@ -1113,6 +1132,7 @@ extern "C" int nl_vesselness_step(nl_ctx *c, float gamma_sq, float alpha_sq, flo
         const int nty = (int)((c->ny + ty - 1) / ty);
         if (rs) vp.qcap = 2 * HM_REGION;
 #define NL_LAUNCH_VESS_V(RSV, FASTV, HR)                                                                                  \
+        allow_lds(hessian_v_kernel<1, RSV, FASTV>, HVCfg<RSV>::lds_bytes());                                              \
         hessian_v_kernel<1, RSV, FASTV><<<nblocks, HVCfg<RSV>::NT, HVCfg<RSV>::lds_bytes(), c->stream>>>(                 \
             gauss_cur(c), cm, pm, wpr, geom(c), HR, vp, vq, (int)za, (int)zb, ntx, nty, nullptr, d_cnt)
 #define NL_LAUNCH_VESS(TYV, FASTV, HR)                                                                                    \
@@ -1122,8 +1142,8 @@ extern "C" int nl_vesselness_step(nl_ctx *c, float gamma_sq, float alpha_sq, flo
             const i64 zb = za + planes_per_launch < z1 ? za + planes_per_launch : z1;
             const int nzc = (int)((zb - za + HM_ZCHUNK - 1) / HM_ZCHUNK);
             const unsigned nblocks = (unsigned)(ntx * nty * nzc);
-            if (rs == 8) { if (c->fast_div) NL_LAUNCH_VESS_V(8, true, hessdv_fast(c)); else NL_LAUNCH_VESS_V(8, false, hessdv_exact(c)); }
-            else if (rs == 4) { if (c->fast_div) NL_LAUNCH_VESS_V(4, true, hessdv_fast(c)); else NL_LAUNCH_VESS_V(4, false, hessdv_exact(c)); }
+            if (rs == 16) { if (c->fast_div) { NL_LAUNCH_VESS_V(16, true, hessdv_fast(c)); } else { NL_LAUNCH_VESS_V(16, false, hessdv_exact(c)); } }
+            else if (rs == 8) { if (c->fast_div) { NL_LAUNCH_VESS_V(8, true, hessdv_fast(c)); } else { NL_LAUNCH_VESS_V(8, false, hessdv_exact(c)); } }
             else if (ty == 8) { if (c->fast_div) NL_LAUNCH_VESS(8, true, hessdv_fast(c)); else NL_LAUNCH_VESS(8, false, hessdv_exact(c)); }
             else { if (c->fast_div) NL_LAUNCH_VESS(16, true, hessdv_fast(c)); else NL_LAUNCH_VESS(16, false, hessdv_exact(c)); }
             NL_CHECK_LAUNCH();

@@ -15,7 +15,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnellie_hip.so")
+LIB_PATH = os.environ.get("NELLIE_HIP_LIB") or os.path.join(_HERE, "libnellie_hip.so")   # the override is for A/B builds (tools/build_variant.sh)
 
 NL_OK, NL_EINVAL, NL_ENODEV, NL_ENOMEM, NL_EHIP, NL_ESTATE, NL_ECOMM = range(7)
 FIELD_GAUSS, FIELD_FROB, FIELD_FRANGI, FIELD_VESSELNESS = 0, 1, 2, 3
@@ -49,6 +49,7 @@ _PROTOS = {
     "nl_sample_minmax": [_p, _int, _i64, _i64, _i64, C.POINTER(_f32), C.POINTER(_f32), C.POINTER(_i64)],
     "nl_sample_hist": [_p, _int, _i64, _i64, _i64, _p, _int, _p],
     "nl_sample_range_hist": [_p, _int, _i64, _i64, _i64, _int, C.POINTER(_f32), C.POINTER(_f32), C.POINTER(_i64), _p, _p, C.POINTER(_int)],
+    "nl_hist_thresholds": [_p, _p, _int, C.POINTER(_f64), C.POINTER(_f64), C.POINTER(_int)],
     "nl_hessian_stats": [_p, C.POINTER(_f64), C.POINTER(_f32), C.POINTER(_f32), C.POINTER(_int)],
     "nl_set_frob_norm": [_p, _f32, _f32],
     "nl_vesselness_step": [_p, _f32, _f32, _f32, _int, _f32, _i64, _i64, C.POINTER(_i64)],
@@ -188,6 +189,20 @@ def load() -> _Lib:
                 "(run `python -m nellie_amd.build`); nellie_amd has no CPU fallback")
         _LIB = _Lib(LIB_PATH)
     return _LIB
+
+
+def hist_thresholds(counts, edges):
+    """(triangle, otsu) bin-centre thresholds of a finished histogram (nl_hist_thresholds; gpu_functions.py:36-50, 64-94).
+    Raises numpy's ValueError where the reference's triangle construction does (one non-empty bin)."""
+    counts = np.ascontiguousarray(counts, dtype=np.int64)
+    edges = np.ascontiguousarray(edges, dtype=np.float32)
+    nbins = int(counts.size)
+    assert edges.size == nbins + 1
+    tri, otsu, status = _f64(0.0), _f64(0.0), _int(0)
+    load().call("nl_hist_thresholds", _ptr(counts), _ptr(edges), nbins, C.byref(tri), C.byref(otsu), C.byref(status))
+    if status.value == 1:
+        raise ValueError("attempt to get argmax of an empty sequence")
+    return np.float32(tri.value), np.float32(otsu.value)
 
 
 def comm_unique_id() -> bytes:

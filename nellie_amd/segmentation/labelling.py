@@ -6,10 +6,9 @@ Same constructor keywords, same `.run()`, same product
 (`im_info.pipeline_paths['im_instance_label']`, int32, ids 1..K per frame in raster order of
 each object's first voxel, exactly scipy.ndimage.label's numbering).
 
-The per-frame thresholds are computed on the host from the memmap views, exactly as the
-reference does even on its GPU path (labelling.py:359-365, 511-532); thresholding, hole
-filling, both labelling passes, the small-object filter and the majority smoothing run on the
-device (nl_label_run).  `chunk_z` / `low_memory` are accepted and ignored: the reference's
+Each Frangi frame is uploaded once; the log-domain threshold is taken from a strided sample
+gathered on the device (labelling.py:385-455), and thresholding, hole filling, both labelling
+passes, the small-object filter and the majority smoothing run there too (nl_label_run).  `chunk_z` / `low_memory` are accepted and ignored: the reference's
 Z-chunked mode is not equivalent to its full-volume mode (per-chunk hole filling and area
 filter); this backend always produces the full-volume result.
 """
@@ -17,7 +16,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from nellie_amd.pipeline import FramePipeline, log10_min_triangle_otsu, min_area_pixels_of
+from nellie_amd.pipeline import FramePipeline, min_area_pixels_of
 from nellie_amd.utils import adaptive_run
 from nellie_amd.utils.base_logger import logger
 from nellie_amd.utils.gpu_functions import otsu_threshold
@@ -123,73 +122,61 @@ class Label:
     def _write_labels_for_frame(self, t, labels):
         self.instance_label_memmap[t, ...] = labels
 
-    # ------------------------------------------------------------------ thresholds (host views)
-    def _sample_nonzero(self, frame, mask=None, mask_frame=None, mask_thresh=None):
-        """labelling.py:385-438, verbatim semantics on host (memmap) views."""
-        flat = frame.reshape(-1)
+    # ------------------------------------------------------------------ thresholds
+    # The Frangi frame is uploaded once per frame and everything that looks at it does so on the device: the optional
+    # intensity mask is applied first (labelling.py:550-552), and the strided positive sample the log-domain threshold
+    # is taken from (labelling.py:385-455) is then gathered from the masked, resident frame -- a voxel the mask removed
+    # is 0 and therefore not a positive sample, which is exactly the reference's `(sample > 0) & (mask > thresh)`.
+    # Only the intensity Otsu threshold (off by default) samples the ORIGINAL image, in its own dtype, on the host.
+    def _positive_stride_sample(self, image):
+        """labelling.py:385-438 without mask arguments, for a host image: the positive values among every
+        (size // threshold_sampling_pixels)-th element; if there are none, among the elements half a stride further;
+        if there are none either, all positive values."""
+        flat = np.asarray(image).reshape(-1)
         if flat.size == 0:
             return flat
-        mask_flat = None
-        mask_mode = None
-        if mask is not None:
-            mask_flat = mask.reshape(-1)
-            mask_mode = "bool"
-        elif mask_frame is not None and mask_thresh is not None:
-            mask_flat = mask_frame.reshape(-1)
-            mask_mode = "thresh"
-        max_samples = max(1, int(self.threshold_sampling_pixels))
-        step = max(int(flat.size) // max_samples, 1)
-        offsets = (0, step // 2) if step > 1 and step // 2 > 0 else (0,)
-        values = flat[:0]
-        for offset in offsets:
-            sample = flat[offset::step]
-            if mask_mode == "bool":
-                values = sample[(sample > 0) & mask_flat[offset::step]]
-            elif mask_mode == "thresh":
-                values = sample[(sample > 0) & (mask_flat[offset::step] > mask_thresh)]
-            else:
-                values = sample[sample > 0]
-            if values.size > 0 or step == 1:
-                return values
-        max_val = float(flat.max())
-        if max_val <= 0:
-            return values
-        if mask_mode == "bool":
-            return flat[(flat > 0) & mask_flat]
-        if mask_mode == "thresh":
-            return flat[(flat > 0) & (mask_flat > mask_thresh)]
-        return flat[flat > 0]
-
-    def _compute_frangi_threshold(self, frame, mask_frame=None, mask_thresh=None):
-        """labelling.py:440-455."""
-        values = self._sample_nonzero(frame, mask_frame=mask_frame, mask_thresh=mask_thresh)
-        if values.size == 0:
-            return None
-        return log10_min_triangle_otsu(np.asarray(values), self.histogram_nbins)
+        stride = max(int(flat.size) // max(1, self.threshold_sampling_pixels), 1)
+        for start in ([0] if stride == 1 else [0, stride // 2]):
+            picked = flat[start::stride]
+            picked = picked[picked > 0]
+            if picked.size > 0 or stride == 1:
+                return picked
+        return flat[flat > 0] if float(flat.max()) > 0 else flat[:0]
 
     def _compute_intensity_otsu_threshold(self, frame):
         """labelling.py:457-465."""
-        values = self._sample_nonzero(frame)
+        values = self._positive_stride_sample(frame)
         if values.size == 0:
             return None
-        thresh, _ = otsu_threshold(np.asarray(values), nbins=self.histogram_nbins)
-        return thresh
+        return otsu_threshold(np.asarray(values), nbins=self.histogram_nbins)[0]
+
+    def _intensity_threshold(self, original_view):
+        """labelling.py:513-520: Otsu of the original image, the user's fixed threshold, or None."""
+        if self.otsu_thresh_intensity:
+            found = self._compute_intensity_otsu_threshold(original_view)
+            return 0 if found is None else found
+        return self.threshold
+
+    def _upload_frame(self, original_view, frangi_view, intensity_thresh):
+        """Frangi frame of one time point -> HBM, intensity-masked when an intensity threshold is in force."""
+        frangi3 = self._as3d(frangi_view)
+        pipe = self._get_pipeline(frangi3.shape)
+        pipe.upload_frangi(frangi3)
+        if intensity_thresh is not None:
+            orig3 = self._as3d(original_view)
+            pipe.ctx.label_intensity_mask(orig3, self._effective_threshold(orig3, intensity_thresh))
+        return pipe
+
+    def _compute_frangi_threshold(self, frame, mask_frame=None, mask_thresh=None):
+        """labelling.py:440-455 for a host Frangi frame (optionally masked by `mask_frame > mask_thresh`)."""
+        pipe = self._upload_frame(mask_frame, frame, mask_thresh if mask_frame is not None else None)
+        return pipe.frangi_threshold(self.threshold_sampling_pixels, self.histogram_nbins)
 
     def _compute_frame_thresholds(self, original_view, frangi_view):
-        """labelling.py:511-532."""
-        intensity_thresh = None
-        if self.otsu_thresh_intensity:
-            intensity_thresh = self._compute_intensity_otsu_threshold(original_view)
-            if intensity_thresh is None:
-                intensity_thresh = 0
-        elif self.threshold is not None:
-            intensity_thresh = self.threshold
-        if intensity_thresh is not None:
-            frangi_thresh = self._compute_frangi_threshold(
-                frangi_view, mask_frame=original_view, mask_thresh=intensity_thresh)
-        else:
-            frangi_thresh = self._compute_frangi_threshold(frangi_view)
-        return intensity_thresh, frangi_thresh
+        """labelling.py:511-532: (intensity threshold or None, Frangi threshold or None)."""
+        intensity_thresh = self._intensity_threshold(original_view)
+        return intensity_thresh, self._compute_frangi_threshold(frangi_view, original_view if intensity_thresh is not None else None,
+                                                                intensity_thresh)
 
     # ------------------------------------------------------------------ frames
     @staticmethod
@@ -208,18 +195,16 @@ class Label:
             return float(original.dtype.type(thresh))
         return float(thresh)
 
-    def _run_frame_full_volume(self, t, original_view, frangi_view, intensity_thresh, frangi_thresh):
-        """labelling.py:538-556: int32 labels of frame t (inputs are never modified)."""
-        logger.info(f'Running semantic segmentation, volume {t}/{(self.num_t or 1) - 1}')
-        frangi3 = self._as3d(frangi_view)
-        pipe = self._get_pipeline(frangi3.shape)
-        pipe.upload_frangi(frangi3)
-        if intensity_thresh is not None:
-            orig3 = self._as3d(original_view)
-            pipe.ctx.label_intensity_mask(orig3, self._effective_threshold(orig3, intensity_thresh))
+    def _label_resident(self, pipe, frangi_view, frangi_thresh):
         pipe.label(frangi_thresh, self.min_area_pixels, fill_holes=not self.im_info.no_z)
         labels = pipe.download_labels()
         return labels[0] if np.asarray(frangi_view).ndim == 2 else labels
+
+    def _run_frame_full_volume(self, t, original_view, frangi_view, intensity_thresh, frangi_thresh):
+        """labelling.py:538-556: int32 labels of frame t (inputs are never modified)."""
+        logger.info(f'Running semantic segmentation, volume {t}/{(self.num_t or 1) - 1}')
+        pipe = self._upload_frame(original_view, frangi_view, intensity_thresh)
+        return self._label_resident(pipe, frangi_view, frangi_thresh)
 
     def _get_labels(self, frame, frangi_thresh=_UNSET):
         """labelling.py:467-509: (mask, labels) for a host Frangi frame."""
@@ -229,14 +214,15 @@ class Label:
         return labels > 0, labels
 
     def _run_segmentation(self):
-        """labelling.py:697-734."""
+        """labelling.py:697-734; the frame is uploaded once and both the threshold and the labels come from that copy."""
         for t in range(self.num_t):
             if self.viewer is not None:
                 self.viewer.status = f'Extracting organelles. Frame: {t + 1} of {self.num_t}.'
             original_view, frangi_view = self._get_frame_views(t)
-            intensity_thresh, frangi_thresh = self._compute_frame_thresholds(original_view, frangi_view)
-            labels = self._run_frame_full_volume(t, original_view, frangi_view, intensity_thresh, frangi_thresh)
-            self._write_labels_for_frame(t, labels)
+            logger.info(f'Running semantic segmentation, volume {t}/{(self.num_t or 1) - 1}')
+            pipe = self._upload_frame(original_view, frangi_view, self._intensity_threshold(original_view))
+            frangi_thresh = pipe.frangi_threshold(self.threshold_sampling_pixels, self.histogram_nbins)
+            self._write_labels_for_frame(t, self._label_resident(pipe, frangi_view, frangi_thresh))
             if (t + 1) % self.flush_interval == 0:
                 self.instance_label_memmap.flush()
         self.instance_label_memmap.flush()
