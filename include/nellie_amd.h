@@ -320,6 +320,47 @@ int nl_label_bits_put(nl_ctx *ctx, int64_t row0, int64_t nrows, const uint64_t *
 int nl_label_bits_allgather(nl_ctx *ctx, const int64_t *slab_plane0, char *err, size_t errlen);
 int nl_label_run_global(nl_ctx *ctx, int64_t min_area, int fill_holes, int64_t *n_labels, char *err, size_t errlen);
 
+/* Label on Z-slabs WITHOUT replication (the production multi-GPU path; the reference's closest precedent is the chunk
+   stitching of labelling.py:585-691 with its union-find :221-288, which however labels chunks independently and is not
+   equivalent to the full-volume result -- this is).  Every rank labels its owned planes plus ONE ghost bit plane per
+   interior side (exchanged with nl_slab_bits_exchange over RCCL, or nl_slab_bits_get / _put through the host).  A
+   component that crosses an interface shows up on both ranks as a tree containing runs of the two planes both ranks see,
+   and the k-th run of such a plane is the same voxels on both sides: `nl_slab_tables` hands those (tree, quantity) pairs
+   to the host, which joins the trees of neighbouring ranks (a graph with a few thousand nodes) and patches the result
+   back.  Three phases, each opened by nl_slab_components(phase):
+     phase 0 (fill)   6-connected background; quantity = 1 if the tree touches a face of the GLOBAL volume; after the
+                      patch nl_slab_apply sets the enclosed background of the owned planes        (labelling.py:486)
+     phase 1 (area)   26-connected foreground; quantity = voxels on the OWNED planes; after the patch (global sums)
+                      nl_slab_apply(min_area) writes the kept-objects mask                        (labelling.py:489-501)
+     nl_slab_majority majority filter of the kept-objects mask (its ghost planes exchanged first)  (labelling.py:503-505)
+     phase 2 (number) 26-connected foreground; quantity = first run of the tree on the owned planes (INT32_MAX: none).
+                      The owner of a component is the lowest rank holding voxels of it; nl_slab_number ranks the trees a
+                      rank owns in raster order, nl_slab_paint adds the rank's base id (exclusive sum of the lower ranks'
+                      counts) and takes the labels of trees owned elsewhere from the host: ids 1..K in raster order of the
+                      first voxel, exactly scipy.ndimage.label's numbering of the whole volume      (labelling.py:507)
+   counts[5] of nl_slab_components: runs in total, then in the low ghost plane, the first owned plane, the last owned plane
+   and the high ghost plane (0 where the slab touches a true face); nl_slab_tables fills roots / values in that order. */
+int nl_slab_label_pack(nl_ctx *ctx, int has_thr, float thr, char *err, size_t errlen);
+int nl_slab_bits_get(nl_ctx *ctx, int which, int64_t plane, uint64_t *host, char *err, size_t errlen);
+int nl_slab_bits_put(nl_ctx *ctx, int which, int64_t plane, const uint64_t *host, char *err, size_t errlen);
+int nl_slab_bits_exchange(nl_ctx *ctx, int which, char *err, size_t errlen);
+int nl_slab_components(nl_ctx *ctx, int phase, int64_t *counts, char *err, size_t errlen);
+int nl_slab_tables(nl_ctx *ctx, int32_t *roots, int32_t *values, char *err, size_t errlen);
+int nl_slab_patch(nl_ctx *ctx, int64_t n, const int32_t *roots, const int32_t *values, char *err, size_t errlen);
+int nl_slab_apply(nl_ctx *ctx, int64_t min_area, char *err, size_t errlen);
+int nl_slab_majority(nl_ctx *ctx, char *err, size_t errlen);
+int nl_slab_number(nl_ctx *ctx, int64_t n_clear, const int32_t *clear, int64_t n_set, const int32_t *set, int64_t *n_local,
+                   char *err, size_t errlen);
+int nl_slab_query(nl_ctx *ctx, int64_t n, const int32_t *idx, int32_t *out, char *err, size_t errlen);
+int nl_slab_paint(nl_ctx *ctx, int64_t base, int64_t n, const int32_t *roots, const int32_t *labels, char *err, size_t errlen);
+
+/* Variable-size all-gather of host bytes over RCCL (ncclAllGather on padded device staging): `recv` receives
+   world * max_bytes bytes, rank r's block at r * max_bytes (its first bytes_of[r] bytes are valid; bytes_of has `world`
+   entries and is filled here).  Used for the threshold samples and the slab tables, so that no data of the path
+   travels through the control plane. */
+int nl_allgather_bytes(nl_ctx *ctx, const void *send, int64_t nbytes, void *recv, int64_t max_bytes, int64_t *bytes_of,
+                       char *err, size_t errlen);
+
 /* D2H of the int32 label volume, local planes [z0, z1) (labelling.py:727-729). */
 int nl_label_store(nl_ctx *ctx, int32_t *host, int64_t z0, int64_t z1, char *err, size_t errlen);
 

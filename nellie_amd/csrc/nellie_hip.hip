@@ -22,6 +22,7 @@ struct RcclApi {
     decltype(&ncclRecv) Recv = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclBroadcast) Broadcast = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
     bool ok = false;
 };
 static RcclApi &rccl() {
@@ -32,10 +33,10 @@ static RcclApi &rccl() {
         if (api.handle) {
 #define NL_SYM(F) api.F = (decltype(api.F))dlsym(api.handle, "nccl" #F)
             NL_SYM(GetUniqueId); NL_SYM(CommInitRank); NL_SYM(CommDestroy); NL_SYM(GetErrorString); NL_SYM(GroupStart);
-            NL_SYM(GroupEnd); NL_SYM(Send); NL_SYM(Recv); NL_SYM(AllReduce); NL_SYM(Broadcast);
+            NL_SYM(GroupEnd); NL_SYM(Send); NL_SYM(Recv); NL_SYM(AllReduce); NL_SYM(Broadcast); NL_SYM(AllGather);
 #undef NL_SYM
             api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.GetErrorString && api.GroupStart &&
-                     api.GroupEnd && api.Send && api.Recv && api.AllReduce && api.Broadcast;
+                     api.GroupEnd && api.Send && api.Recv && api.AllReduce && api.Broadcast && api.AllGather;
         }
     }
     return api;
@@ -248,6 +249,7 @@ extern "C" int nl_ctx_destroy(nl_ctx *c) {
     if (c->d_vq) hipFree(c->d_vq);
     if (c->d_vq_count) hipFree(c->d_vq_count);
     if (c->d_rows) hipFree(c->d_rows);
+    if (c->d_ag) hipFree(c->d_ag);
     if (c->gbits[0]) hipFree(c->gbits[0]);
     if (c->gbits[1]) hipFree(c->gbits[1]);
     if (c->grows) hipFree(c->grows);
@@ -1475,6 +1477,38 @@ extern "C" int nl_allreduce(nl_ctx *c, void *host_inout, int64_t count, int dtyp
     return NL_OK;
 }
 
+// Variable-size all-gather of host bytes (see include/nellie_amd.h).  Two collectives: the sizes, then the padded blocks.
+extern "C" int nl_allgather_bytes(nl_ctx *c, const void *send, int64_t nbytes, void *recv, int64_t max_bytes, int64_t *bytes_of,
+                                  char *err, size_t errlen) {
+    NL_ENTER(c);
+    if (!c->comm) return nl_fail(err, errlen, NL_ESTATE, "nl_allgather_bytes before nl_comm_init");
+    if (nbytes < 0 || max_bytes < 1 || nbytes > max_bytes || !recv || !bytes_of || (nbytes && !send))
+        return nl_fail(err, errlen, NL_EINVAL, "bad all-gather arguments");
+    const int W = c->world;
+    // sizes through the small scratch
+    long long *hs = (long long *)c->h_small;
+    hs[0] = nbytes;
+    NL_HIP(hipMemcpyAsync(c->d_small, hs, 8, hipMemcpyHostToDevice, c->stream));
+    NL_NCCL(rccl().AllGather(c->d_small, (char *)c->d_small + 64, 1, ncclInt64, (ncclComm_t)c->comm, c->stream));
+    NL_HIP(hipMemcpyAsync(hs, (char *)c->d_small + 64, (size_t)W * 8, hipMemcpyDeviceToHost, c->stream));
+    NL_HIP(hipStreamSynchronize(c->stream));
+    for (int r = 0; r < W; ++r) { bytes_of[r] = hs[r]; if (hs[r] > max_bytes) return nl_fail(err, errlen, NL_EINVAL, "rank %d sends %lld bytes, more than max_bytes = %lld", r, hs[r], (long long)max_bytes); }
+    // blocks through a staging buffer that grows on demand
+    const size_t need = (size_t)max_bytes * (size_t)(W + 1);
+    if (need > c->ag_cap) {
+        if (c->d_ag) hipFree(c->d_ag);
+        c->d_ag = nullptr; c->ag_cap = 0;
+        NL_HIP(hipMalloc(&c->d_ag, need));
+        c->ag_cap = need;
+    }
+    char *d_send = (char *)c->d_ag, *d_recv = d_send + max_bytes;
+    if (nbytes) NL_HIP(hipMemcpyAsync(d_send, send, (size_t)nbytes, hipMemcpyHostToDevice, c->stream));
+    NL_NCCL(rccl().AllGather(d_send, d_recv, (size_t)max_bytes, ncclChar, (ncclComm_t)c->comm, c->stream));
+    NL_HIP(hipMemcpyAsync(recv, d_recv, (size_t)max_bytes * W, hipMemcpyDeviceToHost, c->stream));
+    NL_HIP(hipStreamSynchronize(c->stream));
+    return NL_OK;
+}
+
 // ---------------------------------------------------------------------------------- Markers ------
 // Stage after Label (nellie/segmentation/mocap_marking.py:648-703, use_im = 'distance', 3-D).  Volumes:
 //   f[0] distance (float32, the stage product), f[1] / f[2] scratch (squared distances, then the Z-filtered volume and
@@ -1933,7 +1967,10 @@ struct LabelGeo {
     i64 paint_row0, paint_row1;   // rows this context paints ...
     int *paint_out;               // ... into this int32 buffer (row paint_row0 first)
     int *link_scratch = nullptr;  // >= one int per possible run, free until the paint (enables the two-level union-find)
+    int zf_lo = 0, zf_hi = -2;    // planes of this run set that are true Z faces of the volume (-1: none; set by label_geo_faces)
+    i64 gz0 = 0, gnz = 0;         // placement of plane 0 of the run set in the global volume (boundary rules)
 };
+static void label_geo_whole(LabelGeo &g) { g.zf_lo = 0; g.zf_hi = (int)g.nz - 1; g.gz0 = 0; g.gnz = g.nz; }
 
 // runs of `bits` (or of its complement) + union-find over them, flattened
 template <int CONN>
@@ -1970,12 +2007,12 @@ static int build_components(nl_ctx *c, const LabelGeo &g, const unsigned long lo
         uint8_t *plane_done = (uint8_t *)c->d_small + (52 << 10);
         NL_HIP(hipMemsetAsync(rs.link, 0xff, (size_t)rs.nruns * 4, c->stream));
         rl_union_plane_kernel<CONN><<<(unsigned)g.nz, 256, 0, c->stream>>>(rs.runs, row_off, rs.parent, rs.proot, (int)g.ny,
-                                                                         CONN == 6 ? (int)g.nz : 0, (int)g.nx, plane_done);
+                                                                         CONN == 6 ? 1 : 0, g.zf_lo, g.zf_hi, (int)g.nx, plane_done);
         rl_union_cross_kernel<CONN><<<gr, 256, 0, c->stream>>>(rs.runs, row_off, rs.parent, rs.proot, rs.link, rs.nruns, (int)g.ny,
-                                                               CONN == 6 ? (int)g.nz : 0, (int)g.nx, plane_done);
+                                                               CONN == 6 ? 1 : 0, g.zf_lo, g.zf_hi, (int)g.nx, plane_done);
     } else {
         rl_union_kernel<CONN><<<gr, 256, 0, c->stream>>>(rs.runs, row_off, rs.parent, rs.nruns, (int)g.ny,
-                                                         CONN == 6 ? (int)g.nz : 0, (int)g.nx);
+                                                         CONN == 6 ? 1 : 0, g.zf_lo, g.zf_hi, (int)g.nx);
     }
     NL_CHECK_LAUNCH();
     ccl_flatten_kernel<<<grid1d(rs.nruns), 256, 0, c->stream>>>(rs.parent, rs.nruns);
@@ -2020,7 +2057,7 @@ static int label_core(nl_ctx *c, const LabelGeo &g, int64_t min_area, int fill_h
     rs.proot = aux;                                           // in-plane roots during the unions (aux is idle until the areas)
     rs.link = g.link_scratch;
     uint8_t *flag = c->m[0];
-    const VolGeom vg{g.nz, g.ny, g.nx, 0, g.nz};             // boundary rules of the whole volume
+    const VolGeom vg{g.nz, g.ny, g.nx, g.gz0, g.gnz};        // boundary rules: true faces of the global volume only
     int rc;
     *overflow = false;
     if (fill_holes) {
@@ -2050,7 +2087,7 @@ static int label_core(nl_ctx *c, const LabelGeo &g, int64_t min_area, int fill_h
         NL_CHECK_LAUNCH();
     }
     // majority smoothing, second labelling
-    majority_bits_kernel<<<(unsigned)((g.nwords + 255) / 256), 256, 0, c->stream>>>(g.bitsB, g.bitsA, vg, g.wpr);
+    majority_bits_kernel<<<(unsigned)((g.nwords + 255) / 256), 256, 0, c->stream>>>(g.bitsB, g.bitsA, vg, g.wpr, 0, g.nz);
     NL_CHECK_LAUNCH();
     if ((rc = build_components<26>(c, g, g.bitsA, 0, rs, cap, overflow, err, errlen))) return rc;
     if (*overflow) return NL_OK;
@@ -2080,6 +2117,7 @@ extern "C" int nl_label_run(nl_ctx *c, int has_thr, float thr, int64_t min_area,
     g.bitsA = (unsigned long long *)c->m[1]; g.bitsB = (unsigned long long *)c->m[2];
     g.paint_row0 = 0; g.paint_row1 = g.nrows; g.paint_out = (int *)c->f[label_out_index(c)];
     g.link_scratch = g.paint_out;                 // the whole label volume (4N bytes) is idle until the paint
+    label_geo_whole(g);
     ProfScope ps(c, "label");
     const unsigned long long *support = (c->support_epoch + 1 == c->epoch.load() && c->d_support && has_thr && thr >= 0.0f) ? c->d_support : nullptr;
     c->last_label_sparse = support ? 1 : 0;
@@ -2175,11 +2213,312 @@ extern "C" int nl_label_run_global(nl_ctx *c, int64_t min_area, int fill_holes, 
     g.bitsA = c->gbits[0]; g.bitsB = c->gbits[1];
     g.paint_row0 = (c->gz0 + c->own_lo) * c->ny; g.paint_row1 = (c->gz0 + c->own_hi) * c->ny;
     g.paint_out = (int *)c->f[label_out_index(c)] + c->own_lo * c->ny * c->nx;
+    label_geo_whole(g);
     ProfScope ps(c, "label");
     bool overflow = false;
     int rc = label_core(c, g, min_area, fill_holes, n_labels, &overflow, err, errlen);
     if (rc) return rc;
     if (overflow) return nl_fail(err, errlen, NL_ENOMEM, "the global mask has more runs than this slab's scratch volumes hold [out of memory]");
+    return NL_OK;
+}
+
+// ---- Z-slab Label without replication (see label_runs.inc "Z-slab Label" and nellie_amd/sharded.py) -----------------
+struct SlabGeo { LabelGeo g; RunSet rs; int *aux; unsigned int *sel, *scan; int *stage; i64 cap; int row_lo, row_hi; bool has_lo, has_hi; int out_idx; };
+static int slab_geo(nl_ctx *c, SlabGeo &sg, char *err, size_t errlen) {
+    if (c->nx > 65535) return nl_fail(err, errlen, NL_EINVAL, "rows longer than 65535 voxels are not supported on Z-slabs");
+    sg.has_lo = c->gz0 + c->own_lo > 0; sg.has_hi = c->gz0 + c->own_hi < c->gnz;
+    if ((sg.has_lo && c->own_lo < 1) || (sg.has_hi && c->own_hi > c->nzl - 1))
+        return nl_fail(err, errlen, NL_EINVAL, "the slab holds no ghost plane next to an interior interface");
+    c->sl_e0 = c->own_lo - (sg.has_lo ? 1 : 0); c->sl_e1 = c->own_hi + (sg.has_hi ? 1 : 0);
+    const int wpr = (int)((c->nx + 63) / 64);
+    LabelGeo &g = sg.g;
+    g.nz = c->sl_e1 - c->sl_e0; g.ny = c->ny; g.nx = c->nx;
+    g.nrows = g.nz * c->ny; g.wpr = wpr; g.nwords = g.nrows * wpr;
+    g.rows = c->d_rows;
+    g.bitsA = (unsigned long long *)c->m[1] + c->sl_e0 * c->ny * wpr;
+    g.bitsB = (unsigned long long *)c->m[2] + c->sl_e0 * c->ny * wpr;
+    g.gz0 = c->gz0 + c->sl_e0; g.gnz = c->gnz;
+    g.zf_lo = (g.gz0 == 0) ? 0 : -1; g.zf_hi = (g.gz0 + g.nz == c->gnz) ? (int)g.nz - 1 : -1;
+    int free_idx[3], nf = 0;
+    for (int k = 0; k < 4; ++k) if (k != c->i_vmax) free_idx[nf++] = k;
+    sg.cap = c->n / 2;
+    sg.rs.runs = (RunRec *)c->f[free_idx[0]];
+    sg.rs.parent = (int *)c->f[free_idx[1]];
+    sg.aux = sg.rs.parent + sg.cap;
+    sg.rs.proot = sg.aux;
+    sg.rs.link = (int *)c->f[free_idx[2]];
+    sg.rs.row_off = g.rows + (g.nrows + 2);
+    sg.rs.nruns = c->sl_nruns;
+    sg.sel = (unsigned int *)c->f[free_idx[2]]; sg.scan = sg.sel + sg.cap;
+    sg.stage = (int *)c->f[free_idx[2]];
+    sg.out_idx = free_idx[2];
+    sg.row_lo = (int)((c->own_lo - c->sl_e0) * c->ny); sg.row_hi = (int)((c->own_hi - c->sl_e0) * c->ny);
+    g.paint_row0 = sg.row_lo; g.paint_row1 = sg.row_hi;
+    g.paint_out = (int *)c->f[free_idx[2]] + c->own_lo * c->ny * c->nx;
+    g.link_scratch = sg.rs.link;
+    return NL_OK;
+}
+
+/* mask bits of the owned planes: frangi > thr (labelling.py:478) */
+extern "C" int nl_slab_label_pack(nl_ctx *c, int has_thr, float thr, char *err, size_t errlen) {
+    NL_ENTER(c);
+    if (!c->frangi_ready) return nl_fail(err, errlen, NL_ESTATE, "nl_slab_label_pack before a Frangi volume exists");
+    SlabGeo sg; int rc = slab_geo(c, sg, err, errlen); if (rc) return rc;
+    const int wpr = sg.g.wpr;
+    const i64 own_rows = (c->own_hi - c->own_lo) * c->ny;
+    ProfScope ps(c, "label");
+    rl_threshold_pack_kernel<<<grid1d(own_rows * 64, 256, (i64)1 << 22), 256, 0, c->stream>>>(
+        c->f[c->i_vmax] + c->own_lo * c->ny * c->nx, nullptr, (unsigned long long *)c->m[1] + c->own_lo * c->ny * wpr, has_thr, thr, (int)c->nx, own_rows, wpr);
+    NL_CHECK_LAUNCH();
+    c->sl_phase = -1; c->sl_nruns = 0; c->sl_numbered = 0;
+    return NL_OK;
+}
+
+/* one bit plane (local plane index) of mask `which` (0: the working mask, 1: the kept-objects mask) to / from the host */
+extern "C" int nl_slab_bits_get(nl_ctx *c, int which, int64_t plane, uint64_t *host, char *err, size_t errlen) {
+    NL_ENTER(c);
+    const int wpr = (int)((c->nx + 63) / 64);
+    if (!host || plane < 0 || plane >= c->nzl || which < 0 || which > 1) return nl_fail(err, errlen, NL_EINVAL, "bad bit-plane request");
+    const unsigned long long *b = (const unsigned long long *)c->m[1 + which] + plane * c->ny * wpr;
+    NL_HIP(hipMemcpyAsync(host, b, (size_t)c->ny * wpr * 8, hipMemcpyDeviceToHost, c->stream));
+    NL_HIP(hipStreamSynchronize(c->stream));
+    return NL_OK;
+}
+extern "C" int nl_slab_bits_put(nl_ctx *c, int which, int64_t plane, const uint64_t *host, char *err, size_t errlen) {
+    NL_ENTER(c);
+    const int wpr = (int)((c->nx + 63) / 64);
+    if (!host || plane < 0 || plane >= c->nzl || which < 0 || which > 1) return nl_fail(err, errlen, NL_EINVAL, "bad bit-plane request");
+    unsigned long long *b = (unsigned long long *)c->m[1 + which] + plane * c->ny * wpr;
+    NL_HIP(hipMemcpyAsync(b, host, (size_t)c->ny * wpr * 8, hipMemcpyHostToDevice, c->stream));
+    NL_HIP(hipStreamSynchronize(c->stream));
+    return NL_OK;
+}
+/* the same exchange with the Z neighbours over RCCL: my first / last owned bit plane -> their ghost plane, theirs -> mine */
+extern "C" int nl_slab_bits_exchange(nl_ctx *c, int which, char *err, size_t errlen) {
+    NL_ENTER(c);
+    if (!c->comm) return nl_fail(err, errlen, NL_ESTATE, "nl_slab_bits_exchange before nl_comm_init");
+    if (which < 0 || which > 1) return nl_fail(err, errlen, NL_EINVAL, "bad mask selector");
+    const int wpr = (int)((c->nx + 63) / 64);
+    const size_t words = (size_t)c->ny * wpr;
+    unsigned long long *b = (unsigned long long *)c->m[1 + which];
+    const bool has_lo = c->rank > 0, has_hi = c->rank + 1 < c->world;
+    if ((has_lo && c->own_lo < 1) || (has_hi && c->own_hi > c->nzl - 1)) return nl_fail(err, errlen, NL_EINVAL, "no ghost plane to receive into");
+    ncclComm_t comm = (ncclComm_t)c->comm;
+    ProfScope ps(c, "halo");
+    NL_NCCL(rccl().GroupStart());
+    if (has_lo) {
+        NL_NCCL(rccl().Send(b + c->own_lo * words, words, ncclUint64, c->rank - 1, comm, c->stream));
+        NL_NCCL(rccl().Recv(b + (c->own_lo - 1) * words, words, ncclUint64, c->rank - 1, comm, c->stream));
+    }
+    if (has_hi) {
+        NL_NCCL(rccl().Send(b + (c->own_hi - 1) * words, words, ncclUint64, c->rank + 1, comm, c->stream));
+        NL_NCCL(rccl().Recv(b + c->own_hi * words, words, ncclUint64, c->rank + 1, comm, c->stream));
+    }
+    NL_NCCL(rccl().GroupEnd());
+    return NL_OK;
+}
+
+/* Components of the owned planes + ghost planes for one phase (SL_FILL: 6-connected background, SL_AREA / SL_NUMBER:
+   26-connected foreground of the working mask) and the phase's per-tree quantity.  counts[5] = runs in total, in the low
+   ghost plane, the first owned plane, the last owned plane, the high ghost plane (0 where the slab has no such plane). */
+extern "C" int nl_slab_components(nl_ctx *c, int phase, int64_t *counts, char *err, size_t errlen) {
+    NL_ENTER(c);
+    if (phase < SL_FILL || phase > SL_NUMBER || !counts) return nl_fail(err, errlen, NL_EINVAL, "bad phase");
+    SlabGeo sg; int rc = slab_geo(c, sg, err, errlen); if (rc) return rc;
+    LabelGeo &g = sg.g; RunSet &rs = sg.rs;
+    ProfScope ps(c, "label");
+    bool overflow = false;
+    if (phase == SL_FILL) rc = build_components<6>(c, g, g.bitsA, 1, rs, sg.cap, &overflow, err, errlen);
+    else rc = build_components<26>(c, g, g.bitsA, 0, rs, sg.cap, &overflow, err, errlen);
+    if (rc) return rc;
+    if (overflow) return nl_fail(err, errlen, NL_ENOMEM, "the slab's mask has more runs than its scratch volumes hold [out of memory]");
+    c->sl_nruns = rs.nruns; c->sl_phase = phase; c->sl_numbered = 0;
+    // run ranges of the four planes the neighbours also see
+    const i64 ny = c->ny;
+    const i64 prow[4] = {0, (c->own_lo - c->sl_e0) * ny, (c->own_hi - 1 - c->sl_e0) * ny, (c->own_hi - c->sl_e0) * ny};
+    unsigned int *h = (unsigned int *)c->h_small;
+    for (int k = 0; k < 4; ++k) {
+        NL_HIP(hipMemcpyAsync(h + 2 * k, rs.row_off + prow[k], 4, hipMemcpyDeviceToHost, c->stream));
+        NL_HIP(hipMemcpyAsync(h + 2 * k + 1, rs.row_off + prow[k] + ny, 4, hipMemcpyDeviceToHost, c->stream));
+    }
+    if (rs.nruns) {
+        const unsigned gr = (unsigned)((rs.nruns + 255) / 256);
+        if (phase == SL_FILL) {
+            NL_HIP(hipMemsetAsync(c->m[0], 0, (size_t)rs.nruns, c->stream));
+            rl_border_kernel<<<gr, 256, 0, c->stream>>>(rs.runs, rs.parent, c->m[0], rs.nruns, VolGeom{g.nz, g.ny, g.nx, g.gz0, g.gnz});
+        } else if (phase == SL_AREA) {
+            NL_HIP(hipMemsetAsync(sg.aux, 0, (size_t)rs.nruns * 4, c->stream));
+            sl_area_kernel<<<(unsigned)((rs.nruns + RL_CHUNK - 1) / RL_CHUNK), 256, 0, c->stream>>>(rs.runs, rs.parent, sg.aux, rs.nruns, sg.row_lo, sg.row_hi);
+        } else {
+            NL_HIP(hipMemsetD32Async((hipDeviceptr_t)sg.aux, 0x7fffffff, (size_t)rs.nruns, c->stream));
+            sl_first_own_kernel<<<gr, 256, 0, c->stream>>>(rs.runs, rs.parent, sg.aux, rs.nruns, sg.row_lo, sg.row_hi);
+        }
+        NL_CHECK_LAUNCH();
+    }
+    NL_HIP(hipStreamSynchronize(c->stream));
+    for (int k = 0; k < 4; ++k) { c->sl_first[k] = h[2 * k]; c->sl_count[k] = h[2 * k + 1] - h[2 * k]; }
+    if (!sg.has_lo) c->sl_count[0] = 0;
+    if (!sg.has_hi) c->sl_count[3] = 0;
+    counts[0] = rs.nruns;
+    for (int k = 0; k < 4; ++k) counts[1 + k] = c->sl_count[k];
+    return NL_OK;
+}
+
+/* the four tables, concatenated (ghost-low, own-first, own-last, ghost-high): roots[k] = tree of the k-th run of the plane,
+   values[k] = that tree's quantity of the current phase */
+extern "C" int nl_slab_tables(nl_ctx *c, int32_t *roots, int32_t *values, char *err, size_t errlen) {
+    NL_ENTER(c);
+    if (c->sl_phase < 0) return nl_fail(err, errlen, NL_ESTATE, "nl_slab_tables before nl_slab_components");
+    SlabGeo sg; int rc = slab_geo(c, sg, err, errlen); if (rc) return rc;
+    i64 total = 0;
+    for (int k = 0; k < 4; ++k) total += c->sl_count[k];
+    if (total == 0) return NL_OK;
+    if (!roots || !values) return nl_fail(err, errlen, NL_EINVAL, "table buffers are NULL");
+    if (2 * total > c->n) return nl_fail(err, errlen, NL_ENOMEM, "tables larger than the staging volume [out of memory]");
+    int *d_root = sg.stage, *d_val = sg.stage + total;
+    i64 off = 0;
+    for (int k = 0; k < 4; ++k) {
+        if (!c->sl_count[k]) continue;
+        sl_table_kernel<<<(c->sl_count[k] + 255) / 256, 256, 0, c->stream>>>(sg.rs.parent, sg.aux, c->sl_phase == SL_FILL ? c->m[0] : nullptr,
+                                                                          c->sl_first[k], c->sl_count[k], d_root + off, d_val + off);
+        off += c->sl_count[k];
+    }
+    NL_CHECK_LAUNCH();
+    NL_HIP(hipMemcpyAsync(roots, d_root, (size_t)total * 4, hipMemcpyDeviceToHost, c->stream));
+    NL_HIP(hipMemcpyAsync(values, d_val, (size_t)total * 4, hipMemcpyDeviceToHost, c->stream));
+    NL_HIP(hipStreamSynchronize(c->stream));
+    return NL_OK;
+}
+
+/* quantity[roots[i]] = values[i]: what the host learned about trees that continue on other ranks */
+extern "C" int nl_slab_patch(nl_ctx *c, int64_t n, const int32_t *roots, const int32_t *values, char *err, size_t errlen) {
+    NL_ENTER(c);
+    if (c->sl_phase < 0) return nl_fail(err, errlen, NL_ESTATE, "nl_slab_patch before nl_slab_components");
+    if (n == 0) return NL_OK;
+    if (n < 0 || !roots || !values || 2 * n > c->n) return nl_fail(err, errlen, NL_EINVAL, "bad patch arguments");
+    SlabGeo sg; int rc = slab_geo(c, sg, err, errlen); if (rc) return rc;
+    int *d_idx = sg.stage, *d_val = sg.stage + n;
+    NL_HIP(hipMemcpyAsync(d_idx, roots, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    NL_HIP(hipMemcpyAsync(d_val, values, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    sl_patch_kernel<<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>(sg.aux, c->sl_phase == SL_FILL ? c->m[0] : nullptr, d_idx, d_val, (int)n);
+    NL_CHECK_LAUNCH();
+    NL_HIP(hipStreamSynchronize(c->stream));        // the host arrays may go away
+    return NL_OK;
+}
+
+/* SL_FILL: enclosed background of the owned planes -> working mask (labelling.py:486); SL_AREA: runs of objects with
+   >= min_area voxels -> kept-objects mask of the owned planes (labelling.py:495-501) */
+extern "C" int nl_slab_apply(nl_ctx *c, int64_t min_area, char *err, size_t errlen) {
+    NL_ENTER(c);
+    if (c->sl_phase != SL_FILL && c->sl_phase != SL_AREA) return nl_fail(err, errlen, NL_ESTATE, "nl_slab_apply outside the fill / area phases");
+    SlabGeo sg; int rc = slab_geo(c, sg, err, errlen); if (rc) return rc;
+    LabelGeo &g = sg.g; RunSet &rs = sg.rs;
+    ProfScope ps(c, "label");
+    const unsigned gr = (unsigned)((rs.nruns + 255) / 256);
+    if (c->sl_phase == SL_FILL) {
+        if (rs.nruns) sl_fill_kernel<<<gr, 256, 0, c->stream>>>(rs.runs, rs.parent, c->m[0], g.bitsA, rs.nruns, g.wpr, sg.row_lo, sg.row_hi);
+    } else {
+        NL_HIP(hipMemsetAsync(g.bitsB + (i64)sg.row_lo * g.wpr, 0, (size_t)(sg.row_hi - sg.row_lo) * g.wpr * 8, c->stream));
+        const int ma = (int)(min_area > 0x7fffffff ? 0x7fffffff : min_area);
+        if (rs.nruns) sl_keep_kernel<<<gr, 256, 0, c->stream>>>(rs.runs, rs.parent, sg.aux, ma, g.bitsB, rs.nruns, g.wpr, sg.row_lo, sg.row_hi);
+    }
+    NL_CHECK_LAUNCH();
+    return NL_OK;
+}
+
+/* working mask (owned planes) = majority filter of the kept-objects mask, ghost planes included (labelling.py:503-505) */
+extern "C" int nl_slab_majority(nl_ctx *c, char *err, size_t errlen) {
+    NL_ENTER(c);
+    SlabGeo sg; int rc = slab_geo(c, sg, err, errlen); if (rc) return rc;
+    LabelGeo &g = sg.g;
+    ProfScope ps(c, "label");
+    const i64 z_lo = c->own_lo - c->sl_e0, z_hi = c->own_hi - c->sl_e0;
+    majority_bits_kernel<<<(unsigned)(((z_hi - z_lo) * g.ny * g.wpr + 255) / 256), 256, 0, c->stream>>>(g.bitsB, g.bitsA, VolGeom{g.nz, g.ny, g.nx, g.gz0, g.gnz}, g.wpr, z_lo, z_hi);
+    NL_CHECK_LAUNCH();
+    return NL_OK;
+}
+
+/* SL_NUMBER: ranks the trees this rank numbers, in raster order of their first run: the roots on the owned planes, minus
+   `clear` (trees that continue on other ranks), plus `set` (those of them this rank owns).  *n_local = their count. */
+extern "C" int nl_slab_number(nl_ctx *c, int64_t n_clear, const int32_t *clear, int64_t n_set, const int32_t *set, int64_t *n_local,
+                              char *err, size_t errlen) {
+    NL_ENTER(c);
+    if (c->sl_phase != SL_NUMBER) return nl_fail(err, errlen, NL_ESTATE, "nl_slab_number outside the numbering phase");
+    if (n_clear < 0 || n_set < 0 || (n_clear && !clear) || (n_set && !set) || n_clear + n_set > c->n / 4) return nl_fail(err, errlen, NL_EINVAL, "bad selection lists");
+    SlabGeo sg; int rc = slab_geo(c, sg, err, errlen); if (rc) return rc;
+    RunSet &rs = sg.rs;
+    ProfScope ps(c, "label");
+    unsigned long long total = 0;
+    if (rs.nruns) {
+        sl_select_kernel<<<(unsigned)((rs.nruns + 255) / 256), 256, 0, c->stream>>>(rs.runs, rs.parent, sg.sel, rs.nruns, sg.row_lo, sg.row_hi);
+        int *d_idx = (int *)(sg.scan + rs.nruns);                    // behind the scan array (cap >= nruns + the lists: checked above)
+        if (rs.nruns + n_clear + n_set > sg.cap) return nl_fail(err, errlen, NL_ENOMEM, "selection lists do not fit the scratch volume [out of memory]");
+        if (n_clear) {
+            NL_HIP(hipMemcpyAsync(d_idx, clear, (size_t)n_clear * 4, hipMemcpyHostToDevice, c->stream));
+            sl_set_u32_kernel<<<(unsigned)((n_clear + 255) / 256), 256, 0, c->stream>>>(sg.sel, d_idx, (int)n_clear, 0u);
+        }
+        if (n_set) {
+            NL_HIP(hipMemcpyAsync(d_idx + n_clear, set, (size_t)n_set * 4, hipMemcpyHostToDevice, c->stream));
+            sl_set_u32_kernel<<<(unsigned)((n_set + 255) / 256), 256, 0, c->stream>>>(sg.sel, d_idx + n_clear, (int)n_set, 1u);
+        }
+        NL_CHECK_LAUNCH();
+        NL_HIP(hipStreamSynchronize(c->stream));
+        if ((rc = scan_excl_u32(c, sg.sel, sg.scan, rs.nruns, err, errlen))) return rc;
+        unsigned int *h = (unsigned int *)c->h_small;
+        NL_HIP(hipMemcpyAsync(h, sg.scan + rs.nruns - 1, 4, hipMemcpyDeviceToHost, c->stream));
+        NL_HIP(hipMemcpyAsync(h + 1, sg.sel + rs.nruns - 1, 4, hipMemcpyDeviceToHost, c->stream));
+        NL_HIP(hipStreamSynchronize(c->stream));
+        total = (unsigned long long)h[0] + h[1];
+    }
+    if (n_local) *n_local = (int64_t)total;
+    c->sl_numbered = 1;
+    return NL_OK;
+}
+
+/* out[i] = 1-based local rank of the selected run idx[i] (after nl_slab_number) */
+extern "C" int nl_slab_query(nl_ctx *c, int64_t n, const int32_t *idx, int32_t *out, char *err, size_t errlen) {
+    NL_ENTER(c);
+    if (!c->sl_numbered) return nl_fail(err, errlen, NL_ESTATE, "nl_slab_query before nl_slab_number");
+    if (n == 0) return NL_OK;
+    if (n < 0 || !idx || !out) return nl_fail(err, errlen, NL_EINVAL, "bad query");
+    SlabGeo sg; int rc = slab_geo(c, sg, err, errlen); if (rc) return rc;
+    if (sg.rs.nruns + 2 * n > sg.cap) return nl_fail(err, errlen, NL_ENOMEM, "query does not fit the scratch volume [out of memory]");
+    int *d_idx = (int *)(sg.scan + sg.rs.nruns), *d_out = d_idx + n;
+    NL_HIP(hipMemcpyAsync(d_idx, idx, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    sl_gather_kernel<<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>(sg.scan, d_idx, d_out, (int)n, 1);
+    NL_CHECK_LAUNCH();
+    NL_HIP(hipMemcpyAsync(out, d_out, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    NL_HIP(hipStreamSynchronize(c->stream));
+    return NL_OK;
+}
+
+/* int32 labels of the owned planes (labelling.py:507): a selected tree gets base + its local rank, the trees listed in
+   `roots` (they continue on other ranks) get `labels` */
+extern "C" int nl_slab_paint(nl_ctx *c, int64_t base, int64_t n, const int32_t *roots, const int32_t *labels, char *err, size_t errlen) {
+    NL_ENTER(c);
+    if (!c->sl_numbered) return nl_fail(err, errlen, NL_ESTATE, "nl_slab_paint before nl_slab_number");
+    if (n < 0 || (n && (!roots || !labels))) return nl_fail(err, errlen, NL_EINVAL, "bad label patch");
+    SlabGeo sg; int rc = slab_geo(c, sg, err, errlen); if (rc) return rc;
+    LabelGeo &g = sg.g; RunSet &rs = sg.rs;
+    ProfScope ps(c, "label");
+    if (rs.nruns) {
+        sl_ids_kernel<<<(unsigned)((rs.nruns + 255) / 256), 256, 0, c->stream>>>(sg.sel, sg.scan, (int)base, sg.aux, rs.nruns);
+        if (n) {
+            if (rs.nruns + 2 * n > sg.cap) return nl_fail(err, errlen, NL_ENOMEM, "label patch does not fit the scratch volume [out of memory]");
+            int *d_idx = (int *)(sg.scan + rs.nruns), *d_val = d_idx + n;
+            NL_HIP(hipMemcpyAsync(d_idx, roots, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+            NL_HIP(hipMemcpyAsync(d_val, labels, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+            sl_patch_kernel<<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>(sg.aux, nullptr, d_idx, d_val, (int)n);
+        }
+        NL_CHECK_LAUNCH();
+        NL_HIP(hipStreamSynchronize(c->stream));   // the lists sit in the volume the paint is about to overwrite
+    }
+    rl_paint_kernel<<<grid1d((g.paint_row1 - g.paint_row0) * 64, 256, (i64)1 << 22), 256, 0, c->stream>>>(
+        g.bitsA, rs.row_off, rs.parent, sg.aux, g.paint_out, g.paint_row0, g.paint_row1, g.wpr, (int)g.nx);
+    NL_CHECK_LAUNCH();
+    NL_HIP(hipStreamSynchronize(c->stream));
+    c->i_labels = sg.out_idx;
+    c->sl_numbered = 0; c->sl_phase = -1;
     return NL_OK;
 }
 
@@ -2237,6 +2576,7 @@ extern "C" int nl_skel_branch_labels(nl_ctx *c, const uint8_t *pixel_class_host,
     g.rows = c->d_rows;
     g.bitsA = (unsigned long long *)c->m[2]; g.bitsB = (unsigned long long *)c->m[1];
     g.paint_row0 = 0; g.paint_row1 = g.nrows; g.paint_out = (int *)c->f[3];
+    label_geo_whole(g);
     ProfScope ps(c, "network");
     if (pixel_class_host) {
         uint8_t *pc = (uint8_t *)c->f[2];

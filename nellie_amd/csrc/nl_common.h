@@ -82,6 +82,12 @@ struct nl_ctx {
     unsigned long long *gbits[2] = {nullptr, nullptr};   // Z-slab Label: GLOBAL bit masks (lazily allocated)
     unsigned int *grows = nullptr;                       // ... and the global per-row arrays
     i64 blk_cap = 0;
+    // Z-slab Label without replication (nl_slab_*): planes [sl_e0, sl_e1) = owned planes + one ghost plane per interior side
+    i64 sl_e0 = 0, sl_e1 = 0;
+    i64 sl_nruns = 0;
+    int sl_phase = -1;
+    unsigned int sl_first[4] = {0, 0, 0, 0}, sl_count[4] = {0, 0, 0, 0};   // runs of the planes ghost-low, own-first, own-last, ghost-high
+    int sl_numbered = 0;
 
     float hz = 1, hy = 1, hx = 1;            // float32(h)
     float hz2 = 2, hy2 = 2, hx2 = 2;         // float32(2.0*h)
@@ -93,6 +99,7 @@ struct nl_ctx {
     int mask_slots_used = 0;   // per-scale h_mask bit planes written since the frame began
 
     void *comm = nullptr;             // ncclComm_t (RCCL), set by nl_comm_init
+    void *d_ag = nullptr; size_t ag_cap = 0;      // staging of nl_allgather_bytes
     int world = 1, rank = 0;
 
     hipEvent_t t0 = nullptr, t1 = nullptr;

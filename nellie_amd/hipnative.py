@@ -93,6 +93,19 @@ _PROTOS = {
     "nl_label_bits_put": [_p, _i64, _i64, _p],
     "nl_label_bits_allgather": [_p, _p],
     "nl_label_run_global": [_p, _i64, _int, C.POINTER(_i64)],
+    "nl_slab_label_pack": [_p, _int, _f32],
+    "nl_slab_bits_get": [_p, _int, _i64, _p],
+    "nl_slab_bits_put": [_p, _int, _i64, _p],
+    "nl_slab_bits_exchange": [_p, _int],
+    "nl_slab_components": [_p, _int, _p],
+    "nl_slab_tables": [_p, _p, _p],
+    "nl_slab_patch": [_p, _i64, _p, _p],
+    "nl_slab_apply": [_p, _i64],
+    "nl_slab_majority": [_p],
+    "nl_slab_number": [_p, _i64, _p, _i64, _p, C.POINTER(_i64)],
+    "nl_slab_query": [_p, _i64, _p, _p],
+    "nl_slab_paint": [_p, _i64, _i64, _p, _p],
+    "nl_allgather_bytes": [_p, _p, _i64, _p, _i64, _p],
     "nl_pinned_alloc": [C.POINTER(_p), _i64],
     "nl_host_register": [_p, _i64],
     "nl_input_load_async": [_p, _int, _p, _int],
@@ -672,6 +685,81 @@ class Context:
         n = _i64(0)
         self._call("nl_label_run_global", int(min_area), 1 if fill_holes else 0, C.byref(n))
         return int(n.value)
+
+    # ---- Z-slab Label without replication (include/nellie_amd.h "Label on Z-slabs WITHOUT replication") ----
+    def slab_label_pack(self, thr):
+        has = thr is not None
+        self._call("nl_slab_label_pack", 1 if has else 0, float(np.float32(thr)) if has else 0.0)
+
+    def slab_bits_get(self, which, plane):
+        words = self.shape[1] * ((self.shape[2] + 63) // 64)
+        out = np.empty(words, np.uint64)
+        self._call("nl_slab_bits_get", int(which), int(plane), _ptr(out))
+        return out
+
+    def slab_bits_put(self, which, plane, words):
+        a = np.ascontiguousarray(words, dtype=np.uint64)
+        self._call("nl_slab_bits_put", int(which), int(plane), _ptr(a))
+
+    def slab_bits_exchange(self, which):
+        self._call("nl_slab_bits_exchange", int(which))
+
+    def slab_components(self, phase):
+        """-> (runs in total, [runs in the low ghost plane, first owned, last owned, high ghost plane])"""
+        counts = np.zeros(5, np.int64)
+        self._call("nl_slab_components", int(phase), _ptr(counts))
+        self._slab_counts = [int(v) for v in counts[1:]]
+        return int(counts[0]), list(self._slab_counts)
+
+    def slab_tables(self):
+        """-> (roots, values): four int32 arrays each, in the plane order of slab_components"""
+        total = sum(self._slab_counts)
+        roots, vals = np.empty(total, np.int32), np.empty(total, np.int32)
+        if total:
+            self._call("nl_slab_tables", _ptr(roots), _ptr(vals))
+        cuts = np.cumsum([0] + self._slab_counts)
+        return ([roots[cuts[k]:cuts[k + 1]] for k in range(4)], [vals[cuts[k]:cuts[k + 1]] for k in range(4)])
+
+    def slab_patch(self, roots, values):
+        r = np.ascontiguousarray(roots, dtype=np.int32)
+        v = np.ascontiguousarray(values, dtype=np.int32)
+        assert r.size == v.size
+        if r.size:
+            self._call("nl_slab_patch", r.size, _ptr(r), _ptr(v))
+
+    def slab_apply(self, min_area=0):
+        self._call("nl_slab_apply", int(min_area))
+
+    def slab_majority(self):
+        self._call("nl_slab_majority")
+
+    def slab_number(self, clear, select) -> int:
+        c = np.ascontiguousarray(clear, dtype=np.int32)
+        s_ = np.ascontiguousarray(select, dtype=np.int32)
+        n = _i64(0)
+        self._call("nl_slab_number", c.size, _ptr(c) if c.size else None, s_.size, _ptr(s_) if s_.size else None, C.byref(n))
+        return int(n.value)
+
+    def slab_query(self, idx):
+        i = np.ascontiguousarray(idx, dtype=np.int32)
+        out = np.empty(i.size, np.int32)
+        if i.size:
+            self._call("nl_slab_query", i.size, _ptr(i), _ptr(out))
+        return out
+
+    def slab_paint(self, base, roots, labels):
+        r = np.ascontiguousarray(roots, dtype=np.int32)
+        v = np.ascontiguousarray(labels, dtype=np.int32)
+        assert r.size == v.size
+        self._call("nl_slab_paint", int(base), r.size, _ptr(r) if r.size else None, _ptr(v) if v.size else None)
+
+    def allgather_bytes(self, data: bytes, max_bytes: int, world: int):
+        """Variable-size all-gather over RCCL: the list of every rank's bytes."""
+        send = np.frombuffer(data, dtype=np.uint8) if len(data) else np.zeros(0, np.uint8)
+        recv = np.empty(int(max_bytes) * int(world), np.uint8)
+        sizes = np.zeros(int(world), np.int64)
+        self._call("nl_allgather_bytes", _ptr(send) if send.size else None, send.size, _ptr(recv), int(max_bytes), _ptr(sizes))
+        return [recv[r * max_bytes:r * max_bytes + int(sizes[r])].tobytes() for r in range(int(world))]
 
     def label_store(self, z0=0, z1=None, out=None):
         z1 = self.shape[0] if z1 is None else z1

@@ -12,11 +12,16 @@ samples, the 256 histogram counts, max|H|, the largest finite frob_sq and the in
 the sharded Frangi frame equals the single-GPU frame bit for bit.  The <= 1e6 samples of the two
 percentile / log-domain thresholds are gathered (order does not matter: histogram and order statistics).
 
-Label across slabs: the thresholded mask is 1 bit/voxel, so instead of stitching per-slab labellings every
-rank packs the mask bits of its own planes into a GLOBAL bit mask, the bit planes are all-gathered (RCCL
-broadcasts, 1/32 of the float traffic), the run-level labelling -- whose cost scales with the number of runs,
-not voxels -- runs redundantly on the global mask on every rank, and each rank paints only its own planes.
-That IS the single-volume algorithm, so the labels equal the single-GPU labels bit for bit.
+Label across slabs (no replication): every rank labels its own planes plus ONE ghost bit plane per interior side
+(the bit planes travel like the float ghost planes: RCCL send/recv between neighbours).  A component that crosses an
+interface appears on both ranks as a tree containing runs of the two planes both ranks see, and the k-th run of such
+a plane is the same voxels on both sides.  Per phase (hole filling, area filter, numbering) the ranks all-gather the
+(tree, quantity) tables of those planes -- a few thousand int32 pairs -- join the trees of neighbouring ranks (a
+connected-components problem on that small graph, solved identically on every rank) and patch the global answer
+back into the device arrays: "touches a face of the volume" (OR), object size (sum), owner and label of a component
+(the lowest rank holding voxels of it numbers it; ids are offset by the exclusive sum of the lower ranks' counts).
+The result is the single-volume labelling bit for bit, numbering included (labelling.py:467-509; the reference's
+own chunked mode, labelling.py:585-691, stitches per-chunk labellings and is NOT equivalent to its full-volume mode).
 """
 from __future__ import annotations
 
@@ -55,37 +60,102 @@ def slab_geometry(gshape, world, rank, halo):
     return (o1 - o0 + lo + hi, ny, nx), o0 - lo, lo, lo + (o1 - o0)
 
 
-class RcclComm:
-    """Production communicator: ghost planes and scalar all-reduces over RCCL on the context's stream.
-    `host_gather(array) -> concatenated array` moves the <= 1e6 threshold samples through the control plane."""
+SLAB_FILL, SLAB_AREA, SLAB_NUMBER = 0, 1, 2
 
-    def __init__(self, ctx, world, rank, uid: bytes, host_gather):
+
+def unpack_slab_tables(blob):
+    """[4 counts | roots of the 4 planes | values of the 4 planes] (int32) -> (roots[4], values[4])."""
+    blob = np.asarray(blob, np.int32)
+    counts = [int(c) for c in blob[:4]]
+    total = sum(counts)
+    cuts = np.cumsum([0] + counts)
+    r, v = blob[4:4 + total], blob[4 + total:4 + 2 * total]
+    return [r[cuts[k]:cuts[k + 1]] for k in range(4)], [v[cuts[k]:cuts[k + 1]] for k in range(4)]
+
+
+class _Joined:
+    """One node per (rank, tree) that appears in a table: rank, root, val; comp = its component after joining the ranks."""
+    __slots__ = ("rank", "root", "val", "comp", "ncomp")
+
+
+def join_slab_tables(tables):
+    """tables[r] = (roots[4], values[4]) of rank r, planes in the order ghost-low, own-first, own-last, ghost-high.
+    Rank r's last owned plane is rank r+1's low ghost plane and rank r's high ghost plane is rank r+1's first owned
+    plane: the k-th run of such a plane names the same voxels on both sides, which joins the two trees."""
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import connected_components
+    ranks, roots, vals, ids, n = [], [], [], [], 0
+    for r, (rt, vt) in enumerate(tables):
+        allr = np.concatenate([np.asarray(x, np.int64) for x in rt]) if rt else np.zeros(0, np.int64)
+        allv = np.concatenate([np.asarray(x, np.int64) for x in vt]) if vt else np.zeros(0, np.int64)
+        u, first, inv = np.unique(allr, return_index=True, return_inverse=True)
+        cuts = np.cumsum([0] + [len(x) for x in rt])
+        ids.append([n + inv[cuts[k]:cuts[k + 1]] for k in range(4)])
+        ranks.append(np.full(u.size, r, np.int64)); roots.append(u); vals.append(allv[first])
+        n += u.size
+    ea, eb = [], []
+    for r in range(len(tables) - 1):
+        for mine, theirs in ((2, 0), (3, 1)):
+            a, b = ids[r][mine], ids[r + 1][theirs]
+            if a.size != b.size:
+                raise RuntimeError(f"slab tables of ranks {r} and {r + 1} disagree ({a.size} vs {b.size} runs): the ghost bit planes are stale")
+            ea.append(a); eb.append(b)
+    j = _Joined()
+    j.rank = np.concatenate(ranks) if ranks else np.zeros(0, np.int64)
+    j.root = np.concatenate(roots).astype(np.int32) if roots else np.zeros(0, np.int32)
+    j.val = np.concatenate(vals) if vals else np.zeros(0, np.int64)
+    if n == 0:
+        j.comp, j.ncomp = np.zeros(0, np.int64), 0
+        return j
+    ea = np.concatenate(ea) if ea else np.zeros(0, np.int64)
+    eb = np.concatenate(eb) if eb else np.zeros(0, np.int64)
+    g = coo_matrix((np.ones(ea.size, np.int8), (ea, eb)), shape=(n, n))
+    j.ncomp, comp = connected_components(g, directed=False)
+    j.comp = comp.astype(np.int64)
+    return j
+
+
+class RcclComm:
+    """Production communicator: everything the path exchanges travels over RCCL on the context's stream -- float ghost
+    planes and bit planes (ncclSend / ncclRecv between Z neighbours), scalar reductions (ncclAllReduce) and the
+    variable-size gathers of threshold samples and slab tables (ncclAllGather on padded staging)."""
+
+    def __init__(self, ctx, world, rank, uid: bytes, host_gather=None):
         self.world, self.rank = world, rank
         self.ctx = ctx
-        self.host_gather = host_gather
         ctx.comm_init(world, rank, uid)
 
     def exchange_halo(self, ctx, field, depth):
         ctx.halo_exchange(field, depth)
 
+    def exchange_bits(self, ctx, which):
+        ctx.slab_bits_exchange(which)
+
     def allreduce(self, arr, op):
         return self.ctx.allreduce(arr, op)
 
+    def allgather_list(self, arr):
+        a = np.ascontiguousarray(arr)
+        mx = int(self.ctx.allreduce(np.array([a.nbytes], np.int64), "max")[0])
+        blocks = self.ctx.allgather_bytes(a.tobytes(), max(mx, 8), self.world)
+        return [np.frombuffer(b, dtype=a.dtype) for b in blocks]
+
     def allgather(self, arr):
-        return self.host_gather(arr)
+        return np.concatenate(self.allgather_list(arr))
 
     def allgather_mask_bits(self, ctx, slab_plane0):
         ctx.label_bits_allgather(slab_plane0)
 
 
 class ShardedFramePipeline(FramePipeline):
-    def __init__(self, gshape, rank, world, comm_factory, params: FilterParams, device: int = 0, ctx_factory=None):
+    def __init__(self, gshape, rank, world, comm_factory, params: FilterParams, device: int = 0, ctx_factory=None, halo=None):
         """
-        comm_factory(ctx) -> communicator with exchange_halo / allreduce / allgather.
+        comm_factory(ctx) -> communicator with exchange_halo / exchange_bits / allreduce / allgather.
         ctx_factory(local_shape, device, gz0, gnz, own) -> context (default: the HIP context).
+        halo: ghost planes per interior side (default: what the whole Filter needs; Label alone needs 1).
         """
         self.rank, self.world = int(rank), int(world)
-        self.halo = halo_depth(params)
+        self.halo = halo_depth(params) if halo is None else int(halo)
         lshape, gz0, own_lo, own_hi = slab_geometry(gshape, world, rank, self.halo)
         self.lshape, self.gz0, self.own = lshape, gz0, (own_lo, own_hi)
         make = ctx_factory or (lambda shp, dev, g0, gn, own: hipnative.Context(shp, device=dev, gz0=g0, gnz=gn, own=own))
@@ -166,8 +236,74 @@ class ShardedFramePipeline(FramePipeline):
         lo, hi = self.own
         self.ctx.label_load_frangi(np.asarray(frangi, dtype=np.float32), z0=lo, z1=hi)
 
+    def _gather_list(self, arr):
+        f = getattr(self.comm, "allgather_list", None)
+        if f is not None:
+            return f(arr)
+        # communicators that only concatenate: gather the sizes first
+        sizes = self.comm.allgather(np.array([arr.size], np.int64))
+        flat = self.comm.allgather(arr)
+        cuts = np.cumsum(np.concatenate([[0], sizes]))
+        return [flat[cuts[r]:cuts[r + 1]] for r in range(self.world)]
+
+    def _slab_phase(self, phase):
+        """Components of this slab for one phase + the joined view of the trees that continue on other ranks."""
+        _, counts = self.ctx.slab_components(phase)
+        roots, vals = self.ctx.slab_tables()
+        blob = np.concatenate([np.asarray(counts, np.int32)] + [np.asarray(r, np.int32) for r in roots] + [np.asarray(v, np.int32) for v in vals])
+        return join_slab_tables([unpack_slab_tables(b) for b in self._gather_list(blob)])
+
     def label(self, frangi_thresh, min_area, fill_holes=True):
         """labelling.py:467-509 across slabs (see the module docstring); returns the GLOBAL label count."""
+        ctx, comm, me = self.ctx, self.comm, self.rank
+        self.trace.label_thr = None if frangi_thresh is None else float(frangi_thresh)
+        ctx.slab_label_pack(frangi_thresh)
+        if fill_holes:
+            comm.exchange_bits(ctx, 0)
+            j = self._slab_phase(SLAB_FILL)
+            mine = j.rank == me
+            outside = np.zeros(j.ncomp, bool)
+            np.logical_or.at(outside, j.comp, j.val != 0)
+            fix = mine & (j.val == 0) & outside[j.comp]
+            ctx.slab_patch(j.root[fix], np.ones(int(fix.sum()), np.int32))
+            ctx.slab_apply()
+        comm.exchange_bits(ctx, 0)
+        j = self._slab_phase(SLAB_AREA)
+        mine = j.rank == me
+        area = np.zeros(j.ncomp, np.int64)
+        np.add.at(area, j.comp, j.val.astype(np.int64))
+        ctx.slab_patch(j.root[mine], np.minimum(area[j.comp[mine]], 2 ** 31 - 1).astype(np.int32))
+        ctx.slab_apply(int(min_area))
+        comm.exchange_bits(ctx, 1)
+        ctx.slab_majority()
+        comm.exchange_bits(ctx, 0)
+        j = self._slab_phase(SLAB_NUMBER)
+        mine = j.rank == me
+        none = np.int64(2 ** 31 - 1)
+        # the owner of a component: the lowest rank holding voxels of it; its defining run there: the first one
+        owner = np.full(j.ncomp, self.world, np.int64)
+        has = j.val != none
+        np.minimum.at(owner, j.comp[has], j.rank[has])
+        first = np.full(j.ncomp, none, np.int64)
+        own_nodes = mine & has & (owner[j.comp] == me)
+        np.minimum.at(first, j.comp[own_nodes], j.val[own_nodes].astype(np.int64))
+        my_comps = np.flatnonzero(first != none)
+        k_local = ctx.slab_number(j.root[mine], first[my_comps].astype(np.int32))
+        local_id = ctx.slab_query(first[my_comps].astype(np.int32))
+        parts = self._gather_list(np.concatenate([np.array([k_local], np.int64), my_comps.astype(np.int64), local_id.astype(np.int64)]))
+        counts = np.array([int(p[0]) for p in parts], np.int64)
+        base = np.concatenate([[0], np.cumsum(counts)])
+        label_of = np.zeros(j.ncomp, np.int64)
+        for r, p in enumerate(parts):
+            m = (p.size - 1) // 2
+            label_of[p[1:1 + m]] = base[r] + p[1 + m:]
+        ctx.slab_paint(int(base[me]), j.root[mine], label_of[j.comp[mine]].astype(np.int32))
+        self.trace.n_labels = int(base[-1])
+        return self.trace.n_labels
+
+    def label_replicated(self, frangi_thresh, min_area, fill_holes=True):
+        """The first implementation (kept for A/B and as a cross-check in tests): all-gather the global bit mask and run
+        the run-level labelling redundantly on every rank."""
         self.trace.label_thr = None if frangi_thresh is None else float(frangi_thresh)
         self.ctx.label_pack(frangi_thresh)
         plane0 = [slab_range(self.shape[0], self.world, r)[0] for r in range(self.world)] + [self.shape[0]]

@@ -34,6 +34,19 @@ class ThreadComm:
         if self.rank + 1 < self.world:
             ctx.planes_put(field, hi, hi + depth, vals[self.rank + 1][0])
 
+    def exchange_bits(self, ctx, which):
+        lo, hi = ctx.own
+        down = ctx.slab_bits_get(which, lo) if self.rank > 0 else None
+        up = ctx.slab_bits_get(which, hi - 1) if self.rank + 1 < self.world else None
+        vals = self._all((down, up))
+        if self.rank > 0:
+            ctx.slab_bits_put(which, lo - 1, vals[self.rank - 1][1])
+        if self.rank + 1 < self.world:
+            ctx.slab_bits_put(which, hi, vals[self.rank + 1][0])
+
+    def allgather_list(self, arr):
+        return self._all(np.array(arr, copy=True))
+
     def allreduce(self, arr, op):
         vals = self._all(np.array(arr, copy=True))
         st = np.stack(vals)
@@ -75,6 +88,22 @@ class GlooComm:
             ctx.planes_put(field, lo - depth, lo, recv_lo.numpy())
         if recv_hi is not None:
             ctx.planes_put(field, hi, hi + depth, recv_hi.numpy())
+
+    def exchange_bits(self, ctx, which):
+        lo, hi = ctx.own
+        out = [None] * self.world
+        mine = (ctx.slab_bits_get(which, lo) if self.rank > 0 else None,
+                ctx.slab_bits_get(which, hi - 1) if self.rank + 1 < self.world else None)
+        self.dist.all_gather_object(out, mine)
+        if self.rank > 0:
+            ctx.slab_bits_put(which, lo - 1, out[self.rank - 1][1])
+        if self.rank + 1 < self.world:
+            ctx.slab_bits_put(which, hi, out[self.rank + 1][0])
+
+    def allgather_list(self, arr):
+        out = [None] * self.world
+        self.dist.all_gather_object(out, np.array(arr, copy=True))
+        return out
 
     def allreduce(self, arr, op):
         import torch

@@ -1,4 +1,4 @@
-"""One rank of the world_size-2 gloo test (CPU): Z-slab Filter with the oracle-backed context."""
+"""One rank of the world_size-2 gloo test (CPU): Z-slab Filter AND Label with the oracle-backed context."""
 import os
 import sys
 
@@ -16,7 +16,7 @@ def main():
     rank, world = dist.get_rank(), dist.get_world_size()
     from comms import GlooComm
     from fake_ctx import OracleCtx
-    from nellie_amd.pipeline import FilterParams
+    from nellie_amd.pipeline import FilterParams, min_area_pixels_of
     from nellie_amd.sharded import ShardedFramePipeline, slab_range
     from nellie_amd.synthetic import ANISO_03, ISO_01, make_volume
     dr = ANISO_03 if aniso else ISO_01
@@ -29,7 +29,8 @@ def main():
     pipe.filter(own, p)
     fr = pipe.download_frangi()
     thr = pipe.frangi_threshold()
-    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), frangi=fr, o0=o0, o1=o1,
+    n_labels = pipe.label(thr, min_area_pixels_of(dr))
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), frangi=fr, o0=o0, o1=o1, labels=pipe.download_labels(), n_labels=n_labels,
              thr=np.float64(np.nan if thr is None else thr), gamma=[s.gamma for s in pipe.trace.scales],
              mask_count=[s.mask_count for s in pipe.trace.scales], halo=pipe.halo)
     dist.barrier()

@@ -173,3 +173,131 @@ class OracleCtx:
 
     def planes_put(self, field, z0, z1, planes):
         self._field(field)[z0:z1] = planes
+
+    # ------------------------------------------------------------------ Label on slabs (numpy stand-in for nl_slab_*)
+    # Same contract as the device entry points (include/nellie_amd.h): trees over the owned planes + one ghost plane per
+    # interior side, run tables of the four planes the neighbours also see, patches, per-phase application.  The trees
+    # here are scipy's full components (the device keeps face-touching background runs apart): the protocol only needs
+    # a valid forest.
+    def label_load_frangi(self, frangi, z0=0, z1=None):
+        z1 = self.shape[0] if z1 is None else z1
+        self.frangi = np.zeros(self.shape, np.float32)
+        self.frangi[z0:z1] = frangi
+
+    def slab_label_pack(self, thr):
+        lo, hi = self.own
+        self.bits = [np.zeros(self.shape, bool), np.zeros(self.shape, bool)]
+        if thr is not None:
+            self.bits[0][lo:hi] = self.frangi[lo:hi] > np.float32(thr)
+
+    def slab_bits_get(self, which, plane):
+        return self.bits[which][plane].copy()
+
+    def slab_bits_put(self, which, plane, words):
+        self.bits[which][plane] = words
+
+    def _ext(self):
+        lo, hi = self.own
+        e0 = lo - (1 if self.gz0 + lo > 0 else 0)
+        e1 = hi + (1 if self.gz0 + hi < self.gnz else 0)
+        return e0, e1
+
+    def slab_components(self, phase):
+        from scipy import ndimage as ndi
+        lo, hi = self.own
+        e0, e1 = self._ext()
+        m = self.bits[0][e0:e1]
+        if phase == 0:
+            m = ~m
+        nz, ny, nx = m.shape
+        # runs in raster order
+        flat = np.concatenate([np.zeros((nz * ny, 1), bool), m.reshape(nz * ny, nx), np.zeros((nz * ny, 1), bool)], axis=1)
+        d = np.diff(flat.astype(np.int8), axis=1)
+        rows, xs = np.nonzero(d == 1)
+        _, xe = np.nonzero(d == -1)
+        structure = ndi.generate_binary_structure(3, 1) if phase == 0 else np.ones((3, 3, 3), bool)
+        comp, _ = ndi.label(m, structure=structure)
+        rc = comp.reshape(nz * ny, nx)[rows, xs]
+        nruns = rows.size
+        first = {}
+        parent = np.empty(nruns, np.int64)
+        for i in range(nruns):
+            parent[i] = first.setdefault(int(rc[i]), i)
+        self._sl = dict(phase=phase, rows=rows, xs=xs, xe=xe, parent=parent, e0=e0, ny=ny, nx=nx, nz=nz)
+        own_rows = (rows >= (lo - e0) * ny) & (rows < (hi - e0) * ny)
+        if phase == 0:
+            gz = self.gz0 + e0 + rows // ny
+            y = rows % ny
+            face = (gz == 0) | (gz == self.gnz - 1) | (y == 0) | (y == ny - 1) | (xs == 0) | (xe == nx)
+            aux = np.zeros(nruns, np.int64)
+            np.maximum.at(aux, parent, face.astype(np.int64))
+        elif phase == 1:
+            aux = np.zeros(nruns, np.int64)
+            np.add.at(aux, parent[own_rows], (xe - xs)[own_rows])
+        else:
+            aux = np.full(nruns, 2 ** 31 - 1, np.int64)
+            np.minimum.at(aux, parent[own_rows], np.flatnonzero(own_rows))
+        self._sl["aux"] = aux
+        planes = [0 if e0 < lo else None, lo - e0, hi - 1 - e0, (hi - e0) if e1 > hi else None]
+        self._sl["plane_runs"] = [np.flatnonzero(rows // ny == p) if p is not None else np.zeros(0, np.int64) for p in planes]
+        return nruns, [int(r.size) for r in self._sl["plane_runs"]]
+
+    def slab_tables(self):
+        sl = self._sl
+        return ([sl["parent"][r].astype(np.int32) for r in sl["plane_runs"]],
+                [sl["aux"][sl["parent"][r]].astype(np.int32) for r in sl["plane_runs"]])
+
+    def slab_patch(self, roots, values):
+        self._sl["aux"][np.asarray(roots, np.int64)] = np.asarray(values, np.int64)
+
+    def _own_run_mask(self):
+        sl = self._sl
+        lo, hi = self.own
+        return (sl["rows"] >= (lo - sl["e0"]) * sl["ny"]) & (sl["rows"] < (hi - sl["e0"]) * sl["ny"])
+
+    def _paint_runs(self, target, sel, values=None):
+        sl = self._sl
+        view = target[sl["e0"]:sl["e0"] + sl["nz"]].reshape(sl["nz"] * sl["ny"], sl["nx"])
+        for i in np.flatnonzero(sel):
+            view[sl["rows"][i], sl["xs"][i]:sl["xe"][i]] = True if values is None else values[i]
+
+    def slab_apply(self, min_area=0):
+        sl = self._sl
+        own = self._own_run_mask()
+        if sl["phase"] == 0:
+            self._paint_runs(self.bits[0], own & (sl["aux"][sl["parent"]] == 0))
+        else:
+            lo, hi = self.own
+            self.bits[1][lo:hi] = False
+            self._paint_runs(self.bits[1], own & (sl["aux"][sl["parent"]] >= min_area))
+
+    def slab_majority(self):
+        lo, hi = self.own
+        e0, e1 = self._ext()
+        p = np.pad(self.bits[1][e0:e1].astype(np.int32), 1, mode="edge")      # edge = clamp: right at true faces, unused at ghosts
+        s = sum(p[a:a + e1 - e0, b:b + self.shape[1], c:c + self.shape[2]] for a in range(3) for b in range(3) for c in range(3))
+        self.bits[0][lo:hi] = (s >= 14)[lo - e0:hi - e0]
+
+    def slab_number(self, clear, select):
+        sl = self._sl
+        n = sl["parent"].size
+        sel = (sl["parent"] == np.arange(n)) & self._own_run_mask()
+        sel[np.asarray(clear, np.int64)] = False
+        sel[np.asarray(select, np.int64)] = True
+        self._sl["sel"] = sel
+        self._sl["rank_of"] = np.cumsum(sel) - sel          # exclusive
+        return int(sel.sum())
+
+    def slab_query(self, idx):
+        return (self._sl["rank_of"][np.asarray(idx, np.int64)] + 1).astype(np.int32)
+
+    def slab_paint(self, base, roots, labels):
+        sl = self._sl
+        newid = np.where(sl["sel"], base + sl["rank_of"] + 1, 0).astype(np.int64)
+        newid[np.asarray(roots, np.int64)] = np.asarray(labels, np.int64)
+        self.labels = np.zeros(self.shape, np.int32)
+        self._paint_runs(self.labels, self._own_run_mask(), newid[sl["parent"]])
+
+    def label_store(self, z0=0, z1=None, out=None):
+        z1 = self.shape[0] if z1 is None else z1
+        return np.ascontiguousarray(self.labels[z0:z1])

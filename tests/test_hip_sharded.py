@@ -96,3 +96,94 @@ def test_rccl_communicator_world1(hip):
     single.filter(vol, p)
     assert np.array_equal(got, single.download_frangi())
     single.close()
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 4])
+def test_zslab_label_golden_on_hip_slabs(hip, world):
+    """Label without replication on HIP contexts (nl_slab_*): the reference's labels of the label-only golden volumes
+    (cavities, face contacts, 65/66/67-voxel objects), numbering included; the replicated variant agrees."""
+    from conftest import load_golden
+    from nellie_amd.pipeline import FilterParams
+    from nellie_amd.sharded import ShardedFramePipeline, slab_range
+    for name in ("labelonly_24x48x48", "labelonly_aniso_24x48x48"):
+        g = load_golden(name)
+        fr, thr, ma = g["frangi"], float(g["label_thr"]), int(g["min_area_pixels"])
+        for replicated in (False, True):
+            group = ThreadGroup(world)
+            out, errs = [None] * world, []
+
+            def worker(rank):
+                try:
+                    o0, o1 = slab_range(fr.shape[0], world, rank)
+                    pipe = ShardedFramePipeline(fr.shape, rank, world, lambda ctx: ThreadComm(group, rank), FilterParams(dim_res=g["dim_res_dict"]), halo=1)
+                    pipe.upload_frangi(fr[o0:o1])
+                    n = (pipe.label_replicated if replicated else pipe.label)(thr, ma)
+                    out[rank] = (pipe.download_labels(), n)
+                    pipe.close()
+                except Exception as exc:  # noqa: BLE001
+                    errs.append(exc)
+                    group.barrier.abort()
+
+            ts = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+            for t in ts:
+                t.start()
+            for t in ts:
+                t.join()
+            if errs:
+                raise errs[0]
+            lab = np.concatenate([o[0] for o in out])
+            assert np.array_equal(lab, g["labels"]), f"{name} world {world} replicated={replicated}: {int((lab != g['labels']).sum())} voxels differ"
+            assert [o[1] for o in out] == [int(g["labels"].max())] * world
+
+
+def test_zslab_label_random_on_hip_slabs(hip):
+    """Shells, tubes and specks across up to 6 interfaces: slabs == one context, bit for bit."""
+    from nellie_amd import pipeline as pl
+    from nellie_amd.pipeline import FilterParams
+    from nellie_amd.sharded import ShardedFramePipeline, slab_range
+    dr = {"X": 0.1, "Y": 0.1, "Z": 0.1, "T": 1.0}
+    for world, seed in ((2, 0), (5, 1), (7, 2)):
+        rng = np.random.default_rng(seed)
+        shape = (9 * world + 2, 70, 130)
+        zz, yy, xx = np.meshgrid(*[np.arange(s) for s in shape], indexing="ij")
+        fr = np.zeros(shape, np.float32)
+        for _ in range(40):
+            c = [rng.uniform(0, s) for s in shape]
+            r = rng.uniform(2.0, 9.0)
+            d = np.sqrt((zz - c[0]) ** 2 + (yy - c[1]) ** 2 + (xx - c[2]) ** 2)
+            fr[(d < r) & (d > r - rng.uniform(1.2, 3.0))] = 1.0
+        for _ in range(30):
+            y0, x0 = rng.integers(0, shape[1]), rng.integers(0, shape[2])
+            z0, z1 = sorted(rng.integers(0, shape[0], 2))
+            fr[z0:z1 + 1, y0:y0 + 2, x0:x0 + 2] = 1.0
+        fr[rng.random(shape) < 0.02] = 1.0
+        single = pl.FramePipeline(shape)
+        single.upload_frangi(fr)
+        ref_n = single.label(0.5, 12)
+        ref = single.download_labels()
+        single.close()
+        group = ThreadGroup(world)
+        out, errs = [None] * world, []
+
+        def worker(rank):
+            try:
+                o0, o1 = slab_range(shape[0], world, rank)
+                pipe = ShardedFramePipeline(shape, rank, world, lambda ctx: ThreadComm(group, rank), FilterParams(dim_res=dr), halo=2)
+                pipe.upload_frangi(fr[o0:o1])
+                n = pipe.label(0.5, 12)
+                out[rank] = (pipe.download_labels(), n)
+                pipe.close()
+            except Exception as exc:  # noqa: BLE001
+                errs.append(exc)
+                group.barrier.abort()
+
+        ts = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        if errs:
+            raise errs[0]
+        lab = np.concatenate([o[0] for o in out])
+        assert np.array_equal(lab, ref), f"world {world}: {int((lab != ref).sum())} voxels differ"
+        assert [o[1] for o in out] == [ref_n] * world and ref_n > 5

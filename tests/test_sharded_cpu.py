@@ -1,6 +1,7 @@
 """
-CPU tests of the N > 1 path: slab geometry, and the Z-slab Filter host logic under gloo with world_size 2
-(oracle-backed context, tests/fake_ctx.py).  The sharded result must equal the single-volume oracle bit for bit.
+CPU tests of the N > 1 path: slab geometry, the Z-slab Filter AND Label host logic under gloo with world_size 2
+(oracle-backed context, tests/fake_ctx.py), and the Label protocol alone on up to 8 slabs (threads).  The sharded
+results must equal the single-volume oracle bit for bit.
 """
 import os
 import subprocess
@@ -32,7 +33,7 @@ def test_slab_geometry():
 
 
 @pytest.mark.parametrize("aniso", [0, 1])
-def test_zslab_filter_world2_gloo(aniso, tmp_path):
+def test_zslab_filter_and_label_world2_gloo(aniso, tmp_path):
     pytest.importorskip("torch")
     from nellie_amd.synthetic import ANISO_03, ISO_01, make_volume
     port = 29600 + aniso + (os.getpid() % 200)
@@ -55,3 +56,77 @@ def test_zslab_filter_world2_gloo(aniso, tmp_path):
         assert list(p["mask_count"]) == [t["mask_count"] for t in trace]
         assert float(p["thr"]) == float(ref_thr)
     assert np.array_equal(got, ref), f"max |d| = {np.abs(got - ref).max()}"
+    # Label across the two ranks (run tables over the gloo communicator): the whole-volume labels, numbering included
+    ref_lab = orc.label_frame(ref, dr)
+    lab = np.concatenate([p["labels"] for p in parts])
+    assert np.array_equal(lab, ref_lab), f"{int((lab != ref_lab).sum())} label voxels differ"
+    assert all(int(p["n_labels"]) == int(ref_lab.max()) for p in parts) and ref_lab.max() >= 1
+
+
+def _label_slabs_with_threads(frangi, thr, min_area, world, dr):
+    """The Z-slab Label protocol of nellie_amd/sharded.py on `world` oracle-backed contexts, one thread per rank."""
+    import threading
+    from comms import ThreadComm, ThreadGroup
+    from fake_ctx import OracleCtx
+    from nellie_amd.pipeline import FilterParams
+    from nellie_amd.sharded import ShardedFramePipeline, slab_range
+    gshape = frangi.shape
+    group = ThreadGroup(world)
+    out, errs = [None] * world, []
+
+    def worker(rank):
+        try:
+            o0, o1 = slab_range(gshape[0], world, rank)
+            pipe = ShardedFramePipeline(gshape, rank, world, lambda ctx: ThreadComm(group, rank), FilterParams(dim_res=dr), halo=1,
+                                        ctx_factory=lambda shp, dev, g0, gn, ow: OracleCtx(shp, dev, g0, gn, ow))
+            pipe.upload_frangi(frangi[o0:o1])
+            n = pipe.label(thr, min_area)
+            out[rank] = (pipe.download_labels(), n)
+        except Exception as exc:  # noqa: BLE001
+            errs.append(exc)
+            group.barrier.abort()
+
+    ts = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    if errs:
+        raise errs[0]
+    return np.concatenate([o[0] for o in out]), [o[1] for o in out]
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 4])
+def test_zslab_label_protocol_golden(world):
+    """Label without replication: slab trees joined through the run tables of the shared planes == the reference's labels
+    of the whole volume (cavities, face contacts, objects of 65 / 66 / 67 voxels, diagonal-only contacts)."""
+    from conftest import load_golden
+    for name in ("labelonly_24x48x48", "labelonly_aniso_24x48x48"):
+        g = load_golden(name)
+        lab, counts = _label_slabs_with_threads(g["frangi"], float(g["label_thr"]), int(g["min_area_pixels"]), world, g["dim_res_dict"])
+        assert np.array_equal(lab, g["labels"]), f"{name}: {int((lab != g['labels']).sum())} voxels differ at world {world}"
+        assert counts == [int(g["labels"].max())] * world
+
+
+@pytest.mark.parametrize("world,seed", [(2, 0), (3, 1), (5, 2), (8, 3)])
+def test_zslab_label_protocol_random(world, seed):
+    """Random blobs, tubes and shells thrown across the interfaces (U shapes through a neighbour, cavities cut by an
+    interface, objects that fall under the area limit only on one side): sharded == oracle on the whole volume."""
+    rng = np.random.default_rng(seed)
+    shape = (8 * world + 3, 26, 31)
+    zz, yy, xx = np.meshgrid(*[np.arange(s) for s in shape], indexing="ij")
+    fr = np.zeros(shape, np.float32)
+    for _ in range(14):
+        c = [rng.uniform(0, s) for s in shape]
+        r = rng.uniform(1.5, 5.5)
+        d = np.sqrt((zz - c[0]) ** 2 + (yy - c[1]) ** 2 + (xx - c[2]) ** 2)
+        fr[(d < r) & (d > r - rng.uniform(1.2, 3.0))] = 1.0                   # shells: cavities
+    for _ in range(10):
+        y0, x0 = rng.integers(0, shape[1]), rng.integers(0, shape[2])
+        z0, z1 = sorted(rng.integers(0, shape[0], 2))
+        fr[z0:z1 + 1, y0:y0 + 2, x0:x0 + 2] = 1.0                           # tubes along Z
+    fr[rng.random(shape) < 0.02] = 1.0                                       # specks
+    ref = orc.get_labels(fr, 0.5, 12)[1]
+    lab, counts = _label_slabs_with_threads(fr, 0.5, 12, world, {"X": 0.1, "Y": 0.1, "Z": 0.1, "T": 1.0})
+    assert np.array_equal(lab, ref), f"{int((lab != ref).sum())} voxels differ"
+    assert counts == [int(ref.max())] * world
