@@ -2,21 +2,28 @@
 """
 bench.py -- Mvoxel/s of Nellie's segmentation hot path (5-scale Frangi Filter + Label) on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--shape Z Y X] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--shape Z Y X] [--no-cpu-baseline] [--no-io]
 
-One "step" = one pass of the whole hot path (float32 conversion, 5-scale Gaussian cascade,
-Hessian, eigenvalues, Frangi, scale-max, masks, percentile mask + opening, Label thresholds,
-hole filling, two 26-connected labellings, area filter, majority filter, raster renumbering)
-over one synthetic float32 frame that is ALREADY RESIDENT IN HBM when the timed region starts;
-outputs stay in HBM (the PCIe-inclusive rate is a separate, untimed-by-default figure, see
-DESIGN.md).  N = 1: BASELINE.json configs[2], 1024 x 1024 x 1024 float32 (headline).
-N > 1: a 3-D+T stack of N such frames, one frame per rank / GPU (frames are the path's independent
-units, nellie/segmentation/filtering.py:1007, labelling.py:701): no data-path collective, weak scaling.
-The Z-slab decomposition of ONE volume (ghost planes over RCCL) is the sharded pipeline of
-nellie_amd/sharded.py; see DESIGN.md "Multi-GPU" for what is and is not done yet.
+One "step" = one pass of the whole hot path (float32 conversion, 5-scale Gaussian cascade, Hessian, eigenvalues, Frangi,
+scale-max, masks, percentile mask + opening, Label thresholds, hole filling, two 26-connected labellings, area filter,
+majority filter, raster renumbering) over synthetic float32 data that is ALREADY RESIDENT IN HBM when the timed region
+starts; outputs stay in HBM.  `value` is that figure.  The host-to-host rates SURVEY.md 8(d) also asks for (pinned host
+frame in -> both outputs back in pinned host memory, and the streamed 3-D+T stack of BASELINE config 5) are reported in
+the same line under `io`, never as `value`.
+
+N = 1: BASELINE.json configs[2], one 1024 x 1024 x 1024 float32 frame (headline).
+N > 1: ONE volume cut into Z slabs over the N GPUs (nellie_amd/sharded.py): every rank owns 128 planes of 2048 x 2048
+       voxels -- the per-GPU share of BASELINE config 4 -- plus ghost planes, so N = 8 is exactly config 4
+       (1024 x 2048 x 2048, seed 3456) and N = 2, 4 are its first 256 / 512 planes' worth of the same generator (weak
+       scaling: one context holds < 2^31 voxels, so config 4 itself does not fit two GPUs).  Ghost planes, bit planes,
+       scalar reductions and the sample / table gathers all travel over RCCL (xGMI).  `value` = global voxels per wall
+       second of that run.  The slab run lives in a child process per rank (own rendezvous, timeout): if the
+       communication path fails the line is still printed, with `zslab.error`, and `value` falls back to the
+       frame-replica figure (one 1024^3 frame per GPU, no data-path collective), which is always reported as
+       `replicas`.
 
 Prints ONE JSON line (rank 0) with the driver's contract plus `roofline` and `cpu_baseline`.
-The oracle is used here only for the `cpu_baseline` leg and the small accuracy check.
+The oracle is used here only for the `cpu_baseline` leg and the accuracy check that rides with it.
 """
 import argparse
 import json
@@ -30,32 +37,32 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
-RESULT_HOLDER = {}
-HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); 6290 GB/s measured copy
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); 6290 GB/s measured float4 copy
+HBM_COPY_GBS = 6290.0
 B_ALG_TOTAL = 301.0            # Filter 257 + Label 44 bytes/voxel
-# algorithmic bytes per voxel of one launch of each kernel group (DESIGN.md "Kernels")
+# SURVEY.md 8(d)'s pass-structured bytes per voxel, split over the kernel groups of this build (one launch each):
+#   per scale: Z pass 8 + fused Y+X pass 16 (the model's two axis passes) = 24;
+#              Hessian/eigen/Frangi pass 16 + mask pass 6 = 22, of which the walk (Gaussian read 4, frob_sq 4, mask pass 6)
+#              does 14 and the resolve kernel (running maximum 4 r + 4 w) 8;
+#   frame: product 9 + _mask_volume 18 = 27 (one fused epilogue here); Label 44.        5 (24 + 22) + 27 + 44 = 301
 B_ALG_KERNEL = {
-    "load": 8.0,               # 4 r + 4 w
-    "gauss_z": 8.0,            # one axis pass: 4 r + 4 w
-    "gauss_yx": 16.0,          # two axis passes of the model (4 r + 4 w each), one fused launch here
-    "gauss_y": 8.0,
-    "gauss_x": 8.0,
-    "hessian_stats": 4.0,      # 4 r
-    "vesselness": 22.0,        # Hessian/eigen/Frangi pass 16 + mask pass 6, one launch here
-    "finish": 9.0,             # 4 r + 1 r + 4 w
-    "mask_volume": 8.0,        # 4 r + 4 w (fused threshold + opening + multiply)
-    "label": 44.0,             # SURVEY.md 8(d) Label row
+    "load": 8.0, "gauss_z": 8.0, "gauss_yx": 16.0, "gauss_y": 8.0, "gauss_x": 8.0,
+    "hessian_stats": 4.0, "vesselness": 14.0, "vesselness_resolve": 8.0,
+    "finish": 9.0, "mask_volume": 27.0, "label": 44.0,
 }
-
-
-PMC_KERNEL_OF_GROUP = {"vesselness": "hessian_g_kernel<2", "hessian_stats": "hessian_g_kernel<0",
-                       "gauss_yx": "gauss_yx_kernel<4", "gauss_z": "gauss_march_kernel<0, 4"}
+B_ALG_PASS = 22.0              # walk + resolve: what SURVEY 8(d) calls the Hessian/eigen/Frangi + mask passes of a scale
+PMC_KERNEL_OF_GROUP = {"vesselness": ("hessian_v_kernel<2", "hessian_g_kernel<2"), "vesselness_resolve": ("vesselness_queue_kernel<true",),
+                       "hessian_stats": ("hessian_v_kernel<0", "hessian_g_kernel<0"), "gauss_yx": ("gauss_yx_tile_kernel<4",),
+                       "gauss_z": ("gauss_march_kernel<0, 4",)}
+GROUPS = ("load", "gauss_z", "gauss_yx", "gauss_y", "gauss_x", "sample", "hessian_stats", "vesselness", "vesselness_resolve",
+          "finish", "mask_volume", "label", "halo")
+SLAB_PLANES = 128              # owned planes per GPU of the Z-slab run: BASELINE config 4 / 8
+SLAB_YX = (2048, 2048)
 
 
 def pmc_traffic(group, shape):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r*_pmc_hbm_bytes_1024cube.json: separate FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE x2 on gfx950,
-    calibrated on the streaming convert kernel, x1024 for KB).  None when no matching profile is committed."""
+    """HBM bytes per launch of a kernel group from the committed rocprofv3 PMC passes (profiles/r*_pmc_hbm_bytes_1024cube.json:
+    separate FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE x2 on gfx950, x1024 for KB).  None without a matching profile."""
     import glob
     if tuple(shape) != (1024, 1024, 1024) or group not in PMC_KERNEL_OF_GROUP:
         return None
@@ -63,7 +70,7 @@ def pmc_traffic(group, shape):
     if not files:
         return None
     for rec in json.load(open(files[-1])):
-        if PMC_KERNEL_OF_GROUP[group] in rec["kernel"]:
+        if any(pat in rec["kernel"] for pat in PMC_KERNEL_OF_GROUP[group]):
             return round((2.0 * rec["fetch_size_kb_per_launch"] + rec["write_size_kb_per_launch"]) * 1024.0)
     return None
 
@@ -73,15 +80,16 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--shape", type=int, nargs=3, default=None, help="per-GPU slab Z Y X (default 1024^3)")
+    ap.add_argument("--shape", type=int, nargs=3, default=None, help="frame Z Y X (default 1024^3)")
     ap.add_argument("--seed", type=int, default=2345)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-shape", type=int, nargs=3, default=[96, 384, 384])
-    ap.add_argument("--with-io", action="store_true", help="also report the PCIe-inclusive rate (untimed otherwise)")
-    ap.add_argument("--no-zslab-check", action="store_true", help="N > 1: skip the RCCL Z-slab equality check")
-    ap.add_argument("--zslab-timeout", type=float, default=150.0)
-    ap.add_argument("--zslab-child", action="store_true", help="internal: run only the Z-slab check (spawned by the bench)")
-    ap.add_argument("--zslab-force", action="store_true", help="testing: run the check even with --share-device")
+    ap.add_argument("--cpu-shape", type=int, nargs=3, default=[256, 512, 512], help="CPU baseline sample (default: BASELINE config 2)")
+    ap.add_argument("--no-io", action="store_true", help="skip the host-to-host and streamed figures")
+    ap.add_argument("--no-zslab", action="store_true", help="N > 1: frame replicas only")
+    ap.add_argument("--zslab-timeout", type=float, default=420.0)
+    ap.add_argument("--zslab-child", action="store_true", help="internal: the Z-slab run (spawned by the bench)")
+    ap.add_argument("--zslab-planes", type=int, default=SLAB_PLANES)
+    ap.add_argument("--zslab-yx", type=int, nargs=2, default=list(SLAB_YX))
     ap.add_argument("--share-device", action="store_true",
                     help="testing only: every rank uses device 0 (exercise the multi-process control flow on a 1-GPU box)")
     return ap.parse_args()
@@ -94,7 +102,8 @@ def cpu_baseline(shape, seed):
     orc.build_c_helper()
     vol = make_volume(shape, seed)
     t0 = time.perf_counter()
-    fr = orc.filter_frame(vol, ISO_01)
+    run = orc.run_frame(vol, ISO_01)                      # filter_frame = run_frame + mask_volume, kept apart for the parity check
+    fr, thr = orc.mask_volume(run, return_thr=True) if float(np.sum(run)) > 0.0 else (run, None)
     t1 = time.perf_counter()
     lab = orc.label_frame(fr, ISO_01)
     t2 = time.perf_counter()
@@ -102,76 +111,131 @@ def cpu_baseline(shape, seed):
     return {
         "value": round(n / (t2 - t0) / 1e6, 4), "unit": "Mvoxel/s", "cores": 1, "kind": "port",
         "sample": f"oracle Filter+Label on a synthetic {shape[0]}x{shape[1]}x{shape[2]} float32 volume "
-                  f"(same generator, seed {seed}); Filter {n / (t1 - t0) / 1e6:.3f} Mvoxel/s, "
+                  f"(BASELINE config 2 when 256x512x512; same generator, seed {seed}); Filter {n / (t1 - t0) / 1e6:.3f} Mvoxel/s, "
                   f"Label {n / (t2 - t1) / 1e6:.2f} Mvoxel/s, {float(np.mean(fr > 0)) * 100:.2f}% voxels survive, "
-                  f"{int(lab.max())} labels; numpy oracle, 1 thread of {os.cpu_count()} host cores",
-    }, (vol, fr, lab)
+                  f"{int(lab.max())} labels; numpy oracle, 1 thread of {os.cpu_count()} host cores (numpy/scipy kernels are single-threaded here)",
+    }, (vol, run, fr, thr, lab)
 
 
-def accuracy_check(pl, vol, ref_fr, ref_lab):
-    """Every timing run also runs the parity check on the CPU-baseline volume."""
+def accuracy_check(pl, vol, ref_run, ref_fr, ref_thr, ref_lab):
+    """Every timing run also runs the parity check on the CPU-baseline volume: Frangi within
+    |a - b| <= 1e-4 |ref| + 1e-6 max|ref| with identical support -- outside the threshold-tie zone: a voxel whose
+    unmasked value lies within that tolerance of the percentile threshold of _mask_volume may fall on either side, and
+    the opening carries the decision to voxels within L1 distance 2 (counted and reported) --, labels bit-exact given
+    the oracle's Frangi frame, and the end-to-end label agreement."""
     from nellie_amd.synthetic import ISO_01
+    from oracle import nellie_oracle as orc
     pipe = pl.FramePipeline(vol.shape)
     pipe.filter(vol, pl.FilterParams(dim_res=ISO_01))
     fr = pipe.download_frangi()
     scale = float(ref_fr.max()) if ref_fr.size else 1.0
     err = np.abs(fr.astype(np.float64) - ref_fr)
-    ok = bool(np.all(err <= 1e-4 * np.abs(ref_fr) + 1e-6 * scale))
+    bad = err > 1e-4 * np.abs(ref_fr) + 1e-6 * scale
+    if ref_thr is None:
+        zone = np.zeros(ref_fr.shape, bool)
+    else:
+        zone = np.abs(ref_run - np.float32(ref_thr)) <= (2e-4 * abs(float(ref_thr)) + 1e-6 * float(ref_run.max()))
+    n_tie = int(zone.sum())
+    for _ in range(2):
+        zone = orc.binary_dilation6(zone)
+    used = int((zone & (fr != ref_fr)).sum())
+    ok_out = not bool((bad & ~zone).any()) and bool(np.array_equal((fr > 0) & ~zone, (ref_fr > 0) & ~zone))
+    pipe.label(pipe.frangi_threshold(), pl.min_area_pixels_of(ISO_01))
+    e2e = float(np.mean(pipe.download_labels() == ref_lab))
     pipe.upload_frangi(ref_fr)
     pipe.label(pipe.frangi_threshold(), pl.min_area_pixels_of(ISO_01))
     lab_ok = bool(np.array_equal(pipe.download_labels(), ref_lab))
     pipe.close()
-    return {"frangi_within_tol": ok, "frangi_max_norm_err": float(err.max() / scale) if scale else 0.0,
-            "labels_bit_exact_given_same_frangi": lab_ok}
+    return {"volume": list(vol.shape), "frangi_within_tol": ok_out, "frangi_max_norm_err_outside_tie_zone": float(err[~zone].max() / scale) if scale else 0.0,
+            "threshold_tie_voxels": n_tie, "voxels_differing_inside_tie_zone": used,
+            "percentile_threshold_rel_diff": abs(pipe.trace.percentile_thr - float(ref_thr)) / float(ref_thr) if ref_thr else 0.0,
+            "labels_bit_exact_given_same_frangi": lab_ok, "labels_end_to_end_match_fraction": round(e2e, 6)}
 
 
-def zslab_check(dist, rank, world, local_rank, gshape=None):
-    """
-    Z-slab decomposition of ONE volume across the ranks (nellie_amd/sharded.py): ghost planes, all-reduces and the
-    mask bit planes travel over RCCL/xGMI.  Every rank checks its own slab against a single-GPU run of the same
-    volume, bit for bit.  Small volume: this is a correctness + plumbing check on real hardware, not the metric.
-    """
-    import torch
-    from nellie_amd import hipnative
-    from nellie_amd import pipeline as pl
-    from nellie_amd.sharded import RcclComm, ShardedFramePipeline, slab_range
-    from nellie_amd.synthetic import ISO_01, make_volume
-    gshape = gshape or (48 * world, 192, 256)
-    p = pl.FilterParams(dim_res=ISO_01)
-    min_area = pl.min_area_pixels_of(ISO_01)
-    box = [hipnative.comm_unique_id() if rank == 0 else None]
-    dist.broadcast_object_list(box, src=0)
-
-    def host_gather(a):
-        out = [None] * world
-        dist.all_gather_object(out, np.asarray(a))
-        return np.concatenate(out)
-
-    o0, o1 = slab_range(gshape[0], world, rank)
-    vol = make_volume(gshape, 4242)
-    pipe = ShardedFramePipeline(gshape, rank, world, lambda ctx: RcclComm(ctx, world, rank, box[0], host_gather), p,
-                                device=local_rank)
-    pipe.load_input(vol[o0:o1])
-    t0 = time.perf_counter()
-    pipe.filter(None, p)
-    thr = pipe.frangi_threshold()
-    n = pipe.label(thr, min_area)
-    pipe.ctx.sync()
-    ms = (time.perf_counter() - t0) * 1e3
-    fr, lab = pipe.download_frangi(), pipe.download_labels()
-    halo_ms, halo_n = pipe.ctx.prof_get("halo")
+def io_figures(pl, hipnative, shape, p, min_area, vol):
+    """Host-to-host rates (SURVEY 8(d)'s metric definition): a frame in pinned host memory -> both outputs back in pinned host
+    memory (blocking transfers around the resident step), and BASELINE config 5 streamed (H2D / D2H overlapped with compute)."""
+    out = {}
+    n = float(np.prod(shape))
+    pin_in = hipnative.PinnedArray(shape, np.float32)
+    pin_fr = hipnative.PinnedArray(shape, np.float32)
+    pin_lab = hipnative.PinnedArray(shape, np.int32)
+    pin_in.array[...] = vol
+    pipe = pl.FramePipeline(shape)
+    for rep in range(2):                                         # the second pass is the figure (first touches of the pages done)
+        pipe.ctx.sync()
+        t0 = time.perf_counter()
+        pipe.load_input(pin_in.array)
+        pipe.filter(None, p)
+        pipe.label(pipe.frangi_threshold(), min_area)
+        pipe.download_frangi(out=pin_fr.array)
+        pipe.download_labels(out=pin_lab.array)
+        dt = time.perf_counter() - t0
     pipe.close()
-    single = pl.FramePipeline(gshape, device=local_rank)
-    single.filter(vol, p)
-    ok_fr = bool(np.array_equal(single.download_frangi()[o0:o1], fr))
-    single.label(single.frangi_threshold(), min_area)
-    ok_lab = bool(np.array_equal(single.download_labels()[o0:o1], lab))
-    single.close()
-    flags = torch.tensor([int(ok_fr), int(ok_lab)], dtype=torch.int64)
-    dist.all_reduce(flags, op=dist.ReduceOp.MIN)
-    return {"volume": list(gshape), "world": world, "halo_planes": pipe.halo, "labels": int(n),
-            "frangi_equal_to_single_gpu": bool(flags[0]), "labels_equal_to_single_gpu": bool(flags[1]),
-            "first_pass_ms": round(ms, 1), "transport": "RCCL ncclSend/ncclRecv + ncclAllReduce + ncclBroadcast"}
+    for a in (pin_in, pin_fr, pin_lab):
+        a.free()
+    out["pinned_host_to_host_mvoxel_s"] = round(n / dt / 1e6, 1)
+    out["pinned_host_to_host_ms"] = round(dt * 1e3, 1)
+    out["bytes_over_pcie_per_voxel"] = 12
+    # BASELINE config 5 (shortened): a 3-D+T stack of 128 x 512 x 512 frames, host arrays in, host arrays out
+    from nellie_amd.streaming import StreamedSegmenter
+    from nellie_amd.synthetic import make_volume
+    T, fs = 12, (128, 512, 512)
+    frames = np.stack([make_volume(fs, 4567 + t) for t in range(T)])
+    fr, lab = np.empty(frames.shape, np.float32), np.empty(frames.shape, np.int32)
+    seg = StreamedSegmenter(fs, frames.dtype, p)
+    seg.run(frames, fr, lab, flush=False)                        # first touch of the output pages
+    t0 = time.perf_counter()
+    seg.run(frames, fr, lab, flush=False)
+    dt = time.perf_counter() - t0
+    seg.close()
+    out["streamed_config5_mvoxel_s"] = round(frames.size / dt / 1e6, 1)
+    out["streamed_config5_ms_per_frame"] = round(dt / T * 1e3, 2)
+    out["streamed_config5_stack"] = [T] + list(fs)
+    return out
+
+
+def roofline_of(groups, shape, steps, ms_per_step):
+    n_local = float(np.prod(shape))
+    kernel_ms_per_step = sum(g["ms_total"] for g in groups.values()) / max(1, steps)
+    dom = max((g for g in groups if g in B_ALG_KERNEL), key=lambda g: groups[g]["ms_total"])
+    dom_bytes = B_ALG_KERNEL[dom] * n_local
+    dom_gbs = dom_bytes / (groups[dom]["ms_avg"] * 1e-3) / 1e9
+    traffic = pmc_traffic(dom, shape)
+    table = {}
+    for name, g in groups.items():
+        b = B_ALG_KERNEL.get(name)
+        t = pmc_traffic(name, shape)
+        table[name] = {"ms_per_step": round(g["ms_total"] / max(1, steps), 3), "launches_per_step": round(g["launches"] / max(1, steps), 2),
+                       "ms_avg": round(g["ms_avg"], 4),
+                       "alg_bytes_per_voxel_per_launch": b,
+                       "alg_gbs": None if b is None else round(b * n_local / (g["ms_avg"] * 1e-3) / 1e9, 1),
+                       "counter_bytes_per_launch": t,
+                       "counter_gbs": None if t is None else round(t / (g["ms_avg"] * 1e-3) / 1e9, 1)}
+    alg_sum = sum((B_ALG_KERNEL.get(k) or 0.0) * v["launches"] / max(1, steps) for k, v in groups.items())
+    out = {
+        "bound": "hbm", "kernel": dom, "achieved": round(dom_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(dom_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
+        "achieved_by_counters": None if traffic is None else round(traffic / (groups[dom]["ms_avg"] * 1e-3) / 1e9, 1),
+        "frac_of_measured_copy_peak": round(dom_gbs / HBM_COPY_GBS, 4),
+        "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": round(groups[dom]["ms_avg"], 4),
+        "groups": table, "algorithmic_bytes_per_voxel_accounted": round(alg_sum, 1),
+        "pipeline": {
+            "algorithmic_bytes_per_voxel": B_ALG_TOTAL,
+            "kernel_ms_per_step": round(kernel_ms_per_step, 3),
+            "achieved": round(B_ALG_TOTAL * n_local / (ms_per_step * 1e-3) / 1e9, 1),
+            "frac": round(B_ALG_TOTAL * n_local / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+        },
+    }
+    if "vesselness" in groups and "vesselness_resolve" in groups:
+        # the Hessian -> eigen -> Frangi pass of a scale as SURVEY 8(d) counts it: walk + resolve against 22 B/voxel
+        t_pass = groups["vesselness"]["ms_avg"] + groups["vesselness_resolve"]["ms_avg"]
+        tw, tr = pmc_traffic("vesselness", shape), pmc_traffic("vesselness_resolve", shape)
+        out["hessian_eigen_pass"] = {"alg_bytes_per_voxel": B_ALG_PASS, "ms_per_scale": round(t_pass, 4),
+                                     "achieved": round(B_ALG_PASS * n_local / (t_pass * 1e-3) / 1e9, 1),
+                                     "frac": round(B_ALG_PASS * n_local / (t_pass * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                     "achieved_by_counters": None if tw is None or tr is None else round((tw + tr) / (t_pass * 1e-3) / 1e9, 1)}
+    return out
 
 
 def main():
@@ -192,9 +256,7 @@ def main():
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd))
-    n_gpus = args.gpus
-    if world != n_gpus and world > 1:
-        n_gpus = world
+    n_gpus = world if world > 1 else args.gpus
     dist = None
     if world > 1:
         import torch.distributed as dist   # rendezvous + barrier + max-over-ranks only (control plane)
@@ -214,7 +276,7 @@ def main():
     p = pl.FilterParams(dim_res=ISO_01)
     min_area = pl.min_area_pixels_of(ISO_01)
 
-    # rank r owns frame r of the (N, Z, Y, X) stack
+    # ---- the resident-frame measurement: rank r owns frame r of an (N, Z, Y, X) stack (N = 1: THE headline figure)
     t_gen = time.perf_counter()
     vol = make_volume(shape, args.seed + rank)
     t_gen = time.perf_counter() - t_gen
@@ -251,75 +313,46 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # per-kernel-group HIP-event times over the timed region (this rank)
     groups = {}
-    # "vesselness" = the marching Hessian pass of a scale (statistics + masks + queue; one launch per scale),
-    # "vesselness_resolve" = the dense eigen/Frangi kernel over its queue; "hessian_stats" only appears when a
-    # scale falls back to the two-pass scheme
-    for name in ("load", "gauss_z", "gauss_yx", "gauss_y", "gauss_x", "sample", "hessian_stats", "vesselness", "vesselness_resolve", "finish", "mask_volume", "label"):
+    for name in GROUPS:
         ms, k = pipe.ctx.prof_get(name)
         if k:
             groups[name] = {"ms_total": ms, "launches": k, "ms_avg": ms / k}
     n_local = float(np.prod(shape))
-    n_global = n_local * n_gpus
-    kernel_ms_per_step = sum(g["ms_total"] for g in groups.values()) / max(1, args.steps)
     ms_per_step = elapsed / args.steps * 1e3
-    dom = max((g for g in groups if g in B_ALG_KERNEL), key=lambda g: groups[g]["ms_total"])
-    dom_bytes = B_ALG_KERNEL[dom] * n_local
-    dom_gbs = dom_bytes / (groups[dom]["ms_avg"] * 1e-3) / 1e9
-    roofline = {
-        "bound": "hbm", "kernel": dom, "achieved": round(dom_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(dom_gbs / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dom, shape),
-        "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": round(groups[dom]["ms_avg"], 4),
-        "pipeline": {
-            "algorithmic_bytes_per_voxel": B_ALG_TOTAL,
-            "kernel_ms_per_step": round(kernel_ms_per_step, 3),
-            # over the wall time of a step (host round trips included): the resolve kernel overlaps the Gaussian of
-            # the next scale on a side stream, so the per-group times above add up to more than the step takes
-            "achieved": round(B_ALG_TOTAL * n_local / (ms_per_step * 1e-3) / 1e9, 1),
-            "frac": round(B_ALG_TOTAL * n_local / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-        },
-        "groups_ms_per_step": {k: round(v["ms_total"] / max(1, args.steps), 3) for k, v in groups.items()},
-    }
-
-    io = None
-    if args.with_io and world == 1:
-        pipe.ctx.sync()
-        t0 = time.perf_counter()
-        pipe.load_input(vol)
-        step()
-        fr = pipe.download_frangi()
-        lab = pipe.download_labels()
-        io = {"pcie_inclusive_mvoxel_s": round(n_local / (time.perf_counter() - t0) / 1e6, 1)}
-        del fr, lab
-
+    roofline = roofline_of(groups, shape, args.steps, ms_per_step)
     tr = pipe.trace
     fast_div = int(pipe.ctx.info("fast_div"))
+    tile_rows = int(pipe.ctx.info("hessian_tile_rows"))
     pipe.close()
+
+    io = None
+    if not args.no_io and world == 1:
+        io = io_figures(pl, hipnative, shape, p, min_area, vol)
+    del vol
 
     out = None
     if rank == 0:
         cpu = None
         acc = None
         if not args.no_cpu_baseline:
-            cpu, (cvol, cfr, clab) = cpu_baseline(tuple(args.cpu_shape), 1234)
-            acc = accuracy_check(pl, cvol, cfr, clab)
-        value = n_global * args.steps / elapsed / 1e6
+            cpu, (cvol, crun, cfr, cthr, clab) = cpu_baseline(tuple(args.cpu_shape), 1234)
+            acc = accuracy_check(pl, cvol, crun, cfr, cthr, clab)
+        replica_value = n_local * n_gpus * args.steps / elapsed / 1e6
         out = {
-            "metric": "Mvoxel/s multiscale Frangi (5 sigma) + Label, float32", "value": round(value, 1),
+            "metric": "Mvoxel/s multiscale Frangi (5 sigma) + Label, float32", "value": round(replica_value, 1),
             "unit": "Mvoxel/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
                 "workload": f"synthetic {shape[0]}x{shape[1]}x{shape[2]} float32 volume "
                             f"(N(100,5) noise + Gaussian tube segments, seed {args.seed}), 0.1 um isotropic, "
-                            f"{len(p.resolved_sigmas())}-scale Frangi + Label, full hot path per step"
-                            + ("" if n_gpus == 1 else f"; 3-D+T stack of {n_gpus} such frames, one frame per GPU"),
-                "voxels": int(n_global), "per_gpu_shape": list(shape),
+                            f"{len(p.resolved_sigmas())}-scale Frangi + Label, full hot path per step, frame resident in HBM",
+                "voxels": int(n_local * n_gpus), "per_gpu_shape": list(shape),
                 "survival_fraction": round(tr.n_positive / n_local, 5), "labels": int(n_labels),
                 "mask_fraction_per_scale": [round(sc.mask_count / n_local, 4) for sc in tr.scales],
                 "one_pass_scales": int(sum(1 for sc in tr.scales if sc.one_pass)),
-                "host_gen_s": round(t_gen, 1), "h2d_s": round(t_up, 2), "fast_div_proven": fast_div,
+                "host_gen_s": round(t_gen, 1), "h2d_s": round(t_up, 2), "fast_div_proven": fast_div, "hessian_tile_rows": tile_rows,
             },
             "roofline": roofline, "cpu_baseline": cpu,
         }
@@ -332,17 +365,30 @@ def main():
         print(json.dumps(out), flush=True)
         return
 
-    # N > 1: optionally prove the Z-slab decomposition on the real GPUs (RCCL).  It runs in a CHILD process per rank
-    # (own rendezvous on another port, own HIP contexts), so that nothing in the communication path -- a hang inside a
-    # collective, a crash inside the library -- can cost the measured line: the parent waits with a timeout, kills its
-    # child if need be, and rank 0 prints the line either way.
+    # ---- N > 1: the measured line is the Z-slab run of ONE volume over RCCL.  It runs in a CHILD process per rank (own
+    # rendezvous on another port, own HIP contexts), so that nothing in the communication path -- a hang inside a collective,
+    # a crash inside the library -- can cost the line: the parent waits with a timeout, kills its child if need be, and
+    # rank 0 prints the line either way.
     zslab = None
-    if not args.no_zslab_check and (not args.share_device or args.zslab_force):
+    if not args.no_zslab:
         dist.barrier()                                     # rank 0 comes here late (CPU baseline): start the children together
         zslab = run_zslab_child(args, rank)
     if rank == 0:
+        out["replicas"] = {"value": out["value"], "unit": "Mvoxel/s", "ms_per_step": out["ms_per_step"],
+                           "workload": f"3-D+T stack of {n_gpus} frames of {shape[0]}x{shape[1]}x{shape[2]}, one frame per GPU, no data-path collective"}
         if zslab is not None:
             out["zslab"] = zslab
+            if "error" not in zslab and zslab.get("value"):
+                out["value"] = zslab["value"]
+                out["ms_per_step"] = zslab["ms_per_step"]
+                out["config"]["workload"] = zslab["workload"]
+                out["config"]["voxels"] = zslab["voxels"]
+                out["config"]["per_gpu_shape"] = zslab["per_gpu_owned_shape"]
+                out["config"]["parallelism"] = f"zslab{n_gpus}"
+                for k in ("survival_fraction", "labels", "mask_fraction_per_scale", "one_pass_scales"):
+                    out["config"][k] = zslab.get(k)
+            else:
+                out["config"]["workload"] += f"; 3-D+T stack of {n_gpus} such frames, one frame per GPU (Z-slab run failed: see zslab.error)"
         print(json.dumps(out), flush=True)
     sys.stdout.flush()
     os._exit(0)      # skip collective teardown: nothing after the JSON line may hang the job
@@ -354,13 +400,14 @@ def run_zslab_child(args, rank):
     env = dict(os.environ)
     env["MASTER_PORT"] = str((int(env.get("MASTER_PORT", "29500")) - 1024 + 101) % 60000 + 1024)
     env.pop("TORCHELASTIC_USE_AGENT_STORE", None)          # the children rendezvous among themselves (rank 0 hosts the store)
-    cmd = [sys.executable, os.path.abspath(__file__), "--zslab-child", "--gpus", str(args.gpus)]
+    cmd = [sys.executable, os.path.abspath(__file__), "--zslab-child", "--gpus", str(args.gpus), "--steps", str(args.steps),
+           "--warmup", str(args.warmup), "--zslab-planes", str(args.zslab_planes), "--zslab-yx", str(args.zslab_yx[0]), str(args.zslab_yx[1])]
     if args.share_device:
         cmd.append("--share-device")
     try:
         proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, start_new_session=True, text=True)
     except OSError as exc:
-        return {"error": f"could not start the check: {exc}"[:300]}
+        return {"error": f"could not start the Z-slab run: {exc}"[:300]}
     try:
         so, se = proc.communicate(timeout=args.zslab_timeout)
     except subprocess.TimeoutExpired:
@@ -381,7 +428,106 @@ def run_zslab_child(args, rank):
                 return json.loads(line)
             except ValueError:
                 break
-    return {"error": f"child exit code {proc.returncode}: {se.strip()[-300:]}"}
+    return {"error": f"child exit code {proc.returncode}: {se.strip()[-400:]}"}
+
+
+def zslab_run(dist, rank, world, local_rank, args):
+    """ONE volume over `world` GPUs (nellie_amd/sharded.py).  First a small volume against a single-GPU run of the same
+    volume (bit-for-bit equality of both outputs on every rank), then the timed run at 128 owned planes of 2048 x 2048 per GPU."""
+    import torch
+    from nellie_amd import hipnative
+    from nellie_amd import pipeline as pl
+    from nellie_amd.sharded import RcclComm, ShardedFramePipeline, slab_range
+    from nellie_amd.synthetic import ISO_01, make_volume
+    p = pl.FilterParams(dim_res=ISO_01)
+    min_area = pl.min_area_pixels_of(ISO_01)
+    def fresh_uid():                    # an RCCL unique id opens exactly one communicator
+        box = [hipnative.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        return box[0]
+
+    res = {"world": world, "transport": "RCCL: ncclSend/ncclRecv (ghost planes, bit planes), ncclAllReduce (scalars, histograms), "
+                                        "ncclAllGather (threshold samples, slab run tables)"}
+
+    # ---- (1) equality on a small volume
+    gshape = (48 * world, 192, 256)
+    o0, o1 = slab_range(gshape[0], world, rank)
+    vol = make_volume(gshape, 4242)
+    uid = fresh_uid()
+    pipe = ShardedFramePipeline(gshape, rank, world, lambda ctx: RcclComm(ctx, world, rank, uid), p, device=local_rank)
+    ones = pipe.comm.allreduce(np.array([1], np.int64), "sum")
+    res["rccl_ranks"] = int(ones[0])
+    pipe.load_input(vol[o0:o1])
+    pipe.filter(None, p)
+    n_small = pipe.label(pipe.frangi_threshold(), min_area)
+    fr, lab = pipe.download_frangi(), pipe.download_labels()
+    pipe.close()
+    single = pl.FramePipeline(gshape, device=local_rank)
+    single.filter(vol, p)
+    ok_fr = bool(np.array_equal(single.download_frangi()[o0:o1], fr))
+    n_ref = single.label(single.frangi_threshold(), min_area)
+    ok_lab = bool(np.array_equal(single.download_labels()[o0:o1], lab)) and n_ref == n_small
+    single.close()
+    flags = torch.tensor([int(ok_fr), int(ok_lab)], dtype=torch.int64)
+    dist.all_reduce(flags, op=dist.ReduceOp.MIN)
+    res["equality_check"] = {"volume": list(gshape), "labels": int(n_small), "frangi_equal": bool(flags[0]), "labels_equal": bool(flags[1])}
+    res["frangi_equal"], res["labels_equal"] = bool(flags[0]), bool(flags[1])
+
+    # ---- (2) the timed run
+    planes = int(args.zslab_planes)
+    gshape = (planes * world, int(args.zslab_yx[0]), int(args.zslab_yx[1]))
+    o0, o1 = slab_range(gshape[0], world, rank)
+    t_gen = time.perf_counter()
+    own = make_volume((o1 - o0,) + gshape[1:], 3456, z_offset=o0, global_nz=gshape[0])
+    t_gen = time.perf_counter() - t_gen
+    uid2 = fresh_uid()
+    pipe = ShardedFramePipeline(gshape, rank, world, lambda ctx: RcclComm(ctx, world, rank, uid2), p, device=local_rank)
+    pipe.load_input(own)
+    del own
+
+    def step():
+        pipe.filter(None, p)
+        return pipe.label(pipe.frangi_threshold(), min_area)
+
+    for _ in range(max(1, args.warmup)):
+        step()
+    pipe.ctx.prof_reset()
+    pipe.ctx.prof_enable(True)
+    pipe.ctx.sync()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        n_labels = step()
+    pipe.ctx.sync()
+    dist.barrier()
+    elapsed = time.perf_counter() - t0
+    pipe.ctx.prof_enable(False)
+    t = torch.tensor([elapsed], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    groups = {}
+    for name in GROUPS:
+        ms, k = pipe.ctx.prof_get(name)
+        if k:
+            groups[name] = round(ms / args.steps, 3)
+    crc = __import__("zlib").crc32(pipe.download_labels().tobytes())
+    n_global = float(np.prod(gshape))
+    tr = pipe.trace
+    res.update({
+        "value": round(n_global * args.steps / elapsed / 1e6, 1), "unit": "Mvoxel/s", "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "workload": f"ONE synthetic {gshape[0]}x{gshape[1]}x{gshape[2]} float32 volume (seed 3456"
+                    + (", BASELINE config 4" if gshape == (1024, 2048, 2048) else f", the first {gshape[0]} planes' worth of BASELINE config 4's generator")
+                    + f") cut into {world} Z slabs of {planes} owned planes + {pipe.halo} ghost planes per interior side; "
+                      "5-scale Frangi + Label (no replication), full hot path per step, slabs resident in HBM",
+        "voxels": int(n_global), "per_gpu_owned_shape": [planes, gshape[1], gshape[2]], "halo_planes": pipe.halo,
+        "halo_ms": groups.get("halo"), "groups_ms_per_step_rank0": groups, "labels": int(n_labels),
+        "survival_fraction": round(tr.n_positive / n_global, 5),
+        "mask_fraction_per_scale": [round(sc.mask_count / n_global, 4) for sc in tr.scales],
+        "one_pass_scales": int(sum(1 for sc in tr.scales if sc.one_pass)), "host_gen_s": round(t_gen, 1),
+        "labels_crc32_rank0": int(crc),
+    })
+    pipe.close()
+    return res
 
 
 def zslab_child_main(args):
@@ -390,16 +536,16 @@ def zslab_child_main(args):
     local_rank = 0 if args.share_device else int(os.environ.get("LOCAL_RANK", "0"))
     import datetime
     import torch.distributed as dist
-    dist.init_process_group(backend="gloo", init_method="env://", timeout=datetime.timedelta(seconds=120))
-    fake = os.environ.get("NELLIE_ZSLAB_FAKE", "")      # tests of the isolation: "crash" (rank 1 aborts), "hang"
+    dist.init_process_group(backend="gloo", init_method="env://", timeout=datetime.timedelta(seconds=180))
+    fake = os.environ.get("NELLIE_ZSLAB_FAKE", "")      # tests of the isolation: "crash" (the last rank aborts), "hang"
     if fake == "crash" and rank == world - 1:
         os.abort()
     if fake == "hang":
         time.sleep(1e6)
     try:
-        res = zslab_check(dist, rank, world, local_rank)
+        res = zslab_run(dist, rank, world, local_rank, args)
     except Exception as exc:  # noqa: BLE001
-        res = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+        res = {"error": f"{type(exc).__name__}: {exc}"[:400]}
     if rank == 0:
         print(json.dumps(res), flush=True)
     sys.stdout.flush()

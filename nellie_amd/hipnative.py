@@ -436,6 +436,8 @@ class Context:
             keep.append(a); lab_p = _ptr(a)
         if intensity is not None:
             b = np.ascontiguousarray(intensity)
+            if b.dtype not in DTYPE_CODES:          # float16, bool, big-endian maps ...: as filter_load / input_load do
+                b = b.astype(np.float32)
             assert b.shape == self.shape
             keep.append(b); int_p = _ptr(b); code = DTYPE_CODES[b.dtype]
         self._call("nl_markers_begin", lab_p, int_p, code)

@@ -53,6 +53,19 @@ def _canonical(data, axes):
     return data, "".join(axes_list)
 
 
+def detailed_output_name(name, axes, dim_res, ch, t_start, t_end):
+    """Nellie's "detailed" output name (verifier.py:596-613): <name>-<axes>-<axis><resolution>_...-ch<c>[-t<a>_to_<b>], the
+    resolutions rounded to four decimals with '.' written as 'p', axes without a resolution entry (C) left out, the time
+    range present when the source has a T axis."""
+    parts = []
+    for axis in axes:
+        if axis in dim_res:
+            value = dim_res[axis]
+            parts.append(axis + ("None" if value is None else str(round(value, 4)).replace(".", "p")))
+    t_range = f"-t{t_start}_to_{t_end}" if "T" in axes else ""
+    return f"{name}-{axes}-{'_'.join(parts)}-ch{ch}{t_range}"
+
+
 class ImInfo:
     def __init__(self, source, dim_res=None, axes=None, output_dir=None, name=None, ch=0):
         """
@@ -91,19 +104,18 @@ class ImInfo:
         self.nellie_necessities_dir = os.path.join(self.output_dir, "nellie_necessities")
         os.makedirs(self.nellie_necessities_dir, exist_ok=True)
         # "detailed" naming (verifier.py:596-613), built from the SOURCE axes like FileInfo does
-        t_text = f"-t0_to_{self.shape[0] - 1}" if "T" in src_axes else ""
-        dims = []
-        for ax in src_axes:
-            if ax in self.dim_res:
-                v = self.dim_res[ax]
-                dims.append(f"{ax}{'None' if v is None else str(round(v, 4)).replace('.', 'p')}")
-        output_name = f"{name}-{src_axes}-{'_'.join(dims)}-ch{ch}{t_text}"
+        output_name = detailed_output_name(name, src_axes, self.dim_res, ch, 0, self.shape[0] - 1)
         self.user_output_path_no_ext = os.path.join(self.output_dir, output_name)
         self.nellie_necessities_output_path_no_ext = os.path.join(self.nellie_necessities_dir, output_name)
         self.im_path = self.nellie_necessities_output_path_no_ext + ".ome.tif"
         # the re-saved, canonical input (verifier.py:620-695); always T[Z]YX on disk here
         shape4 = self._shape4()
-        if not os.path.exists(self.im_path):
+        # A file source is re-saved once (the reference keys its cache on the source file, verifier.py:620-628).  An in-memory
+        # array or a .npy has no such identity -- a second ImInfo built from DIFFERENT pixels of the same shape would find
+        # the first one's canonical copy under the same name and the stages would silently process stale data -- so for
+        # those the canonical input is always rewritten.
+        from_file = isinstance(source, (str, os.PathLike)) and not os.fspath(source).lower().endswith(".npy")
+        if not (from_file and os.path.exists(self.im_path)):
             ome_tiff.create(self.im_path, shape4, data.dtype, self.dim_res, "input", data=np.asarray(data).reshape(shape4))
         self.im = self.get_memmap(self.im_path)
         self.no_z = not ("Z" in self.axes and self.shape[self.axes.index("Z")] > 1)

@@ -68,6 +68,9 @@ class Filter:
         self.frob_thresh_division = frob_thresh_division
         self.viewer = viewer
         self.low_memory = low_memory
+        if low_memory:
+            logger.info('Filter: low_memory is accepted and ignored by the HIP backend (a frame stays resident in HBM; large '
+                        'volumes shard over Z instead of being chunked, which would change the result).')
         self.max_chunk_voxels = int(max_chunk_voxels)
         self.max_threshold_samples = int(max_threshold_samples)
         self.work_dtype = "float32"

@@ -57,6 +57,9 @@ class Label:
         self.viewer = viewer
         self.chunk_z = None           # accepted, ignored (see module docstring)
         self._user_chunk_z = chunk_z
+        if chunk_z is not None or low_memory:
+            logger.info('Label: chunk_z / low_memory are accepted and ignored by the HIP backend: it always produces the '
+                        'full-volume result (the reference\'s chunked mode fills holes and filters areas per chunk).')
         self.flush_interval = max(1, int(flush_interval))
         min_radius_um = float(min_radius_um)
         x_res = self.im_info.dim_res.get("X") or 1.0

@@ -23,7 +23,7 @@ from nellie_amd.utils.base_logger import logger
 class Markers:
     def __init__(self, im_info, num_t=None, min_radius_um=0.20, max_radius_um=1, use_im="distance", num_sigma=5,
                  viewer=None, prefer_gpu=True, peak_min_distance=2, device="auto", low_memory=False,
-                 max_chunk_voxels=int(1e6)):
+                 max_chunk_voxels=int(1e6), device_index: int = 0):
         self.im_info = im_info
         self.num_t = num_t
         if self.im_info.no_t:
@@ -55,7 +55,7 @@ class Markers:
             raise RuntimeError("GPU backend requested but no HIP device / libnellie_hip.so is available.")
         self.device = device or "auto"
         self.device_type = "hip"
-        self.device_index = 0
+        self.device_index = int(device_index)
         self.use_gpu = True
         self.peak_min_distance = peak_min_distance
         self.low_memory = bool(low_memory)

@@ -17,6 +17,8 @@ behind them: `force_cpu=True` and a missing HIP device raise.
 """
 from __future__ import annotations
 
+import zlib
+
 import numpy as np
 
 from nellie_amd import hipnative
@@ -71,6 +73,7 @@ class HipNetworkKernels:
             skel = (skel > 0).astype(np.int32)
         out, self.n_skeleton_voxels = ctx.skel_pixel_class(skel)
         self._pixel_class_resident = out
+        self._pixel_class_crc = zlib.crc32(np.ascontiguousarray(out).view(np.uint8))
         return out
 
     def _get_branch_skel_labels(self, pixel_class, force_cpu: bool = False):
@@ -79,8 +82,11 @@ class HipNetworkKernels:
         pc = np.asarray(pixel_class)
         ctx = self._hip_context(pc.shape)
         resident = getattr(self, "_pixel_class_resident", None)
+        checksum = getattr(self, "_pixel_class_crc", None)
         self._pixel_class_resident = None
-        if resident is pixel_class:               # the array the previous call returned: its bits are still on the device
+        # the array the previous call returned, UNCHANGED (the caller may have cleaned junctions in place): its bits are
+        # still on the device.  Identity alone is not enough; the checksum costs a fraction of the upload it saves.
+        if resident is pixel_class and checksum is not None and checksum == zlib.crc32(np.ascontiguousarray(pc).view(np.uint8)):
             labels, self.n_branches = ctx.skel_branch_labels(None)
             return labels.reshape(pc.shape)
         if pc.dtype != np.uint8:

@@ -51,7 +51,7 @@ def estimate_frame_bytes(im_info):
 
 
 def frame_fits_on_device(shape_zyx, device: int = 0) -> bool:
-    """The engine needs nl_ctx_bytes(shape) (19 B/voxel) of HBM; the reference's 6x-frame heuristic
+    """The engine needs nl_ctx_bytes(shape) (35 B/voxel: four float32 volumes, three byte volumes and the eigen queue) of HBM; the reference's 6x-frame heuristic
     (adaptive_run.py:88-100) is replaced by the exact figure."""
     lib = hipnative.load()
     need = lib.cdll.nl_ctx_bytes(*[int(s) for s in shape_zyx])

@@ -352,6 +352,40 @@ def network_cases():
     case("network_empty_5x6x7", np.zeros((5, 6, 7), np.int32))
 
 
+def naming_cases():
+    """File names of the on-disk layer as the reference builds them (nellie/im_info/verifier.py:574-618, 805-838):
+    FileInfo._get_output_path / ImInfo.create_output_path called on a plain namespace (pure string logic; the TIFF
+    modules it never touches are stubbed).  Stored as JSON: inputs and the resulting strings, nothing else."""
+    import json
+    from types import SimpleNamespace
+    _import_reference()
+    from nellie.im_info.verifier import FileInfo, ImInfo
+    cases = []
+    specs = [
+        ("cell", "TZYX", {"X": 0.1, "Y": 0.1, "Z": 0.25, "T": 1.5}, 0, 0, 1),
+        ("my.sample", "ZYX", {"X": 0.108333, "Y": 0.108333, "Z": 0.3, "T": None}, 2, 0, 0),
+        ("a-b_c", "TYX", {"X": 0.065, "Y": 0.065, "Z": None, "T": 0.05}, 1, 3, 17),
+        ("img", "YX", {"X": 1.0, "Y": 2.0, "Z": None, "T": None}, 0, 0, 0),
+        ("deep", "TZYX", {"X": 0.12345678, "Y": 1e-5, "Z": 12.0, "T": 100.0}, 0, 0, 63),
+        ("odd", "TCZYX", {"X": 0.2, "Y": 0.2, "Z": 0.5, "T": 2.0}, 3, 5, 9),
+    ]
+    for name, axes, dim_res, ch, t0, t1 in specs:
+        fi = SimpleNamespace(output_naming="detailed", filename_no_ext=name, axes=axes, dim_res=dict(dim_res), ch=ch, t_start=t0, t_end=t1,
+                             output_dir="OUT", nellie_necessities_dir=os.path.join("OUT", "nellie_necessities"))
+        FileInfo._get_output_path(fi)
+        ii = SimpleNamespace(file_info=fi, pipeline_paths={})
+        paths = {}
+        for stage, ext, for_nellie in (("im_preprocessed", ".ome.tif", True), ("im_instance_label", ".ome.tif", True),
+                                       ("features_organelles", ".csv", False)):
+            paths[stage] = ImInfo.create_output_path(ii, stage, ext, for_nellie=for_nellie)
+        cases.append(dict(name=name, axes=axes, dim_res=dim_res, ch=ch, t_start=t0, t_end=t1,
+                          user_no_ext=fi.user_output_path_no_ext, necessities_no_ext=fi.nellie_necessities_output_path_no_ext,
+                          ome_output_path=fi.ome_output_path, pipeline_paths=paths))
+    with open(os.path.join(HERE, "naming_cases.json"), "w") as f:
+        json.dump(cases, f, indent=1)
+    print("naming_cases.json", len(cases))
+
+
 def run_label_case(Label, vol, frangi, dim_res, **kw):
     lab = Label(im_info(frangi.shape, dim_res), num_t=1, device="cpu", **kw)
     ithr, fthr = lab._compute_frame_thresholds(vol, frangi)
@@ -414,6 +448,9 @@ def main():
         return
     if "--only-network" in sys.argv:
         network_cases()
+        return
+    if "--only-naming" in sys.argv:
+        naming_cases()
         return
     from nellie_amd.synthetic import make_volume, ISO_01, ANISO_03
 
@@ -491,6 +528,7 @@ def main():
     markers_cases()
     markers_cases_more()
     network_cases()
+    naming_cases()
 
 
 if __name__ == "__main__":

@@ -112,7 +112,59 @@ def test_two_slabs_equal_one_volume_at_1024_cube(full_run):
         assert np.array_equal(lab, ref), f"slab [{o0},{o1}): {int((lab != ref).sum())} label voxels differ, first at {np.argwhere(lab != ref)[:4].tolist()}"
 
 
-@pytest.mark.skipif(os.environ.get("NELLIE_TEST_C4", "0") != "1", reason="opt-in (NELLIE_TEST_C4=1): ~170 GB of HBM, ~60 GB of host RAM, minutes")
+def test_c2_parity_at_its_own_size(hip):
+    """BASELINE config 2 (256 x 512 x 512, seed 1234) against the oracle at its own size: Frangi within
+    |a - b| <= 1e-4 |ref| + 1e-6 max|ref| with identical support (the threshold-tie relaxation of the golden tests is
+    available but capped), labels bit-exact given the oracle's Frangi frame, thresholds equal."""
+    from nellie_amd import pipeline as pl
+    from nellie_amd.synthetic import ISO_01, make_volume
+    from oracle import nellie_oracle as orc
+    from test_hip_parity import assert_masked_close
+    shape = (256, 512, 512)
+    vol = make_volume(shape, 1234)
+    run_ref = orc.run_frame(vol, ISO_01)
+    ref, thr_ref = orc.mask_volume(run_ref, return_thr=True)
+    p = pl.FilterParams(dim_res=ISO_01)
+    pipe = pl.FramePipeline(shape)
+    pipe.filter(vol, p)
+    fr = pipe.download_frangi()
+    assert abs(pipe.trace.percentile_thr - float(thr_ref)) <= 2e-4 * float(thr_ref)
+    assert_masked_close(fr, ref, run_ref, thr_ref, "C2 256x512x512")
+    ref_lab, ref_lthr = orc.label_frame(ref, ISO_01, return_thr=True)
+    pipe.upload_frangi(ref)
+    lthr = pipe.frangi_threshold()
+    assert lthr == ref_lthr
+    n = pipe.label(lthr, pl.min_area_pixels_of(ISO_01))
+    assert np.array_equal(pipe.download_labels(), ref_lab) and n == int(ref_lab.max()) and n >= 3
+    pipe.close()
+
+
+def test_c5_streamed_equals_per_frame_at_its_frame_size(hip):
+    """BASELINE config 5 at its own frame size (128 x 512 x 512, seeds 4567 + t), 8 frames: the double-buffered streamer
+    (H2D of frame t+1 and D2H of frame t-1 on their own HIP streams while frame t computes) writes the arrays the
+    frame-by-frame path writes."""
+    from nellie_amd import pipeline as pl
+    from nellie_amd.streaming import StreamedSegmenter
+    from nellie_amd.synthetic import ISO_01, make_volume
+    T, fs = 8, (128, 512, 512)
+    frames = np.stack([make_volume(fs, 4567 + t) for t in range(T)])
+    p = pl.FilterParams(dim_res=ISO_01)
+    ma = pl.min_area_pixels_of(ISO_01)
+    fr, lab = np.empty(frames.shape, np.float32), np.empty(frames.shape, np.int32)
+    pipe = pl.FramePipeline(fs)
+    for t in range(T):
+        pipe.filter(frames[t], p)
+        pipe.label(pipe.frangi_threshold(), ma)
+        pipe.download_frangi(out=fr[t]); pipe.download_labels(out=lab[t])
+    pipe.close()
+    fr2, lab2 = np.empty_like(fr), np.empty_like(lab)
+    seg = StreamedSegmenter(fs, frames.dtype, p)
+    seg.run(frames, fr2, lab2, flush=False)
+    seg.close()
+    assert np.array_equal(fr, fr2) and np.array_equal(lab, lab2)
+    assert all(int(lab[t].max()) >= 1 for t in range(T)) and (fr >= 0).all()
+
+
 def test_c4_volume_partition_invariance(hip):
     """BASELINE.json's 8-GPU configuration -- ONE (1024, 2048, 2048) volume, 4.29e9 voxels -- on a single MI355X: the
     eight 128-plane slabs of the 8-GPU decomposition (eight contexts on this device, 288 GB of HBM hold them all) and
@@ -120,8 +172,14 @@ def test_c4_volume_partition_invariance(hip):
     import json
     import time
     free, _ = hip.device_mem_info(0)
-    if free < 200e9:
-        pytest.skip("needs ~170 GB of free HBM")
+    if free < 200e9 or os.environ.get("NELLIE_TEST_C4", "1") == "0":
+        pytest.skip("needs ~170 GB of free HBM (and NELLIE_TEST_C4 != 0)")
+    try:
+        import psutil
+        if psutil.virtual_memory().available < 90e9:
+            pytest.skip("needs ~80 GB of free host RAM")
+    except ImportError:
+        pass
     from nellie_amd.synthetic import make_volume
     shape = (1024, 2048, 2048)
     vol = make_volume(shape, 3456)

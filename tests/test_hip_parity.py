@@ -31,6 +31,9 @@ def assert_frangi_close(got, ref, what=""):
     assert np.array_equal(got > 0, ref > 0), f"{what}: support differs"
 
 
+TIE_ZONE_USED = {}      # what -> voxels that used the relaxation below (printed by test_tie_zone_report)
+
+
 def assert_masked_close(got, ref, run_frame_ref, thr_ref, what="frangi"):
     """
     After _mask_volume (filtering.py:964-966) the frame went through `> percentile` and a binary
@@ -53,6 +56,11 @@ def assert_masked_close(got, ref, run_frame_ref, thr_ref, what="frangi"):
     inside = zone & (got != ref)
     ok = (got[inside] == 0) | (np.abs(got[inside] - run_frame_ref[inside]) <= RTOL * np.abs(run_frame_ref[inside]) + ATOL_REL * run_frame_ref.max())
     assert ok.all(), f"{what}: unexplained values inside the threshold-tie zone"
+    # the relaxation is for a handful of voxels next to an exact tie; a regression that widens the zone must not pass
+    used = int(inside.sum())
+    TIE_ZONE_USED[what] = max(TIE_ZONE_USED.get(what, 0), used)
+    cap = 16 + int(2e-4 * np.count_nonzero(ref))
+    assert used <= cap, f"{what}: {used} voxels needed the threshold-tie relaxation (cap {cap})"
 
 
 def _params(g):
@@ -723,3 +731,39 @@ def test_network_steps_large_vs_oracle(hip):
             k._get_pixel_class(skel, force_cpu=True)
     finally:
         k.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(40, 300, 1000), (24, 200, 1024), (12, 70, 960), (20, 64, 130)])
+def test_label_dense_structure_on_the_x_faces(hip, shape):
+    """Dense specks, shells and blobs hugging x = 0 and x = nx-1 (rows of 15-16 mask words, with and without a partial last
+    word), three runs: bit-exact against the oracle every time.  Found at 1024^3: the first majority-filter kernel gave
+    nondeterministic bits in the column x = nx-1 for some volume sizes (right inputs, right source, wrong code: it passed
+    when compiled for other shapes of the same test) -- the kernel was rewritten with 32-bit indexing and an explicit
+    last-word clamp, and this test pins the faces."""
+    from nellie_amd import pipeline as pl
+    rng = np.random.default_rng(shape[2])
+    fr = np.zeros(shape, np.float32)
+    m = rng.random((shape[0], shape[1], 8)) < 0.25
+    fr[:, :, -8:][m] = 1.0
+    fr[:, :, :8][m[:, :, ::-1]] = 1.0
+    zz, yy, xx = np.meshgrid(*[np.arange(s) for s in shape], indexing="ij", sparse=True)
+    for _ in range(25):
+        c = [rng.uniform(0, shape[0]), rng.uniform(0, shape[1]), rng.choice([abs(rng.normal(0, 3)), shape[2] - 1 - abs(rng.normal(0, 3))])]
+        r = rng.uniform(2.0, 8.0)
+        d = np.sqrt((zz - c[0]) ** 2 + (yy - c[1]) ** 2 + (xx - c[2]) ** 2)
+        fr[(d < r) & (d > r - rng.uniform(1.0, 3.0))] = 1.0
+    for fill, min_area in ((True, 12), (False, 1)):
+        if fill:
+            ref = orc.get_labels(fr, 0.5, min_area)[1]
+        else:
+            ref = orc.label26(orc.majority3(fr > 0.5))            # area filter off, no hole filling: the majority filter alone
+        for rep in range(3):
+            pipe = pl.FramePipeline(shape)
+            pipe.upload_frangi(fr)
+            n = pipe.label(0.5, min_area, fill_holes=fill)
+            lab = pipe.download_labels()
+            pipe.close()
+            bad = np.argwhere(lab != ref)
+            assert bad.size == 0, f"fill={fill} run {rep}: {len(bad)} voxels differ, x in {sorted(set(bad[:, 2].tolist()))[:6]}"
+            assert n == int(ref.max())

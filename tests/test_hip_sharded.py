@@ -187,3 +187,42 @@ def test_zslab_label_random_on_hip_slabs(hip):
         lab = np.concatenate([o[0] for o in out])
         assert np.array_equal(lab, ref), f"world {world}: {int((lab != ref).sum())} voxels differ"
         assert [o[1] for o in out] == [ref_n] * world and ref_n > 5
+
+
+def test_zslab_remove_edges_equals_single_gpu(hip):
+    """Filter(remove_edges=True) on slabs: the ghost planes lose their edge rows too (they feed the opening of the
+    boundary planes), so the sharded frame equals the single-context frame bit for bit."""
+    from nellie_amd import pipeline as pl
+    from nellie_amd.pipeline import FilterParams
+    from nellie_amd.sharded import ShardedFramePipeline, slab_range
+    from nellie_amd.synthetic import ISO_01, make_volume
+    gshape, world = (96, 64, 80), 2
+    vol = make_volume(gshape, 17)
+    p = FilterParams(dim_res=ISO_01)
+    single = pl.FramePipeline(gshape)
+    single.filter(vol, p, remove_edges=True)
+    ref = single.download_frangi()
+    single.close()
+    group = ThreadGroup(world)
+    out, errs = [None] * world, []
+
+    def worker(rank):
+        try:
+            o0, o1 = slab_range(gshape[0], world, rank)
+            pipe = ShardedFramePipeline(gshape, rank, world, lambda ctx: ThreadComm(group, rank), p)
+            pipe.filter(vol[o0:o1], p, remove_edges=True)
+            out[rank] = pipe.download_frangi()
+            pipe.close()
+        except Exception as exc:  # noqa: BLE001
+            errs.append(exc)
+            group.barrier.abort()
+
+    ts = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    if errs:
+        raise errs[0]
+    got = np.concatenate(out)
+    assert (ref > 0).any() and np.array_equal(got, ref), f"{int((got != ref).sum())} voxels differ"

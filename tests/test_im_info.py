@@ -100,3 +100,63 @@ def test_files_read_back_with_an_independent_tiff_reader(tmp_path):
         assert (px.get("SizeX"), px.get("SizeY"), px.get("SizeZ"), px.get("SizeT")) == ("24", "20", "3", "2")
         assert float(px.get("PhysicalSizeX")) == 0.1 and float(px.get("PhysicalSizeY")) == 0.2
         assert float(px.get("PhysicalSizeZ")) == 0.3 and float(px.get("TimeIncrement")) == 1.5
+
+
+@pytest.mark.parametrize("dtype,ome", [(np.float32, "float"), (np.int32, "int32"), (np.uint16, "uint16"), (np.uint8, "uint8"), (np.float64, "double")])
+@pytest.mark.parametrize("shape", [(1, 1, 9, 11), (1, 5, 8, 8), (3, 1, 6, 10), (2, 4, 7, 9)])
+def test_written_files_meet_tifffile_memmap_requirements(tmp_path, dtype, ome, shape):
+    """The writer's files pass an independent strict checker of what `tifffile.memmap` and `ome_types.from_xml` need
+    (tests/tiff_conformance.py), and the bytes at the reported data offset are the array."""
+    from tiff_conformance import check_memmappable_ome_bigtiff
+    rng = np.random.default_rng(1)
+    data = (rng.random(shape) * 100).astype(dtype)
+    path = str(tmp_path / "w.ome.tif")
+    dr = {"X": 0.1, "Y": 0.2, "Z": 0.3 if shape[1] > 1 else None, "T": 1.5 if shape[0] > 1 else None}
+    ome_tiff.create(path, shape, dtype, dr, "frangi filtered im", data=data)
+    info = check_memmappable_ome_bigtiff(path)
+    assert info["dtype"] == np.dtype(dtype) and info["shape"] == shape and info["pixel_type"] == ome
+    assert info["description"] == "frangi filtered im"
+    assert info["dim_res"]["X"] == 0.1 and info["dim_res"]["Y"] == 0.2
+    assert ("Z" in info["dim_res"]) == (dr["Z"] is not None) and ("T" in info["dim_res"]) == (dr["T"] is not None)
+    mapped = np.memmap(path, dtype=info["dtype"], mode="r", offset=info["offset"], shape=info["shape"])     # what tifffile.memmap returns
+    assert np.array_equal(mapped, data)
+
+
+def test_stage_outputs_meet_the_requirements(tmp_path):
+    from tiff_conformance import check_memmappable_ome_bigtiff
+    vol = np.arange(2 * 3 * 4 * 5, dtype=np.uint16).reshape(2, 3, 4, 5)
+    im = ImInfo(vol, dim_res={"X": 0.1, "Y": 0.1, "Z": 0.25, "T": 1.5}, output_dir=str(tmp_path), name="cell")
+    assert check_memmappable_ome_bigtiff(im.im_path)["shape"] == (2, 3, 4, 5)
+    for stage, dt in (("im_preprocessed", "float32"), ("im_instance_label", "int32")):
+        out = im.allocate_memory(im.pipeline_paths[stage], dtype=dt, description=stage, return_memmap=True)
+        out[...] = 3
+        out.flush()
+        info = check_memmappable_ome_bigtiff(im.pipeline_paths[stage])
+        assert info["dtype"] == np.dtype(dt) and info["shape"] == (2, 3, 4, 5) and info["description"] == stage
+
+
+def test_array_sources_never_reuse_a_stale_canonical_copy(tmp_path):
+    """Two different arrays with the same shape / axes / resolutions in the same directory: each ImInfo sees its own pixels."""
+    a = np.full((2, 3, 4), 5, np.float32)
+    b = np.full((2, 3, 4), 9, np.float32)
+    ia = ImInfo(a, dim_res={"X": 1, "Y": 1, "Z": 1, "T": None}, output_dir=str(tmp_path))
+    assert float(np.asarray(ia.im).max()) == 5.0
+    ib = ImInfo(b, dim_res={"X": 1, "Y": 1, "Z": 1, "T": None}, output_dir=str(tmp_path))
+    assert ia.im_path == ib.im_path and float(np.asarray(ib.im).min()) == 9.0
+
+
+def test_detailed_names_equal_the_reference_strings():
+    """tests/golden/naming_cases.json: strings produced by the reference's FileInfo._get_output_path /
+    ImInfo.create_output_path (verifier.py:574-618, 805-828) on the same inputs."""
+    import json
+    from nellie_amd.im_info.verifier import detailed_output_name
+    cases = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "naming_cases.json")))
+    assert len(cases) >= 6
+    for c in cases:
+        name = detailed_output_name(c["name"], c["axes"], c["dim_res"], c["ch"], c["t_start"], c["t_end"])
+        assert os.path.join("OUT", name) == c["user_no_ext"]
+        assert os.path.join("OUT", "nellie_necessities", name) == c["necessities_no_ext"]
+        assert os.path.join("OUT", "nellie_necessities", name) + ".ome.tif" == c["ome_output_path"]
+        for stage, ref in c["pipeline_paths"].items():
+            base = c["user_no_ext"] if stage == "features_organelles" else c["necessities_no_ext"]
+            assert f"{base}-{stage}{'.csv' if stage == 'features_organelles' else '.ome.tif'}" == ref
