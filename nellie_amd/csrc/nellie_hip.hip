@@ -2337,10 +2337,14 @@ extern "C" int nl_slab_components(nl_ctx *c, int phase, int64_t *counts, char *e
     const i64 ny = c->ny;
     const i64 prow[4] = {0, (c->own_lo - c->sl_e0) * ny, (c->own_hi - 1 - c->sl_e0) * ny, (c->own_hi - c->sl_e0) * ny};
     unsigned int *h = (unsigned int *)c->h_small;
+    for (int k = 0; k < 8; ++k) h[k] = 0;
     for (int k = 0; k < 4; ++k) {
+        if ((k == 0 && !sg.has_lo) || (k == 3 && !sg.has_hi)) continue;        // no such plane in this slab
         NL_HIP(hipMemcpyAsync(h + 2 * k, rs.row_off + prow[k], 4, hipMemcpyDeviceToHost, c->stream));
         NL_HIP(hipMemcpyAsync(h + 2 * k + 1, rs.row_off + prow[k] + ny, 4, hipMemcpyDeviceToHost, c->stream));
     }
+    NL_HIP(hipStreamSynchronize(c->stream));
+    const int own_first = (int)h[2];                  // first run of the first owned plane
     if (rs.nruns) {
         const unsigned gr = (unsigned)((rs.nruns + 255) / 256);
         if (phase == SL_FILL) {
@@ -2351,7 +2355,7 @@ extern "C" int nl_slab_components(nl_ctx *c, int phase, int64_t *counts, char *e
             sl_area_kernel<<<(unsigned)((rs.nruns + RL_CHUNK - 1) / RL_CHUNK), 256, 0, c->stream>>>(rs.runs, rs.parent, sg.aux, rs.nruns, sg.row_lo, sg.row_hi);
         } else {
             NL_HIP(hipMemsetD32Async((hipDeviceptr_t)sg.aux, 0x7fffffff, (size_t)rs.nruns, c->stream));
-            sl_first_own_kernel<<<gr, 256, 0, c->stream>>>(rs.runs, rs.parent, sg.aux, rs.nruns, sg.row_lo, sg.row_hi);
+            sl_first_own_kernel<<<gr, 256, 0, c->stream>>>(rs.runs, rs.parent, sg.aux, rs.nruns, sg.row_lo, sg.row_hi, own_first);
         }
         NL_CHECK_LAUNCH();
     }
