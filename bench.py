@@ -447,14 +447,14 @@ def zslab_run(dist, rank, world, local_rank, args):
         return box[0]
 
     res = {"world": world, "transport": "RCCL: ncclSend/ncclRecv (ghost planes, bit planes), ncclAllReduce (scalars, histograms), "
-                                        "ncclAllGather (threshold samples, slab run tables)"}
+                                        "ncclAllGather (threshold samples, slab run tables); the per-step ghost-plane exchanges on a second communicator and stream"}
 
     # ---- (1) equality on a small volume
     gshape = (48 * world, 192, 256)
     o0, o1 = slab_range(gshape[0], world, rank)
     vol = make_volume(gshape, 4242)
-    uid = fresh_uid()
-    pipe = ShardedFramePipeline(gshape, rank, world, lambda ctx: RcclComm(ctx, world, rank, uid), p, device=local_rank)
+    uid, uid_x = fresh_uid(), fresh_uid()
+    pipe = ShardedFramePipeline(gshape, rank, world, lambda ctx: RcclComm(ctx, world, rank, uid, uid2=uid_x), p, device=local_rank)
     ones = pipe.comm.allreduce(np.array([1], np.int64), "sum")
     res["rccl_ranks"] = int(ones[0])
     pipe.load_input(vol[o0:o1])
@@ -480,8 +480,8 @@ def zslab_run(dist, rank, world, local_rank, args):
     t_gen = time.perf_counter()
     own = make_volume((o1 - o0,) + gshape[1:], 3456, z_offset=o0, global_nz=gshape[0])
     t_gen = time.perf_counter() - t_gen
-    uid2 = fresh_uid()
-    pipe = ShardedFramePipeline(gshape, rank, world, lambda ctx: RcclComm(ctx, world, rank, uid2), p, device=local_rank)
+    uid2, uid2_x = fresh_uid(), fresh_uid()
+    pipe = ShardedFramePipeline(gshape, rank, world, lambda ctx: RcclComm(ctx, world, rank, uid2, uid2=uid2_x), p, device=local_rank)
     pipe.load_input(own)
     del own
 
@@ -519,7 +519,7 @@ def zslab_run(dist, rank, world, local_rank, args):
                     + (", BASELINE config 4" if gshape == (1024, 2048, 2048) else f", the first {gshape[0]} planes' worth of BASELINE config 4's generator")
                     + f") cut into {world} Z slabs of {planes} owned planes + {pipe.halo} ghost planes per interior side; "
                       "5-scale Frangi + Label (no replication), full hot path per step, slabs resident in HBM",
-        "voxels": int(n_global), "per_gpu_owned_shape": [planes, gshape[1], gshape[2]], "halo_planes": pipe.halo,
+        "voxels": int(n_global), "per_gpu_owned_shape": [planes, gshape[1], gshape[2]], "halo_planes": pipe.halo, "halo_scheme": pipe.halo_mode,
         "halo_ms": groups.get("halo"), "groups_ms_per_step_rank0": groups, "labels": int(n_labels),
         "survival_fraction": round(tr.n_positive / n_global, 5),
         "mask_fraction_per_scale": [round(sc.mask_count / n_global, 4) for sc in tr.scales],

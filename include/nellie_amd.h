@@ -278,6 +278,13 @@ int nl_comm_init(nl_ctx *ctx, int world, int rank, const char *id128, char *err,
 /* Exchange `depth` ghost planes of a float field with both Z neighbours (ncclSend/ncclRecv in one group,
    asynchronous on the context stream). */
 int nl_halo_exchange(nl_ctx *ctx, int field, int64_t depth, char *err, size_t errlen);
+/* The same for the `depth` owned planes that start `offset` planes inside the boundary (they land at the same distance
+   from the interface on the other side): the per-step exchange of the cascade -- a rank computes every scale on its owned
+   planes +- 4 and fetches, per step, only the r_z(s) planes beyond that from the neighbour that owns them.  async != 0
+   (needs nl_comm_init2: a second communicator with its own unique id) runs the exchange on a stream and communicator of
+   its own, ordered after the work submitted so far; the next nl_gauss_step waits for it, everything else runs beside it. */
+int nl_halo_exchange_at(nl_ctx *ctx, int field, int64_t offset, int64_t depth, int async, char *err, size_t errlen);
+int nl_comm_init2(nl_ctx *ctx, int world, int rank, const char *id128, char *err, size_t errlen);
 
 /* All-reduce of a few host values through RCCL: dtype 0 = int64, 1 = float32; op 0 = sum, 1 = min, 2 = max. */
 int nl_allreduce(nl_ctx *ctx, void *host_inout, int64_t count, int dtype, int op, char *err, size_t errlen);

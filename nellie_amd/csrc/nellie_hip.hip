@@ -256,6 +256,10 @@ extern "C" int nl_ctx_destroy(nl_ctx *c) {
     if (c->h_small) hipHostFree(c->h_small);
     if (c->t0) hipEventDestroy(c->t0);
     if (c->t1) hipEventDestroy(c->t1);
+    if (c->xstream) { hipStreamSynchronize(c->xstream); hipStreamDestroy(c->xstream); }
+    if (c->ev_x_main) hipEventDestroy(c->ev_x_main);
+    if (c->ev_x_done) hipEventDestroy(c->ev_x_done);
+    if (c->comm2 && rccl().ok) rccl().CommDestroy((ncclComm_t)c->comm2);
     if (c->comm && rccl().ok) rccl().CommDestroy((ncclComm_t)c->comm);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -343,6 +347,7 @@ extern "C" int nl_sync(nl_ctx *c, char *err, size_t errlen) {
     NL_HIP(hipSetDevice(c->device));
     NL_HIP(hipStreamSynchronize(c->stream));
     NL_HIP(hipStreamSynchronize(c->side));
+    if (c->xstream) NL_HIP(hipStreamSynchronize(c->xstream));
     return NL_OK;
 }
 
@@ -516,6 +521,10 @@ extern "C" int nl_gauss_step(nl_ctx *c, const double *wz, int rz, const double *
     NL_ENTER(c);
     if (c->ahead_pending) return nl_fail(err, errlen, NL_ESTATE, "nl_gauss_step while a step enqueued ahead is uncommitted");
     if (z0 < 0 || z1 > c->nzl || z0 >= z1) return nl_fail(err, errlen, NL_EINVAL, "bad plane range [%lld,%lld)", (i64)z0, (i64)z1);
+    if (c->halo_pending) {                       // ghost planes of the source volume still travelling (nl_halo_exchange_at, async)
+        NL_HIP(hipStreamWaitEvent(c->stream, c->ev_x_done, 0));
+        c->halo_pending = 0;
+    }
     const VolGeom v = geom(c);
     // three ping-pong volumes f[0..2]: the source of a pass is dead once the pass has run,
     // so "the next one" is always a legal destination
@@ -1354,9 +1363,8 @@ extern "C" int nl_mask_volume_fused(nl_ctx *c, float thr, int64_t *n_positive, c
     NL_HIP(hipStreamSynchronize(c->stream));
     if (n_positive) *n_positive = (int64_t)(*(unsigned long long *)c->h_small);
     c->frangi_ready = 1;
-    // valid as long as only NL_KEEP_SUPPORT entry points follow (whole volumes only: slabs label through nl_label_pack)
-    const bool whole = c->own_lo == 0 && c->own_hi == c->nzl && c->gnz == c->nzl;
-    c->d_support = whole ? (const unsigned long long *)c->m[0] + (i64)(((c->mask_slots_used - 1) & 1) ^ 1) * (c->nzl * c->ny * (i64)((c->nx + 63) / 64)) : nullptr;
+    // valid as long as only NL_KEEP_SUPPORT entry points follow; on a slab it describes the OWNED planes (all nl_slab_label_pack reads)
+    c->d_support = (const unsigned long long *)c->m[0] + (i64)(((c->mask_slots_used - 1) & 1) ^ 1) * (c->nzl * c->ny * (i64)((c->nx + 63) / 64));
     c->support_epoch = c->epoch.load();
     return NL_OK;
 }
@@ -1432,37 +1440,80 @@ extern "C" int nl_comm_init(nl_ctx *c, int world, int rank, const char *id128, c
     return NL_OK;
 }
 
-// Ghost-plane exchange with the Z neighbours over RCCL (xGMI): this rank's first / last `depth` owned planes
-// go to the neighbour's ghost planes, and the neighbours' go into ours.  Asynchronous on the context stream.
-extern "C" int nl_halo_exchange(nl_ctx *c, int field, int64_t depth, char *err, size_t errlen) {
-    NL_ENTER(c);
+// Ghost-plane exchange with the Z neighbours over RCCL (xGMI).  The `depth` owned planes that start `offset` planes inside
+// this rank's boundary go to the neighbour's ghost planes at the same distance from the interface, and the neighbours'
+// come into ours: low side  send [own_lo + offset, +depth)  recv [own_lo - offset - depth, own_lo - offset),
+//                 high side send [own_hi - offset - depth, own_hi - offset)  recv [own_hi + offset, +depth).
+// offset 0 = the classic halo.  Asynchronous on the context stream; with `async` != 0 (and a second communicator,
+// nl_comm_init2) it runs on a stream and a communicator of its own, ordered after everything submitted so far, and the next
+// nl_gauss_step waits for it: the exchange for cascade step s+1 then travels while scale s is being evaluated.
+static int halo_exchange_impl(nl_ctx *c, int field, int64_t offset, int64_t depth, int async, char *err, size_t errlen) {
     if (!c->comm) return nl_fail(err, errlen, NL_ESTATE, "nl_halo_exchange before nl_comm_init");
     c->fsq_cache_valid = 0;
     float *p = field_ptr(c, field);
     if (!p) return nl_fail(err, errlen, NL_EINVAL, "nl_halo_exchange: field %d has no volume", field);
     const i64 plane = c->ny * c->nx;
     const bool has_lo = c->rank > 0, has_hi = c->rank + 1 < c->world;
-    if (depth < 1 || depth > c->own_hi - c->own_lo || (has_lo && depth > c->own_lo) || (has_hi && depth > c->nzl - c->own_hi))
-        return nl_fail(err, errlen, NL_EINVAL, "halo depth %lld does not fit the slab (own %lld, ghosts %lld/%lld)", (i64)depth,
-                       (i64)(c->own_hi - c->own_lo), (i64)c->own_lo, (i64)(c->nzl - c->own_hi));
-    ncclComm_t comm = (ncclComm_t)c->comm;
-    ProfScope ps(c, "halo");
+    if (depth < 1 || offset < 0 || offset + depth > c->own_hi - c->own_lo || (has_lo && offset + depth > c->own_lo) ||
+        (has_hi && offset + depth > c->nzl - c->own_hi))
+        return nl_fail(err, errlen, NL_EINVAL, "halo planes [%lld, %lld) from the interface do not fit the slab (own %lld, ghosts %lld/%lld)", (i64)offset,
+                       (i64)(offset + depth), (i64)(c->own_hi - c->own_lo), (i64)c->own_lo, (i64)(c->nzl - c->own_hi));
+    const bool side = async && c->comm2;
+    ncclComm_t comm = (ncclComm_t)(side ? c->comm2 : c->comm);
+    hipStream_t st = c->stream;
+    if (side) {
+        if (!c->xstream) {
+            NL_HIP(hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking));
+            NL_HIP(hipEventCreateWithFlags(&c->ev_x_main, hipEventDisableTiming));
+            NL_HIP(hipEventCreateWithFlags(&c->ev_x_done, hipEventDisableTiming));
+        }
+        if (c->halo_pending) NL_HIP(hipStreamWaitEvent(c->stream, c->ev_x_done, 0));      // one exchange in flight at a time
+        NL_HIP(hipEventRecord(c->ev_x_main, c->stream));
+        NL_HIP(hipStreamWaitEvent(c->xstream, c->ev_x_main, 0));
+        st = c->xstream;
+    }
+    ProfScope ps(c, "halo", st);
     NL_NCCL(rccl().GroupStart());
     if (has_lo) {
-        NL_NCCL(rccl().Send(p + c->own_lo * plane, (size_t)(depth * plane), ncclFloat, c->rank - 1, comm, c->stream));
-        NL_NCCL(rccl().Recv(p + (c->own_lo - depth) * plane, (size_t)(depth * plane), ncclFloat, c->rank - 1, comm, c->stream));
+        NL_NCCL(rccl().Send(p + (c->own_lo + offset) * plane, (size_t)(depth * plane), ncclFloat, c->rank - 1, comm, st));
+        NL_NCCL(rccl().Recv(p + (c->own_lo - offset - depth) * plane, (size_t)(depth * plane), ncclFloat, c->rank - 1, comm, st));
     }
     if (has_hi) {
-        NL_NCCL(rccl().Send(p + (c->own_hi - depth) * plane, (size_t)(depth * plane), ncclFloat, c->rank + 1, comm, c->stream));
-        NL_NCCL(rccl().Recv(p + c->own_hi * plane, (size_t)(depth * plane), ncclFloat, c->rank + 1, comm, c->stream));
+        NL_NCCL(rccl().Send(p + (c->own_hi - offset - depth) * plane, (size_t)(depth * plane), ncclFloat, c->rank + 1, comm, st));
+        NL_NCCL(rccl().Recv(p + (c->own_hi + offset) * plane, (size_t)(depth * plane), ncclFloat, c->rank + 1, comm, st));
     }
     NL_NCCL(rccl().GroupEnd());
+    if (side) {
+        NL_HIP(hipEventRecord(c->ev_x_done, c->xstream));
+        c->halo_pending = 1;
+    }
+    return NL_OK;
+}
+extern "C" int nl_halo_exchange(nl_ctx *c, int field, int64_t depth, char *err, size_t errlen) {
+    NL_ENTER(c);
+    return halo_exchange_impl(c, field, 0, depth, 0, err, errlen);
+}
+extern "C" int nl_halo_exchange_at(nl_ctx *c, int field, int64_t offset, int64_t depth, int async, char *err, size_t errlen) {
+    NL_ENTER(c);
+    return halo_exchange_impl(c, field, offset, depth, async, err, errlen);
+}
+// second communicator (its own unique id): carries the asynchronous ghost-plane exchanges, so that they do not serialise
+// with the reductions of the first one
+extern "C" int nl_comm_init2(nl_ctx *c, int world, int rank, const char *id128, char *err, size_t errlen) {
+    NL_ENTER(c);
+    if (!id128 || world != c->world || rank != c->rank || !c->comm) return nl_fail(err, errlen, NL_EINVAL, "nl_comm_init2 needs the world / rank of nl_comm_init");
+    ncclUniqueId id;
+    memcpy(&id, id128, 128);
+    ncclComm_t comm;
+    NL_NCCL(rccl().CommInitRank(&comm, world, id, rank));
+    c->comm2 = comm;
     return NL_OK;
 }
 
 // Small all-reduce of host values through RCCL: dtype 0 = int64, 1 = float32; op 0 = sum, 1 = min, 2 = max.
 extern "C" int nl_allreduce(nl_ctx *c, void *host_inout, int64_t count, int dtype, int op, char *err, size_t errlen) {
     NL_ENTER(c);
+    NL_KEEP_SUPPORT(c);
     if (!c->comm) return nl_fail(err, errlen, NL_ESTATE, "nl_allreduce before nl_comm_init");
     const size_t es = dtype == 0 ? 8 : 4;
     if (!host_inout || count < 1 || (size_t)count * es > (1 << 15) || dtype < 0 || dtype > 1 || op < 0 || op > 2)
@@ -1481,6 +1532,7 @@ extern "C" int nl_allreduce(nl_ctx *c, void *host_inout, int64_t count, int dtyp
 extern "C" int nl_allgather_bytes(nl_ctx *c, const void *send, int64_t nbytes, void *recv, int64_t max_bytes, int64_t *bytes_of,
                                   char *err, size_t errlen) {
     NL_ENTER(c);
+    NL_KEEP_SUPPORT(c);
     if (!c->comm) return nl_fail(err, errlen, NL_ESTATE, "nl_allgather_bytes before nl_comm_init");
     if (nbytes < 0 || max_bytes < 1 || nbytes > max_bytes || !recv || !bytes_of || (nbytes && !send))
         return nl_fail(err, errlen, NL_EINVAL, "bad all-gather arguments");
@@ -2267,8 +2319,12 @@ extern "C" int nl_slab_label_pack(nl_ctx *c, int has_thr, float thr, char *err, 
     const int wpr = sg.g.wpr;
     const i64 own_rows = (c->own_hi - c->own_lo) * c->ny;
     ProfScope ps(c, "label");
-    rl_threshold_pack_kernel<<<grid1d(own_rows * 64, 256, (i64)1 << 22), 256, 0, c->stream>>>(
-        c->f[c->i_vmax] + c->own_lo * c->ny * c->nx, nullptr, (unsigned long long *)c->m[1] + c->own_lo * c->ny * wpr, has_thr, thr, (int)c->nx, own_rows, wpr);
+    // right after the fused epilogue the frame is known to be <= 0 outside the opened mask: read it only there
+    const unsigned long long *support = (c->support_epoch + 1 == c->epoch.load() && c->d_support && has_thr && thr >= 0.0f)
+                                            ? c->d_support + c->own_lo * c->ny * wpr : nullptr;
+    c->last_label_sparse = support ? 1 : 0;
+    rl_threshold_pack_kernel<<<grid1d(own_rows * 64, 256, support ? (i64)256 * 64 : (i64)1 << 22), 256, 0, c->stream>>>(
+        c->f[c->i_vmax] + c->own_lo * c->ny * c->nx, support, (unsigned long long *)c->m[1] + c->own_lo * c->ny * wpr, has_thr, thr, (int)c->nx, own_rows, wpr);
     NL_CHECK_LAUNCH();
     c->sl_phase = -1; c->sl_nruns = 0; c->sl_numbered = 0;
     return NL_OK;

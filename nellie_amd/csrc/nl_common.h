@@ -100,6 +100,10 @@ struct nl_ctx {
 
     void *comm = nullptr;             // ncclComm_t (RCCL), set by nl_comm_init
     void *d_ag = nullptr; size_t ag_cap = 0;      // staging of nl_allgather_bytes
+    void *comm2 = nullptr;            // second communicator: asynchronous ghost-plane exchanges (nl_comm_init2)
+    hipStream_t xstream = nullptr;    // ... and their stream
+    hipEvent_t ev_x_main = nullptr, ev_x_done = nullptr;
+    int halo_pending = 0;             // an asynchronous exchange the next nl_gauss_step has to wait for
     int world = 1, rank = 0;
 
     hipEvent_t t0 = nullptr, t1 = nullptr;

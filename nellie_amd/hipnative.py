@@ -78,6 +78,8 @@ _PROTOS = {
     "nl_comm_unique_id": [C.c_char_p],
     "nl_comm_init": [_p, _int, _int, C.c_char_p],
     "nl_halo_exchange": [_p, _int, _i64],
+    "nl_halo_exchange_at": [_p, _int, _i64, _i64, _int],
+    "nl_comm_init2": [_p, _int, _int, C.c_char_p],
     "nl_allreduce": [_p, _p, _i64, _int, _int],
     "nl_mask_volume": [_p, _f32],
     "nl_filter_store": [_p, _p, _i64, _i64],
@@ -581,6 +583,12 @@ class Context:
 
     def halo_exchange(self, field, depth):
         self._call("nl_halo_exchange", int(field), int(depth))
+
+    def halo_exchange_at(self, field, offset, depth, run_async=False):
+        self._call("nl_halo_exchange_at", int(field), int(offset), int(depth), 1 if run_async else 0)
+
+    def comm_init2(self, world, rank, uid: bytes):
+        self._call("nl_comm_init2", int(world), int(rank), uid)
 
     def allreduce(self, arr: np.ndarray, op: str):
         a = np.ascontiguousarray(arr)

@@ -265,6 +265,9 @@ class FramePipeline:
     def _gauss_range(self, rz):
         return 0, self.shape[0]
 
+    def _after_cascade_step(self, k):
+        pass
+
     def _vess_range(self):
         return -1, -1
 
@@ -274,8 +277,8 @@ class FramePipeline:
     def _reduce_counts(self, counts):
         return counts
 
-    def _reduce_stats(self, max_abs, max_fsq, any_inf):
-        return max_abs, max_fsq, any_inf
+    def _reduce_stats(self, max_abs, max_fsq, any_inf, overflow=0):
+        return max_abs, max_fsq, any_inf, overflow
 
     def _reduce_sum(self, n):
         return n
@@ -397,6 +400,7 @@ class FramePipeline:
                 ctx.gauss_commit()
             else:
                 cascade_step(k, False)
+            self._after_cascade_step(k)      # Z slabs: the ghost planes the NEXT step needs start travelling now
             # the next cascade step only reads the Gaussian of THIS scale: enqueue it now, on the side stream, so that
             # it runs beside this scale's Hessian walk (filtering.py:814-835 has no such dependency either)
             ahead = self._gauss_ahead and k + 1 < len(sigmas) and cascade_step(k + 1, True)
@@ -416,14 +420,14 @@ class FramePipeline:
                     settle()
                     vz0, vz1 = self._vess_range()
                     ma, mf, inf_, ovf = ctx.vesselness_spec(spacing, bracket[0], bracket[1], z0=vz0, z1=vz1)
-                    stats = self._reduce_stats(ma, mf, inf_)
-                    spec = not stats[2] and self._reduce_sum(int(ovf)) == 0
+                    stats = self._reduce_stats(ma, mf, inf_, ovf)
+                    spec = not stats[2] and not stats[3]
                     if stats[2]:
                         stats = None     # a +inf frob_sq turned up: the one-pass walk only flags it (the largest finite
                                          # value comes from the statistics pass below), and the scale goes the two-pass way
             if stats is None:
                 stats = self._reduce_stats(*ctx.hessian_stats(spacing))
-            max_abs32, max_fsq32, any_inf = stats
+            max_abs32, max_fsq32, any_inf = stats[:3]
             max_abs = float(max_abs32)
             if max_abs <= 0:
                 max_abs = 1.0
@@ -485,7 +489,7 @@ class FramePipeline:
         self.trace.percentile_thr = float(thr)
         return thr
 
-    _fused_epilogue = True      # a Z-slab pipeline keeps the two-step epilogue (ghost planes of the product)
+    _fused_epilogue = True      # (a Z-slab pipeline on a context without nl_mask_volume_fused keeps the two-step epilogue)
     # Enqueue the cascade step of scale s+1 on the side stream beside the Hessian walk of scale s.  Exact either way.
     # Off by default: at 1024^3 it buys ~1 % (two full-GPU kernels mostly take turns) and it blurs per-kernel timings.
     _gauss_ahead = os.environ.get("NELLIE_GAUSS_AHEAD", "0") == "1"
@@ -509,7 +513,7 @@ class FramePipeline:
                 if positive.size > 0:
                     thr = np.percentile(positive, 1)
                     self.trace.percentile_thr = float(thr)
-                    self.trace.n_positive = self.ctx.mask_volume_fused(thr)
+                    self.trace.n_positive = self._reduce_sum(self.ctx.mask_volume_fused(thr))
                     return self.trace.n_positive
             vz0, vz1 = self._vess_range()
             npos = self.trace.n_positive = self._reduce_sum(self.ctx.filter_finish(vz0, vz1))

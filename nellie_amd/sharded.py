@@ -2,15 +2,23 @@
 Z-slab sharding of ONE frame across the GPUs of a node (the reference has no
 distributed code, its closest precedent is the Z-chunked labelling of labelling.py:585-691).
 
-Rank r owns a contiguous range of Z planes and holds H ghost planes on each interior side.  The raw
-(float32-converted) ghost planes are exchanged ONCE per frame -- over RCCL/xGMI in production
-(`RcclComm` -> nl_halo_exchange) -- and every cascade step then simply computes a Z range that shrinks by
-its radius: H = 2 (Hessian) + 2 (opening of _mask_volume) + sum_s r_z(s), i.e. 24 planes at 0.1 um
-isotropic.  All data-dependent scalars are made global exactly: min / max / positive-count of the lattice
-samples, the 256 histogram counts, max|H|, the largest finite frob_sq and the inf flag are all-reduced
-(sums of integers, mins and maxes: order independent), so every rank derives bit-identical thresholds and
-the sharded Frangi frame equals the single-GPU frame bit for bit.  The <= 1e6 samples of the two
-percentile / log-domain thresholds are gathered (order does not matter: histogram and order statistics).
+Rank r owns a contiguous range of Z planes and holds ghost planes on each interior side.  Two exchange schemes, both
+exact (the sharded Frangi frame equals the single-GPU frame bit for bit):
+
+  "steps" (default)  every rank evaluates each scale on its owned planes +- 4 (2 for the double difference of the Hessian,
+      2 for the opening of _mask_volume) and fetches, per cascade step, only the r_z(s) planes beyond that from the
+      neighbour that owns them (`exchange_halo(..., offset=4, depth=r_z)`): 4 + max r_z ghost planes per side (9 at 0.1 um
+      isotropic), 6 % redundant Gaussian work on 128-plane slabs, and the exchange for step s+1 is issued right after step
+      s -- on a stream and an RCCL communicator of its own -- so it travels while scale s's thresholds, Hessian walk and
+      eigen-solves run; only the first exchange of a frame (4 + r_z(1) raw planes) is exposed.
+  "fat"  the raw ghost planes are exchanged ONCE per frame, H = 4 + sum_s r_z(s) deep (24 planes at 0.1 um isotropic), and
+      every cascade step computes a Z range that shrinks by its radius: one message, up to 37 % redundant Gaussian work at
+      128-plane slabs, nothing to overlap it with.
+
+All data-dependent scalars are made global exactly: min / max / any-positive of the lattice samples (one max-reduction),
+the 256 histogram counts, max|H|, the largest finite frob_sq, the inf and queue-overflow flags (one max-reduction), the
+mask counts (sums of integers): order independent, so every rank derives bit-identical thresholds.  The <= 1e6 samples of
+the two percentile / log-domain thresholds are gathered (order does not matter: histogram and order statistics).
 
 Label across slabs (no replication): every rank labels its own planes plus ONE ghost bit plane per interior side
 (the bit planes travel like the float ghost planes: RCCL send/recv between neighbours).  A component that crosses an
@@ -47,6 +55,20 @@ def halo_depth(p: FilterParams) -> int:
         w = gaussian_weights(delta[0])
         rz += 0 if w is None else (len(w) - 1) // 2
     return rz + 4
+
+
+def step_radii(p: FilterParams):
+    """Z radius of every cascade step (0 where the step has no Z pass)."""
+    out = []
+    for delta in cascade_deltas(p.resolved_sigmas(), z_ratio_of(p.dim_res)):
+        w = gaussian_weights(delta[0])
+        out.append(0 if w is None else (len(w) - 1) // 2)
+    return out
+
+
+def halo_depth_steps(p: FilterParams) -> int:
+    """Ghost planes per interior side of the per-step exchange scheme: 4 + the largest Z radius of a cascade step."""
+    return 4 + max(step_radii(p) + [0])
 
 
 def slab_geometry(gshape, world, rank, halo):
@@ -120,13 +142,16 @@ class RcclComm:
     planes and bit planes (ncclSend / ncclRecv between Z neighbours), scalar reductions (ncclAllReduce) and the
     variable-size gathers of threshold samples and slab tables (ncclAllGather on padded staging)."""
 
-    def __init__(self, ctx, world, rank, uid: bytes, host_gather=None):
+    def __init__(self, ctx, world, rank, uid: bytes, host_gather=None, uid2: bytes = None):
         self.world, self.rank = world, rank
         self.ctx = ctx
         ctx.comm_init(world, rank, uid)
+        self.has_side_channel = uid2 is not None          # a second communicator: asynchronous ghost-plane exchanges
+        if uid2 is not None:
+            ctx.comm_init2(world, rank, uid2)
 
-    def exchange_halo(self, ctx, field, depth):
-        ctx.halo_exchange(field, depth)
+    def exchange_halo(self, ctx, field, depth, offset=0, run_async=False):
+        ctx.halo_exchange_at(field, offset, depth, run_async and self.has_side_channel)
 
     def exchange_bits(self, ctx, which):
         ctx.slab_bits_exchange(which)
@@ -148,14 +173,23 @@ class RcclComm:
 
 
 class ShardedFramePipeline(FramePipeline):
-    def __init__(self, gshape, rank, world, comm_factory, params: FilterParams, device: int = 0, ctx_factory=None, halo=None):
+    def __init__(self, gshape, rank, world, comm_factory, params: FilterParams, device: int = 0, ctx_factory=None, halo=None,
+                 halo_mode=None):
         """
         comm_factory(ctx) -> communicator with exchange_halo / exchange_bits / allreduce / allgather.
         ctx_factory(local_shape, device, gz0, gnz, own) -> context (default: the HIP context).
-        halo: ghost planes per interior side (default: what the whole Filter needs; Label alone needs 1).
+        halo_mode: "steps" (per-step exchange, default; NELLIE_HALO overrides) or "fat" (one exchange per frame).
+        halo: ghost planes per interior side (default: what the scheme needs; Label alone needs 1).
         """
+        import os
         self.rank, self.world = int(rank), int(world)
-        self.halo = halo_depth(params) if halo is None else int(halo)
+        self.halo_mode = halo_mode or os.environ.get("NELLIE_HALO", "steps")
+        if self.halo_mode not in ("steps", "fat"):
+            raise ValueError(f"halo_mode must be 'steps' or 'fat', not {self.halo_mode!r}")
+        self._rz = step_radii(params)
+        need = halo_depth_steps(params) if self.halo_mode == "steps" else halo_depth(params)
+        self.halo = need if halo is None else int(halo)
+        self._filter_ok = self.halo >= need                # a Label-only pipeline may hold a single ghost plane
         lshape, gz0, own_lo, own_hi = slab_geometry(gshape, world, rank, self.halo)
         self.lshape, self.gz0, self.own = lshape, gz0, (own_lo, own_hi)
         make = ctx_factory or (lambda shp, dev, g0, gn, own: hipnative.Context(shp, device=dev, gz0=g0, gnz=gn, own=own))
@@ -165,6 +199,8 @@ class ShardedFramePipeline(FramePipeline):
         self.comm = comm_factory(ctx)
         self.params = params
         self._valid = (0, lshape[0])
+        # threshold + opening + product in one go, ghost planes included (nl_mask_volume_fused works on owned +- 2)
+        self._fused_epilogue = hasattr(ctx, "mask_volume_fused") and hasattr(ctx, "sample_gather_positive")
 
     # ---- loading: own planes in, ghost planes from the neighbours ---------------------------------------
     def _load(self, frame):
@@ -177,20 +213,27 @@ class ShardedFramePipeline(FramePipeline):
         self.ctx.input_load(np.asarray(frame), z0=lo, z1=hi)
 
     def _after_load(self, p):
+        if not self._filter_ok:
+            raise ValueError(f"this slab holds {self.halo} ghost planes, the {self.halo_mode!r} exchange scheme of Filter needs more")
         lo, hi = self.own
         nzl = self.lshape[0]
-        depth = max(lo, nzl - hi)
-        if depth:
-            self.comm.exchange_halo(self.ctx, FIELD_GAUSS, depth)
-        self._valid = (0, nzl)
+        if self.halo_mode == "fat":
+            depth = max(lo, nzl - hi)
+            if depth:
+                self.comm.exchange_halo(self.ctx, FIELD_GAUSS, depth)
+            self._valid = (0, nzl)
+        elif self.world > 1:
+            self.comm.exchange_halo(self.ctx, FIELD_GAUSS, 4 + self._rz[0], 0, False)     # raw planes: nothing to hide them behind
 
-    # ---- shrinking Z ranges -------------------------------------------------------------------------------
-    _fused_epilogue = False
+    # ---- Z ranges of the cascade ------------------------------------------------------------------------------
     _gauss_ahead = False
 
     def _gauss_range(self, rz):
-        v0, v1 = self._valid
         nzl = self.lshape[0]
+        if self.halo_mode == "steps":      # owned planes +- 4, clipped where the slab ends at a true face
+            lo, hi = self.own
+            return max(lo - 4, 0), min(hi + 4, nzl)
+        v0, v1 = self._valid
         z0 = v0 if self.gz0 + v0 == 0 else v0 + rz              # a true face reflects, no shrink
         z1 = v1 if self.gz0 + v1 == self.shape[0] else v1 - rz
         z0 = max(z0, 0)
@@ -198,26 +241,31 @@ class ShardedFramePipeline(FramePipeline):
         self._valid = (z0, z1)
         return z0, z1
 
+    def _after_cascade_step(self, k):
+        """steps scheme: the r_z planes step k+1 needs beyond owned +- 4 leave now and travel beside scale k's work."""
+        if self.halo_mode == "steps" and self.world > 1 and k + 1 < len(self._rz) and self._rz[k + 1] > 0:
+            self.comm.exchange_halo(self.ctx, FIELD_GAUSS, self._rz[k + 1], 4, True)
+
     def _vess_range(self):
         lo, hi = self.own
         return max(lo - 2, 0), min(hi + 2, self.lshape[0])
 
     # ---- exact global scalars -----------------------------------------------------------------------------
     def _reduce_minmax(self, mn, mx, npos):
-        n = int(self.comm.allreduce(np.array([npos], np.int64), "sum")[0])
-        if n == 0:
-            return mn, mx, 0
+        """Global (min, max, any positive sample?) in ONE collective: max over (max, -min, has-samples).  Callers only
+        ask whether the count is zero, so the third value is 0 / 1."""
         big = np.float32(np.inf)
-        gmn = self.comm.allreduce(np.array([mn if npos else big], np.float32), "min")[0]
-        gmx = self.comm.allreduce(np.array([mx if npos else -big], np.float32), "max")[0]
-        return np.float32(gmn), np.float32(gmx), n
+        r = self.comm.allreduce(np.array([mx if npos else -big, -mn if npos else -big, 1.0 if npos else 0.0], np.float32), "max")
+        if r[2] <= 0:
+            return mn, mx, 0
+        return np.float32(-r[1]), np.float32(r[0]), 1
 
     def _reduce_counts(self, counts):
         return self.comm.allreduce(np.ascontiguousarray(counts, dtype=np.int64), "sum")
 
-    def _reduce_stats(self, max_abs, max_fsq, any_inf):
-        r = self.comm.allreduce(np.array([max_abs, max_fsq, 1.0 if any_inf else 0.0], np.float32), "max")
-        return np.float32(r[0]), np.float32(r[1]), bool(r[2] > 0)
+    def _reduce_stats(self, max_abs, max_fsq, any_inf, overflow=0):
+        r = self.comm.allreduce(np.array([max_abs, max_fsq, 1.0 if any_inf else 0.0, 1.0 if overflow else 0.0], np.float32), "max")
+        return np.float32(r[0]), np.float32(r[1]), bool(r[2] > 0), bool(r[3] > 0)
 
     def _reduce_sum(self, n):
         return int(self.comm.allreduce(np.array([n], np.int64), "sum")[0])

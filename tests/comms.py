@@ -24,15 +24,15 @@ class ThreadComm:
         self.g.barrier.wait()
         return vals
 
-    def exchange_halo(self, ctx, field, depth):
+    def exchange_halo(self, ctx, field, depth, offset=0, run_async=False):
         lo, hi = ctx.own
-        down = ctx.planes_get(field, lo, lo + depth) if self.rank > 0 else None
-        up = ctx.planes_get(field, hi - depth, hi) if self.rank + 1 < self.world else None
+        down = ctx.planes_get(field, lo + offset, lo + offset + depth) if self.rank > 0 else None
+        up = ctx.planes_get(field, hi - offset - depth, hi - offset) if self.rank + 1 < self.world else None
         vals = self._all((down, up))
         if self.rank > 0:
-            ctx.planes_put(field, lo - depth, lo, vals[self.rank - 1][1])
+            ctx.planes_put(field, lo - offset - depth, lo - offset, vals[self.rank - 1][1])
         if self.rank + 1 < self.world:
-            ctx.planes_put(field, hi, hi + depth, vals[self.rank + 1][0])
+            ctx.planes_put(field, hi + offset, hi + offset + depth, vals[self.rank + 1][0])
 
     def exchange_bits(self, ctx, which):
         lo, hi = ctx.own
@@ -70,24 +70,24 @@ class GlooComm:
     def __init__(self, dist, rank, world):
         self.dist, self.rank, self.world = dist, rank, world
 
-    def exchange_halo(self, ctx, field, depth):
+    def exchange_halo(self, ctx, field, depth, offset=0, run_async=False):
         import torch
         lo, hi = ctx.own
         reqs, recv_lo, recv_hi = [], None, None
         if self.rank > 0:
-            reqs.append(self.dist.isend(torch.from_numpy(ctx.planes_get(field, lo, lo + depth)), self.rank - 1))
+            reqs.append(self.dist.isend(torch.from_numpy(ctx.planes_get(field, lo + offset, lo + offset + depth)), self.rank - 1))
             recv_lo = torch.empty((depth,) + tuple(ctx.shape[1:]), dtype=torch.float32)
             reqs.append(self.dist.irecv(recv_lo, self.rank - 1))
         if self.rank + 1 < self.world:
-            reqs.append(self.dist.isend(torch.from_numpy(ctx.planes_get(field, hi - depth, hi)), self.rank + 1))
+            reqs.append(self.dist.isend(torch.from_numpy(ctx.planes_get(field, hi - offset - depth, hi - offset)), self.rank + 1))
             recv_hi = torch.empty((depth,) + tuple(ctx.shape[1:]), dtype=torch.float32)
             reqs.append(self.dist.irecv(recv_hi, self.rank + 1))
         for r in reqs:
             r.wait()
         if recv_lo is not None:
-            ctx.planes_put(field, lo - depth, lo, recv_lo.numpy())
+            ctx.planes_put(field, lo - offset - depth, lo - offset, recv_lo.numpy())
         if recv_hi is not None:
-            ctx.planes_put(field, hi, hi + depth, recv_hi.numpy())
+            ctx.planes_put(field, hi + offset, hi + offset + depth, recv_hi.numpy())
 
     def exchange_bits(self, ctx, which):
         lo, hi = ctx.own

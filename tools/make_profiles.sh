@@ -1,18 +1,18 @@
 #!/bin/bash
 # Produces the files committed under profiles/ (run on the GPU box through gpurun; results land in gpurun_out/):
-#   r01_bench_n1_1024cube.json       the default bench line
-#   r01_kernel_stats_1024cube.csv    rocprofv3 --kernel-trace --stats summary of the same bench command
-#   r01_pmc_hbm_bytes_1024cube.json  HBM bytes per kernel launch: FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes
+#   r02_bench_n1_1024cube.json       the default bench line
+#   r02_kernel_stats_1024cube.csv    rocprofv3 --kernel-trace --stats summary of the same bench command
+#   r02_pmc_hbm_bytes_1024cube.json  HBM bytes per kernel launch: FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes
 #                                    (KB units; FETCH_SIZE is doubled on gfx950, see MI355X_MICROARCH.md)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
-python $R/bench.py > /tmp/bench.out 2>/tmp/bench.err; tail -1 /tmp/bench.out > $R/gpurun_out/r01_bench_n1_1024cube.json
-rm -rf /tmp/ks && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -- python $R/bench.py --no-cpu-baseline > /tmp/ks.log 2>&1
-cp $(find /tmp/ks -name '*kernel_stats.csv' | head -1) $R/gpurun_out/r01_kernel_stats_1024cube.csv
+python $R/bench.py > /tmp/bench.out 2>/tmp/bench.err; tail -1 /tmp/bench.out > $R/gpurun_out/r02_bench_n1_1024cube.json
+rm -rf /tmp/ks && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -- python $R/bench.py --no-cpu-baseline --no-io > /tmp/ks.log 2>&1
+cp $(find /tmp/ks -name '*kernel_stats.csv' | head -1) $R/gpurun_out/r02_kernel_stats_1024cube.csv
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$C && rocprofv3 --pmc $C --output-format csv -d /tmp/pmc_$C -- python $R/tools/prof_filter.py 1024 1024 1024 1 > /tmp/pmc_$C.log 2>&1
 done
-python - $(find /tmp/pmc_FETCH_SIZE -name '*counter_collection.csv' | head -1) $(find /tmp/pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1) > $R/gpurun_out/r01_pmc_hbm_bytes_1024cube.json <<'PY'
+python - $(find /tmp/pmc_FETCH_SIZE -name '*counter_collection.csv' | head -1) $(find /tmp/pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1) > $R/gpurun_out/r02_pmc_hbm_bytes_1024cube.json <<'PY'
 import csv, sys, json, collections
 N = 1024 ** 3
 def load(path):
@@ -31,4 +31,4 @@ for k in sorted(f, key=lambda k: -f[k]):
                 "write_bytes_per_voxel": wk * 1024 / N})
 json.dump(out, sys.stdout, indent=1)
 PY
-tail -2 /tmp/ks.log; tail -c 600 $R/gpurun_out/r01_bench_n1_1024cube.json
+tail -2 /tmp/ks.log; tail -c 600 $R/gpurun_out/r02_bench_n1_1024cube.json
