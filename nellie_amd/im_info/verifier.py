@@ -66,6 +66,69 @@ def detailed_output_name(name, axes, dim_res, ch, t_start, t_end):
     return f"{name}-{axes}-{'_'.join(parts)}-ch{ch}{t_range}"
 
 
+class FileInfo:
+    """The part of Nellie's FileInfo (verifier.py:17-700) that `run(file_info)` and `ImInfo(file_info)` consume: where the
+    image lives, its axes, resolutions, channel and time range.  Sources: OME-TIFFs as this package (and Nellie) write
+    them, and .npy arrays; metadata sniffing of arbitrary TIFF / ND2 files stays with Nellie's own class."""
+
+    def __init__(self, filepath, output_dir=None, output_naming="detailed"):
+        self.filepath = os.fspath(filepath)
+        self.output_dir = output_dir
+        if output_naming not in ("detailed", "stable"):
+            raise ValueError(f"Unsupported output naming strategy '{output_naming}'")
+        self.output_naming = output_naming
+        self.filename_no_ext = os.path.splitext(os.path.basename(self.filepath))[0].replace(".ome", "")
+        self.axes = None
+        self.shape = None
+        self.dim_res = {"X": None, "Y": None, "Z": None, "T": None}
+        self.ch = 0
+        self.t_start = self.t_end = None
+        self.good_dims = self.good_axes = False
+
+    def find_metadata(self):
+        if self.filepath.lower().endswith(".npy"):
+            data = np.load(self.filepath, mmap_mode="r")
+            self.axes = {2: "YX", 3: "ZYX", 4: "TZYX"}[data.ndim]
+        else:
+            data, lay = ome_tiff.memmap(self.filepath, mode="r")
+            self.axes = lay.axes
+            self.dim_res.update(lay.dim_res)
+        self.shape = tuple(data.shape)
+        return self
+
+    def load_metadata(self):
+        if self.axes is None:
+            self.find_metadata()
+        if "T" in self.axes and self.t_start is None:
+            self.t_start, self.t_end = 0, self.shape[self.axes.index("T")] - 1
+        self.good_axes = all(a in "TZYX" for a in self.axes) and "X" in self.axes and "Y" in self.axes
+        self.good_dims = all(self.dim_res.get(a) is not None for a in self.axes if a in self.dim_res)
+        return self
+
+    def change_axes(self, new_axes):
+        if self.shape is not None and len(new_axes) != len(self.shape):
+            raise ValueError("New axes must have the same length as the existing shape")
+        self.axes = new_axes
+        return self.load_metadata()
+
+    def change_dim_res(self, dim, new_size):
+        if dim not in self.dim_res:
+            raise ValueError("Invalid dimension")
+        self.dim_res[dim] = new_size
+        return self.load_metadata()
+
+    def change_selected_channel(self, ch):
+        self.ch = int(ch)
+
+    def select_temporal_range(self, start=0, end=None):
+        if self.axes is None:
+            self.find_metadata()
+        if "T" not in self.axes:
+            return
+        n = self.shape[self.axes.index("T")]
+        self.t_start, self.t_end = int(start), (n - 1 if end is None else int(end))
+
+
 class ImInfo:
     def __init__(self, source, dim_res=None, axes=None, output_dir=None, name=None, ch=0):
         """
@@ -74,6 +137,15 @@ class ImInfo:
         axes   : axes of an array / .npy source, e.g. 'ZYX' or 'TZYX' (default by rank: YX, ZYX, TZYX).
         """
         lay = None
+        t_range = None
+        if isinstance(source, FileInfo):                 # ImInfo(file_info), as nellie.run.run builds it (run.py:49)
+            fi = source if source.axes is not None else source.load_metadata()
+            fi.load_metadata()
+            dim_res = dict(fi.dim_res) if dim_res is None else dim_res
+            axes, ch, name = axes or fi.axes, fi.ch, name or fi.filename_no_ext
+            output_dir = output_dir or fi.output_dir
+            t_range = (fi.t_start, fi.t_end) if fi.t_start is not None else None
+            source = fi.filepath
         if isinstance(source, (str, os.PathLike)):
             src_path = os.fspath(source)
             base_dir = os.path.dirname(os.path.abspath(src_path))
@@ -97,6 +169,10 @@ class ImInfo:
         self.dim_res.update(dim_res or {})
         src_axes = axes
         data, self.axes = _canonical(data, axes)
+        t_first, t_last = 0, data.shape[0] - 1
+        if t_range is not None and "T" in src_axes:       # the selected time range (verifier.py:640-660)
+            t_first, t_last = t_range
+            data = data[t_first:t_last + 1]
         self.new_axes = self.axes
         self.shape = data.shape
         self.ch = ch
@@ -104,7 +180,7 @@ class ImInfo:
         self.nellie_necessities_dir = os.path.join(self.output_dir, "nellie_necessities")
         os.makedirs(self.nellie_necessities_dir, exist_ok=True)
         # "detailed" naming (verifier.py:596-613), built from the SOURCE axes like FileInfo does
-        output_name = detailed_output_name(name, src_axes, self.dim_res, ch, 0, self.shape[0] - 1)
+        output_name = detailed_output_name(name, src_axes, self.dim_res, ch, t_first, t_last)
         self.user_output_path_no_ext = os.path.join(self.output_dir, output_name)
         self.nellie_necessities_output_path_no_ext = os.path.join(self.nellie_necessities_dir, output_name)
         self.im_path = self.nellie_necessities_output_path_no_ext + ".ome.tif"
@@ -114,7 +190,7 @@ class ImInfo:
         # array or a .npy has no such identity -- a second ImInfo built from DIFFERENT pixels of the same shape would find
         # the first one's canonical copy under the same name and the stages would silently process stale data -- so for
         # those the canonical input is always rewritten.
-        from_file = isinstance(source, (str, os.PathLike)) and not os.fspath(source).lower().endswith(".npy")
+        from_file = isinstance(source, (str, os.PathLike)) and not os.fspath(source).lower().endswith(".npy") and t_range is None
         if not (from_file and os.path.exists(self.im_path)):
             ome_tiff.create(self.im_path, shape4, data.dtype, self.dim_res, "input", data=np.asarray(data).reshape(shape4))
         self.im = self.get_memmap(self.im_path)

@@ -38,8 +38,13 @@ def run_streamed(im_info, viewer=None, device_index=0):
     return im_info
 
 
-def run(im_info, remove_edges=False, otsu_thresh_intensity=False, threshold=None, timeit=False, device="auto",
+def run(file_info, remove_edges=False, otsu_thresh_intensity=False, threshold=None, timeit=False, device="auto",
         low_memory=False, markers=False):
+    """nellie.run.run's signature (run.py:18-26): `file_info` is a FileInfo (this package's or any object with the same
+    fields) from which the ImInfo is built as run.py:49 does; an ImInfo (anything with `pipeline_paths`) or a path / array
+    is accepted too.  Returns the ImInfo."""
+    from nellie_amd.im_info.verifier import ImInfo
+    im_info = file_info if hasattr(file_info, "pipeline_paths") else ImInfo(file_info)
     t0 = time.perf_counter() if timeit else None
     preprocessing = Filter(im_info, remove_edges=remove_edges, device=device, low_memory=low_memory)
     preprocessing.run()

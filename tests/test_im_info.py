@@ -160,3 +160,22 @@ def test_detailed_names_equal_the_reference_strings():
         for stage, ref in c["pipeline_paths"].items():
             base = c["user_no_ext"] if stage == "features_organelles" else c["necessities_no_ext"]
             assert f"{base}-{stage}{'.csv' if stage == 'features_organelles' else '.ome.tif'}" == ref
+
+
+def test_run_signature_takes_a_file_info(tmp_path):
+    """nellie.run.run(file_info, ...) (run.py:18-26, 49): FileInfo -> ImInfo, channel / time selection, detailed names."""
+    from nellie_amd.im_info.verifier import FileInfo
+    vol = (np.arange(4 * 3 * 6 * 7) % 251).astype(np.uint16).reshape(4, 3, 6, 7)
+    src = str(tmp_path / "stack.ome.tif")
+    ome_tiff.create(src, vol.shape, np.uint16, {"X": 0.2, "Y": 0.2, "Z": 0.5, "T": 2.0}, "raw", data=vol)
+    fi = FileInfo(src, output_dir=str(tmp_path / "out"))
+    fi.find_metadata(); fi.load_metadata()
+    assert fi.axes == "TZYX" and fi.shape == vol.shape and fi.dim_res["Z"] == 0.5 and fi.good_dims and fi.good_axes
+    fi.select_temporal_range(1, 2)
+    im = ImInfo(fi)
+    assert im.shape == (2, 3, 6, 7) and np.array_equal(np.asarray(im.im), vol[1:3])
+    assert os.path.basename(im.im_path) == "stack-TZYX-T2p0_Z0p5_Y0p2_X0p2-ch0-t1_to_2.ome.tif"
+    assert im.im_path.startswith(os.path.join(str(tmp_path / "out"), "nellie_output", "nellie_necessities"))
+    import inspect
+    from nellie_amd.run import run
+    assert list(inspect.signature(run).parameters)[:7] == ["file_info", "remove_edges", "otsu_thresh_intensity", "threshold", "timeit", "device", "low_memory"]
