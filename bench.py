@@ -295,10 +295,10 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    pipe.ctx.prof_enable(True)      # the event pairs of the per-group timers exist (and have been used) before the timed region
     for _ in range(args.warmup):
         step()
     pipe.ctx.prof_reset()
-    pipe.ctx.prof_enable(True)
     barrier()
     t0 = time.perf_counter()
     n_labels = 0
@@ -489,10 +489,13 @@ def zslab_run(dist, rank, world, local_rank, args):
         pipe.filter(None, p)
         return pipe.label(pipe.frangi_threshold(), min_area)
 
-    for _ in range(max(1, args.warmup)):
+    pipe.ctx.prof_enable(True)      # as in the N = 1 run: the timers' event pairs exist and have been used before the timed region
+    # at least two untimed steps: the SECOND pass over a fresh slab context still carries a one-off 40-80 ms stall of the
+    # queue (measured with tools/prof_slab.py; not in any kernel -- the single-GPU context does not show it), steady after
+    n_warm = max(2, args.warmup)
+    for _ in range(n_warm):
         step()
     pipe.ctx.prof_reset()
-    pipe.ctx.prof_enable(True)
     pipe.ctx.sync()
     dist.barrier()
     t0 = time.perf_counter()
@@ -519,7 +522,7 @@ def zslab_run(dist, rank, world, local_rank, args):
                     + (", BASELINE config 4" if gshape == (1024, 2048, 2048) else f", the first {gshape[0]} planes' worth of BASELINE config 4's generator")
                     + f") cut into {world} Z slabs of {planes} owned planes + {pipe.halo} ghost planes per interior side; "
                       "5-scale Frangi + Label (no replication), full hot path per step, slabs resident in HBM",
-        "voxels": int(n_global), "per_gpu_owned_shape": [planes, gshape[1], gshape[2]], "halo_planes": pipe.halo, "halo_scheme": pipe.halo_mode,
+        "voxels": int(n_global), "per_gpu_owned_shape": [planes, gshape[1], gshape[2]], "halo_planes": pipe.halo, "halo_scheme": pipe.halo_mode, "untimed_warmup_steps": n_warm,
         "halo_ms": groups.get("halo"), "groups_ms_per_step_rank0": groups, "labels": int(n_labels),
         "survival_fraction": round(tr.n_positive / n_global, 5),
         "mask_fraction_per_scale": [round(sc.mask_count / n_global, 4) for sc in tr.scales],

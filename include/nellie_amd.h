@@ -26,7 +26,10 @@
  *    own = [0, nz).
  *  - Entry points call hipSetDevice themselves and are synchronous on return unless noted
  *    (nl_* _async variants enqueue on the context stream; nl_sync waits).  One context must
- *    not be used from two threads at once; different contexts may be.
+ *    not be used from two threads at once; different contexts may be.  The one exception are
+ *    the copy-thread calls of the frame streamer -- nl_input_load_async, nl_outputs_fetch_async,
+ *    nl_outputs_wait -- which touch only the copy streams, the input slots and the staging
+ *    volumes and may run beside the compute thread's calls on the same context.
  */
 #ifndef NELLIE_AMD_H
 #define NELLIE_AMD_H
@@ -367,6 +370,20 @@ int nl_slab_paint(nl_ctx *ctx, int64_t base, int64_t n, const int32_t *roots, co
    travels through the control plane. */
 int nl_allgather_bytes(nl_ctx *ctx, const void *send, int64_t nbytes, void *recv, int64_t max_bytes, int64_t *bytes_of,
                        char *err, size_t errlen);
+
+/* The same when the caller does not know the largest block: the library gathers the sizes, uses their maximum (rounded up
+   to 16) as the block size and lands the blocks in a page-locked buffer the CONTEXT owns: *recv (valid until the next
+   call on this context), rank r's block at r * *stride. */
+int nl_allgather_var(nl_ctx *ctx, const void *send, int64_t nbytes, void **recv, int64_t *stride, int64_t *bytes_of,
+                     char *err, size_t errlen);
+
+/* "Fused" reductions: with on != 0, nl_sample_minmax / nl_sample_hist / nl_sample_range_hist / nl_vesselness_spec return the
+   value over ALL ranks of the communicator (range and counts of the lattice samples; max |H|, max frob_sq and the inf /
+   overflow flags of the one-pass walk) -- the RCCL all-reduce runs on the context stream between the kernels, so the
+   host-level nl_allreduce (one more device round trip each) is not needed for them.  The reference has no counterpart:
+   its statistics are whole-volume numpy / cupy reductions (filtering.py:348-380, 555-562).  Requires nl_comm_init; every
+   rank must issue the same sequence of calls. */
+int nl_comm_fuse(nl_ctx *ctx, int on, char *err, size_t errlen);
 
 /* D2H of the int32 label volume, local planes [z0, z1) (labelling.py:727-729). */
 int nl_label_store(nl_ctx *ctx, int32_t *host, int64_t z0, int64_t z1, char *err, size_t errlen);

@@ -228,6 +228,7 @@ extern "C" int nl_ctx_destroy(nl_ctx *c) {
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto &kv : c->prof) for (auto &r : kv.second) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+    for (auto &r : c->prof_pool) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
     for (int k = 0; k < 4; ++k) if (c->f[k]) hipFree(c->f[k]);
     for (int k = 0; k < 3; ++k) if (c->m[k]) hipFree(c->m[k]);
     if (c->d_small) hipFree(c->d_small);
@@ -241,6 +242,9 @@ extern "C" int nl_ctx_destroy(nl_ctx *c) {
     if (c->ev_side) hipEventDestroy(c->ev_side);
     if (c->ev_main) hipEventDestroy(c->ev_main);
     if (c->ev_ahead) hipEventDestroy(c->ev_ahead);
+    if (c->cu_a) { hipStreamSynchronize(c->cu_a); hipStreamDestroy(c->cu_a); }
+    if (c->cu_b) { hipStreamSynchronize(c->cu_b); hipStreamDestroy(c->cu_b); }
+    if (c->ev_cu) hipEventDestroy(c->ev_cu);
     if (c->copy_in) hipStreamDestroy(c->copy_in);
     if (c->copy_out) hipStreamDestroy(c->copy_out);
     if (c->d_blk) hipFree(c->d_blk);
@@ -250,6 +254,7 @@ extern "C" int nl_ctx_destroy(nl_ctx *c) {
     if (c->d_vq_count) hipFree(c->d_vq_count);
     if (c->d_rows) hipFree(c->d_rows);
     if (c->d_ag) hipFree(c->d_ag);
+    if (c->h_ag) hipHostFree(c->h_ag);
     if (c->gbits[0]) hipFree(c->gbits[0]);
     if (c->gbits[1]) hipFree(c->gbits[1]);
     if (c->grows) hipFree(c->grows);
@@ -333,6 +338,23 @@ extern "C" int nl_ctx_create(nl_ctx **out, int device, int64_t nzl, int64_t ny, 
                hipEventCreateWithFlags(&c->ev_ahead, hipEventDisableTiming) != hipSuccess)) {
         rc = nl_fail(err, errlen, NL_EHIP, "stream/event creation failed"); ok = false;
     }
+    {
+        // bit k of a CU mask is compute unit k / 8 of XCD k % 8 on this part (the driver deals the bits round the XCDs), so
+        // "the first n bits" is n / 8 CUs of every XCD and the complement is the rest of every XCD
+        const char *e = getenv("NELLIE_CU_SPLIT");
+        const int n_b = e ? atoi(e) : 0;
+        hipDeviceProp_t prop;
+        if (ok && n_b > 0 && hipGetDeviceProperties(&prop, device) == hipSuccess && n_b < prop.multiProcessorCount) {
+            const int ncu = prop.multiProcessorCount, words = (ncu + 31) / 32;
+            std::vector<uint32_t> ma(words, 0u), mb(words, 0u);
+            for (int k = 0; k < ncu; ++k) ((k < n_b) ? mb : ma)[k >> 5] |= 1u << (k & 31);
+            if (hipExtStreamCreateWithCUMask(&c->cu_a, (uint32_t)words, ma.data()) != hipSuccess ||
+                hipExtStreamCreateWithCUMask(&c->cu_b, (uint32_t)words, mb.data()) != hipSuccess ||
+                hipEventCreateWithFlags(&c->ev_cu, hipEventDisableTiming) != hipSuccess) {
+                rc = nl_fail(err, errlen, NL_EHIP, "CU-masked stream creation failed (NELLIE_CU_SPLIT)"); ok = false;
+            }
+        }
+    }
     if (ok && (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
                hipEventCreate(&c->t0) != hipSuccess || hipEventCreate(&c->t1) != hipSuccess)) {
         rc = nl_fail(err, errlen, NL_EHIP, "stream/event creation failed"); ok = false;
@@ -354,6 +376,13 @@ extern "C" int nl_sync(nl_ctx *c, char *err, size_t errlen) {
 #define NL_ENTER(c)                                                    \
     if (!(c)) return nl_fail(err, errlen, NL_EINVAL, "ctx is NULL");   \
     ++(c)->epoch;                                                      \
+    NL_HIP(hipSetDevice((c)->device));
+
+// Entry points of the copy threads of nellie_amd/streaming.py (nl_input_load_async, nl_outputs_fetch_async, nl_outputs_wait):
+// they run CONCURRENTLY with the compute thread's calls on the same context, touch only the copy streams, the input slots
+// and the staging buffers, and therefore leave `epoch` (the compute state's version) alone.
+#define NL_ENTER_IO(c)                                                 \
+    if (!(c)) return nl_fail(err, errlen, NL_EINVAL, "ctx is NULL");   \
     NL_HIP(hipSetDevice((c)->device));
 
 // nl_mask_volume_fused leaves the support of the Frangi frame (the opened mask, 1 bit/voxel) behind; nl_label_run may
@@ -608,17 +637,18 @@ extern "C" int nl_gauss_step_ahead(nl_ctx *c, const double *wz, int rz, const do
     NL_ENTER(c);
     if (c->ahead_pending) return nl_fail(err, errlen, NL_ESTATE, "a step enqueued ahead is already pending");
     NL_HIP(hipEventRecord(c->ev_main, c->stream));
-    NL_HIP(hipStreamWaitEvent(c->side, c->ev_main, 0));
+    hipStream_t ahead_stream = c->cu_b ? c->cu_b : c->side;
+    NL_HIP(hipStreamWaitEvent(ahead_stream, c->ev_main, 0));
     const int cur_idx = c->i_gauss;
     float *cur_ext = c->gauss_ext;
     hipStream_t main_stream = c->stream;
-    c->stream = c->side;                       // the launch helpers use c->stream
+    c->stream = ahead_stream;                  // the launch helpers use c->stream
     const int rc = nl_gauss_step(c, wz, rz, wy, ry, wx, rx, z0, z1, err, errlen);
     c->stream = main_stream;
     if (rc) { c->i_gauss = cur_idx; c->gauss_ext = cur_ext; return rc; }
     c->ahead_gauss = c->i_gauss;
     c->i_gauss = cur_idx; c->gauss_ext = cur_ext;
-    NL_HIP(hipEventRecord(c->ev_ahead, c->side));
+    NL_HIP(hipEventRecord(c->ev_ahead, ahead_stream));
     c->ahead_pending = 1;
     return NL_OK;
 }
@@ -745,6 +775,36 @@ extern "C" int nl_sample_gather_positive(nl_ctx *c, int field, int64_t sz, int64
     return NL_OK;
 }
 
+#define NL_NCCL(expr)                                                                                  \
+    do {                                                                                               \
+        if (!rccl().ok) return nl_fail(err, errlen, NL_ECOMM, "librccl.so could not be loaded");         \
+        ncclResult_t r_ = (expr);                                                                      \
+        if (r_ != ncclSuccess) return nl_fail(err, errlen, NL_ECOMM, "%s: %s", #expr, rccl().GetErrorString(r_)); \
+    } while (0)
+
+// ---- reductions across the ranks, on the device (nl_comm_fuse) ---------------------------------------------------------
+// With a communicator in "fused" mode the sampling / statistics entry points below finish with the GLOBAL value: the RCCL
+// collective sits on the context stream between the kernels, so a threshold costs one host round trip instead of one per
+// pass plus one per host-level all-reduce.  Every rank must make the same calls in the same order (they do: the path is SPMD).
+static inline bool fused(const nl_ctx *c) { return c->comm && c->fuse_reduce; }
+// res = [min bits, max bits, count lo, count hi] of positive float32 samples: unsigned order = float order
+static int reduce_range(nl_ctx *c, unsigned int *res, char *err, size_t errlen) {
+    NL_NCCL(rccl().GroupStart());
+    NL_NCCL(rccl().AllReduce(res, res, 1, ncclUint32, ncclMin, (ncclComm_t)c->comm, c->stream));
+    NL_NCCL(rccl().AllReduce(res + 1, res + 1, 1, ncclUint32, ncclMax, (ncclComm_t)c->comm, c->stream));
+    NL_NCCL(rccl().AllReduce(res + 2, res + 2, 1, ncclUint64, ncclSum, (ncclComm_t)c->comm, c->stream));
+    NL_NCCL(rccl().GroupEnd());
+    return NL_OK;
+}
+static int reduce_u64_sum(nl_ctx *c, unsigned long long *v, size_t n, char *err, size_t errlen) {
+    NL_NCCL(rccl().AllReduce(v, v, n, ncclUint64, ncclSum, (ncclComm_t)c->comm, c->stream));
+    return NL_OK;
+}
+static int reduce_u32_max(nl_ctx *c, unsigned int *v, size_t n, char *err, size_t errlen) {
+    NL_NCCL(rccl().AllReduce(v, v, n, ncclUint32, ncclMax, (ncclComm_t)c->comm, c->stream));
+    return NL_OK;
+}
+
 extern "C" int nl_sample_minmax(nl_ctx *c, int field, int64_t sz, int64_t sy, int64_t sx, float *mn, float *mx,
                                 int64_t *npos, char *err, size_t errlen) {
     NL_ENTER(c);
@@ -762,6 +822,7 @@ extern "C" int nl_sample_minmax(nl_ctx *c, int field, int64_t sz, int64_t sy, in
         sample_minmax_kernel<<<grid1d(total, 256, 1024), 256, 0, c->stream>>>(fs, geom(c), L, res);
         NL_CHECK_LAUNCH();
     }
+    if (fused(c) && (rc = reduce_range(c, res, err, errlen))) return rc;
     NL_HIP(hipMemcpyAsync(h, res, 16, hipMemcpyDeviceToHost, c->stream));
     NL_HIP(hipStreamSynchronize(c->stream));
     const unsigned long long cnt = *(unsigned long long *)(h + 2);
@@ -794,6 +855,7 @@ extern "C" int nl_sample_hist(nl_ctx *c, int field, int64_t sz, int64_t sy, int6
         sample_hist_kernel<<<grid1d(total, 256, 1024), 256, sh, c->stream>>>(fs, geom(c), L, d_edges, nbins, d_counts, nullptr);
         NL_CHECK_LAUNCH();
     }
+    if (fused(c) && (rc = reduce_u64_sum(c, d_counts, (size_t)nbins, err, errlen))) return rc;
     NL_HIP(hipMemcpyAsync(c->h_small, d_counts, (size_t)nbins * 8, hipMemcpyDeviceToHost, c->stream));
     NL_HIP(hipStreamSynchronize(c->stream));
     memcpy(counts, c->h_small, (size_t)nbins * 8);
@@ -822,13 +884,16 @@ extern "C" int nl_sample_range_hist(nl_ctx *c, int field, int64_t sz, int64_t sy
     h[0] = 0xffffffffu; h[1] = 0; h[2] = 0; h[3] = 0; h[4] = 0;
     NL_HIP(hipMemcpyAsync(res, h, 20, hipMemcpyHostToDevice, c->stream));
     NL_HIP(zero_small(d_counts, (size_t)nbins * 8, c->stream));
-    if (total > 0) {
+    if (total > 0 || fused(c)) {
+        // fused: a rank without lattice points of its own still takes part in the collectives and builds the same edges
         ProfScope ps(c, "sample");
-        sample_minmax_kernel<<<grid1d(total, 256, 1024), 256, 0, c->stream>>>(fs, geom(c), L, res);
+        if (total > 0) sample_minmax_kernel<<<grid1d(total, 256, 1024), 256, 0, c->stream>>>(fs, geom(c), L, res);
+        if (fused(c) && (rc = reduce_range(c, res, err, errlen))) return rc;
         sample_edges_kernel<<<1, 64, 0, c->stream>>>(res, nbins, d_edges, res + 4);
         const size_t sh = (size_t)(nbins + 2) * 4 + (size_t)nbins * 4;
-        sample_hist_kernel<<<grid1d(total, 256, 1024), 256, sh, c->stream>>>(fs, geom(c), L, d_edges, nbins, d_counts, res + 4);
+        if (total > 0) sample_hist_kernel<<<grid1d(total, 256, 1024), 256, sh, c->stream>>>(fs, geom(c), L, d_edges, nbins, d_counts, res + 4);
         NL_CHECK_LAUNCH();
+        if (fused(c) && (rc = reduce_u64_sum(c, d_counts, (size_t)nbins, err, errlen))) return rc;
     }
     NL_HIP(hipMemcpyAsync(c->h_small, c->d_small, bytes, hipMemcpyDeviceToHost, c->stream));
     NL_HIP(hipStreamSynchronize(c->stream));
@@ -1004,9 +1069,15 @@ extern "C" int nl_vesselness_spec(nl_ctx *c, const double spacing[3], float fsq_
         const int nzc = (int)((z1 - z0 + HM_ZCHUNK - 1) / HM_ZCHUNK);
         const unsigned nblocks = (unsigned)(ntx * nty * nzc);
         if (rs) vp.qcap = 2 * HM_SPEC_CAP;              // a wave owns two row segments
+        // a cascade step is running ahead on its share of the compute units: the walk takes the other share
+        hipStream_t hs = (c->ahead_pending && c->cu_a && rs) ? c->cu_a : c->stream;
+        if (hs != c->stream) {
+            NL_HIP(hipEventRecord(c->ev_cu, c->stream));
+            NL_HIP(hipStreamWaitEvent(hs, c->ev_cu, 0));
+        }
 #define NL_LAUNCH_SPEC_V(RSV, FASTV, HR)                                                                                  \
         allow_lds(hessian_v_kernel<2, RSV, FASTV>, HVCfg<RSV>::lds_bytes());                                              \
-        hessian_v_kernel<2, RSV, FASTV><<<nblocks, HVCfg<RSV>::NT, HVCfg<RSV>::lds_bytes(), c->stream>>>(                 \
+        hessian_v_kernel<2, RSV, FASTV><<<nblocks, HVCfg<RSV>::NT, HVCfg<RSV>::lds_bytes(), hs>>>(                        \
             gauss_cur(c), cm, pm, wpr, geom(c), HR, vp, vq, (int)z0, (int)z1, ntx, nty, res, d_cnt)
 #define NL_LAUNCH_SPEC(TYV, FASTV, HR)                                                                                    \
         hessian_g_kernel<2, TYV, FASTV><<<nblocks, HGCfg<TYV>::NT, HGCfg<TYV>::lds_bytes(), c->stream>>>(                 \
@@ -1018,10 +1089,16 @@ extern "C" int nl_vesselness_spec(nl_ctx *c, const double spacing[3], float fsq_
 #undef NL_LAUNCH_SPEC
 #undef NL_LAUNCH_SPEC_V
         NL_CHECK_LAUNCH();
+        if (hs != c->stream) {
+            NL_HIP(hipEventRecord(c->ev_cu, hs));
+            NL_HIP(hipStreamWaitEvent(c->stream, c->ev_cu, 0));
+        }
         c->spec_nregions = nblocks * (unsigned)(rs ? rs : ty);
         c->spec_qcap = vp.qcap;
     }
     unsigned int *h = (unsigned int *)c->h_small;
+    // fused: max |H|, max frob_sq (bit patterns of non-negative floats), the inf and overflow flags -- all "max"; the count stays local
+    if (fused(c)) { int rcr = reduce_u32_max(c, res, 4, err, errlen); if (rcr) return rcr; }
     NL_HIP(hipMemcpyAsync(h, c->d_small, 128, hipMemcpyDeviceToHost, c->stream));      // [0] count, [16..19] statistics
     NL_HIP(hipStreamSynchronize(c->stream));
     c->spec_count = *(unsigned long long *)c->h_small;       // d_small is scratch for the sampling calls in between
@@ -1413,12 +1490,6 @@ extern "C" int nl_planes_put(nl_ctx *c, int field, int64_t z0, int64_t z1, const
     return NL_OK;
 }
 
-#define NL_NCCL(expr)                                                                                  \
-    do {                                                                                               \
-        if (!rccl().ok) return nl_fail(err, errlen, NL_ECOMM, "librccl.so could not be loaded");         \
-        ncclResult_t r_ = (expr);                                                                      \
-        if (r_ != ncclSuccess) return nl_fail(err, errlen, NL_ECOMM, "%s: %s", #expr, rccl().GetErrorString(r_)); \
-    } while (0)
 
 extern "C" int nl_comm_unique_id(char *id128, char *err, size_t errlen) {
     if (!id128) return nl_fail(err, errlen, NL_EINVAL, "id buffer is NULL");
@@ -1528,6 +1599,13 @@ extern "C" int nl_allreduce(nl_ctx *c, void *host_inout, int64_t count, int dtyp
     return NL_OK;
 }
 
+extern "C" int nl_comm_fuse(nl_ctx *c, int on, char *err, size_t errlen) {
+    NL_ENTER(c);
+    if (on && !c->comm) return nl_fail(err, errlen, NL_ESTATE, "nl_comm_fuse before nl_comm_init");
+    c->fuse_reduce = on ? 1 : 0;
+    return NL_OK;
+}
+
 // Variable-size all-gather of host bytes (see include/nellie_amd.h).  Two collectives: the sizes, then the padded blocks.
 extern "C" int nl_allgather_bytes(nl_ctx *c, const void *send, int64_t nbytes, void *recv, int64_t max_bytes, int64_t *bytes_of,
                                   char *err, size_t errlen) {
@@ -1558,6 +1636,47 @@ extern "C" int nl_allgather_bytes(nl_ctx *c, const void *send, int64_t nbytes, v
     NL_NCCL(rccl().AllGather(d_send, d_recv, (size_t)max_bytes, ncclChar, (ncclComm_t)c->comm, c->stream));
     NL_HIP(hipMemcpyAsync(recv, d_recv, (size_t)max_bytes * W, hipMemcpyDeviceToHost, c->stream));
     NL_HIP(hipStreamSynchronize(c->stream));
+    return NL_OK;
+}
+
+// The same without a size negotiated by the caller: the block size is the largest of the gathered sizes, and the blocks land
+// in a page-locked buffer the context owns (*recv, valid until the next call; rank r's block at r * *stride).
+extern "C" int nl_allgather_var(nl_ctx *c, const void *send, int64_t nbytes, void **recv, int64_t *stride, int64_t *bytes_of,
+                                char *err, size_t errlen) {
+    NL_ENTER(c);
+    NL_KEEP_SUPPORT(c);
+    if (!c->comm) return nl_fail(err, errlen, NL_ESTATE, "nl_allgather_var before nl_comm_init");
+    if (nbytes < 0 || !recv || !stride || !bytes_of || (nbytes && !send)) return nl_fail(err, errlen, NL_EINVAL, "bad all-gather arguments");
+    const int W = c->world;
+    long long *hs = (long long *)c->h_small;
+    hs[0] = nbytes;
+    NL_HIP(hipMemcpyAsync(c->d_small, hs, 8, hipMemcpyHostToDevice, c->stream));
+    NL_NCCL(rccl().AllGather(c->d_small, (char *)c->d_small + 64, 1, ncclInt64, (ncclComm_t)c->comm, c->stream));
+    NL_HIP(hipMemcpyAsync(hs, (char *)c->d_small + 64, (size_t)W * 8, hipMemcpyDeviceToHost, c->stream));
+    NL_HIP(hipStreamSynchronize(c->stream));
+    long long mx = 16;
+    for (int r = 0; r < W; ++r) { bytes_of[r] = hs[r]; if (hs[r] > mx) mx = hs[r]; }
+    mx = (mx + 15) & ~15ll;
+    const size_t need = (size_t)mx * (size_t)(W + 1);
+    if (need > c->ag_cap) {
+        if (c->d_ag) hipFree(c->d_ag);
+        c->d_ag = nullptr; c->ag_cap = 0;
+        NL_HIP(hipMalloc(&c->d_ag, need + need / 2));          // head room: the tables of the next phase / frame differ a little
+        c->ag_cap = need + need / 2;
+    }
+    if ((size_t)mx * W > c->h_ag_cap) {
+        if (c->h_ag) hipHostFree(c->h_ag);
+        c->h_ag = nullptr; c->h_ag_cap = 0;
+        const size_t cap = (size_t)mx * W * 3 / 2;
+        NL_HIP(hipHostMalloc(&c->h_ag, cap, hipHostMallocDefault));
+        c->h_ag_cap = cap;
+    }
+    char *d_send = (char *)c->d_ag, *d_recv = d_send + mx;
+    if (nbytes) NL_HIP(hipMemcpyAsync(d_send, send, (size_t)nbytes, hipMemcpyHostToDevice, c->stream));
+    NL_NCCL(rccl().AllGather(d_send, d_recv, (size_t)mx, ncclChar, (ncclComm_t)c->comm, c->stream));
+    NL_HIP(hipMemcpyAsync(c->h_ag, d_recv, (size_t)mx * W, hipMemcpyDeviceToHost, c->stream));
+    NL_HIP(hipStreamSynchronize(c->stream));
+    *recv = c->h_ag; *stride = mx;
     return NL_OK;
 }
 
@@ -2694,7 +2813,7 @@ static int stream_init(nl_ctx *c, char *err, size_t errlen) {
 
 // H2D of a whole local frame into input slot 0/1 on the copy stream (returns at once)
 extern "C" int nl_input_load_async(nl_ctx *c, int slot, const void *host_pinned, int dtype, char *err, size_t errlen) {
-    NL_ENTER(c);
+    NL_ENTER_IO(c);
     const size_t es = dtype_size(dtype);
     if (!es || !host_pinned || slot < 0 || slot > 1) return nl_fail(err, errlen, NL_EINVAL, "bad async load arguments");
     int rc = stream_init(c, err, errlen);
@@ -2736,7 +2855,7 @@ extern "C" int nl_outputs_stage(nl_ctx *c, int with_labels, char *err, size_t er
 
 // D2H of the staged outputs on the second copy stream (returns at once); nl_outputs_wait blocks until they landed
 extern "C" int nl_outputs_fetch_async(nl_ctx *c, float *frangi_pinned, int32_t *labels_pinned, char *err, size_t errlen) {
-    NL_ENTER(c);
+    NL_ENTER_IO(c);
     if (!c->copy_out || !c->d_stage_fr) return nl_fail(err, errlen, NL_ESTATE, "nl_outputs_fetch_async before nl_outputs_stage");
     NL_HIP(hipStreamWaitEvent(c->copy_out, c->ev_staged, 0));
     if (frangi_pinned) NL_HIP(hipMemcpyAsync(frangi_pinned, c->d_stage_fr, (size_t)c->n * 4, hipMemcpyDeviceToHost, c->copy_out));
@@ -2748,7 +2867,7 @@ extern "C" int nl_outputs_fetch_async(nl_ctx *c, float *frangi_pinned, int32_t *
     return NL_OK;
 }
 extern "C" int nl_outputs_wait(nl_ctx *c, char *err, size_t errlen) {
-    NL_ENTER(c);
+    NL_ENTER_IO(c);
     if (c->ev_fetched) NL_HIP(hipEventSynchronize(c->ev_fetched));
     return NL_OK;
 }
@@ -2795,23 +2914,44 @@ extern "C" int nl_timer_end_ms(nl_ctx *c, float *ms, char *err, size_t errlen) {
     if (ms) *ms = t;
     return NL_OK;
 }
-extern "C" int nl_prof_enable(nl_ctx *c, int on) { if (c) c->prof_on = on; return NL_OK; }
+extern "C" int nl_prof_enable(nl_ctx *c, int on) {
+    if (!c) return NL_OK;
+    if (on && !c->prof_on) {                 // stock the pool outside the timed region
+        hipSetDevice(c->device);
+        size_t used = 0;
+        for (auto &kv : c->prof) used += kv.second.size();
+        while (c->prof_pool.size() + used < 1024) {
+            ProfRec r;
+            if (hipEventCreate(&r.a) != hipSuccess) break;
+            if (hipEventCreate(&r.b) != hipSuccess) { hipEventDestroy(r.a); break; }
+            c->prof_pool.push_back(r);
+        }
+    }
+    c->prof_on = on;
+    return NL_OK;
+}
 extern "C" int nl_prof_reset(nl_ctx *c) {
     if (!c) return NL_OK;
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
-    for (auto &kv : c->prof) for (auto &r : kv.second) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+    hipStreamSynchronize(c->side);
+    for (auto &kv : c->prof) for (auto &r : kv.second) c->prof_pool.push_back(r);       // kept for the next scopes
     c->prof.clear();
+    c->prof_sum.clear();
     return NL_OK;
 }
 extern "C" int nl_prof_get(nl_ctx *c, const char *name, double *ms, int64_t *launches) {
     if (!c || !name) return NL_EINVAL;
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
+    hipStreamSynchronize(c->side);
+    if (c->cu_a) hipStreamSynchronize(c->cu_a);
+    if (c->cu_b) hipStreamSynchronize(c->cu_b);
+    if (c->xstream) hipStreamSynchronize(c->xstream);
+    prof_harvest(c, true);
     double tot = 0; int64_t k = 0;
-    auto it = c->prof.find(name);
-    if (it != c->prof.end())
-        for (auto &r : it->second) { float t = 0; if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) { tot += t; ++k; } }
+    auto it = c->prof_sum.find(name);
+    if (it != c->prof_sum.end()) { tot = it->second.first; k = it->second.second; }
     if (ms) *ms = tot;
     if (launches) *launches = k;
     return NL_OK;

@@ -74,6 +74,11 @@ struct nl_ctx {
     hipEvent_t ev_side = nullptr, ev_main = nullptr;
     hipEvent_t ev_ahead = nullptr;       // a cascade step enqueued ahead on `side` (nl_gauss_step_ahead)
     int ahead_pending = 0, ahead_gauss = 0;
+    // NELLIE_CU_SPLIT=n: while a cascade step runs ahead, it is confined to n compute units (stream cu_b) and the Hessian
+    // walk of the current scale to the other ones (stream cu_a) -- a memory-bound and an issue-bound kernel side by side
+    // on disjoint CUs instead of taking turns on all of them
+    hipStream_t cu_a = nullptr, cu_b = nullptr;
+    hipEvent_t ev_cu = nullptr;
     int side_pending = 0;                // work on `side` the main stream has not been ordered after yet
     int last_spec_overflow = 0;          // the last one-pass walk overflowed a queue region (diagnostics)
     float last_fsq_min = 0;    // the exact mask threshold of the last scale (diagnostics)
@@ -99,7 +104,9 @@ struct nl_ctx {
     int mask_slots_used = 0;   // per-scale h_mask bit planes written since the frame began
 
     void *comm = nullptr;             // ncclComm_t (RCCL), set by nl_comm_init
+    int fuse_reduce = 0;              // nl_comm_fuse: the sampling / statistics entry points reduce across the ranks on the device
     void *d_ag = nullptr; size_t ag_cap = 0;      // staging of nl_allgather_bytes
+    void *h_ag = nullptr; size_t h_ag_cap = 0;    // page-locked landing area of nl_allgather_var
     void *comm2 = nullptr;            // second communicator: asynchronous ghost-plane exchanges (nl_comm_init2)
     hipStream_t xstream = nullptr;    // ... and their stream
     hipEvent_t ev_x_main = nullptr, ev_x_done = nullptr;
@@ -109,6 +116,9 @@ struct nl_ctx {
     hipEvent_t t0 = nullptr, t1 = nullptr;
     int prof_on = 0;
     std::map<std::string, std::vector<ProfRec>> prof;
+    std::map<std::string, std::pair<double, int64_t>> prof_sum;      // completed scopes: total ms, count
+    std::vector<ProfRec> prof_pool;      // event pairs ready for use: creating events inside a timed region stalls now and then
+                                         // (one hipEventCreate was measured at 57 ms when the runtime grew its pool)
     std::vector<hipEvent_t> ev_pool;
 };
 
@@ -136,18 +146,36 @@ static inline int nl_fail(char *err, size_t errlen, int code, const char *fmt, .
 
 #define NL_CHECK_LAUNCH() NL_HIP(hipGetLastError())
 
+// Completed event pairs are turned into per-group sums and go back to the pool (all = false: only from the front of each
+// group, as far as the events have completed -- no waiting).
+static inline void prof_harvest(nl_ctx *c, bool all) {
+    for (auto &kv : c->prof) {
+        auto &v = kv.second;
+        size_t k = 0;
+        for (; k < v.size(); ++k) {
+            if (!all && hipEventQuery(v[k].b) != hipSuccess) break;
+            float t = 0;
+            if (hipEventElapsedTime(&t, v[k].a, v[k].b) == hipSuccess) { auto &s = c->prof_sum[kv.first]; s.first += t; s.second += 1; }
+            c->prof_pool.push_back(v[k]);
+        }
+        v.erase(v.begin(), v.begin() + k);
+    }
+}
+
 // RAII profiling scope: records a HIP-event pair on the context stream around a kernel group.
 struct ProfScope {
     nl_ctx *c; ProfRec r; bool on;
     hipStream_t st;
     ProfScope(nl_ctx *ctx, const char *name, hipStream_t stream = nullptr) : c(ctx), on(ctx->prof_on != 0), st(stream ? stream : ctx->stream) {
         if (!on) return;
-        hipEventCreate(&r.a); hipEventCreate(&r.b);
+        if (c->prof_pool.empty()) prof_harvest(c, false);
+        if (!c->prof_pool.empty()) { r = c->prof_pool.back(); c->prof_pool.pop_back(); }
+        else { hipEventCreate(&r.a); hipEventCreate(&r.b); }
         hipEventRecord(r.a, st);
-        c->prof[name].push_back(r);
-        idx = c->prof[name].size() - 1; key = name;
+        key = name;
     }
-    ~ProfScope() { if (on) hipEventRecord(c->prof[key][idx].b, st); }
-    size_t idx = 0; std::string key;
+    // the record is filed only now, complete: a harvest in between never sees a pair whose second event is unrecorded
+    ~ProfScope() { if (on) { hipEventRecord(r.b, st); c->prof[key].push_back(r); } }
+    std::string key;
 };
 

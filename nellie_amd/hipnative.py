@@ -108,6 +108,8 @@ _PROTOS = {
     "nl_slab_query": [_p, _i64, _p, _p],
     "nl_slab_paint": [_p, _i64, _i64, _p, _p],
     "nl_allgather_bytes": [_p, _p, _i64, _p, _i64, _p],
+    "nl_allgather_var": [_p, _p, _i64, _p, _p, _p],
+    "nl_comm_fuse": [_p, _int],
     "nl_pinned_alloc": [C.POINTER(_p), _i64],
     "nl_host_register": [_p, _i64],
     "nl_input_load_async": [_p, _int, _p, _int],
@@ -770,6 +772,19 @@ class Context:
         sizes = np.zeros(int(world), np.int64)
         self._call("nl_allgather_bytes", _ptr(send) if send.size else None, send.size, _ptr(recv), int(max_bytes), _ptr(sizes))
         return [recv[r * max_bytes:r * max_bytes + int(sizes[r])].tobytes() for r in range(int(world))]
+
+    def allgather_var(self, arr: np.ndarray, world: int):
+        """Variable-size all-gather over RCCL of one array per rank (same dtype everywhere): the list of every rank's array."""
+        a = np.ascontiguousarray(arr)
+        recv, stride = C.c_void_p(), C.c_int64(0)
+        sizes = np.zeros(int(world), np.int64)
+        self._call("nl_allgather_var", _ptr(a) if a.size else None, a.nbytes, C.byref(recv), C.byref(stride), _ptr(sizes))
+        blob = np.ctypeslib.as_array(C.cast(recv, C.POINTER(C.c_uint8)), shape=(int(stride.value) * int(world),))
+        st = int(stride.value)
+        return [blob[r * st:r * st + int(sizes[r])].view(a.dtype).copy() for r in range(int(world))]
+
+    def comm_fuse(self, on=True):
+        self._call("nl_comm_fuse", 1 if on else 0)
 
     def label_store(self, z0=0, z1=None, out=None):
         z1 = self.shape[0] if z1 is None else z1

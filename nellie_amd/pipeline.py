@@ -277,11 +277,18 @@ class FramePipeline:
     def _reduce_counts(self, counts):
         return counts
 
-    def _reduce_stats(self, max_abs, max_fsq, any_inf, overflow=0):
+    def _reduce_stats(self, max_abs, max_fsq, any_inf, overflow=0, fused_call=False):
         return max_abs, max_fsq, any_inf, overflow
 
     def _reduce_sum(self, n):
         return n
+
+    def _reduce_mask_count(self, n):
+        """h_mask count of a scale the one-pass walk completed: reporting only (ScaleTrace), nothing downstream waits for it."""
+        return self._reduce_sum(n)
+
+    def _settle_mask_counts(self):
+        """Called once the scale loop is over: Z slabs turn the per-rank counts kept so far into global ones here."""
 
     def _gather(self, samples):
         return samples
@@ -378,7 +385,7 @@ class FramePipeline:
         def settle():
             nonlocal pending
             if pending is not None:
-                pending.mask_count = self._reduce_sum(ctx.vesselness_count())
+                pending.mask_count = self._reduce_mask_count(ctx.vesselness_count())
                 pending = None
 
         deltas = list(cascade_deltas(sigmas, zr))
@@ -420,7 +427,7 @@ class FramePipeline:
                     settle()
                     vz0, vz1 = self._vess_range()
                     ma, mf, inf_, ovf = ctx.vesselness_spec(spacing, bracket[0], bracket[1], z0=vz0, z1=vz1)
-                    stats = self._reduce_stats(ma, mf, inf_, ovf)
+                    stats = self._reduce_stats(ma, mf, inf_, ovf, fused_call=True)    # nl_vesselness_spec reduces them itself on a fused communicator
                     spec = not stats[2] and not stats[3]
                     if stats[2]:
                         stats = None     # a +inf frob_sq turned up: the one-pass walk only flags it (the largest finite
@@ -463,6 +470,7 @@ class FramePipeline:
                 settle()
                 pending = self.trace.scales[-1]      # its kernel overlaps the next scale's Gaussian; count read later
         settle()
+        self._settle_mask_counts()
         if not finish:
             return None
         vz0, vz1 = self._vess_range()

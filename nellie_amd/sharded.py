@@ -33,6 +33,8 @@ own chunked mode, labelling.py:585-691, stitches per-chunk labellings and is NOT
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 from nellie_amd import hipnative
@@ -149,6 +151,11 @@ class RcclComm:
         self.has_side_channel = uid2 is not None          # a second communicator: asynchronous ghost-plane exchanges
         if uid2 is not None:
             ctx.comm_init2(world, rank, uid2)
+        # the sampling / statistics entry points return GLOBAL values (nl_comm_fuse): ShardedFramePipeline then makes the
+        # single-GPU sequence of calls and skips the host-level all-reduce behind each of them
+        self.fused = os.environ.get("NELLIE_FUSE_REDUCE", "1") == "1"
+        if self.fused:
+            ctx.comm_fuse(True)
 
     def exchange_halo(self, ctx, field, depth, offset=0, run_async=False):
         ctx.halo_exchange_at(field, offset, depth, run_async and self.has_side_channel)
@@ -160,10 +167,7 @@ class RcclComm:
         return self.ctx.allreduce(arr, op)
 
     def allgather_list(self, arr):
-        a = np.ascontiguousarray(arr)
-        mx = int(self.ctx.allreduce(np.array([a.nbytes], np.int64), "max")[0])
-        blocks = self.ctx.allgather_bytes(a.tobytes(), max(mx, 8), self.world)
-        return [np.frombuffer(b, dtype=a.dtype) for b in blocks]
+        return self.ctx.allgather_var(np.ascontiguousarray(arr), self.world)
 
     def allgather(self, arr):
         return np.concatenate(self.allgather_list(arr))
@@ -195,8 +199,11 @@ class ShardedFramePipeline(FramePipeline):
         make = ctx_factory or (lambda shp, dev, g0, gn, own: hipnative.Context(shp, device=dev, gz0=g0, gnz=gn, own=own))
         ctx = make(lshape, device, gz0, int(gshape[0]), (own_lo, own_hi))
         super().__init__(gshape, device=device, ctx=ctx)
-        self._chain_hist = False           # the sample range is reduced across the ranks before the histogram pass
         self.comm = comm_factory(ctx)
+        # the sample range is reduced across the ranks before the histogram pass: by the library itself between the two
+        # kernels (a "fused" communicator), or by a host-level all-reduce between two calls
+        self._fused_reduce = bool(getattr(self.comm, "fused", False))
+        self._chain_hist = self._fused_reduce
         self.params = params
         self._valid = (0, lshape[0])
         # threshold + opening + product in one go, ghost planes included (nl_mask_volume_fused works on owned +- 2)
@@ -254,6 +261,8 @@ class ShardedFramePipeline(FramePipeline):
     def _reduce_minmax(self, mn, mx, npos):
         """Global (min, max, any positive sample?) in ONE collective: max over (max, -min, has-samples).  Callers only
         ask whether the count is zero, so the third value is 0 / 1."""
+        if self._fused_reduce:
+            return mn, mx, npos
         big = np.float32(np.inf)
         r = self.comm.allreduce(np.array([mx if npos else -big, -mn if npos else -big, 1.0 if npos else 0.0], np.float32), "max")
         if r[2] <= 0:
@@ -261,14 +270,28 @@ class ShardedFramePipeline(FramePipeline):
         return np.float32(-r[1]), np.float32(r[0]), 1
 
     def _reduce_counts(self, counts):
+        if self._fused_reduce:
+            return counts
         return self.comm.allreduce(np.ascontiguousarray(counts, dtype=np.int64), "sum")
 
-    def _reduce_stats(self, max_abs, max_fsq, any_inf, overflow=0):
+    def _reduce_stats(self, max_abs, max_fsq, any_inf, overflow=0, fused_call=False):
+        if self._fused_reduce and fused_call:
+            return max_abs, max_fsq, bool(any_inf), bool(overflow)
         r = self.comm.allreduce(np.array([max_abs, max_fsq, 1.0 if any_inf else 0.0, 1.0 if overflow else 0.0], np.float32), "max")
         return np.float32(r[0]), np.float32(r[1]), bool(r[2] > 0), bool(r[3] > 0)
 
     def _reduce_sum(self, n):
         return int(self.comm.allreduce(np.array([n], np.int64), "sum")[0])
+
+    def _reduce_mask_count(self, n):
+        return n            # this rank's share; _settle_mask_counts turns all of a frame's counts global in one collective
+
+    def _settle_mask_counts(self):
+        hit = [sc for sc in self.trace.scales if sc.one_pass]
+        if hit:
+            tot = self.comm.allreduce(np.array([sc.mask_count for sc in hit], np.int64), "sum")
+            for sc, t in zip(hit, tot):
+                sc.mask_count = int(t)
 
     def _gather(self, samples):
         return self.comm.allgather(np.ascontiguousarray(samples, dtype=np.float32))

@@ -78,26 +78,44 @@ def test_zslab_filter_equals_single_gpu(hip, gshape, aniso, world, halo_mode):
     assert ref_n >= 1
 
 
-def test_rccl_communicator_world1(hip):
-    """RCCL plumbing on a single device: unique id, communicator, all-reduce, and a 1-rank sharded run."""
+@pytest.mark.parametrize("fused", [True, False])
+def test_rccl_communicator_world1(hip, fused, monkeypatch):
+    """RCCL plumbing on a single device: unique ids, both communicators, all-reduce, variable all-gather, and a 1-rank sharded
+    run of Filter + Label -- with the reductions fused into the sampling / statistics entry points (nl_comm_fuse: the production
+    setting) and as host-level all-reduces; outputs, thresholds and h_mask counts equal the single-GPU run's."""
     from nellie_amd import hipnative
     from nellie_amd import pipeline as pl
     from nellie_amd.sharded import RcclComm, ShardedFramePipeline
     from nellie_amd.synthetic import ISO_01, make_volume
+    monkeypatch.setenv("NELLIE_FUSE_REDUCE", "1" if fused else "0")
     gshape = (40, 48, 56)
     vol = make_volume(gshape, 5)
     p = pl.FilterParams(dim_res=ISO_01)
-    uid = hipnative.comm_unique_id()
-    assert len(uid) == 128
-    pipe = ShardedFramePipeline(gshape, 0, 1, lambda ctx: RcclComm(ctx, 1, 0, uid, lambda a: a), p)
+    ma = pl.min_area_pixels_of(ISO_01)
+    uid, uid2 = hipnative.comm_unique_id(), hipnative.comm_unique_id()
+    assert len(uid) == 128 and uid != uid2
+    pipe = ShardedFramePipeline(gshape, 0, 1, lambda ctx: RcclComm(ctx, 1, 0, uid, uid2=uid2), p)
+    assert pipe.comm.fused == fused and pipe._chain_hist == fused
     assert np.array_equal(pipe.comm.allreduce(np.array([3, 4], np.int64), "sum"), [3, 4])
     assert np.array_equal(pipe.comm.allreduce(np.array([1.5], np.float32), "max"), np.array([1.5], np.float32))
+    for arr in (np.arange(7, dtype=np.int32), np.zeros(0, np.int32), np.arange(5000, dtype=np.int64)):
+        got = pipe.comm.allgather_list(arr)
+        assert len(got) == 1 and got[0].dtype == arr.dtype and np.array_equal(got[0], arr)
     pipe.filter(vol, p)
     got = pipe.download_frangi()
+    thr = pipe.frangi_threshold()
+    n = pipe.label(thr, ma)
+    lab = pipe.download_labels()
+    tr = pipe.trace
     pipe.close()
     single = pl.FramePipeline(gshape)
     single.filter(vol, p)
     assert np.array_equal(got, single.download_frangi())
+    assert thr == single.frangi_threshold()
+    assert n == single.label(thr, ma) and np.array_equal(lab, single.download_labels())
+    for a, b in zip(tr.scales, single.trace.scales):
+        assert (a.gamma, a.max_abs, a.frob_thr, a.mask_count, a.one_pass) == (b.gamma, b.max_abs, b.frob_thr, b.mask_count, b.one_pass)
+    assert tr.n_positive == single.trace.n_positive
     single.close()
 
 
