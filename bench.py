@@ -400,6 +400,10 @@ def run_zslab_child(args, rank):
     env = dict(os.environ)
     env["MASTER_PORT"] = str((int(env.get("MASTER_PORT", "29500")) - 1024 + 101) % 60000 + 1024)
     env.pop("TORCHELASTIC_USE_AGENT_STORE", None)          # the children rendezvous among themselves (rank 0 hosts the store)
+    # the host side of a slab step is a few hundred calls on tiny arrays: BLAS / OpenMP pools of 64-128 threads per rank only
+    # cost wake-ups there (measured: a one-off 60-80 ms stall in the second step of a run, gone with one thread)
+    for var in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+        env.setdefault(var, "1")
     cmd = [sys.executable, os.path.abspath(__file__), "--zslab-child", "--gpus", str(args.gpus), "--steps", str(args.steps),
            "--warmup", str(args.warmup), "--zslab-planes", str(args.zslab_planes), "--zslab-yx", str(args.zslab_yx[0]), str(args.zslab_yx[1])]
     if args.share_device:

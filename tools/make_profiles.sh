@@ -4,6 +4,8 @@
 #   r02_kernel_stats_1024cube.csv    rocprofv3 --kernel-trace --stats summary of the same bench command
 #   r02_pmc_hbm_bytes_1024cube.json  HBM bytes per kernel launch: FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes
 #                                    (KB units; FETCH_SIZE is doubled on gfx950, see MI355X_MICROARCH.md)
+#   r02_zslab_world1_128x2048x2048.json  one rank's share of the 8-GPU Z-slab run of BASELINE config 4 (the bench's Z-slab child at
+#                                    world 1 over a real one-rank RCCL communicator): what a rank costs before any neighbour exists
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py > /tmp/bench.out 2>/tmp/bench.err; tail -1 /tmp/bench.out > $R/gpurun_out/r02_bench_n1_1024cube.json
@@ -31,4 +33,5 @@ for k in sorted(f, key=lambda k: -f[k]):
                 "write_bytes_per_voxel": wk * 1024 / N})
 json.dump(out, sys.stdout, indent=1)
 PY
+RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29533 python $R/bench.py --zslab-child --gpus 1 --steps 10 --warmup 2 2>/tmp/zs.err | tail -1 > $R/gpurun_out/r02_zslab_world1_128x2048x2048.json
 tail -2 /tmp/ks.log; tail -c 600 $R/gpurun_out/r02_bench_n1_1024cube.json

@@ -5,6 +5,9 @@ tools/prof_slab.py [Z Y X] [reps]   (NELLIE_PROF_CALLS=0: no per-call timers, fo
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+if os.environ.get("NELLIE_PROF_TORCH") == "1":      # does importing torch (as bench.py does) change the host-side cost?
+    import torch
+    print("torch threads", torch.get_num_threads())
 from nellie_amd import hipnative, pipeline as pl, sharded
 from nellie_amd.synthetic import ISO_01, make_volume
 
