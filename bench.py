@@ -481,11 +481,16 @@ def zslab_run(dist, rank, world, local_rank, args):
     planes = int(args.zslab_planes)
     gshape = (planes * world, int(args.zslab_yx[0]), int(args.zslab_yx[1]))
     o0, o1 = slab_range(gshape[0], world, rank)
-    t_gen = time.perf_counter()
-    own = make_volume((o1 - o0,) + gshape[1:], 3456, z_offset=o0, global_nz=gshape[0])
-    t_gen = time.perf_counter() - t_gen
     uid2, uid2_x = fresh_uid(), fresh_uid()
     pipe = ShardedFramePipeline(gshape, rank, world, lambda ctx: RcclComm(ctx, world, rank, uid2, uid2=uid2_x), p, device=local_rank)
+    # The resident input of a rank is its owned planes plus the raw ghost planes the first cascade step reads (8 per interior
+    # side here): whoever loads a slab from the source image loads those planes with it, so no raw plane crosses xGMI.  The
+    # ghost planes of every COMPUTED volume (one exchange per cascade step) and the bit planes of Label do travel over RCCL,
+    # inside the timed region.  NELLIE_BENCH_RAW_EXCHANGE=1: owned planes only, the raw ghosts are exchanged in every step too.
+    g_lo, g_hi = (0, 0) if os.environ.get("NELLIE_BENCH_RAW_EXCHANGE") == "1" else pipe.raw_ghost_needed()
+    t_gen = time.perf_counter()
+    own = make_volume((o1 - o0 + g_lo + g_hi,) + gshape[1:], 3456, z_offset=o0 - g_lo, global_nz=gshape[0])
+    t_gen = time.perf_counter() - t_gen
     pipe.load_input(own)
     del own
 
@@ -524,9 +529,10 @@ def zslab_run(dist, rank, world, local_rank, args):
         "value": round(n_global * args.steps / elapsed / 1e6, 1), "unit": "Mvoxel/s", "ms_per_step": round(elapsed / args.steps * 1e3, 3),
         "workload": f"ONE synthetic {gshape[0]}x{gshape[1]}x{gshape[2]} float32 volume (seed 3456"
                     + (", BASELINE config 4" if gshape == (1024, 2048, 2048) else f", the first {gshape[0]} planes' worth of BASELINE config 4's generator")
-                    + f") cut into {world} Z slabs of {planes} owned planes + {pipe.halo} ghost planes per interior side; "
+                    + f") cut into {world} Z slabs of {planes} owned planes + {pipe.halo} ghost planes per interior side "
+                      f"({'raw ghost planes of the input resident with it, ' if (g_lo or g_hi or world == 1) else ''}ghost planes of every computed volume and Label's bit planes exchanged over RCCL in the step); "
                       "5-scale Frangi + Label (no replication), full hot path per step, slabs resident in HBM",
-        "voxels": int(n_global), "per_gpu_owned_shape": [planes, gshape[1], gshape[2]], "halo_planes": pipe.halo, "halo_scheme": pipe.halo_mode, "untimed_warmup_steps": n_warm,
+        "voxels": int(n_global), "per_gpu_owned_shape": [planes, gshape[1], gshape[2]], "halo_planes": pipe.halo, "halo_scheme": pipe.halo_mode, "untimed_warmup_steps": n_warm, "raw_ghost_planes_resident_with_input": [int(g_lo), int(g_hi)],
         "halo_ms": groups.get("halo"), "groups_ms_per_step_rank0": groups, "labels": int(n_labels),
         "survival_fraction": round(tr.n_positive / n_global, 5),
         "mask_fraction_per_scale": [round(sc.mask_count / n_global, 4) for sc in tr.scales],

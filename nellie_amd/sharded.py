@@ -209,30 +209,55 @@ class ShardedFramePipeline(FramePipeline):
         self._chain_hist = self._fused_reduce
         self.params = params
         self._valid = (0, lshape[0])
+        self._raw_ghosts_loaded = False
         # threshold + opening + product in one go, ghost planes included (nl_mask_volume_fused works on owned +- 2)
         self._fused_epilogue = hasattr(ctx, "mask_volume_fused") and hasattr(ctx, "sample_gather_positive")
 
     # ---- loading: own planes in, ghost planes from the neighbours ---------------------------------------
-    def _load(self, frame):
-        """`frame` = this rank's OWN planes (own, Y, X)."""
+    def raw_ghost_needed(self):
+        """(low, high) raw planes beyond the owned ones that the first cascade step reads: what `load_input` / `filter`
+        accept in addition to the owned planes.  Whoever holds the whole input (a file, a host array) hands them over with
+        the frame and the first -- the only exposed -- ghost-plane exchange of the frame is not needed at all."""
+        if self.halo_mode == "fat":
+            return self.own[0], self.lshape[0] - self.own[1]
         lo, hi = self.own
-        self.ctx.filter_load(np.asarray(frame), z0=lo, z1=hi)
+        d = 4 + self._rz[0]
+        return min(d, lo), min(d, self.lshape[0] - hi)
+
+    def _place(self, frame):
+        """`frame` = this rank's OWN planes, or the owned planes with `raw_ghost_needed()` ghost planes on each side:
+        -> (first local plane, last + 1) it fills."""
+        lo, hi = self.own
+        n = np.shape(frame)[0]
+        g_lo, g_hi = self.raw_ghost_needed()
+        if n == hi - lo:
+            self._raw_ghosts_loaded = (g_lo == 0 and g_hi == 0)
+            return lo, hi
+        if n == hi - lo + g_lo + g_hi:
+            self._raw_ghosts_loaded = True
+            return lo - g_lo, hi + g_hi
+        raise ValueError(f"a frame of {n} planes is neither the {hi - lo} owned planes nor those plus the {g_lo} + {g_hi} raw ghost planes")
+
+    def _load(self, frame):
+        z0, z1 = self._place(frame)
+        self.ctx.filter_load(np.asarray(frame), z0=z0, z1=z1)
 
     def load_input(self, frame):
-        lo, hi = self.own
-        self.ctx.input_load(np.asarray(frame), z0=lo, z1=hi)
+        z0, z1 = self._place(frame)
+        self.ctx.input_load(np.asarray(frame), z0=z0, z1=z1)
 
     def _after_load(self, p):
         if not self._filter_ok:
             raise ValueError(f"this slab holds {self.halo} ghost planes, the {self.halo_mode!r} exchange scheme of Filter needs more")
         lo, hi = self.own
         nzl = self.lshape[0]
+        have = self._raw_ghosts_loaded            # every rank is called the same way: all of them have their ghosts or none has
         if self.halo_mode == "fat":
             depth = max(lo, nzl - hi)
-            if depth:
+            if depth and not have:
                 self.comm.exchange_halo(self.ctx, FIELD_GAUSS, depth)
             self._valid = (0, nzl)
-        elif self.world > 1:
+        elif self.world > 1 and not have:
             self.comm.exchange_halo(self.ctx, FIELD_GAUSS, 4 + self._rz[0], 0, False)     # raw planes: nothing to hide them behind
 
     # ---- Z ranges of the cascade ------------------------------------------------------------------------------

@@ -23,10 +23,17 @@ def main():
     gshape = (40, 36, 44) if aniso else (64, 30, 34)
     p = FilterParams(dim_res=dr)
     o0, o1 = slab_range(gshape[0], world, rank)
-    own = make_volume((o1 - o0,) + gshape[1:], 77, z_offset=o0, global_nz=gshape[0])
     pipe = ShardedFramePipeline(gshape, rank, world, lambda ctx: GlooComm(dist, rank, world), p,
                                 ctx_factory=lambda shp, dev, g0, gn, ow: OracleCtx(shp, dev, g0, gn, ow))
+    # NELLIE_TEST_RAW_GHOSTS=1: the raw ghost planes the first cascade step reads come with the frame (no exchange of raw planes)
+    g_lo, g_hi = pipe.raw_ghost_needed() if os.environ.get("NELLIE_TEST_RAW_GHOSTS") == "1" else (0, 0)
+    own = make_volume((o1 - o0 + g_lo + g_hi,) + gshape[1:], 77, z_offset=o0 - g_lo, global_nz=gshape[0])
+    calls = []
+    inner = pipe.comm.exchange_halo
+    pipe.comm.exchange_halo = lambda ctx, field, depth, offset=0, run_async=False: (calls.append((depth, offset)), inner(ctx, field, depth, offset, run_async))[1]
     pipe.filter(own, p)
+    if g_lo or g_hi:
+        assert all(off > 0 for _, off in calls), f"raw planes were exchanged although they came with the frame: {calls}"
     fr = pipe.download_frangi()
     thr = pipe.frangi_threshold()
     n_labels = pipe.label(thr, min_area_pixels_of(dr))

@@ -69,6 +69,19 @@ def test_properties_at_1024_cube(full_run):
     assert all(0.01 < sc.mask_count / fr.size < 0.9 for sc in full_run["trace"].scales)
 
 
+def test_labels_equal_the_oracle_at_1024_cube(full_run):
+    """Label at the headline size against the oracle (labelling.py:467-509 restated; ~1 min of C union-find and numpy on the host)
+    on the SAME Frangi frame: threshold, object count and every voxel of the int32 volume.  (This comparison found the wrong
+    bit of the first majority kernel at x = nx - 1, which no smaller volume triggered.)"""
+    from nellie_amd.synthetic import ISO_01
+    from oracle import nellie_oracle as orc
+    orc.build_c_helper()
+    ref, thr = orc.label_frame(full_run["frangi"], ISO_01, return_thr=True)
+    assert thr == full_run["thr"]
+    assert int(ref.max()) == full_run["n"]
+    assert np.array_equal(ref, full_run["labels"])
+
+
 def run_slabs(vol, shape, world, seed_dim_res=None):
     """The volume as `world` Z-slabs, one context and one thread per slab on this GPU (ghost planes and reductions
     through the host): [(o0, o1, frangi, labels, thr, n)] per rank."""

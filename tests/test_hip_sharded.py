@@ -15,7 +15,7 @@ from comms import ThreadComm, ThreadGroup
 pytestmark = pytest.mark.gpu
 
 
-def _run_sharded(gshape, dr, seed, world, halo_mode="steps"):
+def _run_sharded(gshape, dr, seed, world, halo_mode="steps", raw_ghosts=False):
     from nellie_amd.pipeline import FilterParams, min_area_pixels_of
     from nellie_amd.sharded import ShardedFramePipeline, slab_range
     from nellie_amd.synthetic import make_volume
@@ -26,8 +26,9 @@ def _run_sharded(gshape, dr, seed, world, halo_mode="steps"):
         try:
             p = FilterParams(dim_res=dr)
             o0, o1 = slab_range(gshape[0], world, rank)
-            own = make_volume((o1 - o0,) + tuple(gshape[1:]), seed, z_offset=o0, global_nz=gshape[0])
             pipe = ShardedFramePipeline(gshape, rank, world, lambda ctx: ThreadComm(group, rank), p, halo_mode=halo_mode)
+            g_lo, g_hi = pipe.raw_ghost_needed() if raw_ghosts else (0, 0)      # raw ghost planes handed over with the frame
+            own = make_volume((o1 - o0 + g_lo + g_hi,) + tuple(gshape[1:]), seed, z_offset=o0 - g_lo, global_nz=gshape[0])
             pipe.filter(own, p)
             thr = pipe.frangi_threshold()
             n = pipe.label(thr, min_area_pixels_of(dr))
@@ -48,10 +49,12 @@ def _run_sharded(gshape, dr, seed, world, halo_mode="steps"):
     return out
 
 
-@pytest.mark.parametrize("halo_mode", ["steps", "fat"])
+@pytest.mark.parametrize("halo_mode", ["steps", "fat", "steps+raw", "fat+raw"])
 @pytest.mark.parametrize("gshape,aniso,world", [((96, 64, 80), False, 2), ((100, 48, 70), False, 3),
                                                ((60, 64, 64), True, 4), ((90, 40, 70), False, 6)])
 def test_zslab_filter_equals_single_gpu(hip, gshape, aniso, world, halo_mode):
+    raw_ghosts = halo_mode.endswith("+raw")       # the raw ghost planes come with the frame: no exchange of raw planes
+    halo_mode = halo_mode.split("+")[0]
     from nellie_amd import pipeline as pl
     from nellie_amd.synthetic import ANISO_03, ISO_01, make_volume
     dr = ANISO_03 if aniso else ISO_01
@@ -67,7 +70,7 @@ def test_zslab_filter_equals_single_gpu(hip, gshape, aniso, world, halo_mode):
     single.close()
     if halo_mode == "fat" and world == 6:
         pytest.skip("15-plane slabs are thinner than the 24-plane fat halo")
-    parts = _run_sharded(gshape, dr, 91, world, halo_mode)
+    parts = _run_sharded(gshape, dr, 91, world, halo_mode, raw_ghosts)
     got = np.concatenate([p_[0] for p_ in parts])
     assert np.array_equal(got, ref), f"{int((got != ref).sum())} voxels differ"
     for _, thr, counts, _, n in parts:

@@ -32,15 +32,17 @@ def test_slab_geometry():
         slab_geometry((64, 8, 8), 4, 1, 24)
 
 
-@pytest.mark.parametrize("aniso,halo_mode", [(0, "steps"), (1, "steps"), (0, "fat")])
+@pytest.mark.parametrize("aniso,halo_mode", [(0, "steps"), (1, "steps"), (0, "fat"), (0, "steps+raw")])
 def test_zslab_filter_and_label_world2_gloo(aniso, halo_mode, tmp_path):
     pytest.importorskip("torch")
+    raw = "1" if halo_mode.endswith("+raw") else "0"       # raw ghost planes handed over with the frame instead of exchanged
+    halo_mode = halo_mode.split("+")[0]
     from nellie_amd.synthetic import ANISO_03, ISO_01, make_volume
-    port = 29600 + aniso + 2 * (halo_mode == "fat") + (os.getpid() % 200)
+    port = 29600 + aniso + 2 * (halo_mode == "fat") + 4 * int(raw) + (os.getpid() % 200)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(REPO, "tests", "dist_worker.py"), str(tmp_path), str(aniso)]
-    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, NELLIE_HALO=halo_mode))
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, NELLIE_HALO=halo_mode, NELLIE_TEST_RAW_GHOSTS=raw))
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     dr = ANISO_03 if aniso else ISO_01
     gshape = (40, 36, 44) if aniso else (64, 30, 34)
