@@ -91,7 +91,15 @@ static unsigned resolve_grid(unsigned blocks) {
     return (cap > 0 && (unsigned)cap < blocks) ? (unsigned)cap : blocks;
 }
 static float *gauss_cur(const nl_ctx *c) { return c->gauss_ext ? c->gauss_ext : c->f[c->i_gauss]; }
-static VolGeom geom(const nl_ctx *c) { return VolGeom{c->nzl, c->ny, c->nx, c->gz0, c->gnz}; }
+static VolGeom geom(const nl_ctx *c) {
+    VolGeom v{c->nzl, c->ny, c->nx, c->gz0, c->gnz};
+    // 128-element chunks read 128 + 2R elements for 128 outputs; 256 halves the excess (about 1 % of the Gaussian passes at 1024^3,
+    // within run-to-run noise) but also halves the number of workgroups, so only where those are plentiful
+    static int forced = -1;
+    if (forced < 0) { const char *e = getenv("NELLIE_GM_CHUNK"); forced = e ? atoi(e) : 0; }
+    v.chunk = forced > 0 ? forced : (c->n >= ((i64)1 << 29) ? 256 : 128);
+    return v;
+}
 // tile height of the Hessian kernels (experiment knob; 8 -> 512-thread workgroups, 16 -> 1024)
 static int hm_ty() {
     static int v = -1;
@@ -515,8 +523,8 @@ static void launch_gauss_march(nl_ctx *c, const float *src, float *dst, const Vo
     GaussWS ws;
     for (int k = 0; k <= GM_MAX_R; ++k) ws.w[k] = k <= R ? gw.w[k] : 0.0;
     dim3 grid;
-    if (AXIS == 0) grid = dim3((unsigned)((c->nx + 63) / 64), (unsigned)((c->ny + 3) / 4), (unsigned)((z1 - z0 + GM_CHUNK - 1) / GM_CHUNK));
-    else grid = dim3((unsigned)((c->nx + 63) / 64), (unsigned)((z1 - z0 + 3) / 4), (unsigned)((c->ny + GM_CHUNK - 1) / GM_CHUNK));
+    if (AXIS == 0) grid = dim3((unsigned)((c->nx + 63) / 64), (unsigned)((c->ny + 3) / 4), (unsigned)((z1 - z0 + v.chunk - 1) / v.chunk));
+    else grid = dim3((unsigned)((c->nx + 63) / 64), (unsigned)((z1 - z0 + 3) / 4), (unsigned)((c->ny + v.chunk - 1) / v.chunk));
     gauss_march_kernel<AXIS, R><<<grid, 256, 0, c->stream>>>(src, dst, v, z0, z1, ws);
 }
 template <int R>
@@ -584,7 +592,7 @@ extern "C" int nl_gauss_step(nl_ctx *c, const double *wz, int rz, const double *
         for (int k = 0; k <= GM_MAX_R; ++k) { wsy.w[k] = k <= ry ? gy.w[k] : 0.0; wsx.w[k] = k <= rx ? gx.w[k] : 0.0; }
         const int dst = (src + 1) % 3;
         ProfScope ps(c, "gauss_yx");
-        const dim3 g2((unsigned)((c->nx + GYX_COLS - 1) / GYX_COLS), (unsigned)((c->ny + GM_CHUNK - 1) / GM_CHUNK), (unsigned)(z1 - z0));
+        const dim3 g2((unsigned)((c->nx + GYX_COLS - 1) / GYX_COLS), (unsigned)((c->ny + v.chunk - 1) / v.chunk), (unsigned)(z1 - z0));
         const int vec4 = (c->nx % 4 == 0) ? 1 : 0;
         if (gyx_tiled()) {
             switch (ry) {
@@ -1800,7 +1808,7 @@ extern "C" int nl_markers_log_step(nl_ctx *c, const double *wz2, const double *w
     const i64 z0 = 0, z1 = c->nzl;
     const dim3 blk(256, 1, 1);
     const dim3 grid((unsigned)((c->nx + 255) / 256), (unsigned)c->ny, (unsigned)c->nzl);
-    const dim3 g2((unsigned)((c->nx + GYX_COLS - 1) / GYX_COLS), (unsigned)((c->ny + GM_CHUNK - 1) / GM_CHUNK), (unsigned)c->nzl);
+    const dim3 g2((unsigned)((c->nx + GYX_COLS - 1) / GYX_COLS), (unsigned)((c->ny + v.chunk - 1) / v.chunk), (unsigned)c->nzl);
     float *dist = c->f[0], *tz = c->f[1], *lap = c->f[2];
     const float *use = c->mk_use ? c->mk_use : dist;            // the image the LoG runs on
     auto ws_of = [](const GaussW &g) { GaussWS w; for (int k = 0; k <= GM_MAX_R; ++k) w.w[k] = k <= g.r ? g.w[k] : 0.0; return w; };
@@ -1817,7 +1825,7 @@ extern "C" int nl_markers_log_step(nl_ctx *c, const double *wz2, const double *w
     auto yx = [&](const GaussW &gy, const GaussW &gx, bool acc) {
         const GaussWS wy = ws_of(gy), wx = ws_of(gx);
         if (can_split && ryx >= split_from) {
-            const dim3 gym((unsigned)((c->nx + 63) / 64), (unsigned)((c->nzl + 3) / 4), (unsigned)((c->ny + GM_CHUNK - 1) / GM_CHUNK));
+            const dim3 gym((unsigned)((c->nx + 63) / 64), (unsigned)((c->nzl + 3) / 4), (unsigned)((c->ny + v.chunk - 1) / v.chunk));
             const dim3 gxk((unsigned)((c->nx + GX_SEG - 1) / GX_SEG), (unsigned)c->ny, (unsigned)c->nzl);
             const int vec4 = (c->nx % 4 == 0) ? 1 : 0;
             switch (ryx) {
