@@ -8,8 +8,8 @@
 #                                    world 1 over a real one-rank RCCL communicator): what a rank costs before any neighbour exists
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
-python $R/bench.py > /tmp/bench.out 2>/tmp/bench.err; tail -1 /tmp/bench.out > $R/gpurun_out/r02_bench_n1_1024cube.json
-rm -rf /tmp/ks && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -- python $R/bench.py --no-cpu-baseline --no-io > /tmp/ks.log 2>&1
+python $R/bench.py --steps 10 --warmup 2 > /tmp/bench.out 2>/tmp/bench.err; tail -1 /tmp/bench.out > $R/gpurun_out/r02_bench_n1_1024cube.json
+rm -rf /tmp/ks && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-io > /tmp/ks.log 2>&1
 cp $(find /tmp/ks -name '*kernel_stats.csv' | head -1) $R/gpurun_out/r02_kernel_stats_1024cube.csv
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$C && rocprofv3 --pmc $C --output-format csv -d /tmp/pmc_$C -- python $R/tools/prof_filter.py 1024 1024 1024 1 > /tmp/pmc_$C.log 2>&1
