@@ -518,6 +518,11 @@ static int fill_gw(GaussW &gw, const double *w, int r, char *err, size_t errlen)
     return NL_OK;
 }
 
+static bool gm_z2() {
+    static int on = -1;
+    if (on < 0) { const char *e = getenv("NELLIE_GM_Z2"); on = (e && !atoi(e)) ? 0 : 1; }
+    return on != 0;
+}
 template <int AXIS, int R>
 static void launch_gauss_march(nl_ctx *c, const float *src, float *dst, const VolGeom &v, i64 z0, i64 z1, const GaussW &gw) {
     GaussWS ws;
@@ -525,6 +530,11 @@ static void launch_gauss_march(nl_ctx *c, const float *src, float *dst, const Vo
     dim3 grid;
     if (AXIS == 0) grid = dim3((unsigned)((c->nx + 63) / 64), (unsigned)((c->ny + 3) / 4), (unsigned)((z1 - z0 + v.chunk - 1) / v.chunk));
     else grid = dim3((unsigned)((c->nx + 63) / 64), (unsigned)((z1 - z0 + 3) / 4), (unsigned)((c->ny + v.chunk - 1) / v.chunk));
+    if (AXIS == 0 && R <= 6 && (c->nx & 1) == 0 && ((size_t)src & 7) == 0 && ((size_t)dst & 7) == 0 && gm_z2()) {
+        grid.x = (unsigned)((c->nx / 2 + 63) / 64);              // two columns per thread (float2 accesses): see gauss_march_z2_kernel
+        gauss_march_z2_kernel<(R <= 6 ? R : 1)><<<grid, 256, 0, c->stream>>>(src, dst, v, z0, z1, ws);
+        return;
+    }
     gauss_march_kernel<AXIS, R><<<grid, 256, 0, c->stream>>>(src, dst, v, z0, z1, ws);
 }
 template <int R>
