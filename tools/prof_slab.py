@@ -1,13 +1,12 @@
 #!/usr/bin/env python3
 """One rank's share of a Z-slab run (world 1 over a real one-rank RCCL communicator): wall time per step, HIP-event time per
 kernel group and the wall time of every host-level context call, for a slab of BASELINE config 4's per-GPU size.
-tools/prof_slab.py [Z Y X] [reps]   (NELLIE_PROF_CALLS=0: no per-call timers, for rocprofv3 runs)"""
+tools/prof_slab.py [Z Y X] [reps]
+  NELLIE_PROF_CALLS=0  no per-call timers (for rocprofv3 runs)      NELLIE_PROF_PY=1  cProfile of the timed steps
+  NELLIE_PROF_LOG=1    (start, end) of every library call of step NELLIE_PROF_STEP (default: the last): gaps and longest calls"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-if os.environ.get("NELLIE_PROF_TORCH") == "1":      # does importing torch (as bench.py does) change the host-side cost?
-    import torch
-    print("torch threads", torch.get_num_threads())
 from nellie_amd import hipnative, pipeline as pl, sharded
 from nellie_amd.synthetic import ISO_01, make_volume
 
@@ -26,28 +25,6 @@ def step():
 
 ctx.prof_enable(True)
 step()
-if os.environ.get("NELLIE_PROF_GW") == "1":
-    lines = {}
-    def gw(sigma):
-        T = time.perf_counter
-        t = [T()]
-        sd = float(sigma)
-        if not sd > 1e-15:
-            return None
-        lw = int(3.0 * sd + 0.5)
-        sigma2 = sd * sd
-        x = np.arange(-lw, lw + 1); t.append(T())
-        x2 = x ** 2; t.append(T())
-        arg = -0.5 / sigma2 * x2; t.append(T())
-        phi_x = np.exp(arg); t.append(T())
-        phi_x = phi_x / phi_x.sum(); t.append(T())
-        r = np.ascontiguousarray(phi_x[::-1]); t.append(T())
-        for k in range(len(t) - 1):
-            lines[k] = lines.get(k, 0.0) + t[k + 1] - t[k]
-        return r
-    pl.gaussian_weights = gw
-    import atexit
-    atexit.register(lambda: print("gaussian_weights lines (ms total):", {k: round(v * 1e3, 3) for k, v in lines.items()}))
 acc, cnt = {}, {}
 log = []
 if os.environ.get("NELLIE_PROF_LOG") == "1":
