@@ -53,7 +53,7 @@ B_ALG_KERNEL = {
 B_ALG_PASS = 22.0              # walk + resolve: what SURVEY 8(d) calls the Hessian/eigen/Frangi + mask passes of a scale
 PMC_KERNEL_OF_GROUP = {"vesselness": ("hessian_v_kernel<2", "hessian_g_kernel<2"), "vesselness_resolve": ("vesselness_queue_kernel<true",),
                        "hessian_stats": ("hessian_v_kernel<0", "hessian_g_kernel<0"), "gauss_yx": ("gauss_yx_tile_kernel<4",),
-                       "gauss_z": ("gauss_march_kernel<0, 4",)}
+                       "gauss_z": ("gauss_march_z2_kernel<4", "gauss_march_kernel<0, 4")}
 GROUPS = ("load", "gauss_z", "gauss_yx", "gauss_y", "gauss_x", "sample", "hessian_stats", "vesselness", "vesselness_resolve",
           "finish", "mask_volume", "label", "halo")
 SLAB_PLANES = 128              # owned planes per GPU of the Z-slab run: BASELINE config 4 / 8
