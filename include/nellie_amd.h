@@ -404,6 +404,21 @@ int nl_outputs_stage(nl_ctx *ctx, int with_labels, char *err, size_t errlen);
 int nl_outputs_fetch_async(nl_ctx *ctx, float *frangi_pinned, int32_t *labels_pinned, char *err, size_t errlen);
 int nl_outputs_wait(nl_ctx *ctx, char *err, size_t errlen);
 
+/* Packed outputs.  Both products are ~98 % zeros; the dense download (8 B/voxel, the reference's blocking .get() per
+   frame: filtering.py:1023, labelling.py:727) is what bounds a streamed stack.  nl_outputs_pack leaves in a staging buffer of
+   the context, per volume: 1 bit per voxel (!= 0 / label > 0; rows padded to 64-voxel words), one u32 per row + 1 (index of
+   the row's first item) and the items -- the non-zero float32 values in raster order, and ONE int32 label per maximal X-run
+   of labelled voxels.  *nbytes = size of the blob; 0 = this frame does not pack (more than n / 4 items, or X-neighbours
+   with different labels): fall back to nl_outputs_stage / nl_outputs_fetch_async.  nl_outputs_fetch_packed_async copies the
+   blob to page-locked host memory on the download stream (nl_outputs_wait blocks until it landed; it is one of the
+   copy-thread calls).  nl_outputs_unpack is host code: it expands a blob into dense (nz, ny, nx) arrays with `threads` host
+   threads; zero_fill = 0 if the arrays are known to hold zeros (a freshly created file), rows without content are then
+   not touched at all. */
+int nl_outputs_pack(nl_ctx *ctx, int with_labels, int64_t *nbytes, char *err, size_t errlen);
+int nl_outputs_fetch_packed_async(nl_ctx *ctx, void *host_pinned, int64_t nbytes, char *err, size_t errlen);
+int nl_outputs_unpack(const void *blob, int64_t nbytes, float *frangi, int32_t *labels, int zero_fill, int threads,
+                      char *err, size_t errlen);
+
 /* ------------------------------------------------------------------ test hooks -------- */
 /* Known-answer hook for the fused device routine (filtering.py:581-585 + 744-766): for n explicit
    Hessians h6[n][6] = (hxx,hxy,hxz,hyy,hyz,hzz) writes out4[n][4] = (l1,l2,l3 sorted by |.|, Frangi

@@ -4,6 +4,8 @@
 #include <stdarg.h>
 #include <stdlib.h>
 #include <type_traits>
+#include <thread>
+#include <vector>
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 #include "nl_common.h"
@@ -55,6 +57,7 @@ static RcclApi &rccl() {
 #include "markers.inc"
 #include "label_voxels.inc"
 #include "label_runs.inc"
+#include "pack_out.inc"
 #include "network.inc"
 #include "thresholds.inc"
 
@@ -262,6 +265,7 @@ extern "C" int nl_ctx_destroy(nl_ctx *c) {
     if (c->d_vq_count) hipFree(c->d_vq_count);
     if (c->d_rows) hipFree(c->d_rows);
     if (c->d_ag) hipFree(c->d_ag);
+    if (c->d_pack) hipFree(c->d_pack);
     if (c->h_ag) hipHostFree(c->h_ag);
     if (c->gbits[0]) hipFree(c->gbits[0]);
     if (c->gbits[1]) hipFree(c->gbits[1]);
@@ -2887,6 +2891,161 @@ extern "C" int nl_outputs_fetch_async(nl_ctx *c, float *frangi_pinned, int32_t *
 extern "C" int nl_outputs_wait(nl_ctx *c, char *err, size_t errlen) {
     NL_ENTER_IO(c);
     if (c->ev_fetched) NL_HIP(hipEventSynchronize(c->ev_fetched));
+    return NL_OK;
+}
+
+// ---- packed outputs (pack_out.inc) ----------------------------------------------------------------------------------
+#define NL_PK_MAGIC 0x4b43415031304c4ell          // "NL01PACK"
+struct PkHeader {                                 // 16 x int64, at the start of the blob; offsets in bytes from the blob's start
+    long long magic, nz, ny, nx, wpr, n_values, n_runs, with_labels;
+    long long off_fb, off_lb, off_fo, off_lo, off_fv, off_lr, total, reserved;
+};
+static inline size_t pk_pad(size_t b) { return (b + 15) & ~(size_t)15; }
+
+// Frangi frame (+ labels) of the current frame -> packed blob in a staging buffer of the context (compute stream; the next
+// frame may then overwrite the volumes).  *nbytes = size of the blob, 0 when the frame does not pack (more than a quarter
+// of the voxels non-zero, or X-neighbours with different labels): use nl_outputs_stage / nl_outputs_fetch_async then.
+extern "C" int nl_outputs_pack(nl_ctx *c, int with_labels, int64_t *nbytes, char *err, size_t errlen) {
+    NL_ENTER(c);
+    NL_JOIN_SIDE(c);
+    if (!nbytes) return nl_fail(err, errlen, NL_EINVAL, "nbytes is NULL");
+    if (with_labels && c->i_labels < 0) return nl_fail(err, errlen, NL_ESTATE, "nl_outputs_pack(with_labels) before nl_label_run");
+    if (c->own_lo != 0 || c->own_hi != c->nzl) return nl_fail(err, errlen, NL_EINVAL, "packed outputs are for whole local volumes (no ghost planes)");
+    int rc = stream_init(c, err, errlen);
+    if (rc) return rc;
+    const i64 rows = c->nzl * c->ny;
+    const int wpr = (int)((c->nx + 63) / 64), nx = (int)c->nx;
+    PkHeader h{};
+    h.magic = NL_PK_MAGIC; h.nz = c->nzl; h.ny = c->ny; h.nx = c->nx; h.wpr = wpr; h.with_labels = with_labels ? 1 : 0;
+    const size_t bits_b = pk_pad((size_t)rows * wpr * 8), off_b = pk_pad((size_t)(rows + 1) * 4);
+    h.off_fb = pk_pad(sizeof(PkHeader)); h.off_lb = h.off_fb + bits_b; h.off_fo = h.off_lb + (with_labels ? bits_b : 0);
+    h.off_lo = h.off_fo + off_b; h.off_fv = h.off_lo + (with_labels ? off_b : 0);
+    const size_t cap = (size_t)h.off_fv + pk_pad((size_t)c->n) + 64;              // room for n / 4 items in total
+    if (cap > c->pack_cap) {
+        if (c->d_pack) hipFree(c->d_pack);
+        c->d_pack = nullptr; c->pack_cap = 0;
+        NL_HIP(hipMalloc(&c->d_pack, cap));
+        c->pack_cap = cap;
+    }
+    char *blob = (char *)c->d_pack;
+    NL_HIP(hipStreamWaitEvent(c->stream, c->ev_fetched, 0));     // the previous frame's blob has left the staging buffer
+    unsigned int *cnt = c->d_rows;                                // per-row counts (Label's row tables are free between frames)
+    unsigned int *flag = (unsigned int *)c->d_small + 40;
+    unsigned long long *d_total = (unsigned long long *)c->d_small + 16;
+    unsigned long long *h_tot = (unsigned long long *)c->h_small;
+    NL_HIP(zero_small(flag, 4, c->stream));
+    const unsigned grid = grid1d(rows * 64, 256, (i64)1 << 22);
+    ProfScope ps(c, "pack");
+    // counts, bit planes, row offsets
+    pk_count_kernel<0><<<grid, 256, 0, c->stream>>>((const unsigned int *)c->f[c->i_vmax], (unsigned long long *)(blob + h.off_fb), cnt, rows, nx, wpr, flag);
+    NL_CHECK_LAUNCH();
+    if ((rc = scan_excl_u32(c, cnt, (unsigned int *)(blob + h.off_fo), rows, err, errlen))) return rc;
+    NL_HIP(hipMemcpyAsync(&h_tot[0], d_total, 8, hipMemcpyDeviceToHost, c->stream));
+    if (with_labels) {
+        pk_count_kernel<1><<<grid, 256, 0, c->stream>>>((const unsigned int *)c->f[c->i_labels], (unsigned long long *)(blob + h.off_lb), cnt, rows, nx, wpr, flag);
+        NL_CHECK_LAUNCH();
+        if ((rc = scan_excl_u32(c, cnt, (unsigned int *)(blob + h.off_lo), rows, err, errlen))) return rc;
+        NL_HIP(hipMemcpyAsync(&h_tot[1], d_total, 8, hipMemcpyDeviceToHost, c->stream));
+    }
+    NL_HIP(hipMemcpyAsync(&h_tot[2], flag, 4, hipMemcpyDeviceToHost, c->stream));
+    NL_HIP(hipStreamSynchronize(c->stream));
+    h.n_values = (long long)h_tot[0]; h.n_runs = with_labels ? (long long)h_tot[1] : 0;
+    const bool bad = (*(unsigned int *)&h_tot[2]) != 0u;
+    h.off_lr = h.off_fv + pk_pad((size_t)h.n_values * 4);
+    h.total = h.off_lr + pk_pad((size_t)h.n_runs * 4);
+    if (bad || (size_t)h.total > c->pack_cap || h.n_values > 0xffffffffll || h.n_runs > 0xffffffffll) { *nbytes = 0; return NL_OK; }
+    // header, the closing entries of the offset tables, then the items
+    unsigned int *h_u = (unsigned int *)(h_tot + 4);
+    h_u[0] = (unsigned int)h.n_values; h_u[1] = (unsigned int)h.n_runs;
+    PkHeader *h_hdr = (PkHeader *)(h_tot + 8);
+    *h_hdr = h;
+    NL_HIP(hipMemcpyAsync(blob, h_hdr, sizeof(PkHeader), hipMemcpyHostToDevice, c->stream));
+    NL_HIP(hipMemcpyAsync(blob + h.off_fo + (size_t)rows * 4, &h_u[0], 4, hipMemcpyHostToDevice, c->stream));
+    if (with_labels) NL_HIP(hipMemcpyAsync(blob + h.off_lo + (size_t)rows * 4, &h_u[1], 4, hipMemcpyHostToDevice, c->stream));
+    if (h.n_values) pk_emit_kernel<0><<<grid, 256, 0, c->stream>>>((const unsigned int *)c->f[c->i_vmax], (const unsigned long long *)(blob + h.off_fb),
+                                                                 (const unsigned int *)(blob + h.off_fo), (unsigned int *)(blob + h.off_fv), rows, nx, wpr);
+    if (h.n_runs) pk_emit_kernel<1><<<grid, 256, 0, c->stream>>>((const unsigned int *)c->f[c->i_labels], (const unsigned long long *)(blob + h.off_lb),
+                                                               (const unsigned int *)(blob + h.off_lo), (unsigned int *)(blob + h.off_lr), rows, nx, wpr);
+    NL_CHECK_LAUNCH();
+    NL_HIP(hipEventRecord(c->ev_staged, c->stream));
+    // the pinned scratch the header travelled through is reused by the next entry point: let the copies finish
+    NL_HIP(hipStreamSynchronize(c->stream));
+    *nbytes = h.total;
+    return NL_OK;
+}
+
+// D2H of the packed blob on the second copy stream (returns at once); nl_outputs_wait blocks until it landed
+extern "C" int nl_outputs_fetch_packed_async(nl_ctx *c, void *host_pinned, int64_t nbytes, char *err, size_t errlen) {
+    NL_ENTER_IO(c);
+    if (!c->copy_out || !c->d_pack) return nl_fail(err, errlen, NL_ESTATE, "nl_outputs_fetch_packed_async before nl_outputs_pack");
+    if (!host_pinned || nbytes < (int64_t)sizeof(PkHeader) || (size_t)nbytes > c->pack_cap) return nl_fail(err, errlen, NL_EINVAL, "bad packed fetch arguments");
+    NL_HIP(hipStreamWaitEvent(c->copy_out, c->ev_staged, 0));
+    NL_HIP(hipMemcpyAsync(host_pinned, c->d_pack, (size_t)nbytes, hipMemcpyDeviceToHost, c->copy_out));
+    NL_HIP(hipEventRecord(c->ev_fetched, c->copy_out));
+    return NL_OK;
+}
+
+// Host only: expand a packed blob into the caller's dense arrays (labels may be NULL).  zero_fill = 0 when the arrays are
+// known to hold zeros already (a freshly created file or calloc'ed array): only rows with content are touched then.
+extern "C" int nl_outputs_unpack(const void *blob_, int64_t nbytes, float *frangi, int32_t *labels, int zero_fill, int threads,
+                                 char *err, size_t errlen) {
+    const char *blob = (const char *)blob_;
+    if (!blob || nbytes < (int64_t)sizeof(PkHeader) || !frangi) return nl_fail(err, errlen, NL_EINVAL, "bad unpack arguments");
+    PkHeader h;
+    memcpy(&h, blob, sizeof(h));
+    if (h.magic != NL_PK_MAGIC || h.total > nbytes || h.wpr != (h.nx + 63) / 64) return nl_fail(err, errlen, NL_EINVAL, "not a packed-output blob");
+    if (labels && !h.with_labels) return nl_fail(err, errlen, NL_EINVAL, "the blob holds no labels");
+    const i64 rows = h.nz * h.ny, nx = h.nx;
+    const int wpr = (int)h.wpr;
+    const unsigned long long *fb = (const unsigned long long *)(blob + h.off_fb), *lb = (const unsigned long long *)(blob + h.off_lb);
+    const unsigned int *fo = (const unsigned int *)(blob + h.off_fo), *lo = (const unsigned int *)(blob + h.off_lo);
+    const float *fv = (const float *)(blob + h.off_fv);
+    const int32_t *lr = (const int32_t *)(blob + h.off_lr);
+    auto work = [&](i64 r0, i64 r1) {
+        for (i64 row = r0; row < r1; ++row) {
+            float *dst = frangi + row * nx;
+            if (zero_fill) memset(dst, 0, (size_t)nx * 4);
+            unsigned int k = fo[row];
+            if (fo[row + 1] != k) {
+                const unsigned long long *bw = fb + row * wpr;
+                for (int w = 0; w < wpr; ++w) {
+                    unsigned long long b = bw[w];
+                    float *d64 = dst + (i64)w * 64;
+                    while (b) { d64[__builtin_ctzll(b)] = fv[k++]; b &= b - 1; }
+                }
+            }
+            if (!labels) continue;
+            int32_t *ld = labels + row * nx;
+            if (zero_fill) memset(ld, 0, (size_t)nx * 4);
+            unsigned int q = lo[row];
+            if (lo[row + 1] == q) continue;
+            const unsigned long long *bw = lb + row * wpr;
+            int32_t cur = 0;
+            bool open = false;                            // the previous word ended inside a run
+            for (int w = 0; w < wpr; ++w) {
+                unsigned long long b = bw[w];
+                int32_t *d64 = ld + (i64)w * 64;
+                if (!b) { open = false; continue; }
+                bool first = true;
+                while (b) {
+                    const int s = __builtin_ctzll(b);
+                    const unsigned long long rest = ~(b >> s);
+                    const int len = rest ? __builtin_ctzll(rest) : 64 - s;
+                    if (!(first && s == 0 && open)) cur = lr[q++];
+                    for (int t = 0; t < len; ++t) d64[s + t] = cur;
+                    b = (s + len >= 64) ? 0ull : (b & ~(((1ull << len) - 1ull) << s));
+                    first = false;
+                }
+                open = (bw[w] >> 63) != 0;
+            }
+        }
+    };
+    int nt = threads < 1 ? 1 : (threads > 64 ? 64 : threads);
+    if (rows < 4096) nt = 1;
+    if (nt == 1) { work(0, rows); return NL_OK; }
+    std::vector<std::thread> pool;
+    for (int t = 0; t < nt; ++t) pool.emplace_back(work, rows * t / nt, rows * (t + 1) / nt);
+    for (auto &th : pool) th.join();
     return NL_OK;
 }
 

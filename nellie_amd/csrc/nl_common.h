@@ -42,6 +42,7 @@ struct nl_ctx {
     hipEvent_t ev_in[2] = {nullptr, nullptr};
     hipEvent_t ev_staged = nullptr, ev_fetched = nullptr;
     float *d_stage_fr = nullptr;
+    void *d_pack = nullptr; size_t pack_cap = 0;       // packed outputs (pack_out.inc): header | bit planes | row offsets | items
     int *d_stage_lab = nullptr;
     void *d_small = nullptr;   // scratch for reductions / histograms / weights (64 KiB)
     void *h_small = nullptr;   // pinned mirror

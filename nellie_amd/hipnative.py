@@ -50,6 +50,9 @@ _PROTOS = {
     "nl_sample_hist": [_p, _int, _i64, _i64, _i64, _p, _int, _p],
     "nl_sample_range_hist": [_p, _int, _i64, _i64, _i64, _int, C.POINTER(_f32), C.POINTER(_f32), C.POINTER(_i64), _p, _p, C.POINTER(_int)],
     "nl_hist_thresholds": [_p, _p, _int, C.POINTER(_f64), C.POINTER(_f64), C.POINTER(_int)],
+    "nl_outputs_pack": [_p, _int, _p],
+    "nl_outputs_fetch_packed_async": [_p, _p, _i64],
+    "nl_outputs_unpack": [_p, _i64, _p, _p, _int, _int],
     "nl_hessian_stats": [_p, C.POINTER(_f64), C.POINTER(_f32), C.POINTER(_f32), C.POINTER(_int)],
     "nl_set_frob_norm": [_p, _f32, _f32],
     "nl_vesselness_step": [_p, _f32, _f32, _f32, _int, _f32, _i64, _i64, C.POINTER(_i64)],
@@ -220,6 +223,16 @@ def hist_thresholds(counts, edges):
     if status.value == 1:
         raise ValueError("attempt to get argmax of an empty sequence")
     return np.float32(tri.value), np.float32(otsu.value)
+
+
+def outputs_unpack(blob, nbytes, frangi, labels=None, zero_fill=True, threads=8):
+    """Expand a packed-output blob (Context.outputs_pack) into dense C-contiguous arrays; host code, `threads` host threads."""
+    assert frangi.dtype == np.float32 and frangi.flags.c_contiguous and frangi.flags.writeable
+    if labels is not None:
+        assert labels.dtype == np.int32 and labels.flags.c_contiguous and labels.shape == frangi.shape
+    src = blob._p if hasattr(blob, "_p") else _ptr(blob)
+    load().call("nl_outputs_unpack", src, int(nbytes), _ptr(frangi), None if labels is None else _ptr(labels),
+                1 if zero_fill else 0, int(threads))
 
 
 def comm_unique_id() -> bytes:
@@ -638,6 +651,15 @@ class Context:
 
     def outputs_wait(self):
         self._call("nl_outputs_wait")
+
+    def outputs_pack(self, with_labels=True) -> int:
+        """Pack the frame's products on the device (see include/nellie_amd.h); bytes of the blob, 0 if it does not pack."""
+        n = _i64(0)
+        self._call("nl_outputs_pack", 1 if with_labels else 0, C.byref(n))
+        return int(n.value)
+
+    def outputs_fetch_packed_async(self, pinned, nbytes):
+        self._call("nl_outputs_fetch_packed_async", pinned._p if hasattr(pinned, "_p") else _ptr(pinned), int(nbytes))
 
     # ---------------------------------------------------------------- Label
     def label_load_frangi(self, frangi: np.ndarray, z0=0, z1=None):

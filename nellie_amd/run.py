@@ -32,7 +32,7 @@ def run_streamed(im_info, viewer=None, device_index=0):
         def status(t, n):
             if viewer is not None:
                 viewer.status = f"Preprocessing + extracting organelles. Frame: {t + 1} of {n}."
-        seg.run(im, fr, lab, status=status)
+        seg.run(im, fr, lab, status=status, outputs_zeroed=True)      # both files were created (zero-filled) a few lines up
     finally:
         seg.close()
     return im_info

@@ -1,0 +1,142 @@
+"""Packed outputs (include/nellie_amd.h: nl_outputs_pack / nl_outputs_unpack).  The host half -- the expansion of a blob into
+dense arrays -- needs no GPU: a numpy model of the packer builds blobs for adversarial rows; the device half is checked
+against it and against the dense download in the gpu test below."""
+import numpy as np
+import pytest
+
+MAGIC = 0x4b43415031304c4e
+
+
+def pad16(b):
+    return (b + 15) & ~15
+
+
+def pack_model(frangi, labels=None):
+    """The layout nl_outputs_pack produces, built with numpy."""
+    nz, ny, nx = frangi.shape
+    rows, wpr = nz * ny, (nx + 63) // 64
+
+    def bits_of(mask):
+        padded = np.zeros((rows, wpr * 64), bool)
+        padded[:, :nx] = mask.reshape(rows, nx)
+        return np.packbits(padded.reshape(rows, wpr, 8, 8)[:, :, ::-1, ::-1].reshape(rows, wpr, 64), axis=-1, bitorder="big").view(">u8").astype("<u8").reshape(rows, wpr)
+
+    f = frangi.reshape(rows, nx)
+    fmask = f.view(np.uint32) != 0
+    fb = bits_of(fmask)
+    fo = np.concatenate([[0], np.cumsum(fmask.sum(1))]).astype(np.uint32)
+    fv = f[fmask].astype(np.float32)
+    parts = {"fb": fb.tobytes(), "fo": fo.tobytes(), "fv": fv.tobytes(), "lb": b"", "lo": b"", "lr": b""}
+    n_runs = 0
+    if labels is not None:
+        l = labels.reshape(rows, nx)
+        lmask = l > 0
+        starts = lmask & ~np.concatenate([np.zeros((rows, 1), bool), lmask[:, :-1]], axis=1)
+        parts["lb"] = bits_of(lmask).tobytes()
+        parts["lo"] = np.concatenate([[0], np.cumsum(starts.sum(1))]).astype(np.uint32).tobytes()
+        parts["lr"] = l[starts].astype(np.int32).tobytes()
+        n_runs = int(starts.sum())
+    off, order, offs = pad16(128), ("fb", "lb", "fo", "lo", "fv", "lr"), {}
+    for k in order:
+        offs[k] = off
+        off += pad16(len(parts[k]))
+    hdr = np.zeros(16, np.int64)
+    hdr[:8] = [MAGIC, nz, ny, nx, wpr, fv.size, n_runs, 0 if labels is None else 1]
+    hdr[8:15] = [offs["fb"], offs["lb"], offs["fo"], offs["lo"], offs["fv"], offs["lr"], off]
+    blob = bytearray(off)
+    blob[:128] = hdr.tobytes()
+    for k in order:
+        blob[offs[k]:offs[k] + len(parts[k])] = parts[k]
+    return np.frombuffer(bytes(blob), np.uint8).copy()
+
+
+def volumes(shape, seed, density=0.03):
+    rng = np.random.default_rng(seed)
+    nz, ny, nx = shape
+    fr = np.where(rng.random(shape) < density, rng.random(shape, dtype=np.float32) + np.float32(1e-6), np.float32(0)).astype(np.float32)
+    lab = np.zeros(shape, np.int32)
+    for _ in range(max(4, int(density * nz * ny * 2))):          # X-runs, some crossing 64-voxel words, some ending at the row end
+        z, y = rng.integers(nz), rng.integers(ny)
+        x0 = int(rng.integers(nx)); ln = int(rng.integers(1, 150))
+        if (lab[z, y, max(x0 - 1, 0):x0 + ln + 1] == 0).all():
+            lab[z, y, x0:x0 + ln] = rng.integers(1, 1 << 20)
+    lab[0, 0, :] = 7                                              # a run that is a whole row
+    if nz * ny > 1:                                               # a run of one voxel at the very end of a row
+        lab[-1, -1, max(nx - 2, 0):] = 0
+        lab[-1, -1, nx - 1] = 9
+    fr[0, 0, 0] = np.float32(-0.0) if nx > 1 else fr[0, 0, 0]   # a non-zero bit pattern that compares equal to zero
+    return fr, lab
+
+
+@pytest.mark.parametrize("shape", [(3, 5, 64), (2, 7, 1), (4, 6, 200), (2, 3, 4100), (5, 9, 63), (1, 1, 129)])
+@pytest.mark.parametrize("zero_fill", [True, False])
+def test_unpack_expands_model_blobs(shape, zero_fill):
+    from nellie_amd import hipnative
+    fr, lab = volumes(shape, sum(shape))
+    blob = pack_model(fr, lab)
+    out_f = np.zeros(shape, np.float32) if not zero_fill else np.full(shape, 5.0, np.float32)
+    out_l = np.zeros(shape, np.int32) if not zero_fill else np.full(shape, -3, np.int32)
+    hipnative.outputs_unpack(blob, blob.nbytes, out_f, out_l, zero_fill=zero_fill, threads=3)
+    assert np.array_equal(out_f.view(np.uint32), fr.view(np.uint32))      # bit patterns: -0.0 survives
+    assert np.array_equal(out_l, lab)
+    only_f = np.full(shape, 1.0, np.float32)
+    hipnative.outputs_unpack(blob, blob.nbytes, only_f, None, zero_fill=True, threads=1)
+    assert np.array_equal(only_f.view(np.uint32), fr.view(np.uint32))
+
+
+def test_unpack_rejects_what_is_not_a_blob():
+    from nellie_amd import hipnative
+    out = np.zeros((2, 2, 2), np.float32)
+    with pytest.raises(ValueError):
+        hipnative.outputs_unpack(np.zeros(256, np.uint8), 256, out)
+    fr, lab = volumes((2, 2, 2), 1)
+    blob = pack_model(fr, None)
+    with pytest.raises(ValueError):                                      # no labels inside
+        hipnative.outputs_unpack(blob, blob.nbytes, out, np.zeros((2, 2, 2), np.int32))
+    with pytest.raises(ValueError):                                      # truncated
+        hipnative.outputs_unpack(blob, blob.nbytes - 16, out)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(24, 48, 48), (9, 33, 200), (3, 4, 4100), (40, 64, 129)])
+def test_device_pack_equals_dense_download(hip, shape):
+    """nl_outputs_pack on real products of the path: the blob equals the numpy model's byte for byte, and its expansion
+    equals the dense downloads."""
+    from nellie_amd import hipnative
+    from nellie_amd import pipeline as pl
+    from nellie_amd.synthetic import ISO_01, make_volume
+    pipe = pl.FramePipeline(shape)
+    pipe.filter(make_volume(shape, 11), pl.FilterParams(dim_res=ISO_01))
+    n = pipe.label(pipe.frangi_threshold(), pl.min_area_pixels_of(ISO_01))
+    fr, lab = pipe.download_frangi(), pipe.download_labels()
+    nbytes = pipe.ctx.outputs_pack(True)
+    assert nbytes > 0
+    land = hipnative.PinnedArray((nbytes,), np.uint8)
+    pipe.ctx.outputs_fetch_packed_async(land, nbytes)
+    pipe.ctx.outputs_wait()
+    model = pack_model(fr, lab)
+    assert nbytes == model.nbytes
+    hdr = model[:128].view(np.int64)
+    assert np.array_equal(land.array[:128].view(np.int64), hdr)
+    rows, wpr = shape[0] * shape[1], (shape[2] + 63) // 64
+    sizes = {8: rows * wpr * 8, 9: rows * wpr * 8, 10: (rows + 1) * 4, 11: (rows + 1) * 4, 12: int(hdr[5]) * 4, 13: int(hdr[6]) * 4}
+    for k, size in sizes.items():                                 # every section (the padding between them is not specified)
+        o = int(hdr[k])
+        assert np.array_equal(land.array[o:o + size], model[o:o + size]), f"section {k}"
+    out_f, out_l = np.full(shape, 2.0, np.float32), np.full(shape, -1, np.int32)
+    hipnative.outputs_unpack(land, nbytes, out_f, out_l, zero_fill=True, threads=4)
+    assert np.array_equal(out_f, fr) and np.array_equal(out_l, lab) and lab.max() == n
+    land.free()
+    pipe.close()
+
+
+@pytest.mark.gpu
+def test_dense_frame_does_not_pack(hip):
+    """More than a quarter of the voxels non-zero: nbytes == 0, the caller takes the dense download."""
+    from nellie_amd import pipeline as pl
+    shape = (8, 32, 64)
+    pipe = pl.FramePipeline(shape)
+    pipe.upload_frangi(np.ones(shape, np.float32))
+    pipe.label(0.5, 1)
+    assert pipe.ctx.outputs_pack(True) == 0
+    pipe.close()
