@@ -64,6 +64,13 @@ static RcclApi &rccl() {
 // =================================================================================================
 // host side: context, launch helpers, C-ABI
 // =================================================================================================
+// workgroups of the lattice reductions (range, histogram): every workgroup ends with atomics on the same few words, which
+// retire ~10 ns apart -- 1024 workgroups spent 10-30 us on that alone (a 1e6-point gather is not longer); NELLIE_SAMPLE_GRID
+static i64 sample_grid_cap() {
+    static i64 v = 0;
+    if (!v) { const char *e = getenv("NELLIE_SAMPLE_GRID"); v = (e && atoll(e) > 0) ? atoll(e) : 256; }
+    return v;
+}
 static inline unsigned int grid1d(i64 n, int block = 256, i64 cap = 256 * 32) {
     i64 g = (n + block - 1) / block;
     if (g > cap) g = cap;
@@ -841,7 +848,7 @@ extern "C" int nl_sample_minmax(nl_ctx *c, int field, int64_t sz, int64_t sy, in
     NL_HIP(hipMemcpyAsync(res, h, 16, hipMemcpyHostToDevice, c->stream));
     if (total > 0) {
         ProfScope ps(c, "sample");
-        sample_minmax_kernel<<<grid1d(total, 256, 1024), 256, 0, c->stream>>>(fs, geom(c), L, res);
+        sample_minmax_kernel<<<grid1d(total, 256, sample_grid_cap()), 256, 0, c->stream>>>(fs, geom(c), L, res);
         NL_CHECK_LAUNCH();
     }
     if (fused(c) && (rc = reduce_range(c, res, err, errlen))) return rc;
@@ -874,7 +881,7 @@ extern "C" int nl_sample_hist(nl_ctx *c, int field, int64_t sz, int64_t sy, int6
     if (total > 0) {
         ProfScope ps(c, "sample");
         const size_t sh = (size_t)(nbins + 2) * 4 + (size_t)nbins * 4;
-        sample_hist_kernel<<<grid1d(total, 256, 1024), 256, sh, c->stream>>>(fs, geom(c), L, d_edges, nbins, d_counts, nullptr);
+        sample_hist_kernel<<<grid1d(total, 256, sample_grid_cap()), 256, sh, c->stream>>>(fs, geom(c), L, d_edges, nbins, d_counts, nullptr);
         NL_CHECK_LAUNCH();
     }
     if (fused(c) && (rc = reduce_u64_sum(c, d_counts, (size_t)nbins, err, errlen))) return rc;
@@ -909,11 +916,11 @@ extern "C" int nl_sample_range_hist(nl_ctx *c, int field, int64_t sz, int64_t sy
     if (total > 0 || fused(c)) {
         // fused: a rank without lattice points of its own still takes part in the collectives and builds the same edges
         ProfScope ps(c, "sample");
-        if (total > 0) sample_minmax_kernel<<<grid1d(total, 256, 1024), 256, 0, c->stream>>>(fs, geom(c), L, res);
+        if (total > 0) sample_minmax_kernel<<<grid1d(total, 256, sample_grid_cap()), 256, 0, c->stream>>>(fs, geom(c), L, res);
         if (fused(c) && (rc = reduce_range(c, res, err, errlen))) return rc;
         sample_edges_kernel<<<1, 64, 0, c->stream>>>(res, nbins, d_edges, res + 4);
         const size_t sh = (size_t)(nbins + 2) * 4 + (size_t)nbins * 4;
-        if (total > 0) sample_hist_kernel<<<grid1d(total, 256, 1024), 256, sh, c->stream>>>(fs, geom(c), L, d_edges, nbins, d_counts, res + 4);
+        if (total > 0) sample_hist_kernel<<<grid1d(total, 256, sample_grid_cap()), 256, sh, c->stream>>>(fs, geom(c), L, d_edges, nbins, d_counts, res + 4);
         NL_CHECK_LAUNCH();
         if (fused(c) && (rc = reduce_u64_sum(c, d_counts, (size_t)nbins, err, errlen))) return rc;
     }
