@@ -155,6 +155,11 @@ int nl_sample_hist(nl_ctx *ctx, int field, int64_t sz, int64_t sy, int64_t sx,
    they equal np.linspace(np.float32(min), np.float32(max), nbins + 1, dtype=float32) bit for bit. */
 int nl_sample_range_hist(nl_ctx *ctx, int field, int64_t sz, int64_t sy, int64_t sx, int nbins, float *mn, float *mx,
                          int64_t *n_positive, int64_t *counts, float *edges, int *valid, char *err, size_t errlen);
+/* The same for two fields that need nothing from each other (the gamma samples of the Gaussian and the raw Frobenius
+   samples of a scale: filtering.py:365-380, 421-444) in ONE device round trip; every output is an array of two (counts:
+   2 x nbins, edges: 2 x (nbins + 1)), [0] = field_a. */
+int nl_sample_range_hist2(nl_ctx *ctx, int field_a, int field_b, int64_t sz, int64_t sy, int64_t sx, int nbins, float *mn, float *mx,
+                          int64_t *npos, int64_t *counts, float *edges, int *valid, char *err, size_t errlen);
 
 /* The two histogram thresholds of nellie/utils/gpu_functions.py on a finished histogram (host arithmetic, no device
    work; callable without a context): `counts[nbins]` int64 as numpy.histogram returns them, `edges[nbins + 1]`

@@ -894,22 +894,21 @@ extern "C" int nl_sample_hist(nl_ctx *c, int field, int64_t sz, int64_t sy, int6
 // nl_sample_minmax + nl_sample_hist in one go: the bin edges numpy would build from the range are formed on the
 // device, so the two passes need no host round trip in between.  *valid: 0 no positive sample, 1 ok, 2 range not finite
 // (the caller raises numpy's ValueError then).  edges (may be NULL) receives the nbins + 1 device-built edges.
-extern "C" int nl_sample_range_hist(nl_ctx *c, int field, int64_t sz, int64_t sy, int64_t sx, int nbins, float *mn, float *mx,
-                                    int64_t *npos, int64_t *counts, float *edges, int *valid, char *err, size_t errlen) {
-    NL_ENTER(c);
-    if (!counts || !valid || nbins < 1 || nbins > 2048) return nl_fail(err, errlen, NL_EINVAL, "bad histogram arguments (nbins=%d)", nbins);
+// the kernels of one range + edges + histogram chain, working in the `slot`-th half of the small scratch (device and pinned)
+#define NL_RH_SLOT 32768
+static int range_hist_enqueue(nl_ctx *c, int field, int64_t sz, int64_t sy, int64_t sx, int nbins, int slot, char *err, size_t errlen) {
     Lattice L; FieldSrc fs; int rc;
     if ((rc = make_lattice(c, sz, sy, sx, L, err, errlen))) return rc;
     if ((rc = make_field(c, field, fs, err, errlen))) return rc;
     if ((rc = use_fsq_cache(c, fs, L, err, errlen))) return rc;
     const i64 total = L.cz * L.cy * L.cx;
-    // d_small layout (contiguous, one transfer back): counts (u64 x nbins) | edges (f32 x nbins+1, padded) | range, count, flag
+    // layout (contiguous, one transfer back): counts (u64 x nbins) | edges (f32 x nbins+1, padded) | range, count, flag
     const size_t off_edges = (size_t)nbins * 8, off_res = off_edges + (((size_t)(nbins + 1) * 4 + 15) & ~(size_t)15);
-    const size_t bytes = off_res + 32;
-    unsigned long long *d_counts = (unsigned long long *)c->d_small;
-    float *d_edges = (float *)((char *)c->d_small + off_edges);
-    unsigned int *res = (unsigned int *)((char *)c->d_small + off_res);
-    unsigned int *h = (unsigned int *)c->h_small;
+    char *d0 = (char *)c->d_small + (size_t)slot * NL_RH_SLOT, *h0 = (char *)c->h_small + (size_t)slot * NL_RH_SLOT;
+    unsigned long long *d_counts = (unsigned long long *)d0;
+    float *d_edges = (float *)(d0 + off_edges);
+    unsigned int *res = (unsigned int *)(d0 + off_res);
+    unsigned int *h = (unsigned int *)(h0 + off_res);
     h[0] = 0xffffffffu; h[1] = 0; h[2] = 0; h[3] = 0; h[4] = 0;
     NL_HIP(hipMemcpyAsync(res, h, 20, hipMemcpyHostToDevice, c->stream));
     NL_HIP(zero_small(d_counts, (size_t)nbins * 8, c->stream));
@@ -924,9 +923,12 @@ extern "C" int nl_sample_range_hist(nl_ctx *c, int field, int64_t sz, int64_t sy
         NL_CHECK_LAUNCH();
         if (fused(c) && (rc = reduce_u64_sum(c, d_counts, (size_t)nbins, err, errlen))) return rc;
     }
-    NL_HIP(hipMemcpyAsync(c->h_small, c->d_small, bytes, hipMemcpyDeviceToHost, c->stream));
-    NL_HIP(hipStreamSynchronize(c->stream));
-    const unsigned int *hr = (const unsigned int *)((const char *)c->h_small + off_res);
+    return NL_OK;
+}
+static void range_hist_read(const nl_ctx *c, int nbins, int slot, float *mn, float *mx, int64_t *npos, int64_t *counts, float *edges, int *valid) {
+    const size_t off_edges = (size_t)nbins * 8, off_res = off_edges + (((size_t)(nbins + 1) * 4 + 15) & ~(size_t)15);
+    const char *h0 = (const char *)c->h_small + (size_t)slot * NL_RH_SLOT;
+    const unsigned int *hr = (const unsigned int *)(h0 + off_res);
     const unsigned long long cnt = *(const unsigned long long *)(hr + 2);
     if (npos) *npos = (int64_t)cnt;
     *valid = (int)hr[4];
@@ -934,8 +936,38 @@ extern "C" int nl_sample_range_hist(nl_ctx *c, int field, int64_t sz, int64_t sy
         if (mn) memcpy(mn, &hr[0], 4);
         if (mx) memcpy(mx, &hr[1], 4);
     }
-    memcpy(counts, c->h_small, (size_t)nbins * 8);
-    if (edges) memcpy(edges, (const char *)c->h_small + off_edges, (size_t)(nbins + 1) * 4);
+    memcpy(counts, h0, (size_t)nbins * 8);
+    if (edges) memcpy(edges, h0 + off_edges, (size_t)(nbins + 1) * 4);
+}
+
+extern "C" int nl_sample_range_hist(nl_ctx *c, int field, int64_t sz, int64_t sy, int64_t sx, int nbins, float *mn, float *mx,
+                                    int64_t *npos, int64_t *counts, float *edges, int *valid, char *err, size_t errlen) {
+    NL_ENTER(c);
+    if (!counts || !valid || nbins < 1 || nbins > 2048) return nl_fail(err, errlen, NL_EINVAL, "bad histogram arguments (nbins=%d)", nbins);
+    int rc = range_hist_enqueue(c, field, sz, sy, sx, nbins, 0, err, errlen);
+    if (rc) return rc;
+    const size_t bytes = (size_t)nbins * 8 + (((size_t)(nbins + 1) * 4 + 15) & ~(size_t)15) + 32;
+    NL_HIP(hipMemcpyAsync(c->h_small, c->d_small, bytes, hipMemcpyDeviceToHost, c->stream));
+    NL_HIP(hipStreamSynchronize(c->stream));
+    range_hist_read(c, nbins, 0, mn, mx, npos, counts, edges, valid);
+    return NL_OK;
+}
+
+// Two independent fields in one round trip (the gamma samples of the Gaussian and the raw Frobenius samples of a scale:
+// filtering.py:365-380 and 421-444 need nothing from each other).  Arrays of two: [0] = field_a, [1] = field_b.
+extern "C" int nl_sample_range_hist2(nl_ctx *c, int field_a, int field_b, int64_t sz, int64_t sy, int64_t sx, int nbins, float *mn, float *mx,
+                                     int64_t *npos, int64_t *counts, float *edges, int *valid, char *err, size_t errlen) {
+    NL_ENTER(c);
+    if (!counts || !valid || !mn || !mx || !npos || nbins < 1 || nbins > 2048) return nl_fail(err, errlen, NL_EINVAL, "bad histogram arguments (nbins=%d)", nbins);
+    int rc;
+    if ((rc = range_hist_enqueue(c, field_a, sz, sy, sx, nbins, 0, err, errlen))) return rc;
+    if ((rc = range_hist_enqueue(c, field_b, sz, sy, sx, nbins, 1, err, errlen))) return rc;
+    const size_t bytes = (size_t)nbins * 8 + (((size_t)(nbins + 1) * 4 + 15) & ~(size_t)15) + 32;
+    for (int k = 0; k < 2; ++k)
+        NL_HIP(hipMemcpyAsync((char *)c->h_small + (size_t)k * NL_RH_SLOT, (char *)c->d_small + (size_t)k * NL_RH_SLOT, bytes, hipMemcpyDeviceToHost, c->stream));
+    NL_HIP(hipStreamSynchronize(c->stream));
+    for (int k = 0; k < 2; ++k)
+        range_hist_read(c, nbins, k, mn + k, mx + k, npos + k, counts + (size_t)k * nbins, edges ? edges + (size_t)k * (nbins + 1) : nullptr, valid + k);
     return NL_OK;
 }
 

@@ -49,6 +49,7 @@ _PROTOS = {
     "nl_sample_minmax": [_p, _int, _i64, _i64, _i64, C.POINTER(_f32), C.POINTER(_f32), C.POINTER(_i64)],
     "nl_sample_hist": [_p, _int, _i64, _i64, _i64, _p, _int, _p],
     "nl_sample_range_hist": [_p, _int, _i64, _i64, _i64, _int, C.POINTER(_f32), C.POINTER(_f32), C.POINTER(_i64), _p, _p, C.POINTER(_int)],
+    "nl_sample_range_hist2": [_p, _int, _int, _i64, _i64, _i64, _int, _p, _p, _p, _p, _p, _p],
     "nl_hist_thresholds": [_p, _p, _int, C.POINTER(_f64), C.POINTER(_f64), C.POINTER(_int)],
     "nl_outputs_pack": [_p, _int, _p],
     "nl_outputs_fetch_packed_async": [_p, _p, _i64],
@@ -418,6 +419,16 @@ class Context:
         self._call("nl_sample_range_hist", int(field), sz, sy, sx, int(nbins), C.byref(mn), C.byref(mx), C.byref(n),
                    _ptr(counts), _ptr(edges), C.byref(valid))
         return np.float32(mn.value), np.float32(mx.value), int(n.value), counts, edges, int(valid.value)
+
+    def sample_range_hist2(self, field_a, field_b, strides, nbins=256):
+        """sample_range_hist of two independent fields in one device round trip: two (min, max, n_positive, counts, edges, valid)."""
+        mn, mx, n, valid = np.zeros(2, np.float32), np.zeros(2, np.float32), np.zeros(2, np.int64), np.zeros(2, np.int32)
+        counts = np.zeros((2, nbins), np.int64)
+        edges = np.zeros((2, nbins + 1), np.float32)
+        sz, sy, sx = (int(s) for s in strides)
+        self._call("nl_sample_range_hist2", int(field_a), int(field_b), sz, sy, sx, int(nbins), _ptr(mn), _ptr(mx), _ptr(n),
+                   _ptr(counts), _ptr(edges), _ptr(valid))
+        return tuple((np.float32(mn[k]), np.float32(mx[k]), int(n[k]), counts[k], edges[k], int(valid[k])) for k in range(2))
 
     def hessian_stats(self, spacing):
         sp = (_f64 * 3)(*[float(s) for s in spacing])

@@ -226,6 +226,7 @@ class FramePipeline:
         # range + histogram of a threshold in one device round trip (a Z-slab pipeline reduces the range across ranks
         # between the two passes and keeps them apart)
         self._chain_hist = hasattr(self.ctx, "sample_range_hist") and os.environ.get("NELLIE_CHAIN_HIST", "1") != "0"
+        self._pair_hist = hasattr(self.ctx, "sample_range_hist2") and os.environ.get("NELLIE_PAIR_HIST", "1") != "0"
         self.check_device_edges = os.environ.get("NELLIE_CHECK_EDGES", "0") == "1"
         self._one_pass_test_scale = 1.0      # tests: shifts the prediction to force a miss
 
@@ -309,12 +310,13 @@ class FramePipeline:
             mn, mx = rng[0] / np.float32(max_abs), rng[1] / np.float32(max_abs)
         return (mn, mx) if (mn > 0 and np.isfinite(mx)) else None
 
-    def _threshold_from_field(self, fld, strides, known_range=None):
-        """min(triangle, otsu) over the positive lattice samples of a device field, or None if none."""
+    def _threshold_from_field(self, fld, strides, known_range=None, pre=None):
+        """min(triangle, otsu) over the positive lattice samples of a device field, or None if none.
+        pre: the field's sample_range_hist result when it was fetched together with another field's."""
         if known_range is not None:
             mn, mx, npos = known_range[0], known_range[1], 1
         elif self._chain_hist:
-            mn, mx, counts, npos = self._range_hist(fld, strides)
+            mn, mx, counts, npos = self._range_hist(fld, strides, pre)
             if npos == 0:
                 return None
             return float(min_triangle_otsu(counts, histogram_edges(mn, mx, 256)))
@@ -326,24 +328,25 @@ class FramePipeline:
         counts = self._reduce_counts(self.ctx.sample_hist(fld, strides, edges))
         return float(min_triangle_otsu(counts, edges))
 
-    def _range_hist(self, fld, strides):
+    def _range_hist(self, fld, strides, pre=None):
         """Range and 256-bin histogram of the positive lattice samples in one device round trip (single GPU: no
         cross-rank reduction sits between the two passes).  The device builds numpy's float32 edges itself; the host
         builds them again for the threshold arithmetic (and raises numpy's errors for degenerate ranges)."""
-        mn, mx, npos, counts, dev_edges, valid = self.ctx.sample_range_hist(fld, strides, 256)
+        mn, mx, npos, counts, dev_edges, valid = pre if pre is not None else self.ctx.sample_range_hist(fld, strides, 256)
         if npos and valid == 1 and self.check_device_edges:
             assert np.array_equal(dev_edges, histogram_edges(mn, mx, 256)), "device-built histogram edges differ from numpy's"
         return mn, mx, counts, npos
 
-    def _fsq_bracket(self, strides, division):
+    def _fsq_bracket(self, strides, division, pre=None):
         """Predicted [lo, hi] for the un-normalised frob_sq threshold of the current scale, or None.
         Normalising by 1 instead of the (unknown) global max |H| rescales samples and threshold alike
         (filtering.py:421-444), so the histogram threshold of sqrt(frob_sq) predicts sqrt(fsq_min) up to float32
         rounding -- unless the rounding moves the histogram argmax to another bin, which the bracket then misses."""
-        self.ctx.set_frob_norm(1.0, 0.0)
+        if pre is None:
+            self.ctx.set_frob_norm(1.0, 0.0)
         self._raw_frob_range = None
         if self._chain_hist:
-            mn, mx, counts, npos = self._range_hist(FIELD_FROB, strides)
+            mn, mx, counts, npos = self._range_hist(FIELD_FROB, strides, pre)
             if npos == 0 or not np.isfinite(mx):
                 return None
             self._raw_frob_range = (np.float32(mn), np.float32(mx))
@@ -412,7 +415,14 @@ class FramePipeline:
             # it runs beside this scale's Hessian walk (filtering.py:814-835 has no such dependency either)
             ahead = self._gauss_ahead and k + 1 < len(sigmas) and cascade_step(k + 1, True)
             # gamma (filtering.py:365-380, 839-840)
-            gamma = self._threshold_from_field(FIELD_GAUSS, strides)
+            # the gamma samples and the raw Frobenius samples of the bracket need nothing from each other: one round trip
+            want_bracket = bool(self.one_pass and mask and p.frob_thresh_division and p.frob_thresh is None)
+            pair = None
+            if want_bracket and self._chain_hist and self._pair_hist:
+                ctx.set_spacing(spacing)
+                ctx.set_frob_norm(1.0, 0.0)
+                pair = ctx.sample_range_hist2(FIELD_GAUSS, FIELD_FROB, strides, 256)
+            gamma = self._threshold_from_field(FIELD_GAUSS, strides, pre=None if pair is None else pair[0])
             if gamma is None or gamma <= 0:
                 gamma = _EPS32
             gamma_sq = 2.0 * (float(gamma) ** 2)
@@ -420,9 +430,10 @@ class FramePipeline:
             # mask threshold can be bracketed beforehand (nl_vesselness_spec), by a pass of their own otherwise
             spec = False
             stats = None
-            if self.one_pass and mask and p.frob_thresh_division and p.frob_thresh is None:
-                ctx.set_spacing(spacing)
-                bracket = self._fsq_bracket(strides, float(p.frob_thresh_division))
+            if want_bracket:
+                if pair is None:
+                    ctx.set_spacing(spacing)
+                bracket = self._fsq_bracket(strides, float(p.frob_thresh_division), None if pair is None else pair[1])
                 if bracket is not None:
                     settle()
                     vz0, vz1 = self._vess_range()
