@@ -316,10 +316,10 @@ class FramePipeline:
         if known_range is not None:
             mn, mx, npos = known_range[0], known_range[1], 1
         elif self._chain_hist:
-            mn, mx, counts, npos = self._range_hist(fld, strides, pre)
+            mn, mx, counts, npos, edges = self._range_hist(fld, strides, pre)
             if npos == 0:
                 return None
-            return float(min_triangle_otsu(counts, histogram_edges(mn, mx, 256)))
+            return float(min_triangle_otsu(counts, edges))
         else:
             mn, mx, npos = self._reduce_minmax(*self.ctx.sample_minmax(fld, strides))
         if npos == 0:
@@ -330,12 +330,14 @@ class FramePipeline:
 
     def _range_hist(self, fld, strides, pre=None):
         """Range and 256-bin histogram of the positive lattice samples in one device round trip (single GPU: no
-        cross-rank reduction sits between the two passes).  The device builds numpy's float32 edges itself; the host
-        builds them again for the threshold arithmetic (and raises numpy's errors for degenerate ranges)."""
+        cross-rank reduction sits between the two passes).  The device builds numpy's float32 edges itself and they serve
+        the threshold arithmetic too (the GPU tests run with NELLIE_CHECK_EDGES=1: every such chain compares them with
+        numpy's, bit for bit); a degenerate range goes through numpy on the host, which raises numpy's errors."""
         mn, mx, npos, counts, dev_edges, valid = pre if pre is not None else self.ctx.sample_range_hist(fld, strides, 256)
         if npos and valid == 1 and self.check_device_edges:
             assert np.array_equal(dev_edges, histogram_edges(mn, mx, 256)), "device-built histogram edges differ from numpy's"
-        return mn, mx, counts, npos
+        edges = dev_edges if (npos and valid == 1) else (histogram_edges(mn, mx, 256) if npos else None)
+        return mn, mx, counts, npos, edges
 
     def _fsq_bracket(self, strides, division, pre=None):
         """Predicted [lo, hi] for the un-normalised frob_sq threshold of the current scale, or None.
@@ -346,11 +348,10 @@ class FramePipeline:
             self.ctx.set_frob_norm(1.0, 0.0)
         self._raw_frob_range = None
         if self._chain_hist:
-            mn, mx, counts, npos = self._range_hist(FIELD_FROB, strides, pre)
+            mn, mx, counts, npos, edges = self._range_hist(FIELD_FROB, strides, pre)
             if npos == 0 or not np.isfinite(mx):
                 return None
             self._raw_frob_range = (np.float32(mn), np.float32(mx))
-            edges = histogram_edges(mn, mx, 256)
         else:
             mn, mx, npos = self._reduce_minmax(*self.ctx.sample_minmax(FIELD_FROB, strides))
             if npos == 0 or not np.isfinite(mx):

@@ -1,5 +1,8 @@
 import glob
 import os
+
+# every range + histogram chain of the GPU tests also checks that the bin edges the device built are numpy's, bit for bit
+os.environ.setdefault("NELLIE_CHECK_EDGES", "1")
 import sys
 
 import numpy as np
