@@ -39,6 +39,31 @@ __global__ void __launch_bounds__(64 * YB) march(const T *in, T *out, int nz, in
     for (int k = 0; p + k < c1; ++k) out[base + (size_t)(p + k) * plane] = in[base + (size_t)(p + k) * plane];
 }
 
+// the fused Y+X pass's shape: a workgroup of T threads owns T*V columns of ONE plane and walks a chunk of rows (W rows in
+// flight per thread), writing the rows it read: lanes along X, consecutive rows 4 KiB apart
+template <typename T, int NT, int W>
+__global__ void __launch_bounds__(NT) ymarch(const T *in, T *out, int nz, int ny, int nxv, int chunk) {
+    const int x = blockIdx.x * NT + threadIdx.x;
+    if (x >= nxv) return;
+    const int z = blockIdx.z;
+    const int c0 = blockIdx.y * chunk, c1 = c0 + chunk < ny ? c0 + chunk : ny;
+    const size_t base = (size_t)z * ny * nxv + x;
+    T nxt[W];
+#pragma unroll
+    for (int k = 0; k < W; ++k) nxt[k] = in[base + (size_t)(c0 + k < ny ? c0 + k : ny - 1) * nxv];
+    int p = c0;
+    for (; p + W <= c1; p += W) {
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            const T v = nxt[k];
+            const int q = p + k + W;
+            nxt[k] = in[base + (size_t)(q < ny ? q : ny - 1) * nxv];
+            out[base + (size_t)(p + k) * nxv] = v;
+        }
+    }
+    for (int k = 0; p + k < c1; ++k) out[base + (size_t)(p + k) * nxv] = in[base + (size_t)(p + k) * nxv];
+}
+
 template <typename F> static float time_ms(F f, int reps) {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     f(); CK(hipDeviceSynchronize());
@@ -73,5 +98,14 @@ int main() {
     MARCH(float, 1, 9, 256) MARCH(float, 2, 9, 256) MARCH(float, 8, 9, 256) MARCH(float, 16, 9, 256)
     MARCH(float2, 4, 9, 256) MARCH(float2, 2, 9, 256) MARCH(float2, 8, 9, 256) MARCH(float2, 4, 4, 256)
     MARCH(float4, 4, 9, 256) MARCH(float4, 2, 9, 256) MARCH(float4, 4, 4, 256) MARCH(float4, 1, 9, 256)
+#define YMARCH(T, NT, W, CH)                                                                                  \
+    {                                                                                                         \
+        const int nxv = nx / VecOf<T>::N;                                                                     \
+        dim3 grid((nxv + NT - 1) / NT, (ny + CH - 1) / CH, nz);                                               \
+        char nm[64]; snprintf(nm, 64, "ymarch %-6s threads %3d  in flight %2d  chunk %4d", #T, NT, W, CH);    \
+        report(nm, time_ms([&] { ymarch<T, NT, W><<<grid, NT>>>((const T *)in, (T *)out, nz, ny, nxv, CH); }, 5)); \
+    }
+    YMARCH(float, 256, 9, 256) YMARCH(float, 256, 9, 128) YMARCH(float, 320, 9, 256) YMARCH(float2, 128, 9, 256) YMARCH(float2, 256, 9, 256)
+    YMARCH(float2, 160, 9, 256) YMARCH(float4, 64, 9, 256) YMARCH(float4, 128, 9, 256) YMARCH(float2, 256, 4, 256)
     return 0;
 }
