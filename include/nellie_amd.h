@@ -169,6 +169,12 @@ int nl_sample_range_hist2(nl_ctx *ctx, int field_a, int field_b, int64_t sz, int
    (numpy raises "attempt to get argmax of an empty sequence" there; *triangle is 0, *otsu is valid). */
 int nl_hist_thresholds(const int64_t *counts, const float *edges, int nbins, double *triangle, double *otsu, int *status,
                        char *err, size_t errlen);
+/* The same for either edge type numpy.histogram produces: edges_f64 = 0 -> `edges` is float32[nbins + 1] (float32 data), 1 ->
+   float64[nbins + 1] (integer and float64 data -- Label's intensity thresholds on the original image, labelling.py:414-431:
+   the bin centres are then float64 like the reference's).  *otsu_var (may be NULL) = the between-class variance at the
+   threshold, the second value of gpu_functions.py:50. */
+int nl_hist_thresholds_ex(const int64_t *counts, const void *edges, int edges_f64, int nbins, double *triangle, double *otsu,
+                          double *otsu_var, int *status, char *err, size_t errlen);
 
 /* Hessian by double finite differences of the current Gaussian volume (xp.gradient twice,
    filtering.py:518-536) on the owned planes; returns
@@ -417,12 +423,13 @@ int nl_outputs_wait(nl_ctx *ctx, char *err, size_t errlen);
    with different labels): fall back to nl_outputs_stage / nl_outputs_fetch_async.  nl_outputs_fetch_packed_async copies the
    blob to page-locked host memory on the download stream (nl_outputs_wait blocks until it landed; it is one of the
    copy-thread calls).  nl_outputs_unpack is host code: it expands a blob into dense (nz, ny, nx) arrays with `threads` host
-   threads; zero_fill = 0 if the arrays are known to hold zeros (a freshly created file), rows without content are then
-   not touched at all. */
+   threads; dst_elems = elements each destination array holds -- a blob whose header describes another volume, or whose
+   sections / row offsets do not fit its size, is refused before anything is written; zero_fill = 0 if the arrays are known
+   to hold zeros (a freshly created file), rows without content are then not touched at all. */
 int nl_outputs_pack(nl_ctx *ctx, int with_labels, int64_t *nbytes, char *err, size_t errlen);
 int nl_outputs_fetch_packed_async(nl_ctx *ctx, void *host_pinned, int64_t nbytes, char *err, size_t errlen);
-int nl_outputs_unpack(const void *blob, int64_t nbytes, float *frangi, int32_t *labels, int zero_fill, int threads,
-                      char *err, size_t errlen);
+int nl_outputs_unpack(const void *blob, int64_t nbytes, float *frangi, int32_t *labels, int64_t dst_elems, int zero_fill,
+                      int threads, char *err, size_t errlen);
 
 /* ------------------------------------------------------------------ test hooks -------- */
 /* Known-answer hook for the fused device routine (filtering.py:581-585 + 744-766): for n explicit

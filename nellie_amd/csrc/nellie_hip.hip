@@ -975,7 +975,16 @@ extern "C" int nl_hist_thresholds(const int64_t *counts, const float *edges, int
                                   char *err, size_t errlen) {
     if (!counts || !edges || !triangle || !otsu || !status || nbins < 1 || nbins > (1 << 20))
         return nl_fail(err, errlen, NL_EINVAL, "bad histogram arguments (nbins=%d)", nbins);
-    hist_thresholds_host(counts, edges, nbins, triangle, otsu, status);
+    hist_thresholds_host<float>(counts, edges, nbins, triangle, otsu, status);
+    return NL_OK;
+}
+
+extern "C" int nl_hist_thresholds_ex(const int64_t *counts, const void *edges, int edges_f64, int nbins, double *triangle, double *otsu,
+                                     double *otsu_var, int *status, char *err, size_t errlen) {
+    if (!counts || !edges || !triangle || !otsu || !status || nbins < 1 || nbins > (1 << 20))
+        return nl_fail(err, errlen, NL_EINVAL, "bad histogram arguments (nbins=%d)", nbins);
+    if (edges_f64) hist_thresholds_host<double>(counts, (const double *)edges, nbins, triangle, otsu, status, otsu_var);
+    else hist_thresholds_host<float>(counts, (const float *)edges, nbins, triangle, otsu, status, otsu_var);
     return NL_OK;
 }
 
@@ -3026,16 +3035,36 @@ extern "C" int nl_outputs_fetch_packed_async(nl_ctx *c, void *host_pinned, int64
 
 // Host only: expand a packed blob into the caller's dense arrays (labels may be NULL).  zero_fill = 0 when the arrays are
 // known to hold zeros already (a freshly created file or calloc'ed array): only rows with content are touched then.
-extern "C" int nl_outputs_unpack(const void *blob_, int64_t nbytes, float *frangi, int32_t *labels, int zero_fill, int threads,
-                                 char *err, size_t errlen) {
+extern "C" int nl_outputs_unpack(const void *blob_, int64_t nbytes, float *frangi, int32_t *labels, int64_t dst_elems, int zero_fill,
+                                 int threads, char *err, size_t errlen) {
     const char *blob = (const char *)blob_;
     if (!blob || nbytes < (int64_t)sizeof(PkHeader) || !frangi) return nl_fail(err, errlen, NL_EINVAL, "bad unpack arguments");
     PkHeader h;
     memcpy(&h, blob, sizeof(h));
-    if (h.magic != NL_PK_MAGIC || h.total > nbytes || h.wpr != (h.nx + 63) / 64) return nl_fail(err, errlen, NL_EINVAL, "not a packed-output blob");
+    if (h.magic != NL_PK_MAGIC || h.total > nbytes || h.total < (long long)sizeof(PkHeader) || h.nz < 0 || h.ny < 0 || h.nx < 0 ||
+        h.wpr != (h.nx + 63) / 64)
+        return nl_fail(err, errlen, NL_EINVAL, "not a packed-output blob");
     if (labels && !h.with_labels) return nl_fail(err, errlen, NL_EINVAL, "the blob holds no labels");
     const i64 rows = h.nz * h.ny, nx = h.nx;
     const int wpr = (int)h.wpr;
+    // the destination arrays are the caller's: the header of a blob from another context (or a damaged one) must not decide
+    // how far they are written
+    if (dst_elems != rows * nx)
+        return nl_fail(err, errlen, NL_EINVAL, "the blob describes a %lld x %lld x %lld volume, the destination holds %lld elements",
+                       (i64)h.nz, (i64)h.ny, (i64)h.nx, (i64)dst_elems);
+    // every section inside the blob
+    {
+        const long long bits_b = rows * wpr * 8, off_b = (rows + 1) * 4;
+        auto inside = [&](long long off, long long len) { return off >= (long long)sizeof(PkHeader) && len >= 0 && off <= h.total && len <= h.total - off; };
+        bool ok = h.n_values >= 0 && h.n_runs >= 0 && inside(h.off_fb, bits_b) && inside(h.off_fo, off_b) && inside(h.off_fv, h.n_values * 4);
+        if (h.with_labels) ok = ok && inside(h.off_lb, bits_b) && inside(h.off_lo, off_b) && inside(h.off_lr, h.n_runs * 4);
+        if (!ok) return nl_fail(err, errlen, NL_EINVAL, "packed-output blob: a section lies outside its %lld bytes", (i64)h.total);
+        // the per-row item offsets are what indexes the item arrays: monotone and inside the counts
+        const unsigned int *fo_ = (const unsigned int *)(blob + h.off_fo);
+        if (fo_[0] != 0 || (long long)fo_[rows] > h.n_values) ok = false;
+        if (h.with_labels) { const unsigned int *lo_ = (const unsigned int *)(blob + h.off_lo); if (lo_[0] != 0 || (long long)lo_[rows] > h.n_runs) ok = false; }
+        if (!ok) return nl_fail(err, errlen, NL_EINVAL, "packed-output blob: row offsets disagree with the item counts");
+    }
     const unsigned long long *fb = (const unsigned long long *)(blob + h.off_fb), *lb = (const unsigned long long *)(blob + h.off_lb);
     const unsigned int *fo = (const unsigned int *)(blob + h.off_fo), *lo = (const unsigned int *)(blob + h.off_lo);
     const float *fv = (const float *)(blob + h.off_fv);

@@ -51,9 +51,10 @@ _PROTOS = {
     "nl_sample_range_hist": [_p, _int, _i64, _i64, _i64, _int, C.POINTER(_f32), C.POINTER(_f32), C.POINTER(_i64), _p, _p, C.POINTER(_int)],
     "nl_sample_range_hist2": [_p, _int, _int, _i64, _i64, _i64, _int, _p, _p, _p, _p, _p, _p],
     "nl_hist_thresholds": [_p, _p, _int, C.POINTER(_f64), C.POINTER(_f64), C.POINTER(_int)],
+    "nl_hist_thresholds_ex": [_p, _p, _int, _int, C.POINTER(_f64), C.POINTER(_f64), C.POINTER(_f64), C.POINTER(_int)],
     "nl_outputs_pack": [_p, _int, _p],
     "nl_outputs_fetch_packed_async": [_p, _p, _i64],
-    "nl_outputs_unpack": [_p, _i64, _p, _p, _int, _int],
+    "nl_outputs_unpack": [_p, _i64, _p, _p, _i64, _int, _int],
     "nl_hessian_stats": [_p, C.POINTER(_f64), C.POINTER(_f32), C.POINTER(_f32), C.POINTER(_int)],
     "nl_set_frob_norm": [_p, _f32, _f32],
     "nl_vesselness_step": [_p, _f32, _f32, _f32, _int, _f32, _i64, _i64, C.POINTER(_i64)],
@@ -212,18 +213,26 @@ def load() -> _Lib:
     return _LIB
 
 
-def hist_thresholds(counts, edges):
-    """(triangle, otsu) bin-centre thresholds of a finished histogram (nl_hist_thresholds; gpu_functions.py:36-50, 64-94).
+def hist_thresholds(counts, edges, with_variance=False):
+    """(triangle, otsu) bin-centre thresholds of a finished histogram (nl_hist_thresholds_ex; gpu_functions.py:36-50, 64-94),
+    in the dtype of the edges: float32 edges (float32 data) give float32 centres, anything else is numpy's float64 path
+    (integer / float64 data).  with_variance: (triangle, otsu, between-class variance at otsu).
     Raises numpy's ValueError where the reference's triangle construction does (one non-empty bin)."""
     counts = np.ascontiguousarray(counts, dtype=np.int64)
-    edges = np.ascontiguousarray(edges, dtype=np.float32)
+    edges = np.asarray(edges)
+    f64 = edges.dtype != np.float32
+    edges = np.ascontiguousarray(edges, dtype=np.float64 if f64 else np.float32)
     nbins = int(counts.size)
     assert edges.size == nbins + 1
-    tri, otsu, status = _f64(0.0), _f64(0.0), _int(0)
-    load().call("nl_hist_thresholds", _ptr(counts), _ptr(edges), nbins, C.byref(tri), C.byref(otsu), C.byref(status))
+    tri, otsu, var, status = _f64(0.0), _f64(0.0), _f64(0.0), _int(0)
+    load().call("nl_hist_thresholds_ex", _ptr(counts), _ptr(edges), 1 if f64 else 0, nbins, C.byref(tri), C.byref(otsu), C.byref(var),
+                C.byref(status))
     if status.value == 1:
         raise ValueError("attempt to get argmax of an empty sequence")
-    return np.float32(tri.value), np.float32(otsu.value)
+    out_t = np.float64 if f64 else np.float32
+    if with_variance:
+        return out_t(tri.value), out_t(otsu.value), np.float64(var.value)
+    return out_t(tri.value), out_t(otsu.value)
 
 
 def outputs_unpack(blob, nbytes, frangi, labels=None, zero_fill=True, threads=8):
@@ -233,7 +242,7 @@ def outputs_unpack(blob, nbytes, frangi, labels=None, zero_fill=True, threads=8)
         assert labels.dtype == np.int32 and labels.flags.c_contiguous and labels.shape == frangi.shape
     src = blob._p if hasattr(blob, "_p") else _ptr(blob)
     load().call("nl_outputs_unpack", src, int(nbytes), _ptr(frangi), None if labels is None else _ptr(labels),
-                1 if zero_fill else 0, int(threads))
+                int(frangi.size), 1 if zero_fill else 0, int(threads))
 
 
 def comm_unique_id() -> bytes:

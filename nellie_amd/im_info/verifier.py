@@ -77,7 +77,9 @@ class FileInfo:
         if output_naming not in ("detailed", "stable"):
             raise ValueError(f"Unsupported output naming strategy '{output_naming}'")
         self.output_naming = output_naming
-        self.filename_no_ext = os.path.splitext(os.path.basename(self.filepath))[0].replace(".ome", "")
+        # verifier.py:126: splitext of the basename and nothing more ("foo.ome.tif" -> "foo.ome"): Nellie's later stages rebuild
+        # the paths of these files from their own FileInfo, so the names have to agree character for character
+        self.filename_no_ext = os.path.splitext(os.path.basename(self.filepath))[0]
         self.axes = None
         self.shape = None
         self.dim_res = {"X": None, "Y": None, "Z": None, "T": None}
@@ -96,11 +98,27 @@ class FileInfo:
         self.shape = tuple(data.shape)
         return self
 
+    def _check_time_range(self):
+        """verifier.py:393-408, 526-539: an out-of-range selection is an error, not a shorter stack."""
+        if self.axes is None or self.shape is None or "T" not in self.axes or self.t_start is None or self.t_end is None:
+            return
+        max_t = self.shape[self.axes.index("T")] - 1
+        if self.t_start < 0 or self.t_end < 0:
+            raise ValueError("Temporal range must be >= 0")
+        if self.t_start > self.t_end:
+            raise ValueError("Start frame must be <= end frame")
+        if self.t_start > max_t or self.t_end > max_t:
+            raise ValueError("Temporal range out of bounds")
+
     def load_metadata(self):
         if self.axes is None:
             self.find_metadata()
-        if "T" in self.axes and self.t_start is None:
-            self.t_start, self.t_end = 0, self.shape[self.axes.index("T")] - 1
+        if "T" in self.axes:
+            if self.t_start is None:
+                self.t_start = 0
+            if self.t_end is None:
+                self.t_end = self.shape[self.axes.index("T")] - 1
+        self._check_time_range()
         self.good_axes = all(a in "TZYX" for a in self.axes) and "X" in self.axes and "Y" in self.axes
         self.good_dims = all(self.dim_res.get(a) is not None for a in self.axes if a in self.dim_res)
         return self
@@ -121,12 +139,23 @@ class FileInfo:
         self.ch = int(ch)
 
     def select_temporal_range(self, start=0, end=None):
+        """verifier.py:475-506, same exceptions."""
         if self.axes is None:
             self.find_metadata()
         if "T" not in self.axes:
-            return
-        n = self.shape[self.axes.index("T")]
-        self.t_start, self.t_end = int(start), (n - 1 if end is None else int(end))
+            raise KeyError("No time dimension to select")
+        if start < 0:
+            raise IndexError("Start frame must be >= 0")
+        max_t = self.shape[self.axes.index("T")] - 1
+        if end is None:
+            end = max_t
+        if end < 0:
+            raise IndexError("End frame must be >= 0")
+        if start > end:
+            raise ValueError("Start frame must be <= end frame")
+        if start > max_t or end > max_t:
+            raise IndexError("Temporal range out of bounds")
+        self.t_start, self.t_end = int(start), int(end)
 
 
 class ImInfo:
@@ -138,6 +167,7 @@ class ImInfo:
         """
         lay = None
         t_range = None
+        output_naming = "detailed"
         if isinstance(source, FileInfo):                 # ImInfo(file_info), as nellie.run.run builds it (run.py:49)
             fi = source if source.axes is not None else source.load_metadata()
             fi.load_metadata()
@@ -145,11 +175,12 @@ class ImInfo:
             axes, ch, name = axes or fi.axes, fi.ch, name or fi.filename_no_ext
             output_dir = output_dir or fi.output_dir
             t_range = (fi.t_start, fi.t_end) if fi.t_start is not None else None
+            output_naming = fi.output_naming
             source = fi.filepath
         if isinstance(source, (str, os.PathLike)):
             src_path = os.fspath(source)
             base_dir = os.path.dirname(os.path.abspath(src_path))
-            name = name or os.path.splitext(os.path.basename(src_path))[0].replace(".ome", "")
+            name = name or os.path.splitext(os.path.basename(src_path))[0]
             if src_path.lower().endswith(".npy"):
                 data = np.load(src_path, mmap_mode="r")
             else:
@@ -172,6 +203,8 @@ class ImInfo:
         t_first, t_last = 0, data.shape[0] - 1
         if t_range is not None and "T" in src_axes:       # the selected time range (verifier.py:640-660)
             t_first, t_last = t_range
+            if not (0 <= t_first <= t_last <= data.shape[0] - 1):
+                raise ValueError("Temporal range out of bounds")      # the reference's np.take raises here (verifier.py:640-660)
             data = data[t_first:t_last + 1]
         self.new_axes = self.axes
         self.shape = data.shape
@@ -180,7 +213,8 @@ class ImInfo:
         self.nellie_necessities_dir = os.path.join(self.output_dir, "nellie_necessities")
         os.makedirs(self.nellie_necessities_dir, exist_ok=True)
         # "detailed" naming (verifier.py:596-613), built from the SOURCE axes like FileInfo does
-        output_name = detailed_output_name(name, src_axes, self.dim_res, ch, t_first, t_last)
+        # "stable" naming is the bare file name (verifier.py:597-598)
+        output_name = name if output_naming == "stable" else detailed_output_name(name, src_axes, self.dim_res, ch, t_first, t_last)
         self.user_output_path_no_ext = os.path.join(self.output_dir, output_name)
         self.nellie_necessities_output_path_no_ext = os.path.join(self.nellie_necessities_dir, output_name)
         self.im_path = self.nellie_necessities_output_path_no_ext + ".ome.tif"
@@ -190,8 +224,20 @@ class ImInfo:
         # array or a .npy has no such identity -- a second ImInfo built from DIFFERENT pixels of the same shape would find
         # the first one's canonical copy under the same name and the stages would silently process stale data -- so for
         # those the canonical input is always rewritten.
-        from_file = isinstance(source, (str, os.PathLike)) and not os.fspath(source).lower().endswith(".npy") and t_range is None
-        if not (from_file and os.path.exists(self.im_path)):
+        # The detailed name carries the time range, so a canonical copy found under it is this selection's -- provided it has the
+        # expected shape and dtype (a "stable" name does not say which frames it holds: rewritten unless the whole stack is taken).
+        from_file = isinstance(source, (str, os.PathLike)) and not os.fspath(source).lower().endswith(".npy")
+        if from_file and output_naming == "stable" and t_range is not None and "T" in src_axes:
+            from_file = False
+        reuse = False
+        if from_file and os.path.exists(self.im_path):
+            try:
+                old, _ = ome_tiff.memmap(self.im_path, mode="r")
+                reuse = int(np.prod(old.shape)) == int(np.prod(shape4)) and old.dtype == data.dtype
+                del old
+            except Exception:
+                reuse = False
+        if not reuse:
             ome_tiff.create(self.im_path, shape4, data.dtype, self.dim_res, "input", data=np.asarray(data).reshape(shape4))
         self.im = self.get_memmap(self.im_path)
         self.no_z = not ("Z" in self.axes and self.shape[self.axes.index("Z")] > 1)

@@ -44,9 +44,11 @@ def _host_histogram(matrix, nbins):
 
 
 def otsu_threshold(matrix, nbins=256, xp=None):
-    """gpu_functions.py:23-50 for a host array: (threshold, None) -- the stage only uses the threshold."""
+    """gpu_functions.py:23-50 for a host array: (threshold, between-class variance at it), in the dtype numpy's histogram
+    edges have for the data (float32 for float32, float64 for integer and float64 images)."""
     counts, edges = _host_histogram(matrix, nbins)
-    return hipnative.hist_thresholds(counts, edges)[1], None
+    _, otsu, var = hipnative.hist_thresholds(counts, edges, with_variance=True)
+    return otsu, var
 
 
 def triangle_threshold(matrix, nbins=256, xp=None):

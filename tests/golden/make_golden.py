@@ -369,8 +369,20 @@ def naming_cases():
         ("deep", "TZYX", {"X": 0.12345678, "Y": 1e-5, "Z": 12.0, "T": 100.0}, 0, 0, 63),
         ("odd", "TCZYX", {"X": 0.2, "Y": 0.2, "Z": 0.5, "T": 2.0}, 3, 5, 9),
     ]
-    for name, axes, dim_res, ch, t0, t1 in specs:
-        fi = SimpleNamespace(output_naming="detailed", filename_no_ext=name, axes=axes, dim_res=dict(dim_res), ch=ch, t_start=t0, t_end=t1,
+    # (file name on disk, naming strategy): filename_no_ext as FileInfo.__init__ derives it (verifier.py:124-126) -- a plain
+    # splitext, so "x.ome.tif" keeps its ".ome" -- and the "stable" strategy (verifier.py:597-598)
+    import tempfile
+    extra = [("plain.tif", "detailed"), ("stack.ome.tif", "detailed"), ("my.omega.sample.ome.tif", "detailed"),
+             ("stack.ome.tif", "stable"), ("a.b.c.nd2", "stable")]
+    named = [(n, "detailed", None) for n in ("cell", "my.sample", "a-b_c", "img", "deep", "odd")]
+    with tempfile.TemporaryDirectory() as tmp:
+        for fname, naming in extra:
+            real = FileInfo(os.path.join(tmp, fname), output_dir=os.path.join(tmp, "o"), output_naming=naming)
+            named.append((real.filename_no_ext, naming, fname))
+    specs = specs + [("x", "TZYX", {"X": 0.1, "Y": 0.1, "Z": 0.25, "T": 1.5}, 0, 0, 1)] * len(extra)
+    for (name, axes, dim_res, ch, t0, t1), (fn_no_ext, naming, fname) in zip(specs, named):
+        name = fn_no_ext
+        fi = SimpleNamespace(output_naming=naming, filename_no_ext=name, axes=axes, dim_res=dict(dim_res), ch=ch, t_start=t0, t_end=t1,
                              output_dir="OUT", nellie_necessities_dir=os.path.join("OUT", "nellie_necessities"))
         FileInfo._get_output_path(fi)
         ii = SimpleNamespace(file_info=fi, pipeline_paths={})
@@ -378,7 +390,7 @@ def naming_cases():
         for stage, ext, for_nellie in (("im_preprocessed", ".ome.tif", True), ("im_instance_label", ".ome.tif", True),
                                        ("features_organelles", ".csv", False)):
             paths[stage] = ImInfo.create_output_path(ii, stage, ext, for_nellie=for_nellie)
-        cases.append(dict(name=name, axes=axes, dim_res=dim_res, ch=ch, t_start=t0, t_end=t1,
+        cases.append(dict(name=name, naming=naming, filename=fname, axes=axes, dim_res=dim_res, ch=ch, t_start=t0, t_end=t1,
                           user_no_ext=fi.user_output_path_no_ext, necessities_no_ext=fi.nellie_necessities_output_path_no_ext,
                           ome_output_path=fi.ome_output_path, pipeline_paths=paths))
     with open(os.path.join(HERE, "naming_cases.json"), "w") as f:

@@ -81,6 +81,30 @@ def test_host_thresholds_match_reference_formulas():
         assert gf.triangle_threshold(v) == orc.triangle_threshold(v)
 
 
+def test_host_thresholds_keep_numpys_edge_dtype():
+    """Label's intensity thresholds run on the original image (labelling.py:414-431): uint16 / float64 data give float64
+    histogram edges and float64 bin centres; float32 data float32 ones.  Value, dtype and the variance gpu_functions.py:50
+    returns beside the threshold all equal the numpy formulas."""
+    from nellie_amd.utils import gpu_functions as gf
+    from oracle import nellie_oracle as orc
+    rng = np.random.default_rng(5)
+    for k, data in enumerate((rng.gamma(2.0, 300.0, 30000).astype(np.uint16), rng.gamma(2.0, 0.3, 30000), rng.random(5000).astype(np.float32),
+                              rng.integers(1, 4096, 40000).astype(np.uint16))):
+        flat = data.reshape(-1)
+        counts, edges = np.histogram(flat, bins=256, range=(flat.min(), flat.max()))
+        want = orc.otsu_from_hist(counts, edges)
+        got, var = gf.otsu_threshold(data)
+        assert got == want and got.dtype == want.dtype == edges.dtype, (k, got, want)
+        c = counts / np.sum(counts)
+        centres = (edges[:-1] + edges[1:]) / 2.0
+        w1 = np.cumsum(c); m1 = np.cumsum(c * centres) / w1
+        w2 = np.cumsum(c[::-1])[::-1]; m2 = (np.cumsum((c * centres)[::-1]) / w2[::-1])[::-1]
+        v12 = w1[:-1] * w2[1:] * (m1[:-1] - m2[1:]) ** 2
+        assert var == v12[np.argmax(v12)]
+        tri = gf.triangle_threshold(data)
+        assert tri == orc.triangle_from_hist(counts, edges) and tri.dtype == edges.dtype
+
+
 def test_host_parameters_match_oracle():
     from nellie_amd import pipeline as pl
     from oracle import nellie_oracle as orc

@@ -151,9 +151,13 @@ def test_detailed_names_equal_the_reference_strings():
     import json
     from nellie_amd.im_info.verifier import detailed_output_name
     cases = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "naming_cases.json")))
-    assert len(cases) >= 6
+    from nellie_amd.im_info.verifier import FileInfo
+    assert len(cases) >= 11
     for c in cases:
-        name = detailed_output_name(c["name"], c["axes"], c["dim_res"], c["ch"], c["t_start"], c["t_end"])
+        if c.get("filename"):          # filename_no_ext as the reference's FileInfo.__init__ derives it ("x.ome.tif" -> "x.ome")
+            assert FileInfo(os.path.join("somewhere", c["filename"]), output_naming=c["naming"]).filename_no_ext == c["name"]
+        name = c["name"] if c.get("naming") == "stable" else \
+            detailed_output_name(c["name"], c["axes"], c["dim_res"], c["ch"], c["t_start"], c["t_end"])
         assert os.path.join("OUT", name) == c["user_no_ext"]
         assert os.path.join("OUT", "nellie_necessities", name) == c["necessities_no_ext"]
         assert os.path.join("OUT", "nellie_necessities", name) + ".ome.tif" == c["ome_output_path"]
@@ -174,8 +178,25 @@ def test_run_signature_takes_a_file_info(tmp_path):
     fi.select_temporal_range(1, 2)
     im = ImInfo(fi)
     assert im.shape == (2, 3, 6, 7) and np.array_equal(np.asarray(im.im), vol[1:3])
-    assert os.path.basename(im.im_path) == "stack-TZYX-T2p0_Z0p5_Y0p2_X0p2-ch0-t1_to_2.ome.tif"
+    assert os.path.basename(im.im_path) == "stack.ome-TZYX-T2p0_Z0p5_Y0p2_X0p2-ch0-t1_to_2.ome.tif"
     assert im.im_path.startswith(os.path.join(str(tmp_path / "out"), "nellie_output", "nellie_necessities"))
+    # the canonical copy of a selection is reused (its name carries the range), not rewritten
+    mtime = os.path.getmtime(im.im_path)
+    im_again = ImInfo(fi)
+    assert im_again.im_path == im.im_path and os.path.getmtime(im.im_path) == mtime
+    # an out-of-range selection is an error, as in the reference (verifier.py:475-506, 393-408)
+    with pytest.raises(IndexError):
+        fi.select_temporal_range(0, 9)
+    with pytest.raises(ValueError):
+        fi.select_temporal_range(3, 1)
+    fi.t_start, fi.t_end = 0, 9
+    with pytest.raises(ValueError):
+        ImInfo(fi)
+    # "stable" naming = the bare file name (verifier.py:597-598)
+    fs = FileInfo(src, output_dir=str(tmp_path / "out_stable"), output_naming="stable")
+    ims = ImInfo(fs)
+    assert os.path.basename(ims.im_path) == "stack.ome.ome.tif"
+    assert os.path.basename(ims.pipeline_paths["im_instance_label"]) == "stack.ome-im_instance_label.ome.tif"
     import inspect
     from nellie_amd.run import run
     assert list(inspect.signature(run).parameters)[:7] == ["file_info", "remove_edges", "otsu_thresh_intensity", "threshold", "timeit", "device", "low_memory"]

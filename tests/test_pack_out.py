@@ -97,6 +97,37 @@ def test_unpack_rejects_what_is_not_a_blob():
         hipnative.outputs_unpack(blob, blob.nbytes - 16, out)
 
 
+def test_unpack_never_trusts_the_header_for_the_destination():
+    """A blob from a context of another shape, or with damaged section offsets / counts, is refused before a single element
+    of the caller's arrays is written."""
+    from nellie_amd import hipnative
+    fr, lab = volumes((3, 4, 70), 2)
+    blob = pack_model(fr, lab)
+    small = np.full((2, 4, 70), 7.0, np.float32)
+    with pytest.raises(ValueError, match="destination"):
+        hipnative.outputs_unpack(blob, blob.nbytes, small)
+    assert (small == 7.0).all()
+    with pytest.raises(AssertionError):                                  # labels of another shape than the frame
+        hipnative.outputs_unpack(blob, blob.nbytes, np.zeros((3, 4, 70), np.float32), np.zeros((3, 4, 71), np.int32))
+    hdr_fields = {"off_fb": 8, "off_lb": 9, "off_fo": 10, "off_lo": 11, "off_fv": 12, "off_lr": 13}
+    for name, k in hdr_fields.items():
+        bad = blob.copy()
+        bad[:128].view(np.int64)[k] = blob.nbytes - 8                    # the section would run past the end
+        out = np.full((3, 4, 70), 7.0, np.float32)
+        with pytest.raises(ValueError):
+            hipnative.outputs_unpack(bad, bad.nbytes, out, np.zeros((3, 4, 70), np.int32))
+        assert (out == 7.0).all(), name
+    for k in (5, 6):                                                     # n_values / n_runs smaller than the row offsets say
+        bad = blob.copy()
+        bad[:128].view(np.int64)[k] = 1
+        with pytest.raises(ValueError):
+            hipnative.outputs_unpack(bad, bad.nbytes, np.zeros((3, 4, 70), np.float32), np.zeros((3, 4, 70), np.int32))
+    bad = blob.copy()
+    bad[:128].view(np.int64)[5] = 1 << 40                                # ... or absurdly large
+    with pytest.raises(ValueError):
+        hipnative.outputs_unpack(bad, bad.nbytes, np.zeros((3, 4, 70), np.float32))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(24, 48, 48), (9, 33, 200), (3, 4, 4100), (40, 64, 129)])
 def test_device_pack_equals_dense_download(hip, shape):
