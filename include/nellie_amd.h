@@ -288,6 +288,13 @@ int nl_planes_put(nl_ctx *ctx, int field, int64_t z0, int64_t z1, const float *h
    calls nl_comm_init on its context. */
 int nl_comm_unique_id(char *id128, char *err, size_t errlen);
 int nl_comm_init(nl_ctx *ctx, int world, int rank, const char *id128, char *err, size_t errlen);
+/* Loopback transport: an id from nl_comm_loopback_id makes nl_comm_init / nl_comm_init2 build a communicator between
+   `world` contexts of THIS process (one host thread per rank, any devices of the process -- typically all on one GPU).
+   Every exchange above -- ghost planes, bit planes, fused reductions, variable all-gathers -- then runs through the same
+   code with the same pointers, offsets, counts, streams and events as over RCCL, the data moving by device-to-device
+   copies on those streams: the N >= 2 paths are testable on a one-GPU box.  NELLIE_LOOPBACK_DELAY_US=n puts a random
+   0..n us spin in front of every transfer (stress for missing stream dependencies). */
+int nl_comm_loopback_id(char *id128, char *err, size_t errlen);
 
 /* Exchange `depth` ghost planes of a float field with both Z neighbours (ncclSend/ncclRecv in one group,
    asynchronous on the context stream). */

@@ -27,7 +27,7 @@ struct RcclApi {
     decltype(&ncclAllGather) AllGather = nullptr;
     bool ok = false;
 };
-static RcclApi &rccl() {
+static RcclApi &rccl_real() {
     static RcclApi api;
     if (!api.handle) {
         const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
@@ -43,6 +43,70 @@ static RcclApi &rccl() {
     }
     return api;
 }
+
+#include "loopback.inc"
+
+// What the entry points call: the same names, dispatched per communicator -- a communicator created from a loopback id
+// (nl_comm_loopback_id) lives in loopback.inc, every other one is RCCL's.  librccl.so is only loaded when a real id is asked
+// for or used.
+struct CommApi {
+    std::atomic<int> n_real{0};
+    static ncclResult_t missing() { return (ncclResult_t)lb::kMissing; }
+    ncclResult_t GetUniqueId(ncclUniqueId *id) { return rccl_real().ok ? rccl_real().GetUniqueId(id) : missing(); }
+    ncclResult_t CommInitRank(ncclComm_t *comm, int world, ncclUniqueId id, int rank) {
+        if (lb::is_loopback_id(id.internal)) return lb::comm_init(comm, world, id.internal, rank);
+        if (!rccl_real().ok) return missing();
+        const ncclResult_t r = rccl_real().CommInitRank(comm, world, id, rank);
+        if (r == ncclSuccess) ++n_real;
+        return r;
+    }
+    ncclResult_t CommDestroy(ncclComm_t comm) {
+        if (lb::is_ours(comm)) return lb::comm_destroy(comm);
+        if (!rccl_real().ok) return missing();
+        --n_real;
+        return rccl_real().CommDestroy(comm);
+    }
+    const char *GetErrorString(ncclResult_t r) {
+        if ((int)r == lb::kMissing) return "librccl.so could not be loaded";
+        if (rccl_real().handle && rccl_real().ok) return rccl_real().GetErrorString(r);
+        switch (r) {
+            case ncclInvalidArgument: return "invalid argument (loopback transport)";
+            case ncclSystemError: return "rendezvous timed out or a peer failed (loopback transport)";
+            case ncclUnhandledCudaError: return "HIP error (loopback transport)";
+            default: return "error (loopback transport)";
+        }
+    }
+    ncclResult_t GroupStart() {
+        lb::group_start();
+        return n_real.load() > 0 ? rccl_real().GroupStart() : ncclSuccess;
+    }
+    ncclResult_t GroupEnd() {
+        const ncclResult_t r = lb::group_end();
+        const ncclResult_t q = n_real.load() > 0 ? rccl_real().GroupEnd() : ncclSuccess;
+        return r != ncclSuccess ? r : q;
+    }
+    ncclResult_t Send(const void *buf, size_t count, ncclDataType_t dt, int peer, ncclComm_t comm, hipStream_t st) {
+        if (lb::is_ours(comm)) return lb::submit(lb::Op{0, buf, nullptr, count, dt, ncclSum, peer, (lb::Comm *)comm, st});
+        return rccl_real().Send(buf, count, dt, peer, comm, st);
+    }
+    ncclResult_t Recv(void *buf, size_t count, ncclDataType_t dt, int peer, ncclComm_t comm, hipStream_t st) {
+        if (lb::is_ours(comm)) return lb::submit(lb::Op{1, nullptr, buf, count, dt, ncclSum, peer, (lb::Comm *)comm, st});
+        return rccl_real().Recv(buf, count, dt, peer, comm, st);
+    }
+    ncclResult_t AllReduce(const void *src, void *dst, size_t count, ncclDataType_t dt, ncclRedOp_t op, ncclComm_t comm, hipStream_t st) {
+        if (lb::is_ours(comm)) return lb::submit(lb::Op{2, src, dst, count, dt, op, -1, (lb::Comm *)comm, st});
+        return rccl_real().AllReduce(src, dst, count, dt, op, comm, st);
+    }
+    ncclResult_t AllGather(const void *src, void *dst, size_t count, ncclDataType_t dt, ncclComm_t comm, hipStream_t st) {
+        if (lb::is_ours(comm)) return lb::submit(lb::Op{3, src, dst, count, dt, ncclSum, -1, (lb::Comm *)comm, st});
+        return rccl_real().AllGather(src, dst, count, dt, comm, st);
+    }
+    ncclResult_t Broadcast(const void *src, void *dst, size_t count, ncclDataType_t dt, int root, ncclComm_t comm, hipStream_t st) {
+        if (lb::is_ours(comm)) return lb::submit(lb::Op{4, src, dst, count, dt, ncclSum, root, (lb::Comm *)comm, st});
+        return rccl_real().Broadcast(src, dst, count, dt, root, comm, st);
+    }
+};
+static CommApi &rccl() { static CommApi api; return api; }
 
 #define NL_MASK_SLOTS 2      // cumulative h_mask bit planes (ping-pong between consecutive scales)
 #define NL_VERSION "nellie_amd-hip 0.1.0 (gfx950)"
@@ -283,8 +347,8 @@ extern "C" int nl_ctx_destroy(nl_ctx *c) {
     if (c->xstream) { hipStreamSynchronize(c->xstream); hipStreamDestroy(c->xstream); }
     if (c->ev_x_main) hipEventDestroy(c->ev_x_main);
     if (c->ev_x_done) hipEventDestroy(c->ev_x_done);
-    if (c->comm2 && rccl().ok) rccl().CommDestroy((ncclComm_t)c->comm2);
-    if (c->comm && rccl().ok) rccl().CommDestroy((ncclComm_t)c->comm);
+    if (c->comm2) rccl().CommDestroy((ncclComm_t)c->comm2);
+    if (c->comm) rccl().CommDestroy((ncclComm_t)c->comm);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
     return NL_OK;
@@ -806,7 +870,6 @@ extern "C" int nl_sample_gather_positive(nl_ctx *c, int field, int64_t sz, int64
 
 #define NL_NCCL(expr)                                                                                  \
     do {                                                                                               \
-        if (!rccl().ok) return nl_fail(err, errlen, NL_ECOMM, "librccl.so could not be loaded");         \
         ncclResult_t r_ = (expr);                                                                      \
         if (r_ != ncclSuccess) return nl_fail(err, errlen, NL_ECOMM, "%s: %s", #expr, rccl().GetErrorString(r_)); \
     } while (0)
@@ -1567,6 +1630,14 @@ extern "C" int nl_comm_unique_id(char *id128, char *err, size_t errlen) {
     NL_NCCL(rccl().GetUniqueId(&id));
     static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
     memcpy(id128, &id, 128);
+    return NL_OK;
+}
+
+// An id of the loopback transport (loopback.inc): `world` contexts of THIS process, one host thread per rank, exchange
+// through device-to-device copies on the very streams, with the very offsets and counts RCCL would be given.
+extern "C" int nl_comm_loopback_id(char *id128, char *err, size_t errlen) {
+    if (!id128) return nl_fail(err, errlen, NL_EINVAL, "id buffer is NULL");
+    lb::get_unique_id(id128);
     return NL_OK;
 }
 

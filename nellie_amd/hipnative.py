@@ -81,6 +81,7 @@ _PROTOS = {
     "nl_planes_get": [_p, _int, _i64, _i64, _p],
     "nl_planes_put": [_p, _int, _i64, _i64, _p],
     "nl_comm_unique_id": [C.c_char_p],
+    "nl_comm_loopback_id": [C.c_char_p],
     "nl_comm_init": [_p, _int, _int, C.c_char_p],
     "nl_halo_exchange": [_p, _int, _i64],
     "nl_halo_exchange_at": [_p, _int, _i64, _i64, _int],
@@ -245,10 +246,12 @@ def outputs_unpack(blob, nbytes, frangi, labels=None, zero_fill=True, threads=8)
                 int(frangi.size), 1 if zero_fill else 0, int(threads))
 
 
-def comm_unique_id() -> bytes:
-    """128-byte RCCL unique id (rank 0 creates it and hands it to the other ranks out of band)."""
+def comm_unique_id(loopback: bool = False) -> bytes:
+    """128-byte communicator id (rank 0 creates it and hands it to the other ranks out of band).  loopback=True: an id of
+    the in-process loopback transport (nl_comm_loopback_id) -- the ranks are then contexts of this process, one host thread
+    each, and every exchange runs through the same library code as over RCCL."""
     buf = C.create_string_buffer(128)
-    load().call("nl_comm_unique_id", buf)
+    load().call("nl_comm_loopback_id" if loopback else "nl_comm_unique_id", buf)
     return buf.raw
 
 

@@ -106,8 +106,6 @@ def join_slab_tables(tables):
     """tables[r] = (roots[4], values[4]) of rank r, planes in the order ghost-low, own-first, own-last, ghost-high.
     Rank r's last owned plane is rank r+1's low ghost plane and rank r's high ghost plane is rank r+1's first owned
     plane: the k-th run of such a plane names the same voxels on both sides, which joins the two trees."""
-    from scipy.sparse import coo_matrix
-    from scipy.sparse.csgraph import connected_components
     ranks, roots, vals, ids, n = [], [], [], [], 0
     for r, (rt, vt) in enumerate(tables):
         allr = np.concatenate([np.asarray(x, np.int64) for x in rt]) if rt else np.zeros(0, np.int64)
@@ -133,10 +131,27 @@ def join_slab_tables(tables):
         return j
     ea = np.concatenate(ea) if ea else np.zeros(0, np.int64)
     eb = np.concatenate(eb) if eb else np.zeros(0, np.int64)
-    g = coo_matrix((np.ones(ea.size, np.int8), (ea, eb)), shape=(n, n))
-    j.ncomp, comp = connected_components(g, directed=False)
-    j.comp = comp.astype(np.int64)
+    j.ncomp, j.comp = _components(n, ea, eb)
     return j
+
+
+def _components(n, ea, eb):
+    """Connected components of the graph (n nodes, undirected edges ea[i] -- eb[i]) by min-label propagation with pointer
+    jumping (numpy only: the product path carries no scipy).  -> (count, component id per node); ids number the components
+    by their smallest node, so every rank derives the same numbering from the same tables."""
+    lab = np.arange(n, dtype=np.int64)
+    if ea.size:
+        while True:
+            m = np.minimum(lab[ea], lab[eb])
+            new = lab.copy()
+            np.minimum.at(new, ea, m)
+            np.minimum.at(new, eb, m)
+            new = new[new]                       # labels are node indices: jump to the label's own label
+            if np.array_equal(new, lab):
+                break
+            lab = new
+    u, comp = np.unique(lab, return_inverse=True)
+    return int(u.size), comp.astype(np.int64)
 
 
 class RcclComm:

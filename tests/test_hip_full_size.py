@@ -149,6 +149,13 @@ def test_c2_parity_at_its_own_size(hip):
     assert lthr == ref_lthr
     n = pipe.label(lthr, pl.min_area_pixels_of(ISO_01))
     assert np.array_equal(pipe.download_labels(), ref_lab) and n == int(ref_lab.max()) and n >= 3
+    # end to end at this size (device Frangi -> device labels), what bench.py's accuracy block reports as 1.0
+    pipe.upload_frangi(fr)
+    n_e2e = pipe.label(pipe.frangi_threshold(), pl.min_area_pixels_of(ISO_01))
+    lab_e2e = pipe.download_labels()
+    n_diff = int((lab_e2e != ref_lab).sum())
+    print(f"C2 end to end: {n_diff} label voxels differ, {n_e2e} vs {int(ref_lab.max())} labels")
+    assert n_diff == 0 and n_e2e == int(ref_lab.max())
     pipe.close()
 
 

@@ -261,8 +261,10 @@ def test_end_to_end_vs_oracle(shape, seed, aniso, pipes):
     pipe.label(pipe.frangi_threshold(), pl.min_area_pixels_of(dr))
     lab = pipe.download_labels()
     match = float(np.mean(lab == ref_lab))
-    print(f"end-to-end label match fraction {match:.6f}, labels {lab.max()} vs {ref_lab.max()}")
-    assert match > 0.999
+    n_diff = int((lab != ref_lab).sum())
+    print(f"E2E {shape} seed {seed}: end-to-end label match fraction {match:.8f} ({n_diff} voxels), labels {lab.max()} vs {ref_lab.max()}")
+    # measured on these seeded volumes (MI355X, round 3): identical labellings
+    assert n_diff == 0 and int(lab.max()) == int(ref_lab.max())
 
 
 @pytest.mark.parametrize("name", FILTER_2D_CASES)
@@ -616,6 +618,46 @@ def test_run_on_disk_layout(hip, tmp_path):
         assert np.array_equal(np.asarray(lab[t]), orc.label_frame(np.asarray(fr[t]), ISO_01))
         m, d, b = orc.markers_frame(vols[t], np.asarray(lab[t]), ISO_01)
         assert np.array_equal(np.asarray(mk[t]), m) and np.array_equal(np.asarray(di[t]), d) and np.array_equal(np.asarray(bo[t]), b)
+
+
+def test_c1_ome_tiff_file_through_the_stage_api(hip, tmp_path):
+    """BASELINE config 1 as SURVEY 8(d) scopes it (the sample file is absent: a generated small OME-TIFF): uint16 ZYX
+    OME-TIFF on disk -> FileInfo -> ImInfo -> Filter(max_radius_um=0.375).run() -> Label().run(), i.e. a SINGLE sigma
+    (sigma = [1.25] at 0.1 um), outputs reopened from the files and compared with the oracle; then the default run(file_info)
+    on the same file."""
+    import os
+    from nellie_amd.im_info import ome_tiff
+    from nellie_amd.im_info.verifier import FileInfo, ImInfo
+    from nellie_amd.run import run
+    from nellie_amd.segmentation.filtering import Filter
+    from nellie_amd.segmentation.labelling import Label
+    from nellie_amd.synthetic import ISO_01, make_volume
+    vol = make_volume((24, 56, 64), 77, dtype=np.uint16)
+    src = str(tmp_path / "yeast_like.ome.tif")
+    ome_tiff.create(src, (1,) + vol.shape, np.uint16, ISO_01, "raw", data=vol[None])
+    fi = FileInfo(src, output_dir=str(tmp_path / "out"))
+    fi.find_metadata(); fi.load_metadata()
+    assert fi.good_axes and fi.good_dims and fi.dim_res["Z"] == ISO_01["Z"]
+    im_info = ImInfo(fi)
+    assert os.path.basename(im_info.im_path).startswith("yeast_like.ome-")
+    flt = Filter(im_info, max_radius_um=0.375, device="gpu")
+    flt.run()
+    assert [float(s) for s in flt.sigmas] == [1.25] == orc.default_sigmas(ISO_01, 0.25, 0.375)
+    Label(im_info, device="gpu").run()
+    fr = np.asarray(im_info.get_memmap(im_info.pipeline_paths["im_preprocessed"], read_mode="r"))[0]
+    lab = np.asarray(im_info.get_memmap(im_info.pipeline_paths["im_instance_label"], read_mode="r"))[0]
+    ref = orc.filter_frame(vol, ISO_01, sigmas=[1.25])
+    assert (ref > 0).any()
+    assert_frangi_close(fr, ref, "single sigma")
+    assert np.array_equal(lab, orc.label_frame(fr, ISO_01)) and lab.max() >= 1
+    assert np.array_equal(np.asarray(im_info.get_memmap(im_info.im_path, read_mode="r"))[0], vol), "input file was modified"
+    # the default five-scale run(file_info) on the same source (a second output directory)
+    fi2 = FileInfo(src, output_dir=str(tmp_path / "out5"))
+    im2 = run(fi2, device="gpu")
+    fr5 = np.asarray(im2.get_memmap(im2.pipeline_paths["im_preprocessed"], read_mode="r"))[0]
+    lab5 = np.asarray(im2.get_memmap(im2.pipeline_paths["im_instance_label"], read_mode="r"))[0]
+    assert_frangi_close(fr5, orc.filter_frame(vol, ISO_01), "five sigmas")
+    assert np.array_equal(lab5, orc.label_frame(fr5, ISO_01))
 
 
 def test_streamed_stack_equals_per_stage_run(hip, tmp_path):

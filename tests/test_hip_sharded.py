@@ -15,18 +15,32 @@ from comms import ThreadComm, ThreadGroup
 pytestmark = pytest.mark.gpu
 
 
-def _run_sharded(gshape, dr, seed, world, halo_mode="steps", raw_ghosts=False):
+def _comm_factory(transport, world, group):
+    """rank -> comm_factory(ctx).  "host": planes and scalars travel through numpy arrays (nl_planes_get / _put); "loopback":
+    the production RcclComm over the library's loopback transport -- the nccl* call sites, their plane offsets and counts,
+    both communicators, the side stream and its events run exactly as over RCCL (include/nellie_amd.h: nl_comm_loopback_id)."""
+    if transport == "host":
+        return lambda rank: (lambda ctx: ThreadComm(group, rank))
+    from nellie_amd import hipnative
+    from nellie_amd.sharded import RcclComm
+    uid, uid2 = hipnative.comm_unique_id(loopback=True), hipnative.comm_unique_id(loopback=True)
+    assert uid[:8] == b"NLLOOPBK" and uid != uid2
+    return lambda rank: (lambda ctx: RcclComm(ctx, world, rank, uid, uid2=uid2))
+
+
+def _run_sharded(gshape, dr, seed, world, halo_mode="steps", raw_ghosts=False, transport="host"):
     from nellie_amd.pipeline import FilterParams, min_area_pixels_of
     from nellie_amd.sharded import ShardedFramePipeline, slab_range
     from nellie_amd.synthetic import make_volume
     group = ThreadGroup(world)
+    factory = _comm_factory(transport, world, group)
     out, errs = [None] * world, []
 
     def worker(rank):
         try:
             p = FilterParams(dim_res=dr)
             o0, o1 = slab_range(gshape[0], world, rank)
-            pipe = ShardedFramePipeline(gshape, rank, world, lambda ctx: ThreadComm(group, rank), p, halo_mode=halo_mode)
+            pipe = ShardedFramePipeline(gshape, rank, world, factory(rank), p, halo_mode=halo_mode)
             g_lo, g_hi = pipe.raw_ghost_needed() if raw_ghosts else (0, 0)      # raw ghost planes handed over with the frame
             own = make_volume((o1 - o0 + g_lo + g_hi,) + tuple(gshape[1:]), seed, z_offset=o0 - g_lo, global_nz=gshape[0])
             pipe.filter(own, p)
@@ -79,6 +93,105 @@ def test_zslab_filter_equals_single_gpu(hip, gshape, aniso, world, halo_mode):
     lab = np.concatenate([p_[3] for p_ in parts])
     assert np.array_equal(lab, ref_lab), f"{int((lab != ref_lab).sum())} label voxels differ"
     assert ref_n >= 1
+
+
+def _single_reference(gshape, dr, seed):
+    from nellie_amd import pipeline as pl
+    from nellie_amd.synthetic import make_volume
+    single = pl.FramePipeline(gshape)
+    p = pl.FilterParams(dim_res=dr)
+    single.filter(make_volume(gshape, seed), p)
+    ref = single.download_frangi()
+    thr = single.frangi_threshold()
+    counts = [s.mask_count for s in single.trace.scales]
+    n = single.label(thr, pl.min_area_pixels_of(dr))
+    lab = single.download_labels()
+    single.close()
+    return ref, thr, counts, n, lab
+
+
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("halo_mode", ["steps", "fat", "steps+raw"])
+@pytest.mark.parametrize("gshape,aniso,world", [((96, 64, 80), False, 2), ((100, 48, 70), False, 3),
+                                               ((60, 64, 64), True, 4), ((90, 40, 70), False, 6)])
+def test_zslab_over_the_loopback_transport(hip, gshape, aniso, world, halo_mode, fused, monkeypatch):
+    """The N >= 2 exchange code itself -- ncclSend / ncclRecv of float and bit planes (halo_exchange_impl,
+    nl_slab_bits_exchange), the fused all-reduces between the sampling kernels, nl_allgather_var with several blocks, the
+    second communicator with its stream and events, the cascade step running ahead (NELLIE_GAUSS_AHEAD, default on slabs)
+    -- on world contexts of one GPU: Filter and Label equal the single-context result bit for bit."""
+    from nellie_amd.synthetic import ANISO_03, ISO_01
+    monkeypatch.setenv("NELLIE_FUSE_REDUCE", "1" if fused else "0")
+    raw_ghosts = halo_mode.endswith("+raw")
+    halo_mode = halo_mode.split("+")[0]
+    if halo_mode == "fat" and world == 6:
+        pytest.skip("15-plane slabs are thinner than the 24-plane fat halo")
+    dr = ANISO_03 if aniso else ISO_01
+    ref, ref_thr, ref_counts, ref_n, ref_lab = _single_reference(gshape, dr, 91)
+    parts = _run_sharded(gshape, dr, 91, world, halo_mode, raw_ghosts, transport="loopback")
+    got = np.concatenate([p_[0] for p_ in parts])
+    assert np.array_equal(got, ref), f"{int((got != ref).sum())} voxels differ"
+    for _, thr, counts, _, n in parts:
+        assert thr == ref_thr and counts == ref_counts and n == ref_n
+    lab = np.concatenate([p_[3] for p_ in parts])
+    assert (ref > 0).any() and ref_n >= 1
+    assert np.array_equal(lab, ref_lab), f"{int((lab != ref_lab).sum())} label voxels differ"
+
+
+@pytest.mark.parametrize("delay_us,seed", [(200, 7), (1500, 8)])
+@pytest.mark.parametrize("world", [2, 4])
+def test_zslab_loopback_with_randomised_transfer_delays(hip, world, delay_us, seed, monkeypatch):
+    """Every transfer of the loopback transport is held back by a random spin on its stream (NELLIE_LOOPBACK_DELAY_US): the
+    asynchronous ghost-plane exchange then finishes long after the host has moved on, and any consumer that is not ordered
+    behind it by an event reads stale planes.  Results must not move."""
+    from nellie_amd.synthetic import ISO_01
+    monkeypatch.setenv("NELLIE_LOOPBACK_DELAY_US", str(delay_us))
+    monkeypatch.setenv("NELLIE_GAUSS_AHEAD", "1")
+    gshape = (32 * world, 56, 72)
+    ref, ref_thr, ref_counts, ref_n, ref_lab = _single_reference(gshape, ISO_01, seed)
+    for _ in range(2):
+        parts = _run_sharded(gshape, ISO_01, seed, world, "steps", False, transport="loopback")
+        assert np.array_equal(np.concatenate([p_[0] for p_ in parts]), ref)
+        assert np.array_equal(np.concatenate([p_[3] for p_ in parts]), ref_lab)
+        assert all(p_[1] == ref_thr and p_[2] == ref_counts and p_[4] == ref_n for p_ in parts)
+
+
+def test_loopback_collectives_known_answers(hip):
+    """The transport itself against numpy: all-reduce (sum / min / max, int64 and float32), variable all-gather with empty
+    and unequal blocks, on 3 ranks."""
+    from nellie_amd import hipnative
+    world = 3
+    uid = hipnative.comm_unique_id(loopback=True)
+    out, errs = [None] * world, []
+
+    def worker(rank):
+        try:
+            ctx = hipnative.Context((8, 16, 16), gz0=0, gnz=8, own=(0, 8))
+            ctx.comm_init(world, rank, uid)
+            res = {}
+            res["sum"] = ctx.allreduce(np.array([rank + 1, 10 * rank], np.int64), "sum")
+            res["min"] = ctx.allreduce(np.array([rank + 1, -rank], np.int64), "min")
+            res["maxf"] = ctx.allreduce(np.array([0.5 * rank, -1.0 - rank], np.float32), "max")
+            res["gather"] = ctx.allgather_var(np.arange(rank * 1000, dtype=np.int32) + rank, world)
+            res["gather_bytes"] = ctx.allgather_var(np.frombuffer(bytes([rank] * (rank + 1)), np.uint8).copy(), world)
+            out[rank] = res
+            ctx.close()
+        except Exception as exc:  # noqa: BLE001
+            errs.append(exc)
+
+    ts = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    if errs:
+        raise errs[0]
+    for rank in range(world):
+        r = out[rank]
+        assert np.array_equal(r["sum"], [6, 30]) and np.array_equal(r["min"], [1, -2])
+        assert np.array_equal(r["maxf"], np.array([1.0, -1.0], np.float32))
+        for q in range(world):
+            assert np.array_equal(r["gather"][q], np.arange(q * 1000, dtype=np.int32) + q)
+            assert bytes(r["gather_bytes"][q]) == bytes([q] * (q + 1))
 
 
 @pytest.mark.parametrize("fused", [True, False])
