@@ -216,6 +216,26 @@ int nl_set_spacing(nl_ctx *ctx, const double spacing[3], char *err, size_t errle
 int nl_vesselness_spec(nl_ctx *ctx, const double spacing[3], float fsq_lo, float fsq_hi, int64_t z0, int64_t z1,
                        float *max_abs, float *max_frob_sq, int *any_inf, int *overflow, char *err, size_t errlen);
 
+/* Device-resident threshold chain (csrc/chain.inc): the four data-dependent scalars of a scale -- gamma, the walk's bracket,
+   max |H| and the Frobenius threshold (filtering.py:365-380, 421-444, 555-566) -- are computed by small kernels between the large
+   ones, which read them from device memory, so a frame's scale loop is enqueued without a single wait:
+     nl_chain_begin(n)            a frame of n scales (<= 16) starts
+     nl_gauss_step ...            the cascade step of scale k, as always
+     nl_chain_scale(...)          everything else of scale k: lattice histograms, thresholds, walk, exact histogram, resolve kernel
+                                  (sz, sy, sx: lattice strides; division / margin / test_scale: frob_thresh_division, the relative
+                                  half-width of the bracket, a factor on the predicted threshold (1.0; tests force misses with it))
+     nl_chain_finish(...)         THE wait: per scale flags[k] (0 = stands), gamma, max |H|, the threshold, this context's h_mask count
+   Every histogram and every derived scalar is logged, and nl_chain_finish repeats the arithmetic on the host with the code of
+   the synchronous entry points and compares bit for bit: a difference, or any condition the fast path does not handle (no
+   positive sample, degenerate triangle, +inf, queue overflow, bracket miss, empty scale), gives a non-zero flag and the caller
+   redoes the frame with nl_sample_range_hist2 / nl_vesselness_spec / nl_vesselness_resolve.  Same results either way.
+   nl_chain_log: test hook, the logged record of scale k (which: 0 Gaussian, 1 raw Frobenius, 2 normalised Frobenius samples). */
+int nl_chain_begin(nl_ctx *ctx, int n_scales, char *err, size_t errlen);
+int nl_chain_scale(nl_ctx *ctx, const double spacing[3], int64_t sz, int64_t sy, int64_t sx, double alpha_sq, double beta_sq,
+                   double division, double margin, double test_scale, int64_t z0, int64_t z1, char *err, size_t errlen);
+int nl_chain_finish(nl_ctx *ctx, int *flags, double *gamma, double *max_abs, double *thr, int64_t *mask_count, char *err, size_t errlen);
+int nl_chain_log(nl_ctx *ctx, int k, int which, int64_t *counts, float *edges, float *range, double *scalars, char *err, size_t errlen);
+
 /* Second half of nl_vesselness_spec, with the arguments nl_vesselness_step takes (nl_set_frob_norm first).
    *hit = 1: the exact threshold lies inside the bracket; the parked voxels got the exact h_mask test and the scale
    is complete, bit-identical to nl_vesselness_step (`mask_count` as there).  *hit = 0: no effect. */

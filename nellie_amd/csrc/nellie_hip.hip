@@ -124,6 +124,7 @@ static CommApi &rccl() { static CommApi api; return api; }
 #include "pack_out.inc"
 #include "network.inc"
 #include "thresholds.inc"
+#include "chain.inc"
 
 // =================================================================================================
 // host side: context, launch helpers, C-ABI
@@ -347,6 +348,8 @@ extern "C" int nl_ctx_destroy(nl_ctx *c) {
     if (c->xstream) { hipStreamSynchronize(c->xstream); hipStreamDestroy(c->xstream); }
     if (c->ev_x_main) hipEventDestroy(c->ev_x_main);
     if (c->ev_x_done) hipEventDestroy(c->ev_x_done);
+    if (c->d_chain) hipFree(c->d_chain);
+    if (c->h_chain) hipHostFree(c->h_chain);
     if (c->comm2) rccl().CommDestroy((ncclComm_t)c->comm2);
     if (c->comm) rccl().CommDestroy((ncclComm_t)c->comm);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -772,7 +775,7 @@ static int make_lattice(const nl_ctx *c, i64 sz, i64 sy, i64 sx, Lattice &L, cha
 
 static int make_field(nl_ctx *c, int field, FieldSrc &fs, char *err, size_t errlen) {
     fs.field = field; fs.hp = hessp(c); fs.max_abs = c->frob_max_abs; fs.max_finite = c->frob_max_finite;
-    fs.two_d = c->two_d; fs.bits = nullptr; fs.wpr = 0; fs.fsq_cache = nullptr;
+    fs.two_d = c->two_d; fs.bits = nullptr; fs.wpr = 0; fs.fsq_cache = nullptr; fs.norm_dev = nullptr;
     if (field == NL_FIELD_GAUSS) fs.p = gauss_cur(c);
     else if (field == NL_FIELD_FROB) {
         if (!c->have_spacing) return nl_fail(err, errlen, NL_ESTATE, "NL_FIELD_FROB before nl_hessian_stats");
@@ -959,7 +962,13 @@ extern "C" int nl_sample_hist(nl_ctx *c, int field, int64_t sz, int64_t sy, int6
 // (the caller raises numpy's ValueError then).  edges (may be NULL) receives the nbins + 1 device-built edges.
 // the kernels of one range + edges + histogram chain, working in the `slot`-th half of the small scratch (device and pinned)
 #define NL_RH_SLOT 32768
+static int range_hist_enqueue_at(nl_ctx *c, int field, int64_t sz, int64_t sy, int64_t sx, int nbins, char *d0, char *h0, char *err, size_t errlen);
 static int range_hist_enqueue(nl_ctx *c, int field, int64_t sz, int64_t sy, int64_t sx, int nbins, int slot, char *err, size_t errlen) {
+    return range_hist_enqueue_at(c, field, sz, sy, sx, nbins, (char *)c->d_small + (size_t)slot * NL_RH_SLOT, (char *)c->h_small + (size_t)slot * NL_RH_SLOT, err, errlen);
+}
+// d0: the record in device memory; h0: its pinned mirror (the initial state of the range words is uploaded from there), or NULL
+// when the record was initialised by the caller (chain_init_kernel)
+static int range_hist_enqueue_at(nl_ctx *c, int field, int64_t sz, int64_t sy, int64_t sx, int nbins, char *d0, char *h0, char *err, size_t errlen) {
     Lattice L; FieldSrc fs; int rc;
     if ((rc = make_lattice(c, sz, sy, sx, L, err, errlen))) return rc;
     if ((rc = make_field(c, field, fs, err, errlen))) return rc;
@@ -967,14 +976,15 @@ static int range_hist_enqueue(nl_ctx *c, int field, int64_t sz, int64_t sy, int6
     const i64 total = L.cz * L.cy * L.cx;
     // layout (contiguous, one transfer back): counts (u64 x nbins) | edges (f32 x nbins+1, padded) | range, count, flag
     const size_t off_edges = (size_t)nbins * 8, off_res = off_edges + (((size_t)(nbins + 1) * 4 + 15) & ~(size_t)15);
-    char *d0 = (char *)c->d_small + (size_t)slot * NL_RH_SLOT, *h0 = (char *)c->h_small + (size_t)slot * NL_RH_SLOT;
     unsigned long long *d_counts = (unsigned long long *)d0;
     float *d_edges = (float *)(d0 + off_edges);
     unsigned int *res = (unsigned int *)(d0 + off_res);
-    unsigned int *h = (unsigned int *)(h0 + off_res);
-    h[0] = 0xffffffffu; h[1] = 0; h[2] = 0; h[3] = 0; h[4] = 0;
-    NL_HIP(hipMemcpyAsync(res, h, 20, hipMemcpyHostToDevice, c->stream));
-    NL_HIP(zero_small(d_counts, (size_t)nbins * 8, c->stream));
+    if (h0) {
+        unsigned int *h = (unsigned int *)(h0 + off_res);
+        h[0] = 0xffffffffu; h[1] = 0; h[2] = 0; h[3] = 0; h[4] = 0;
+        NL_HIP(hipMemcpyAsync(res, h, 20, hipMemcpyHostToDevice, c->stream));
+        NL_HIP(zero_small(d_counts, (size_t)nbins * 8, c->stream));
+    }
     if (total > 0 || fused(c)) {
         // fused: a rank without lattice points of its own still takes part in the collectives and builds the same edges
         ProfScope ps(c, "sample");
@@ -1110,7 +1120,7 @@ extern "C" int nl_hessian_stats(nl_ctx *c, const double spacing[3], float *max_a
         hessian_v_kernel<0, RSV, FASTV><<<(unsigned)(ntx * (int)((c->ny + 2 * RSV - 1) / (2 * RSV)) * nzc), HVCfg<RSV>::NT, \
                                           HVCfg<RSV>::lds_bytes(), c->stream>>>(                                          \
             gauss_cur(c), nullptr, nullptr, 0, geom(c), HR, vp, VQueue{}, (int)c->own_lo, (int)c->own_hi, ntx,        \
-            (int)((c->ny + 2 * RSV - 1) / (2 * RSV)), res, nullptr)
+            (int)((c->ny + 2 * RSV - 1) / (2 * RSV)), res, nullptr, nullptr)
         if (hv_rs(c) == 16) { if (c->fast_div) { NL_LAUNCH_STATS_V(16, true, hessdv_fast(c)); } else { NL_LAUNCH_STATS_V(16, false, hessdv_exact(c)); } }
         else if (hv_rs(c) == 8) { if (c->fast_div) { NL_LAUNCH_STATS_V(8, true, hessdv_fast(c)); } else { NL_LAUNCH_STATS_V(8, false, hessdv_exact(c)); } }
         else if (hm_ty() == 8) { if (c->fast_div) NL_LAUNCH_STATS(8, true, hessdv_fast(c)); else NL_LAUNCH_STATS(8, false, hessdv_exact(c)); }
@@ -1169,20 +1179,18 @@ static VessP make_vessp(nl_ctx *c, float gamma_sq, float alpha_sq, float beta_sq
     return vp;
 }
 
-// ---- one-pass vesselness (MODE 2 of the Hessian kernel + the resolve kernel), see hessian.inc ---------------
-extern "C" int nl_vesselness_spec(nl_ctx *c, const double spacing[3], float fsq_lo, float fsq_hi, int64_t z0, int64_t z1,
-                                  float *max_abs, float *max_frob_sq, int *any_inf, int *overflow, char *err, size_t errlen) {
-    NL_ENTER(c);
+// The walk of a scale in MODE 2, enqueued: statistics into res[0..3] (all "max": bit patterns of non-negative floats, flags),
+// h_mask count of the decided voxels into *d_cnt (both zeroed by the caller).  dev_lohi != NULL: the bracket is read from device
+// memory by the kernel (chain.inc) and fsq_lo / fsq_hi are ignored.
+static int spec_enqueue(nl_ctx *c, const double spacing[3], float fsq_lo, float fsq_hi, int64_t z0, int64_t z1, unsigned int *res,
+                        unsigned long long *d_cnt, const float *dev_lohi, char *err, size_t errlen) {
     if (z0 < 0 && z1 < 0) { z0 = c->own_lo; z1 = c->own_hi; }
     if (z0 < 0 || z1 > c->nzl || z0 >= z1) return nl_fail(err, errlen, NL_EINVAL, "bad plane range [%lld,%lld)", (i64)z0, (i64)z1);
     if (z0 > c->own_lo || z1 < c->own_hi) return nl_fail(err, errlen, NL_EINVAL, "the plane range must cover the owned planes");
     NL_JOIN_SIDE(c);
     if (!c->spec_ok) return nl_fail(err, errlen, NL_ESTATE, "one-pass vesselness is not available for this context (queue too large)");
-    if (!(fsq_lo <= fsq_hi)) return nl_fail(err, errlen, NL_EINVAL, "empty bracket [%g,%g]", (double)fsq_lo, (double)fsq_hi);
+    if (!dev_lohi && !(fsq_lo <= fsq_hi)) return nl_fail(err, errlen, NL_EINVAL, "empty bracket [%g,%g]", (double)fsq_lo, (double)fsq_hi);
     { int rcs = set_spacing(c, spacing, err, errlen); if (rcs) return rcs; }
-    unsigned long long *d_cnt = (unsigned long long *)c->d_small;
-    unsigned int *res = (unsigned int *)c->d_small + 16;
-    NL_HIP(zero_small(c->d_small, 128, c->stream));
     VessP vp{};
     vp.cnt_lo = (int)c->own_lo; vp.cnt_hi = (int)c->own_hi;
     vp.have_prev = c->mask_slots_used > 0;
@@ -1197,6 +1205,7 @@ extern "C" int nl_vesselness_spec(nl_ctx *c, const double spacing[3], float fsq_
         const unsigned long long *pm = (unsigned long long *)c->m[0] + (i64)((k_scale + 1) & 1) * slot_words;
         const VQueue vq{(float4 *)c->d_vq, c->d_vq_count};
         const int rs = hv_rs(c);
+        if (dev_lohi && !rs) return nl_fail(err, errlen, NL_ESTATE, "the device-resident chain needs the two-voxel walk");
         const int ty = rs ? 2 * rs : hm_ty();
         const int nty = (int)((c->ny + ty - 1) / ty);
         const int nzc = (int)((z1 - z0 + HM_ZCHUNK - 1) / HM_ZCHUNK);
@@ -1208,10 +1217,11 @@ extern "C" int nl_vesselness_spec(nl_ctx *c, const double spacing[3], float fsq_
             NL_HIP(hipEventRecord(c->ev_cu, c->stream));
             NL_HIP(hipStreamWaitEvent(hs, c->ev_cu, 0));
         }
+#define NL_DEV_LOHI dev_lohi
 #define NL_LAUNCH_SPEC_V(RSV, FASTV, HR)                                                                                  \
         allow_lds(hessian_v_kernel<2, RSV, FASTV>, HVCfg<RSV>::lds_bytes());                                              \
         hessian_v_kernel<2, RSV, FASTV><<<nblocks, HVCfg<RSV>::NT, HVCfg<RSV>::lds_bytes(), hs>>>(                        \
-            gauss_cur(c), cm, pm, wpr, geom(c), HR, vp, vq, (int)z0, (int)z1, ntx, nty, res, d_cnt)
+            gauss_cur(c), cm, pm, wpr, geom(c), HR, vp, vq, (int)z0, (int)z1, ntx, nty, res, d_cnt, NL_DEV_LOHI)
 #define NL_LAUNCH_SPEC(TYV, FASTV, HR)                                                                                    \
         hessian_g_kernel<2, TYV, FASTV><<<nblocks, HGCfg<TYV>::NT, HGCfg<TYV>::lds_bytes(), c->stream>>>(                 \
             gauss_cur(c), cm, pm, wpr, geom(c), HR, vp, vq, (int)z0, (int)z1, ntx, nty, res, d_cnt)
@@ -1221,6 +1231,7 @@ extern "C" int nl_vesselness_spec(nl_ctx *c, const double spacing[3], float fsq_
         else { if (c->fast_div) NL_LAUNCH_SPEC(16, true, hessdv_fast(c)); else NL_LAUNCH_SPEC(16, false, hessdv_exact(c)); }
 #undef NL_LAUNCH_SPEC
 #undef NL_LAUNCH_SPEC_V
+#undef NL_DEV_LOHI
         NL_CHECK_LAUNCH();
         if (hs != c->stream) {
             NL_HIP(hipEventRecord(c->ev_cu, hs));
@@ -1229,9 +1240,21 @@ extern "C" int nl_vesselness_spec(nl_ctx *c, const double spacing[3], float fsq_
         c->spec_nregions = nblocks * (unsigned)(rs ? rs : ty);
         c->spec_qcap = vp.qcap;
     }
-    unsigned int *h = (unsigned int *)c->h_small;
     // fused: max |H|, max frob_sq (bit patterns of non-negative floats), the inf and overflow flags -- all "max"; the count stays local
     if (fused(c)) { int rcr = reduce_u32_max(c, res, 4, err, errlen); if (rcr) return rcr; }
+    c->spec_z0 = z0; c->spec_z1 = z1;
+    return NL_OK;
+}
+
+// ---- one-pass vesselness (MODE 2 of the Hessian kernel + the resolve kernel), see hessian.inc ---------------
+extern "C" int nl_vesselness_spec(nl_ctx *c, const double spacing[3], float fsq_lo, float fsq_hi, int64_t z0, int64_t z1,
+                                  float *max_abs, float *max_frob_sq, int *any_inf, int *overflow, char *err, size_t errlen) {
+    NL_ENTER(c);
+    unsigned long long *d_cnt = (unsigned long long *)c->d_small;
+    unsigned int *res = (unsigned int *)c->d_small + 16;
+    NL_HIP(zero_small(c->d_small, 128, c->stream));
+    { int rc = spec_enqueue(c, spacing, fsq_lo, fsq_hi, z0, z1, res, d_cnt, nullptr, err, errlen); if (rc) return rc; }
+    unsigned int *h = (unsigned int *)c->h_small;
     NL_HIP(hipMemcpyAsync(h, c->d_small, 128, hipMemcpyDeviceToHost, c->stream));      // [0] count, [16..19] statistics
     NL_HIP(hipStreamSynchronize(c->stream));
     c->spec_count = *(unsigned long long *)c->h_small;       // d_small is scratch for the sampling calls in between
@@ -1240,7 +1263,7 @@ extern "C" int nl_vesselness_spec(nl_ctx *c, const double spacing[3], float fsq_
     if (max_frob_sq) memcpy(max_frob_sq, &h[1], 4);
     if (any_inf) *any_inf = (int)h[2];
     if (overflow) *overflow = (int)h[3];
-    c->spec_lo = fsq_lo; c->spec_hi = fsq_hi; c->spec_z0 = z0; c->spec_z1 = z1;
+    c->spec_lo = fsq_lo; c->spec_hi = fsq_hi;
     c->spec_valid = (h[2] == 0 && h[3] == 0) ? 1 : 0;
     c->last_spec_overflow = (int)h[3];
     return NL_OK;
@@ -1260,21 +1283,12 @@ extern "C" int nl_vesselness_count(nl_ctx *c, int64_t *mask_count, char *err, si
     return NL_OK;
 }
 
-extern "C" int nl_vesselness_resolve(nl_ctx *c, float gamma_sq, float alpha_sq, float beta_sq, int use_thr, float thr,
-                                     int *hit, int64_t *mask_count, char *err, size_t errlen) {
-    NL_ENTER(c);
-    if (!hit) return nl_fail(err, errlen, NL_EINVAL, "hit is NULL");
-    *hit = 0;
-    if (!c->spec_valid) return NL_OK;
-    VessP vp = make_vessp(c, gamma_sq, alpha_sq, beta_sq, use_thr, thr);
-    if (!(vp.fsq_min >= c->spec_lo && vp.fsq_min <= c->spec_hi)) { c->spec_valid = 0; return NL_OK; }
+// The resolve kernel of a scale, enqueued on the side stream (ordered after everything submitted to the main stream so far);
+// commits the scale's mask slot.  dev_params != NULL: gamma_sq, fsq_min and m_inf are read from device memory (chain.inc).
+static int resolve_enqueue(nl_ctx *c, VessP vp, unsigned long long *d_cnt, const float *dev_params, char *err, size_t errlen) {
     const i64 plane = c->ny * c->nx, z0 = c->spec_z0, z1 = c->spec_z1;
-    // The kernel runs on the side stream, ordered after everything submitted to the main stream so far; the main
-    // stream is free to go on with the Gaussian of the next scale.  Its counter lives outside the sampling scratch.
-    unsigned long long *d_cnt = (unsigned long long *)((char *)c->d_small + (48 << 10));
     NL_HIP(hipEventRecord(c->ev_main, c->stream));
     NL_HIP(hipStreamWaitEvent(c->side, c->ev_main, 0));
-    NL_HIP(zero_small(d_cnt, 8, c->side));
     vp.qcap = c->spec_qcap;
     vp.idx_lo = (c->own_lo - z0) * plane; vp.idx_hi = (c->own_hi - z0) * plane;
     {
@@ -1288,7 +1302,8 @@ extern "C" int nl_vesselness_resolve(nl_ctx *c, float gamma_sq, float alpha_sq, 
         if (vp.first)
             NL_HIP(hipMemsetAsync(c->f[c->i_vmax] + z0 * plane, 0, (size_t)(z1 - z0) * plane * 4, c->side));
         vesselness_queue_kernel<true><<<resolve_grid((c->spec_nregions + 3) / 4), 256, 0, c->side>>>(
-            (const float4 *)c->d_vq, c->d_vq_count, c->spec_nregions, c->f[c->i_vmax], z0 * plane, vp, cm, pm, wpr, (int)c->ny, (int)c->nx, z0, d_cnt);
+            (const float4 *)c->d_vq, c->d_vq_count, c->spec_nregions, c->f[c->i_vmax], z0 * plane, vp, cm, pm, wpr, (int)c->ny, (int)c->nx, z0, d_cnt,
+            dev_params);
         NL_CHECK_LAUNCH();
     }
     NL_HIP(hipEventRecord(c->ev_side, c->side));
@@ -1301,10 +1316,186 @@ extern "C" int nl_vesselness_resolve(nl_ctx *c, float gamma_sq, float alpha_sq, 
     if (serial) NL_HIP(hipStreamWaitEvent(c->stream, c->ev_side, 0));
     c->side_pending = 1;
     c->spec_valid = 0;
+    return NL_OK;
+}
+
+extern "C" int nl_vesselness_resolve(nl_ctx *c, float gamma_sq, float alpha_sq, float beta_sq, int use_thr, float thr,
+                                     int *hit, int64_t *mask_count, char *err, size_t errlen) {
+    NL_ENTER(c);
+    if (!hit) return nl_fail(err, errlen, NL_EINVAL, "hit is NULL");
+    *hit = 0;
+    if (!c->spec_valid) return NL_OK;
+    VessP vp = make_vessp(c, gamma_sq, alpha_sq, beta_sq, use_thr, thr);
+    if (!(vp.fsq_min >= c->spec_lo && vp.fsq_min <= c->spec_hi)) { c->spec_valid = 0; return NL_OK; }
+    // The kernel's counter lives outside the sampling scratch.
+    unsigned long long *d_cnt = (unsigned long long *)((char *)c->d_small + (48 << 10));
+    NL_HIP(hipEventRecord(c->ev_main, c->stream));
+    NL_HIP(hipStreamWaitEvent(c->side, c->ev_main, 0));
+    NL_HIP(zero_small(d_cnt, 8, c->side));
+    { int rc = resolve_enqueue(c, vp, d_cnt, nullptr, err, errlen); if (rc) return rc; }
     *hit = 1;
     if (mask_count) {        // asking for the count here waits for the kernel; nl_vesselness_count can be called later instead
         int rcc = nl_vesselness_count(c, mask_count, err, errlen);
         if (rcc) return rcc;
+    }
+    return NL_OK;
+}
+
+
+// ---- device-resident threshold chain (chain.inc) -----------------------------------------------------------------------------
+static void host_edges(float first, float last, int nbins, float *edges) {       // sample_edges_kernel on the host (verification)
+    if (first == last) { first = first - 0.5f; last = last + 0.5f; }
+    volatile float delta = last - first;
+    const float div = (float)nbins;
+    volatile float step = delta / div;
+    for (int i = 0; i <= nbins; ++i) {
+        volatile float y = (float)i;
+        if (step == 0.0f) { y = y / div; y = y * delta; } else y = y * step;
+        y = y + first;
+        edges[i] = (i == nbins) ? last : y;
+    }
+}
+static inline unsigned int f2u(float x) { unsigned int u; memcpy(&u, &x, 4); return u; }
+static inline float u2f(unsigned int u) { float x; memcpy(&x, &u, 4); return x; }
+static inline float py_min_f(float a, float b) { return b < a ? b : a; }       // python's min(a, b)
+
+// The host repeats what the chain's kernels decided for one scale, with the code of the synchronous path, and compares bit for
+// bit.  Returns the record's flags, NL_CF_VERIFY added on any difference.
+static int chain_verify(const ChainScale &s, double division, double margin, double test_scale) {
+    if (s.flags) return s.flags;
+    int bad = 0;
+    double tri, otsu; int st;
+    {   // gamma
+        hist_thresholds_host<float>((const int64_t *)s.h_gauss.counts, s.h_gauss.edges, NL_CHAIN_BINS, &tri, &otsu, &st);
+        const float g = py_min_f((float)tri, (float)otsu);
+        const float gamma = g > 0.0f ? g : 1.1920929e-07f;
+        const float gamma_sq = (float)(2.0 * std::pow((double)gamma, 2.0));
+        if (st || f2u(gamma) != f2u(s.gamma) || f2u(gamma_sq) != f2u(s.gamma_sq)) bad = 1;
+        float e[NL_CHAIN_BINS + 1];
+        host_edges(u2f(s.h_gauss.res[0]), u2f(s.h_gauss.res[1]), NL_CHAIN_BINS, e);
+        if (memcmp(e, s.h_gauss.edges, sizeof(e))) bad = 1;
+    }
+    {   // bracket
+        hist_thresholds_host<float>((const int64_t *)s.h_raw.counts, s.h_raw.edges, NL_CHAIN_BINS, &tri, &otsu, &st);
+        const double t = (double)py_min_f((float)tri, (float)otsu) * test_scale / division;
+        const float lo = (float)(t * t * (1.0 - margin)), hi = (float)(t * t * (1.0 + margin));
+        if (st || f2u(lo) != f2u(s.fsq_lo) || f2u(hi) != f2u(s.fsq_hi)) bad = 1;
+        float e[NL_CHAIN_BINS + 1];
+        host_edges(u2f(s.h_raw.res[0]), u2f(s.h_raw.res[1]), NL_CHAIN_BINS, e);
+        if (memcmp(e, s.h_raw.edges, sizeof(e))) bad = 1;
+    }
+    {   // statistics -> normalisation -> exact threshold -> mask test
+        const float max_abs32 = u2f(s.stats[0]), max_fsq32 = u2f(s.stats[1]);
+        const float max_abs = max_abs32 <= 0.0f ? 1.0f : max_abs32;
+        volatile float mf = sqrtf(max_fsq32); mf = mf / max_abs;
+        volatile float mn = u2f(s.h_raw.res[0]) / max_abs, mx = u2f(s.h_raw.res[1]) / max_abs;
+        if (f2u(max_abs) != f2u(s.max_abs) || f2u((float)mf) != f2u(s.max_frob) || f2u((float)mn) != f2u(s.nmn) || f2u((float)mx) != f2u(s.nmx) ||
+            f2u(s.norm[0]) != f2u(max_abs) || s.norm[1] != 0.0f) bad = 1;
+        float e[NL_CHAIN_BINS + 1];
+        host_edges((float)mn, (float)mx, NL_CHAIN_BINS, e);
+        if (memcmp(e, s.h_exact.edges, sizeof(e))) bad = 1;
+        hist_thresholds_host<float>((const int64_t *)s.h_exact.counts, s.h_exact.edges, NL_CHAIN_BINS, &tri, &otsu, &st);
+        const float thr = py_min_f((float)tri, (float)otsu);
+        const float thr_cmp = (float)((double)thr / division);
+        const float fsq_min = mask_threshold_on_fsq(max_abs, 1, thr_cmp);
+        if (st || f2u(thr) != f2u(s.thr) || f2u(thr_cmp) != f2u(s.thr_cmp) || f2u(fsq_min) != f2u(s.fsq_min) || s.m_inf != ((0.0f > thr_cmp) ? 1 : 0)) bad = 1;
+        if (!(fsq_min >= s.fsq_lo && fsq_min <= s.fsq_hi) || !((float)mf > thr_cmp)) bad = 1;      // (the kernel would have flagged these)
+    }
+    return bad ? NL_CF_VERIFY : 0;
+}
+
+extern "C" int nl_chain_begin(nl_ctx *c, int n_scales, char *err, size_t errlen) {
+    NL_ENTER(c);
+    if (n_scales < 1 || n_scales > NL_CHAIN_MAX_SCALES) return nl_fail(err, errlen, NL_EINVAL, "a chain holds 1..%d scales", NL_CHAIN_MAX_SCALES);
+    if (c->two_d || !c->spec_ok || !hv_rs(c)) return nl_fail(err, errlen, NL_ESTATE, "the device-resident chain needs the 3-D one-pass walk");
+    if (!c->d_chain) {
+        NL_HIP(hipMalloc(&c->d_chain, sizeof(ChainScale) * NL_CHAIN_MAX_SCALES));
+        NL_HIP(hipHostMalloc(&c->h_chain, sizeof(ChainScale) * NL_CHAIN_MAX_SCALES, hipHostMallocDefault));
+    }
+    chain_init_kernel<<<16, 256, 0, c->stream>>>((ChainScale *)c->d_chain, n_scales);
+    chain_init2_kernel<<<1, 64, 0, c->stream>>>((ChainScale *)c->d_chain, n_scales);
+    NL_CHECK_LAUNCH();
+    c->chain_n = n_scales; c->chain_k = 0;
+    return NL_OK;
+}
+
+// One scale of the frame, enqueued without a single wait: see chain.inc.  The Gaussian of the scale is current (nl_gauss_step).
+extern "C" int nl_chain_scale(nl_ctx *c, const double spacing[3], int64_t sz, int64_t sy, int64_t sx, double alpha_sq, double beta_sq,
+                              double division, double margin, double test_scale, int64_t z0, int64_t z1, char *err, size_t errlen) {
+    NL_ENTER(c);
+    if (!c->d_chain || c->chain_k >= c->chain_n) return nl_fail(err, errlen, NL_ESTATE, "nl_chain_scale outside nl_chain_begin .. nl_chain_finish");
+    if (!(division != 0.0)) return nl_fail(err, errlen, NL_EINVAL, "the chain needs a non-zero threshold division");
+    int rc;
+    if ((rc = set_spacing(c, spacing, err, errlen))) return rc;
+    ChainScale *cs = (ChainScale *)c->d_chain + c->chain_k;
+    c->chain_par[c->chain_k][0] = division; c->chain_par[c->chain_k][1] = margin; c->chain_par[c->chain_k][2] = test_scale;
+    ++c->chain_k;
+    c->frob_max_abs = 1.0f; c->frob_max_finite = 0.0f;                    // the bracket round: max_abs := 1 (pipeline.py _fsq_bracket)
+    if ((rc = range_hist_enqueue_at(c, NL_FIELD_GAUSS, sz, sy, sx, NL_CHAIN_BINS, (char *)&cs->h_gauss, nullptr, err, errlen))) return rc;
+    if ((rc = range_hist_enqueue_at(c, NL_FIELD_FROB, sz, sy, sx, NL_CHAIN_BINS, (char *)&cs->h_raw, nullptr, err, errlen))) return rc;
+    chain_thr1_kernel<<<1, 64, 0, c->stream>>>(cs, division, margin, test_scale);
+    NL_CHECK_LAUNCH();
+    if ((rc = spec_enqueue(c, spacing, 0.0f, 0.0f, z0, z1, cs->stats, &cs->cnt_walk, &cs->fsq_lo, err, errlen))) return rc;
+    chain_post_kernel<<<1, 64, 0, c->stream>>>(cs);
+    NL_CHECK_LAUNCH();
+    {   // the exact round: edges from the normalised range, histogram of the cached frob_sq under the device's normalisation
+        Lattice L; FieldSrc fs;
+        if ((rc = make_lattice(c, sz, sy, sx, L, err, errlen))) return rc;
+        if ((rc = make_field(c, NL_FIELD_FROB, fs, err, errlen))) return rc;
+        if ((rc = use_fsq_cache(c, fs, L, err, errlen))) return rc;
+        fs.norm_dev = cs->norm;
+        const i64 total = L.cz * L.cy * L.cx;
+        ProfScope ps(c, "sample");
+        sample_edges_kernel<<<1, 64, 0, c->stream>>>(cs->h_exact.res, NL_CHAIN_BINS, cs->h_exact.edges, cs->h_exact.res + 4);
+        const size_t sh = (size_t)(NL_CHAIN_BINS + 2) * 4 + (size_t)NL_CHAIN_BINS * 4;
+        if (total > 0) sample_hist_kernel<<<grid1d(total, 256, sample_grid_cap()), 256, sh, c->stream>>>(fs, geom(c), L, cs->h_exact.edges, NL_CHAIN_BINS, cs->h_exact.counts, cs->h_exact.res + 4);
+        NL_CHECK_LAUNCH();
+        if (fused(c) && (rc = reduce_u64_sum(c, cs->h_exact.counts, NL_CHAIN_BINS, err, errlen))) return rc;
+    }
+    chain_thr2_kernel<<<1, 64, 0, c->stream>>>(cs, division);
+    NL_CHECK_LAUNCH();
+    VessP vp{};
+    vp.alpha_sq = (float)alpha_sq; vp.beta_sq = (float)beta_sq; vp.use_thr = 1;
+    vp.cnt_lo = (int)c->own_lo; vp.cnt_hi = (int)c->own_hi;
+    vp.first = c->mask_slots_used == 0 ? 1 : 0;
+    return resolve_enqueue(c, vp, &cs->cnt_resolve, (const float *)cs, err, errlen);
+}
+
+// The one wait of the frame: per scale flags (0 = the chain's result stands), gamma, max |H|, the Frobenius threshold and this
+// context's h_mask count.  Any non-zero flag: redo the frame the synchronous way.
+extern "C" int nl_chain_finish(nl_ctx *c, int *flags, double *gamma, double *max_abs, double *thr, int64_t *mask_count, char *err, size_t errlen) {
+    NL_ENTER(c);
+    if (!c->d_chain || c->chain_k < 1) return nl_fail(err, errlen, NL_ESTATE, "nl_chain_finish without scales");
+    NL_JOIN_SIDE(c);
+    const int n = c->chain_k;
+    NL_HIP(hipMemcpyAsync(c->h_chain, c->d_chain, sizeof(ChainScale) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    NL_HIP(hipStreamSynchronize(c->stream));
+    const ChainScale *h = (const ChainScale *)c->h_chain;
+    for (int k = 0; k < n; ++k) {
+        const int f = chain_verify(h[k], c->chain_par[k][0], c->chain_par[k][1], c->chain_par[k][2]);
+        if (flags) flags[k] = f;
+        if (gamma) gamma[k] = (double)h[k].gamma;
+        if (max_abs) max_abs[k] = (double)h[k].max_abs;
+        if (thr) thr[k] = (double)h[k].thr;
+        if (mask_count) mask_count[k] = (int64_t)(h[k].cnt_walk + h[k].cnt_resolve);
+    }
+    c->chain_n = 0;
+    return NL_OK;
+}
+
+// Test hook: the logged record of scale k after nl_chain_finish -- which: 0 Gaussian samples, 1 raw Frobenius samples, 2 normalised
+// Frobenius samples; counts[256], edges[257], range[2] (min, max of the positive samples), scalars[8] = fsq_lo, fsq_hi, gamma_sq,
+// fsq_min, thr_cmp, max_frob, tri, otsu (of that histogram).
+extern "C" int nl_chain_log(nl_ctx *c, int k, int which, int64_t *counts, float *edges, float *range, double *scalars, char *err, size_t errlen) {
+    if (!c || !c->h_chain || k < 0 || k >= NL_CHAIN_MAX_SCALES || which < 0 || which > 2) return nl_fail(err, errlen, NL_EINVAL, "bad chain log request");
+    const ChainScale &s = ((const ChainScale *)c->h_chain)[k];
+    const ChainHist &h = which == 0 ? s.h_gauss : (which == 1 ? s.h_raw : s.h_exact);
+    if (counts) memcpy(counts, h.counts, sizeof(h.counts));
+    if (edges) memcpy(edges, h.edges, sizeof(h.edges));
+    if (range) { range[0] = u2f(h.res[0]); range[1] = u2f(h.res[1]); }
+    if (scalars) {
+        scalars[0] = s.fsq_lo; scalars[1] = s.fsq_hi; scalars[2] = s.gamma_sq; scalars[3] = s.fsq_min; scalars[4] = s.thr_cmp; scalars[5] = s.max_frob;
+        scalars[6] = s.tri[which]; scalars[7] = s.otsu[which];
     }
     return NL_OK;
 }
@@ -1355,7 +1546,7 @@ extern "C" int nl_vesselness_step(nl_ctx *c, float gamma_sq, float alpha_sq, flo
 #define NL_LAUNCH_VESS_V(RSV, FASTV, HR)                                                                                  \
         allow_lds(hessian_v_kernel<1, RSV, FASTV>, HVCfg<RSV>::lds_bytes());                                              \
         hessian_v_kernel<1, RSV, FASTV><<<nblocks, HVCfg<RSV>::NT, HVCfg<RSV>::lds_bytes(), c->stream>>>(                 \
-            gauss_cur(c), cm, pm, wpr, geom(c), HR, vp, vq, (int)za, (int)zb, ntx, nty, nullptr, d_cnt)
+            gauss_cur(c), cm, pm, wpr, geom(c), HR, vp, vq, (int)za, (int)zb, ntx, nty, nullptr, d_cnt, nullptr)
 #define NL_LAUNCH_VESS(TYV, FASTV, HR)                                                                                    \
         hessian_g_kernel<1, TYV, FASTV><<<nblocks, HGCfg<TYV>::NT, HGCfg<TYV>::lds_bytes(), c->stream>>>(                 \
             gauss_cur(c), cm, pm, wpr, geom(c), HR, vp, vq, (int)za, (int)zb, ntx, nty, nullptr, d_cnt)
@@ -1370,7 +1561,7 @@ extern "C" int nl_vesselness_step(nl_ctx *c, float gamma_sq, float alpha_sq, flo
             NL_CHECK_LAUNCH();
             const unsigned nregions = nblocks * (unsigned)(rs ? rs : ty);
             vesselness_queue_kernel<false><<<resolve_grid((nregions + 3) / 4), 256, 0, c->stream>>>(vq.ent, vq.count, nregions, c->f[c->i_vmax], za * plane, vp,
-                                                                                      nullptr, nullptr, wpr, (int)c->ny, (int)c->nx, za, nullptr);
+                                                                                      nullptr, nullptr, wpr, (int)c->ny, (int)c->nx, za, nullptr, nullptr);
             NL_CHECK_LAUNCH();
         }
 #undef NL_LAUNCH_VESS

@@ -103,6 +103,9 @@ struct nl_ctx {
     float frob_max_abs = 1.0f, frob_max_finite = 0.0f;
     int frangi_ready = 0;
     int mask_slots_used = 0;   // per-scale h_mask bit planes written since the frame began
+    void *d_chain = nullptr, *h_chain = nullptr;     // device-resident threshold chain (chain.inc): records of a frame's scales, pinned mirror
+    int chain_n = 0, chain_k = 0;
+    double chain_par[16][3] = {};                    // (division, margin, test scale) each scale was enqueued with
 
     void *comm = nullptr;             // ncclComm_t (RCCL), set by nl_comm_init
     int fuse_reduce = 0;              // nl_comm_fuse: the sampling / statistics entry points reduce across the ranks on the device

@@ -1,0 +1,332 @@
+"""
+Frame engines behind the stage classes (`Filter`, `Label`, `run`): how ONE (Z, Y, X) frame is laid out over contexts.
+
+  SingleContext   one context on one GPU (nellie_amd/pipeline.py): the common case.
+  LocalSlabs      the frame as W Z-slab contexts driven from THIS process, one host thread per slab
+                  (nellie_amd/sharded.py) -- on the GPUs named by `devices=[...]`, or on one GPU when a frame is too large
+                  for one context (a context indexes < 2^31 voxels).  Ghost planes, bit planes, reductions and tables travel
+                  through the library's in-process transport (include/nellie_amd.h: nl_comm_loopback_id): device-to-device
+                  copies on the contexts' own streams, same call sites as RCCL.
+  RankSlab        one rank of a multi-process job (`torchrun`, `mpirun`: WORLD_SIZE / RANK / LOCAL_RANK): this process
+                  owns one slab on its GPU and exchanges over RCCL; the id of the communicator is handed over through a
+                  file next to the outputs.  Every rank writes its own planes of the shared output files.
+
+All three give the same bits: the sharded frame equals the single-context frame (tests/test_hip_sharded.py,
+tests/test_sharded_cpu.py).  This replaces the reference's memory ladder (nellie/utils/adaptive_run.py:88-113,
+filtering.py:1047-1076), whose chunked rungs change the result.
+"""
+from __future__ import annotations
+
+import os
+import threading
+import time
+from dataclasses import dataclass
+from typing import Callable, Optional
+
+import numpy as np
+
+from nellie_amd.pipeline import FilterParams, FramePipeline
+
+MAX_CONTEXT_VOXELS = (1 << 31) - 1          # nl_ctx_create: int32 voxel indices inside a context
+
+
+@dataclass
+class ShardSpec:
+    """One rank of a multi-process Z-slab job.  comm_factory(ctx) -> communicator (default: RCCL, the id travelling through
+    `rendezvous_dir`); ctx_factory as ShardedFramePipeline takes it (tests put a CPU double there)."""
+    rank: int
+    world: int
+    device: int = 0
+    comm_factory: Optional[Callable] = None
+    ctx_factory: Optional[Callable] = None
+    rendezvous_dir: Optional[str] = None
+    tag: str = ""
+
+    @staticmethod
+    def from_env(rendezvous_dir=None):
+        """WORLD_SIZE / RANK / LOCAL_RANK as torchrun and mpirun export them; None for a single process."""
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        if world <= 1:
+            return None
+        return ShardSpec(rank=int(os.environ.get("RANK", "0")), world=world, device=int(os.environ.get("LOCAL_RANK", "0")),
+                         rendezvous_dir=rendezvous_dir, tag=os.environ.get("MASTER_PORT", ""))
+
+
+def slabs_needed(shape_zyx, halo: int, n_devices: int = 1) -> int:
+    """Smallest slab count (a multiple of the device count) whose slabs, ghost planes included, fit a context."""
+    nz, ny, nx = (int(s) for s in shape_zyx)
+    plane = ny * nx
+    w = max(1, int(n_devices))
+    while True:
+        owned = -(-nz // w)
+        local = owned + (2 * halo if w > 1 else 0)
+        if local * plane <= MAX_CONTEXT_VOXELS:
+            return w
+        if owned <= halo:
+            raise MemoryError(f"a {nz} x {ny} x {nx} frame cannot be cut into Z slabs that fit a context "
+                              f"({plane} voxels per plane, {halo} ghost planes per side)")
+        w += max(1, int(n_devices))
+
+
+class SingleContext:
+    kind = "single"
+
+    def __init__(self, shape, device=0):
+        self.pipe = FramePipeline(shape, device=device)
+        self.world = 1
+
+    @property
+    def trace(self):
+        return self.pipe.trace
+
+    def filter(self, frame, params, mask=True, remove_edges=False):
+        return self.pipe.filter(frame, params, mask=mask, remove_edges=remove_edges)
+
+    def download_frangi(self, out=None):
+        return self.pipe.download_frangi(out=out)
+
+    def upload_frangi(self, frangi):
+        self.pipe.upload_frangi(frangi)
+
+    def frangi_threshold(self, max_samples=1_000_000, nbins=256):
+        return self.pipe.frangi_threshold(max_samples, nbins)
+
+    def label(self, thr, min_area, fill_holes=True):
+        return self.pipe.label(thr, min_area, fill_holes=fill_holes)
+
+    def download_labels(self, out=None):
+        return self.pipe.download_labels(out=out)
+
+    def barrier(self):
+        pass
+
+    def close(self):
+        self.pipe.close()
+
+
+def _planes(frame, z0, z1):
+    """Planes [z0, z1) of a host frame / memory map as a contiguous array."""
+    return np.ascontiguousarray(frame[z0:z1])
+
+
+class _SlabBase:
+    """What LocalSlabs and RankSlab share: a ShardedFramePipeline takes its planes out of the whole frame (with the raw
+    ghost planes the first cascade step reads, so no raw plane is exchanged) and puts its own planes into whole-frame outputs."""
+
+    @staticmethod
+    def _filter_one(pipe, frame, params, mask, remove_edges):
+        from nellie_amd.sharded import slab_range
+        o0, o1 = slab_range(pipe.shape[0], pipe.world, pipe.rank)
+        g_lo, g_hi = pipe.raw_ghost_needed()
+        return pipe.filter(_planes(frame, o0 - g_lo, o1 + g_hi), params, mask=mask, remove_edges=remove_edges)
+
+    @staticmethod
+    def _own(pipe):
+        from nellie_amd.sharded import slab_range
+        return slab_range(pipe.shape[0], pipe.world, pipe.rank)
+
+    @classmethod
+    def _download(cls, pipe, which, out):
+        o0, o1 = cls._own(pipe)
+        view = out[o0:o1]
+        get = pipe.download_frangi if which == "frangi" else pipe.download_labels
+        if isinstance(view, np.ndarray) and view.flags.c_contiguous and view.flags.writeable:
+            got = get(out=view)
+            if got is not view:             # a context that does not fill `out` in place
+                view[...] = got
+        else:
+            view[...] = get()
+
+
+class LocalSlabs(_SlabBase):
+    kind = "local-slabs"
+
+    def __init__(self, shape, params: FilterParams, devices=(0,), n_slabs=None, halo_mode=None, halo=None,
+                 comm_factory_of_rank=None, ctx_factory=None):
+        from nellie_amd import hipnative
+        from nellie_amd.sharded import RcclComm, ShardedFramePipeline, halo_depth, halo_depth_steps
+        self.shape = tuple(int(s) for s in shape)
+        devices = [int(d) for d in devices] or [0]
+        mode = halo_mode or os.environ.get("NELLIE_HALO", "steps")
+        need = halo_depth_steps(params) if mode == "steps" else halo_depth(params)
+        self.world = int(n_slabs) if n_slabs else slabs_needed(self.shape, need if halo is None else halo, len(devices))
+        W = self.world
+        if comm_factory_of_rank is None:
+            uid, uid2 = hipnative.comm_unique_id(loopback=True), hipnative.comm_unique_id(loopback=True)
+            comm_factory_of_rank = lambda rank: (lambda ctx: RcclComm(ctx, W, rank, uid, uid2=uid2))
+        self.devices = [devices[r * len(devices) // W] for r in range(W)]       # contiguous blocks of slabs per device
+        self.pipes = [None] * W
+
+        def build(r):
+            self.pipes[r] = ShardedFramePipeline(self.shape, r, W, comm_factory_of_rank(r), params, device=self.devices[r],
+                                                 ctx_factory=ctx_factory, halo=halo, halo_mode=halo_mode)
+        self._each(build)
+
+    def _each(self, fn):
+        """fn(rank) on one host thread per slab (the library calls release the GIL; the slabs rendezvous inside them)."""
+        out, errs = [None] * self.world, []
+
+        def work(r):
+            try:
+                out[r] = fn(r)
+            except BaseException as exc:  # noqa: BLE001
+                errs.append(exc)
+        ts = [threading.Thread(target=work, args=(r,)) for r in range(self.world)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        if errs:
+            raise errs[0]
+        return out
+
+    @property
+    def trace(self):
+        return self.pipes[0].trace
+
+    def filter(self, frame, params, mask=True, remove_edges=False):
+        return self._each(lambda r: self._filter_one(self.pipes[r], frame, params, mask, remove_edges))[0]
+
+    def download_frangi(self, out=None):
+        out = np.empty(self.shape, np.float32) if out is None else out
+        self._each(lambda r: self._download(self.pipes[r], "frangi", out))
+        return out
+
+    def upload_frangi(self, frangi):
+        self._each(lambda r: self.pipes[r].upload_frangi(_planes(frangi, *self._own(self.pipes[r]))))
+
+    def frangi_threshold(self, max_samples=1_000_000, nbins=256):
+        return self._each(lambda r: self.pipes[r].frangi_threshold(max_samples, nbins))[0]
+
+    def label(self, thr, min_area, fill_holes=True):
+        return self._each(lambda r: self.pipes[r].label(thr, min_area, fill_holes=fill_holes))[0]
+
+    def download_labels(self, out=None):
+        out = np.empty(self.shape, np.int32) if out is None else out
+        self._each(lambda r: self._download(self.pipes[r], "labels", out))
+        return out
+
+    def barrier(self):
+        pass
+
+    def close(self):
+        def shut(r):
+            if self.pipes[r] is not None:
+                self.pipes[r].close()
+        self._each(shut)
+
+
+def _exchange_ids(spec: ShardSpec, n_ids: int, make_id, timeout_s=300.0):
+    """Rank 0 creates `n_ids` communicator ids and leaves them in a file of the rendezvous directory; the others pick them up."""
+    d = spec.rendezvous_dir or os.getcwd()
+    os.makedirs(d, exist_ok=True)
+    _exchange_ids.counter = getattr(_exchange_ids, "counter", 0) + 1
+    path = os.path.join(d, f".nellie_comm_{spec.tag or 'job'}_{spec.world}_{_exchange_ids.counter}.id")
+    if spec.rank == 0:
+        blob = b"".join(make_id() for _ in range(n_ids))
+        tmp = path + f".tmp{os.getpid()}"
+        with open(tmp, "wb") as f:
+            f.write(blob)
+        os.replace(tmp, path)             # the file appears complete or not at all
+        return [blob[i * 128:(i + 1) * 128] for i in range(n_ids)], path
+    t0 = time.time()
+    while not os.path.exists(path):
+        if time.time() - t0 > timeout_s:
+            raise TimeoutError(f"rank {spec.rank}: no communicator id from rank 0 at {path}")
+        time.sleep(0.02)
+    blob = open(path, "rb").read()
+    return [blob[i * 128:(i + 1) * 128] for i in range(n_ids)], path
+
+
+class RankSlab(_SlabBase):
+    kind = "rank-slab"
+
+    def __init__(self, shape, params: FilterParams, spec: ShardSpec, halo_mode=None, halo=None):
+        from nellie_amd.sharded import RcclComm, ShardedFramePipeline
+        self.shape = tuple(int(s) for s in shape)
+        self.spec, self.world = spec, spec.world
+        self._id_file = None
+        comm_factory = spec.comm_factory
+        if comm_factory is None:
+            from nellie_amd import hipnative
+            (uid, uid2), self._id_file = _exchange_ids(spec, 2, hipnative.comm_unique_id)
+            comm_factory = lambda ctx: RcclComm(ctx, spec.world, spec.rank, uid, uid2=uid2)
+        self.pipe = ShardedFramePipeline(self.shape, spec.rank, spec.world, comm_factory, params, device=spec.device,
+                                         ctx_factory=spec.ctx_factory, halo=halo, halo_mode=halo_mode)
+        self.barrier()
+        if self._id_file and spec.rank == 0:
+            try:
+                os.remove(self._id_file)
+            except OSError:
+                pass
+
+    @property
+    def trace(self):
+        return self.pipe.trace
+
+    def filter(self, frame, params, mask=True, remove_edges=False):
+        return self._filter_one(self.pipe, frame, params, mask, remove_edges)
+
+    def download_frangi(self, out=None):
+        """This rank's planes into the whole-frame array (the other ranks fill theirs)."""
+        out = np.zeros(self.shape, np.float32) if out is None else out
+        self._download(self.pipe, "frangi", out)
+        return out
+
+    def upload_frangi(self, frangi):
+        self.pipe.upload_frangi(_planes(frangi, *self._own(self.pipe)))
+
+    def frangi_threshold(self, max_samples=1_000_000, nbins=256):
+        return self.pipe.frangi_threshold(max_samples, nbins)
+
+    def label(self, thr, min_area, fill_holes=True):
+        return self.pipe.label(thr, min_area, fill_holes=fill_holes)
+
+    def download_labels(self, out=None):
+        out = np.zeros(self.shape, np.int32) if out is None else out
+        self._download(self.pipe, "labels", out)
+        return out
+
+    def barrier(self):
+        """Every rank has reached this point (a one-element all-reduce on the communicator)."""
+        self.pipe.comm.allreduce(np.array([1], np.int64), "sum")
+
+    def close(self):
+        self.pipe.close()
+
+
+def plan_engine(shape_zyx, params: FilterParams, devices=None, shard: Optional[ShardSpec] = None, halo_mode=None, label_only=False):
+    """("single" | "local-slabs" | "rank-slab", slab count) make_engine would build -- without building it."""
+    shape = tuple(int(s) for s in shape_zyx)
+    if len(shape) == 2:
+        return "single", 1
+    if shard is not None and shard.world > 1:
+        return "rank-slab", shard.world
+    from nellie_amd.sharded import halo_depth, halo_depth_steps
+    mode = halo_mode or os.environ.get("NELLIE_HALO", "steps")
+    need = 1 if label_only else (halo_depth_steps(params) if mode == "steps" else halo_depth(params))
+    w = slabs_needed(shape, need, len(devices) if devices else 1)
+    forced = int(os.environ.get("NELLIE_FORCE_SLABS", "0"))
+    if forced > 1:
+        w = max(w, forced)
+    return ("single", 1) if w == 1 else ("local-slabs", w)
+
+
+def make_engine(shape_zyx, params: FilterParams, device_index=0, devices=None, shard: Optional[ShardSpec] = None,
+                halo_mode=None, label_only=False):
+    """The engine for a frame of this shape.  2-D images and frames that fit one context on one GPU: SingleContext.
+    `devices` with more than one entry, or a frame beyond a context's index range: LocalSlabs.  `shard`: RankSlab.
+    label_only: the slabs only ever run Label (one ghost plane per side instead of the Filter halo)."""
+    shape = tuple(int(s) for s in shape_zyx)
+    halo = 1 if label_only else None
+    if len(shape) == 2:
+        if shard is not None and shard.world > 1:
+            raise NotImplementedError("Z-slab sharding needs a Z axis: run 2-D images in one process")
+        return SingleContext(shape, device=device_index)
+    if shard is not None and shard.world > 1:
+        return RankSlab(shape, params, shard, halo_mode=halo_mode, halo=halo)
+    devs = [int(d) for d in devices] if devices else [int(device_index)]
+    _, w = plan_engine(shape, params, devs, None, halo_mode, label_only)
+    if w == 1:
+        return SingleContext(shape, device=devs[0])
+    return LocalSlabs(shape, params, devices=devs, n_slabs=w, halo_mode=halo_mode, halo=halo)

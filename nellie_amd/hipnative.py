@@ -116,6 +116,10 @@ _PROTOS = {
     "nl_allgather_bytes": [_p, _p, _i64, _p, _i64, _p],
     "nl_allgather_var": [_p, _p, _i64, _p, _p, _p],
     "nl_comm_fuse": [_p, _int],
+    "nl_chain_begin": [_p, _int],
+    "nl_chain_scale": [_p, _p, _i64, _i64, _i64, _f64, _f64, _f64, _f64, _f64, _i64, _i64],
+    "nl_chain_finish": [_p, _p, _p, _p, _p, _p],
+    "nl_chain_log": [_p, _int, _int, _p, _p, _p, _p],
     "nl_pinned_alloc": [C.POINTER(_p), _i64],
     "nl_host_register": [_p, _i64],
     "nl_input_load_async": [_p, _int, _p, _int],
@@ -577,6 +581,32 @@ class Context:
         self._call("nl_vesselness_spec", sp, float(np.float32(fsq_lo)), float(np.float32(fsq_hi)), int(z0), int(z1),
                    C.byref(ma), C.byref(mf), C.byref(inf), C.byref(ovf))
         return np.float32(ma.value), np.float32(mf.value), bool(inf.value), bool(ovf.value)
+
+    # ---- device-resident threshold chain (include/nellie_amd.h: nl_chain_*)
+    def chain_begin(self, n_scales):
+        self._call("nl_chain_begin", int(n_scales))
+        self._chain_n = int(n_scales)
+
+    def chain_scale(self, spacing, strides, alpha_sq, beta_sq, division, margin, test_scale=1.0, z0=-1, z1=-1):
+        sp = (_f64 * 3)(*[float(s) for s in spacing])
+        sz, sy, sx = (int(s) for s in strides)
+        self._call("nl_chain_scale", sp, sz, sy, sx, float(alpha_sq), float(beta_sq), float(division), float(margin), float(test_scale),
+                   int(z0), int(z1))
+
+    def chain_finish(self):
+        """-> (flags, gamma, max_abs, thr, mask_count) arrays over the scales; flags all zero: the chain's result stands."""
+        n = self._chain_n
+        flags = np.zeros(n, np.int32)
+        gamma, max_abs, thr = np.zeros(n), np.zeros(n), np.zeros(n)
+        counts = np.zeros(n, np.int64)
+        self._call("nl_chain_finish", _ptr(flags), _ptr(gamma), _ptr(max_abs), _ptr(thr), _ptr(counts))
+        return flags, gamma, max_abs, thr, counts
+
+    def chain_log(self, k, which):
+        counts, edges = np.zeros(256, np.int64), np.zeros(257, np.float32)
+        rng, sc = np.zeros(2, np.float32), np.zeros(8)
+        self._call("nl_chain_log", int(k), int(which), _ptr(counts), _ptr(edges), _ptr(rng), _ptr(sc))
+        return counts, edges, rng, dict(zip(("fsq_lo", "fsq_hi", "gamma_sq", "fsq_min", "thr_cmp", "max_frob", "tri", "otsu"), sc))
 
     def vesselness_resolve(self, gamma_sq, alpha_sq, beta_sq, thr) -> bool:
         """hit: False means the bracket missed and vesselness_step must run.  Asynchronous on a hit: the kernel runs

@@ -378,6 +378,17 @@ class FramePipeline:
         else:
             self._load(frame)
         self._after_load(p)
+        if self._chain_usable(p, mask):
+            if self._scales_on_the_device(p, max_samples):
+                return self._finish_frame(finish, p, mask)
+            # a condition the device-resident chain leaves to the host turned up: the frame is redone, synchronously
+            self.chain_fallbacks += 1
+            self.trace = FrameTrace()
+            if frame is None:
+                ctx.filter_begin()
+            else:
+                self._load(frame)
+            self._after_load(p)
         zr = z_ratio_of(p.dim_res)
         spacing = spacing_of(p.dim_res)
         sigmas = p.resolved_sigmas()
@@ -482,6 +493,75 @@ class FramePipeline:
                 settle()
                 pending = self.trace.scales[-1]      # its kernel overlaps the next scale's Gaussian; count read later
         settle()
+        return self._finish_frame(finish, p, mask)
+
+    # Device-resident threshold chain (csrc/chain.inc): the scale loop without a host round trip; NELLIE_DEVICE_CHAIN=0: off
+    _device_chain = os.environ.get("NELLIE_DEVICE_CHAIN", "1") == "1"
+    chain_fallbacks = 0
+
+    def _chain_usable(self, p: FilterParams, mask: bool) -> bool:
+        return bool(self._device_chain and self.one_pass and mask and not self.two_d and p.frob_thresh is None and p.frob_thresh_division
+                    and hasattr(self.ctx, "chain_begin") and self._chain_reductions_on_device())
+
+    def _chain_reductions_on_device(self) -> bool:
+        return True            # one GPU: nothing to reduce (a Z-slab pipeline needs its fused communicator)
+
+    def _scales_on_the_device(self, p: FilterParams, max_samples: int) -> bool:
+        """The sigma loop of compute_vesselness with every threshold decided on the device (nl_chain_*): kernels only, ONE
+        wait at the end.  True: the trace is filled and the frame stands; False: the caller redoes the frame synchronously."""
+        ctx = self.ctx
+        zr = z_ratio_of(p.dim_res)
+        spacing = spacing_of(p.dim_res)
+        sigmas = p.resolved_sigmas()
+        if not 1 <= len(sigmas) <= 16:
+            return False
+        strides = self._strides(max_samples)
+        deltas = list(cascade_deltas(sigmas, zr))
+        ctx.chain_begin(len(sigmas))
+        ahead = False
+
+        def cascade_step(k, run_ahead):
+            delta = deltas[k]
+            if not any(s > 0 for s in delta):
+                return False
+            ws = [gaussian_weights(d) for d in delta]
+            z0, z1 = self._gauss_range(0 if ws[0] is None else (len(ws[0]) - 1) // 2)
+            ctx.gauss_step(*ws, z0=z0, z1=z1, **({"ahead": True} if run_ahead else {}))
+            return True
+
+        for k in range(len(sigmas)):
+            if ahead:
+                ctx.gauss_commit()
+            else:
+                cascade_step(k, False)
+            self._after_cascade_step(k)
+            ahead = self._gauss_ahead and k + 1 < len(sigmas) and cascade_step(k + 1, True)
+            vz0, vz1 = self._vess_range()
+            ctx.chain_scale(spacing, strides, float(p.alpha_sq), float(p.beta_sq), float(p.frob_thresh_division), self.one_pass_margin,
+                            self._one_pass_test_scale, z0=vz0, z1=vz1)
+        if ahead:
+            ctx.gauss_commit()
+        flags, gamma, max_abs, thr, counts = ctx.chain_finish()
+        self.last_chain_flags = [int(f) for f in flags]
+        if not self._all_ranks_agree(not flags.any()):
+            return False
+        if self.check_device_edges:
+            for k in range(len(sigmas)):
+                for which in range(3):
+                    _, edges, rng, _ = ctx.chain_log(k, which)
+                    assert np.array_equal(edges, histogram_edges(rng[0], rng[1], 256)), "device-built histogram edges differ from numpy's"
+        for k, sigma in enumerate(sigmas):
+            self.trace.scales.append(ScaleTrace(float(sigma), float(gamma[k]), float(max_abs[k]), float(thr[k]),
+                                                self._reduce_mask_count(int(counts[k])), False, True))
+        return True
+
+    def _all_ranks_agree(self, ok: bool) -> bool:
+        return ok
+
+    def _finish_frame(self, finish: bool, p: FilterParams, mask: bool):
+        """The product `vesselness * masks` (filtering.py:926) once every scale is in."""
+        ctx = self.ctx
+        sigmas = p.resolved_sigmas()
         self._settle_mask_counts()
         if not finish:
             return None

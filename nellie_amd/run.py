@@ -7,52 +7,116 @@ im_border.
 """
 from __future__ import annotations
 
+import os
 import time
 
 from nellie_amd.segmentation.filtering import Filter
 from nellie_amd.segmentation.labelling import Label
 
 
-def run_streamed(im_info, viewer=None, device_index=0):
+def _wait_for(path, timeout_s=600.0):
+    t0 = time.time()
+    while not os.path.exists(path):
+        if time.time() - t0 > timeout_s:
+            raise TimeoutError(f"no {path} after {timeout_s} s")
+        time.sleep(0.02)
+
+
+def run_streamed(im_info, viewer=None, device_index=0, devices=None, shard=None):
     """
     Filter + Label of every frame with the three legs overlapped (nellie_amd/streaming.py): same two files as
     `run()`, default parameters only (no remove_edges / intensity thresholds), 3-D frames.
+
+    Frames of a T stack are independent ("for C5 prefer frame-parallel"):
+      devices=[...]  one streamer per GPU in this process (one host thread each), GPU k takes frames k, k + N, ...;
+      shard="env"    this process is one rank of a multi-process job (WORLD_SIZE / RANK / LOCAL_RANK): it takes frames
+                     RANK, RANK + WORLD_SIZE, ... on GPU LOCAL_RANK; rank 0 creates the two files, the others map them.
+    No data crosses between the GPUs; the files are the ones a single GPU writes.
     """
+    from nellie_amd.engine import ShardSpec
     from nellie_amd.pipeline import FilterParams
     from nellie_amd.streaming import StreamedSegmenter
     if im_info.no_z:
         raise NotImplementedError("streaming covers 3-D frames")
+    spec = ShardSpec.from_env() if shard == "env" else shard
+    rank, world = (spec.rank, spec.world) if spec is not None else (0, 1)
+    fr_path, lab_path = im_info.pipeline_paths["im_preprocessed"], im_info.pipeline_paths["im_instance_label"]
+    marker = f"{lab_path}.ready_{spec.tag}" if spec is not None else None
     im = im_info.get_memmap(im_info.im_path)
-    fr = im_info.allocate_memory(im_info.pipeline_paths["im_preprocessed"], dtype="float32",
-                                 description="frangi filtered im", return_memmap=True)
-    lab = im_info.allocate_memory(im_info.pipeline_paths["im_instance_label"], dtype="int32",
-                                  description="instance segmentation", return_memmap=True)
-    seg = StreamedSegmenter(im.shape[1:], im.dtype, FilterParams(dim_res=im_info.dim_res), device=device_index)
-    try:
-        def status(t, n):
-            if viewer is not None:
-                viewer.status = f"Preprocessing + extracting organelles. Frame: {t + 1} of {n}."
-        seg.run(im, fr, lab, status=status, outputs_zeroed=True)      # both files were created (zero-filled) a few lines up
-    finally:
-        seg.close()
+    if rank == 0:
+        fr = im_info.allocate_memory(fr_path, dtype="float32", description="frangi filtered im", return_memmap=True)
+        lab = im_info.allocate_memory(lab_path, dtype="int32", description="instance segmentation", return_memmap=True)
+        if marker:
+            open(marker, "w").close()
+    else:
+        _wait_for(marker)
+        fr, lab = im_info.get_memmap(fr_path), im_info.get_memmap(lab_path)
+    devs = [spec.device] if spec is not None else ([int(d) for d in devices] if devices else [int(device_index)])
+    params = FilterParams(dim_res=im_info.dim_res)
+    num_t = im.shape[0]
+
+    def lane(k, n_lanes, first, device):
+        """frames first + k, first + k + n_lanes, ... on one GPU"""
+        sl = slice(first + k, None, n_lanes)
+        if len(range(num_t)[sl]) == 0:
+            return
+        seg = StreamedSegmenter(im.shape[1:], im.dtype, params, device=device)
+        try:
+            def status(t, n):
+                if viewer is not None and k == 0:
+                    viewer.status = f"Preprocessing + extracting organelles. Frame: {t * n_lanes + 1} of {num_t}."
+            seg.run(im[sl], fr[sl], lab[sl], status=status, outputs_zeroed=True)   # both files were created (zero-filled) above
+        finally:
+            seg.close()
+
+    if len(devs) == 1:
+        lane(0, world, rank, devs[0])
+    else:
+        import threading
+        errs = []
+
+        def work(k):
+            try:
+                lane(k, len(devs), 0, devs[k])
+            except BaseException as exc:  # noqa: BLE001
+                errs.append(exc)
+        ts = [threading.Thread(target=work, args=(k,)) for k in range(len(devs))]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        if errs:
+            raise errs[0]
+    fr.flush(); lab.flush()
+    if spec is not None:                                       # every rank done before anyone reads the files
+        open(f"{lab_path}.done_{spec.tag}_{rank}", "w").close()
+        if rank == 0:
+            for r in range(world):
+                _wait_for(f"{lab_path}.done_{spec.tag}_{r}")
+            for r in range(world):
+                os.remove(f"{lab_path}.done_{spec.tag}_{r}")
+            os.remove(marker)
     return im_info
 
 
 def run(file_info, remove_edges=False, otsu_thresh_intensity=False, threshold=None, timeit=False, device="auto",
-        low_memory=False, markers=False):
+        low_memory=False, markers=False, devices=None, shard=None):
     """nellie.run.run's signature (run.py:18-26): `file_info` is a FileInfo (this package's or any object with the same
     fields) from which the ImInfo is built as run.py:49 does; an ImInfo (anything with `pipeline_paths`) or a path / array
-    is accepted too.  Returns the ImInfo."""
+    is accepted too.  Returns the ImInfo.
+    devices=[...]: every 3-D frame runs as Z slabs over these GPUs; shard="env": this process is one rank (WORLD_SIZE / RANK /
+    LOCAL_RANK) of a multi-process Z-slab job over RCCL -- see nellie_amd/engine.py.  Frames beyond one context's size are
+    cut into slabs without being asked."""
     from nellie_amd.im_info.verifier import ImInfo
     im_info = file_info if hasattr(file_info, "pipeline_paths") else ImInfo(file_info)
     t0 = time.perf_counter() if timeit else None
-    preprocessing = Filter(im_info, remove_edges=remove_edges, device=device, low_memory=low_memory)
+    preprocessing = Filter(im_info, remove_edges=remove_edges, device=device, low_memory=low_memory, devices=devices, shard=shard)
     preprocessing.run()
     if timeit:
         t1 = time.perf_counter()
         print(f"[timeit] Filter: {t1 - t0:.3f}s")
     segmenting = Label(im_info, otsu_thresh_intensity=otsu_thresh_intensity, threshold=threshold, device=device,
-                       low_memory=low_memory)
+                       low_memory=low_memory, devices=devices, shard=shard)
     segmenting.run()
     if timeit:
         t2 = time.perf_counter()

@@ -15,6 +15,8 @@ Deliberate differences from the reference (documented in DESIGN.md):
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 from nellie_amd.pipeline import FilterParams, FramePipeline, default_sigmas, sample_strides
@@ -40,11 +42,22 @@ class Filter:
         max_chunk_voxels: int = int(1e6),
         max_threshold_samples: int = int(1e6),
         device_index: int = 0,
+        devices=None,
+        shard=None,
     ):
+        """The reference's keywords, plus where a frame runs (nellie_amd/engine.py):
+        device_index  the GPU of a single-context run;
+        devices       list of GPUs: every 3-D frame is cut into Z slabs over them (one process, one host thread per slab);
+        shard         "env" (read WORLD_SIZE / RANK / LOCAL_RANK: this process is one rank of a multi-process Z-slab job, RCCL
+                      between the ranks) or an engine.ShardSpec.
+        A frame too large for one context (>= 2^31 voxels) is cut into slabs on its own; results never depend on the layout."""
         self.im_info = im_info
         self.device = device
         self.device_type = self._resolve_backend(device)
         self.device_index = int(device_index)
+        self.devices = list(devices) if devices else None
+        self.shard = shard
+        self._engine = None
         self.truncate = 3.0
         if not self.im_info.no_z:
             z_res = self.im_info.dim_res.get("Z") or self.im_info.dim_res.get("X") or 1.0
@@ -108,10 +121,33 @@ class Filter:
             self._pipeline_key = key
         return self._pipeline
 
+    def _shard_spec(self):
+        from nellie_amd.engine import ShardSpec
+        shard = self.shard if self.shard is not None else (os.environ.get("NELLIE_SHARD") or None)
+        if isinstance(shard, str):
+            if shard != "env":
+                raise ValueError("shard must be 'env' or an engine.ShardSpec")
+            shard = ShardSpec.from_env(rendezvous_dir=os.path.dirname(self.im_info.pipeline_paths["im_preprocessed"]))
+        return shard
+
+    def _get_engine(self, shape):
+        """The engine of a frame of this shape (nellie_amd/engine.py): one context, Z slabs in this process, or this rank's slab."""
+        from nellie_amd.engine import make_engine
+        key = tuple(int(s) for s in shape)
+        if self._engine is None or self._engine_key != key:
+            if self._engine is not None:
+                self._engine.close()
+            self._engine = make_engine(key, self._params(), device_index=self.device_index, devices=self.devices, shard=self._shard_spec())
+            self._engine_key = key
+        return self._engine
+
     def close(self):
         if self._pipeline is not None:
             self._pipeline.close()
             self._pipeline = None
+        if self._engine is not None:
+            self._engine.close()
+            self._engine = None
 
     # ------------------------------------------------------------------ setup (filtering.py:201-323)
     def _get_t(self):
@@ -121,13 +157,22 @@ class Filter:
             else:
                 self.num_t = self.im_info.shape[self.im_info.axes.index("T")]
 
-    def _allocate_memory(self):
+    def _allocate_memory(self, engine=None):
+        """filtering.py:201-216.  In a multi-process run rank 0 creates the file, the other ranks map it once it exists
+        (every rank writes its own planes of every frame)."""
         logger.debug("Allocating memory for frangi filter.")
-        self.im_memmap = self.im_info.get_memmap(self.im_info.im_path)
+        if self.im_memmap is None:
+            self.im_memmap = self.im_info.get_memmap(self.im_info.im_path)
         self.shape = self.im_memmap.shape
         im_frangi_path = self.im_info.pipeline_paths["im_preprocessed"]
-        self.frangi_memmap = self.im_info.allocate_memory(
-            im_frangi_path, dtype=self.out_dtype, description="frangi filtered im", return_memmap=True)
+        multi = engine is not None and engine.kind == "rank-slab"
+        if not multi or engine.spec.rank == 0:
+            self.frangi_memmap = self.im_info.allocate_memory(
+                im_frangi_path, dtype=self.out_dtype, description="frangi filtered im", return_memmap=True)
+        if multi:
+            engine.barrier()
+            if engine.spec.rank != 0:
+                self.frangi_memmap = self.im_info.get_memmap(im_frangi_path)
 
     def _get_sigma_vec(self, sigma: float):
         if self.im_info.no_z:
@@ -217,17 +262,27 @@ class Filter:
         return out[0] if self.im_info.no_z else out
 
     def _run_filter(self, mask=True):
-        """filtering.py:1005-1031."""
+        """filtering.py:1005-1031.  A frame that runs as Z slabs (engine.py) goes through the same loop: every slab takes
+        its planes of the input map and puts its planes into the output map."""
         for t in range(self.num_t):
             if self.viewer is not None:
                 self.viewer.status = f"Preprocessing. Frame: {t + 1} of {self.num_t}."
             logger.info(f"Running Frangi filter on t={t}.")
-            filtered_im = self._filter_frame(t, mask=mask)
-            if self.im_info.no_t or self.num_t == 1:
-                self.frangi_memmap[:] = filtered_im[:]
+            frame_view = self.im_memmap[t, ...]
+            from nellie_amd.engine import plan_engine
+            if plan_engine(frame_view.shape, self._params(), self.devices, self._shard_spec())[0] == "single":
+                filtered_im = self._filter_frame(t, mask=mask)
+                if self.im_info.no_t or self.num_t == 1:
+                    self.frangi_memmap[:] = filtered_im[:]
+                else:
+                    self.frangi_memmap[t, ...] = filtered_im
             else:
-                self.frangi_memmap[t, ...] = filtered_im
+                engine = self._get_engine(frame_view.shape)
+                engine.filter(frame_view, self._params(), mask=mask, remove_edges=bool(self.remove_edges))
+                engine.download_frangi(out=self.frangi_memmap[t, ...])
             self.frangi_memmap.flush()
+        if self._engine is not None:
+            self._engine.barrier()
 
     def run(self, mask=True):
         """filtering.py:1033-1076.  The ladder has GPU rungs only; OOM re-raises as MemoryError."""
@@ -235,8 +290,12 @@ class Filter:
         adaptive_run.normalize_device(self.device)
         try:
             self._get_t()
-            self._allocate_memory()
             self._set_default_sigmas()
+            self.im_memmap = self.im_info.get_memmap(self.im_info.im_path)
+            engine = None
+            if self._shard_spec() is not None:       # the communicator has to exist before the ranks can agree on the files
+                engine = self._get_engine(self.im_memmap.shape[1:])
+            self._allocate_memory(engine)
             self._run_filter(mask=mask)
         finally:
             self.close()

@@ -14,6 +14,8 @@ filter); this backend always produces the full-volume result.
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 from nellie_amd.pipeline import FramePipeline, min_area_pixels_of
@@ -38,11 +40,18 @@ class Label:
                  device="auto",
                  low_memory: bool = False,
                  max_chunk_voxels: int = int(1e6),
-                 device_index: int = 0):
+                 device_index: int = 0,
+                 devices=None,
+                 shard=None):
+        """The reference's keywords, plus where a frame runs -- `device_index`, `devices`, `shard`: as for Filter
+        (nellie_amd/segmentation/filtering.py, nellie_amd/engine.py)."""
         self.im_info = im_info
         self.device = device
         self.device_type = self._resolve_backend(device)
         self.device_index = int(device_index)
+        self.devices = list(devices) if devices else None
+        self.shard = shard
+        self._engine = None
         self.num_t = num_t
         if num_t is None and not self.im_info.no_t:
             self.num_t = im_info.shape[im_info.axes.index('T')]
@@ -97,10 +106,38 @@ class Label:
             self._pipeline = FramePipeline(shape3, device=self.device_index)
         return self._pipeline
 
+    def _shard_spec(self):
+        from nellie_amd.engine import ShardSpec
+        shard = self.shard if self.shard is not None else (os.environ.get("NELLIE_SHARD") or None)
+        if isinstance(shard, str):
+            if shard != "env":
+                raise ValueError("shard must be 'env' or an engine.ShardSpec")
+            shard = ShardSpec.from_env(rendezvous_dir=os.path.dirname(self.im_info.pipeline_paths["im_instance_label"]))
+        return shard
+
+    def _engine_params(self):
+        from nellie_amd.pipeline import FilterParams
+        return FilterParams(dim_res=self.im_info.dim_res)
+
+    def _get_engine(self, shape3):
+        """Z slabs of a frame of this shape (nellie_amd/engine.py; one ghost plane per side is all Label needs)."""
+        from nellie_amd.engine import make_engine
+        key = tuple(int(s) for s in shape3)
+        if self._engine is None or self._engine_key != key:
+            if self._engine is not None:
+                self._engine.close()
+            self._engine = make_engine(key, self._engine_params(), device_index=self.device_index, devices=self.devices,
+                                       shard=self._shard_spec(), label_only=True)
+            self._engine_key = key
+        return self._engine
+
     def close(self):
         if self._pipeline is not None:
             self._pipeline.close()
             self._pipeline = None
+        if self._engine is not None:
+            self._engine.close()
+            self._engine = None
 
     def _get_t(self):
         if self.num_t is None:
@@ -109,15 +146,21 @@ class Label:
             else:
                 self.num_t = self.im_info.shape[self.im_info.axes.index('T')]
 
-    def _allocate_memory(self):
-        """labelling.py:337-353."""
+    def _allocate_memory(self, engine=None):
+        """labelling.py:337-353.  Multi-process runs: rank 0 creates the label file, the others map it once it exists."""
         logger.debug('Allocating memory for semantic segmentation.')
         self.im_memmap = self.im_info.get_memmap(self.im_info.im_path)
         self.frangi_memmap = self.im_info.get_memmap(self.im_info.pipeline_paths['im_preprocessed'])
         self.shape = self.frangi_memmap.shape
-        self.instance_label_memmap = self.im_info.allocate_memory(
-            self.im_info.pipeline_paths['im_instance_label'], dtype='int32',
-            description='instance segmentation', return_memmap=True)
+        path = self.im_info.pipeline_paths['im_instance_label']
+        multi = engine is not None and engine.kind == "rank-slab"
+        if not multi or engine.spec.rank == 0:
+            self.instance_label_memmap = self.im_info.allocate_memory(
+                path, dtype='int32', description='instance segmentation', return_memmap=True)
+        if multi:
+            engine.barrier()
+            if engine.spec.rank != 0:
+                self.instance_label_memmap = self.im_info.get_memmap(path)
 
     def _get_frame_views(self, t):
         return self.im_memmap[t, ...], self.frangi_memmap[t, ...]
@@ -223,12 +266,28 @@ class Label:
                 self.viewer.status = f'Extracting organelles. Frame: {t + 1} of {self.num_t}.'
             original_view, frangi_view = self._get_frame_views(t)
             logger.info(f'Running semantic segmentation, volume {t}/{(self.num_t or 1) - 1}')
+            from nellie_amd.engine import plan_engine
+            shape3 = self._as3d(frangi_view).shape if np.asarray(frangi_view).ndim == 2 else tuple(frangi_view.shape)
+            kind = "single" if self.im_info.no_z else plan_engine(shape3, self._engine_params(), self.devices, self._shard_spec(), label_only=True)[0]
+            if kind != "single":
+                if self._intensity_threshold(original_view) is not None:
+                    raise NotImplementedError("intensity thresholds (otsu_thresh_intensity / threshold) are not available on Z-slab runs")
+                engine = self._get_engine(shape3)
+                engine.upload_frangi(frangi_view)
+                frangi_thresh = engine.frangi_threshold(self.threshold_sampling_pixels, self.histogram_nbins)
+                engine.label(frangi_thresh, self.min_area_pixels, fill_holes=True)
+                engine.download_labels(out=self.instance_label_memmap[t, ...])
+                if (t + 1) % self.flush_interval == 0:
+                    self.instance_label_memmap.flush()
+                continue
             pipe = self._upload_frame(original_view, frangi_view, self._intensity_threshold(original_view))
             frangi_thresh = pipe.frangi_threshold(self.threshold_sampling_pixels, self.histogram_nbins)
             self._write_labels_for_frame(t, self._label_resident(pipe, frangi_view, frangi_thresh))
             if (t + 1) % self.flush_interval == 0:
                 self.instance_label_memmap.flush()
         self.instance_label_memmap.flush()
+        if self._engine is not None:
+            self._engine.barrier()
 
     def run(self):
         """labelling.py:736-778."""
@@ -236,7 +295,11 @@ class Label:
         adaptive_run.normalize_device(self.device)
         try:
             self._get_t()
-            self._allocate_memory()
+            engine = None
+            if self._shard_spec() is not None and not self.im_info.no_z:   # the communicator first: the ranks agree on the files through it
+                frangi = self.im_info.get_memmap(self.im_info.pipeline_paths['im_preprocessed'])
+                engine = self._get_engine(frangi.shape[1:])
+            self._allocate_memory(engine)
             self._run_segmentation()
         finally:
             self.close()

@@ -325,6 +325,17 @@ class ShardedFramePipeline(FramePipeline):
     def _reduce_sum(self, n):
         return int(self.comm.allreduce(np.array([n], np.int64), "sum")[0])
 
+    # the device-resident threshold chain needs every reduction of a scale on the device, between the kernels
+    def _chain_reductions_on_device(self) -> bool:
+        return bool(self._fused_reduce) and self.world >= 1
+
+    def _all_ranks_agree(self, ok: bool) -> bool:
+        """Every rank decides from the same global histograms and statistics; the reduction only guards the fallback (a
+        collective sequence of its own) against a rank that disagrees."""
+        if self.world == 1:
+            return ok
+        return bool(self.comm.allreduce(np.array([1 if ok else 0], np.int64), "min")[0])
+
     def _reduce_mask_count(self, n):
         return n            # this rank's share; _settle_mask_counts turns all of a frame's counts global in one collective
 

@@ -678,6 +678,24 @@ def test_streamed_stack_equals_per_stage_run(hip, tmp_path):
     assert np.asarray(b.get_memmap(b.pipeline_paths["im_instance_label"], read_mode="r")).max() >= 1
 
 
+def test_streamed_stack_frame_parallel_lanes(hip, tmp_path):
+    """run_streamed(devices=[...]): one streamer per GPU, GPU k takes frames k, k + N, ... (here two lanes on device 0) --
+    the files of the single-lane run."""
+    from nellie_amd.im_info.verifier import ImInfo
+    from nellie_amd.run import run_streamed
+    from nellie_amd.synthetic import ISO_01, make_volume
+    vols = np.stack([make_volume((20, 40, 56), 80 + t, dtype=np.uint16) for t in range(5)])
+    a = ImInfo(vols, dim_res=ISO_01, output_dir=str(tmp_path / "a"), name="s")
+    b = ImInfo(vols, dim_res=ISO_01, output_dir=str(tmp_path / "b"), name="s")
+    run_streamed(a)
+    run_streamed(b, devices=[0, 0])
+    for key in ("im_preprocessed", "im_instance_label"):
+        x = a.get_memmap(a.pipeline_paths[key], read_mode="r")
+        y = b.get_memmap(b.pipeline_paths[key], read_mode="r")
+        assert x.dtype == y.dtype and np.array_equal(x, y), key
+    assert all(np.asarray(y[t]).max() >= 1 for t in range(5))
+
+
 def test_remove_edges_golden(hip):
     """Filter(remove_edges=True) behind the stage API (filtering.py:931-932, 969-1000)."""
     from fakes import ArrayImInfo
@@ -812,3 +830,73 @@ def test_label_dense_structure_on_the_x_faces(hip, shape):
             bad = np.argwhere(lab != ref)
             assert bad.size == 0, f"fill={fill} run {rep}: {len(bad)} voxels differ, x in {sorted(set(bad[:, 2].tolist()))[:6]}"
             assert n == int(ref.max())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Device-resident threshold chain (csrc/chain.inc, nl_chain_*): the scale loop without a host round trip
+# ---------------------------------------------------------------------------------------------------------------------
+def _run_both_ways(vol, dr, **kw):
+    from nellie_amd import pipeline as pl
+    out = []
+    for chain in (True, False):
+        pipe = pl.FramePipeline(vol.shape)
+        pipe._device_chain = chain
+        for k, v in kw.items():
+            setattr(pipe, k, v)
+        pipe.filter(vol, pl.FilterParams(dim_res=dr))
+        tr = [(s.sigma, s.gamma, s.max_abs, s.frob_thr, s.mask_count, s.skipped) for s in pipe.trace.scales]
+        out.append((pipe.download_frangi(), tr, pipe.trace.n_positive, pipe.trace.percentile_thr, pipe.chain_fallbacks,
+                    getattr(pipe, "last_chain_flags", None)))
+        pipe.close()
+    return out
+
+
+@pytest.mark.parametrize("shape,seed,aniso", [((40, 96, 96), 21, False), ((33, 70, 130), 22, True), ((64, 128, 136), 23, False),
+                                              ((96, 160, 200), 24, False)])
+def test_device_chain_equals_the_synchronous_path(hip, shape, seed, aniso):
+    """Thresholds decided by kernels (gamma, bracket, max |H|, Frobenius threshold, mask test) and read by the walk and the
+    resolve kernel from device memory: same trace, same Frangi frame as the path that takes every histogram to the host --
+    and the chain stood (no flag, nothing redone), i.e. the host's repetition of the arithmetic agreed bit for bit."""
+    from nellie_amd.synthetic import ANISO_03, ISO_01, make_volume
+    vol = make_volume(shape, seed)
+    (fr_c, tr_c, np_c, pt_c, fb_c, flags), (fr_s, tr_s, np_s, pt_s, fb_s, _) = _run_both_ways(vol, ANISO_03 if aniso else ISO_01)
+    assert fb_c == 0 and flags == [0] * len(tr_c), f"the chain fell back: flags {flags}"
+    assert fb_s == 0
+    assert tr_c == tr_s
+    assert np_c == np_s and pt_c == pt_s
+    assert np.array_equal(fr_c, fr_s) and (fr_c > 0).any()
+
+
+def test_device_chain_falls_back_on_a_bracket_miss(hip):
+    """A prediction pushed off by 50 % misses the bracket: the chain flags it (NL_CF_MISS = 128), the frame is redone the
+    synchronous way (which goes two-pass) and the result is the one-pass result."""
+    from nellie_amd.synthetic import ISO_01, make_volume
+    vol = make_volume((40, 96, 96), 21)
+    (fr_c, tr_c, _, _, fb_c, flags), (fr_s, tr_s, _, _, _, _) = _run_both_ways(vol, ISO_01, _one_pass_test_scale=1.5)
+    assert fb_c == 1 and all(f & 128 for f in flags), flags
+    assert tr_c == tr_s and np.array_equal(fr_c, fr_s)
+    ref = _run_both_ways(vol, ISO_01)[0][0]
+    assert np.array_equal(fr_c, ref)
+
+
+@pytest.mark.parametrize("name", FILTER_CASES)
+def test_device_chain_on_the_golden_cases(name, hip):
+    """Every golden Filter case through the default pipeline (chain on): the frames the synchronous path gives -- including
+    the cases the chain hands back (zeros, constant, single voxel, empty scales, fixed thresholds)."""
+    from nellie_amd import pipeline as pl
+    g = load_golden(name)
+    vol, dr, kw = g["input"], g["dim_res_dict"], dict(g["kwargs"])
+    frames = []
+    for chain in (True, False):
+        pipe = pl.FramePipeline(vol.shape)
+        pipe._device_chain = chain
+        try:
+            pipe.filter(vol, pl.FilterParams(dim_res=dr, **kw))
+            frames.append((pipe.download_frangi(), [(s.gamma, s.max_abs, s.frob_thr, s.mask_count, s.skipped) for s in pipe.trace.scales]))
+        except ValueError as exc:
+            frames.append(("raised", str(exc)))
+        pipe.close()
+    if isinstance(frames[0][0], str) or isinstance(frames[1][0], str):
+        assert isinstance(frames[0][0], str) and isinstance(frames[1][0], str)
+    else:
+        assert frames[0][1] == frames[1][1] and np.array_equal(frames[0][0], frames[1][0])

@@ -363,3 +363,44 @@ def test_zslab_remove_edges_equals_single_gpu(hip):
         raise errs[0]
     got = np.concatenate(out)
     assert (ref > 0).any() and np.array_equal(got, ref), f"{int((got != ref).sum())} voxels differ"
+
+
+@pytest.mark.parametrize("how", ["force3", "devices00"])
+def test_stage_api_runs_a_frame_as_local_slabs(hip, how, tmp_path, monkeypatch):
+    """Filter(...).run() / Label(...).run() / run(file_info) with the frame cut into Z slabs inside the process
+    (nellie_amd/engine.py: LocalSlabs over the loopback transport) -- forced on a small frame the way a frame beyond 2^31
+    voxels gets it, and through devices=[...] -- write the files the single-context run writes (2 frames, uint16 input)."""
+    import os
+    from nellie_amd.im_info import ome_tiff
+    from nellie_amd.im_info.verifier import FileInfo, ImInfo
+    from nellie_amd.run import run
+    from nellie_amd.synthetic import ISO_01, make_volume
+    vols = np.stack([make_volume((72, 48, 60), 30 + t, dtype=np.uint16) for t in range(2)])
+    src = str(tmp_path / "stack.ome.tif")
+    ome_tiff.create(src, vols.shape, np.uint16, ISO_01, "raw", data=vols)
+    single = run(FileInfo(src, output_dir=str(tmp_path / "single")), device="gpu")
+    kw = {}
+    if how == "force3":
+        monkeypatch.setenv("NELLIE_FORCE_SLABS", "3")
+    else:
+        kw["devices"] = [0, 0]
+    sharded = run(FileInfo(src, output_dir=str(tmp_path / how)), device="gpu", **kw)
+    for key in ("im_preprocessed", "im_instance_label"):
+        a = np.asarray(single.get_memmap(single.pipeline_paths[key], read_mode="r"))
+        b = np.asarray(sharded.get_memmap(sharded.pipeline_paths[key], read_mode="r"))
+        assert a.dtype == b.dtype and np.array_equal(a, b), f"{key}: {int((a != b).sum())} voxels differ"
+    lab = np.asarray(sharded.get_memmap(sharded.pipeline_paths["im_instance_label"], read_mode="r"))
+    assert lab.max() >= 1 and np.array_equal(np.asarray(sharded.get_memmap(sharded.im_path, read_mode="r")), vols)
+
+
+def test_stage_api_remove_edges_on_local_slabs(hip, monkeypatch):
+    """Filter(remove_edges=True) through the slab engine == the single-context stage (in-memory ImInfo)."""
+    from fakes import ArrayImInfo
+    from nellie_amd.segmentation.filtering import Filter
+    from nellie_amd.synthetic import ISO_01, make_volume
+    vols = make_volume((80, 64, 72), 19)[None]
+    a, b = ArrayImInfo(vols, ISO_01), ArrayImInfo(vols, ISO_01)
+    Filter(a, remove_edges=True, device="gpu").run()
+    monkeypatch.setenv("NELLIE_FORCE_SLABS", "2")
+    Filter(b, remove_edges=True, device="gpu").run()
+    assert (a.store["frangi"] > 0).any() and np.array_equal(a.store["frangi"], b.store["frangi"])

@@ -65,6 +65,54 @@ def test_zslab_filter_and_label_world2_gloo(aniso, halo_mode, tmp_path):
     assert all(int(p["n_labels"]) == int(ref_lab.max()) for p in parts) and ref_lab.max() >= 1
 
 
+def test_stage_api_world2_gloo_writes_the_single_rank_files(tmp_path):
+    """Filter(im_info, shard=...).run() / Label(im_info, shard=...).run() as two gloo ranks (nellie_amd/engine.py: RankSlab):
+    rank 0 creates the output files, both ranks write their own planes of both frames; the files hold what a single rank
+    (here: the oracle) produces, bit for bit."""
+    pytest.importorskip("torch")
+    from nellie_amd.im_info import ome_tiff
+    from nellie_amd.im_info.verifier import ImInfo
+    from nellie_amd.synthetic import ISO_01, make_volume
+    vols = np.stack([make_volume((64, 30, 34), 70 + t) for t in range(2)])
+    src = str(tmp_path / "stack.ome.tif")
+    ome_tiff.create(src, vols.shape, np.float32, ISO_01, "raw", data=vols)
+    out_dir = str(tmp_path / "out")
+    im_info = ImInfo(src, output_dir=out_dir)                      # makes the canonical copy the ranks reuse
+    port = 29900 + (os.getpid() % 90)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(REPO, "tests", "dist_stage_worker.py"), src, out_dir]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    fr = np.asarray(im_info.get_memmap(im_info.pipeline_paths["im_preprocessed"], read_mode="r"))
+    lab = np.asarray(im_info.get_memmap(im_info.pipeline_paths["im_instance_label"], read_mode="r"))
+    assert fr.shape == vols.shape == lab.shape and fr.dtype == np.float32 and lab.dtype == np.int32
+    for t in range(2):
+        ref = orc.filter_frame(vols[t], ISO_01)
+        assert np.array_equal(fr[t], ref), f"t={t}: {int((fr[t] != ref).sum())} voxels differ"
+        assert np.array_equal(lab[t], orc.label_frame(ref, ISO_01)) and lab[t].max() >= 1
+    assert np.array_equal(np.asarray(im_info.get_memmap(im_info.im_path, read_mode="r")), vols), "input file was modified"
+
+
+def test_engine_plans():
+    """Which engine a frame gets (nellie_amd/engine.py): one context up to its index range, slabs beyond it or over several GPUs."""
+    from nellie_amd.engine import ShardSpec, plan_engine, slabs_needed
+    from nellie_amd.pipeline import FilterParams
+    from nellie_amd.synthetic import ISO_01
+    p = FilterParams(dim_res=ISO_01)
+    assert plan_engine((1024, 1024, 1024), p) == ("single", 1)
+    assert plan_engine((320, 2048, 2048), p) == ("single", 1)
+    assert plan_engine((600, 2048, 2048), p) == ("local-slabs", 2)          # 2.5e9 voxels: beyond one context
+    assert plan_engine((1024, 2048, 2048), p, devices=list(range(8))) == ("local-slabs", 8)
+    assert plan_engine((1024, 2048, 2048), p) == ("local-slabs", 3)
+    assert plan_engine((512, 512), p, devices=[0, 1]) == ("single", 1)      # 2-D images never shard
+    assert plan_engine((64, 64, 64), p, shard=ShardSpec(rank=1, world=4)) == ("rank-slab", 4)
+    for shape, w in (((1024, 2048, 2048), 3), ((600, 2048, 2048), 2)):
+        owned = -(-shape[0] // w)
+        assert (owned + 18) * shape[1] * shape[2] < 2 ** 31 and slabs_needed(shape, 9) == w
+    with pytest.raises(MemoryError):
+        slabs_needed((64, 40000, 40000), 9)                                 # a plane alone does not fit
+
+
 def _label_slabs_with_threads(frangi, thr, min_area, world, dr):
     """The Z-slab Label protocol of nellie_amd/sharded.py on `world` oracle-backed contexts, one thread per rank."""
     import threading

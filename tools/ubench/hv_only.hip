@@ -6,4 +6,4 @@
 #include "../../nellie_amd/csrc/hessian.inc"
 #include "../../nellie_amd/csrc/hessian_pair.inc"
 template __global__ void hessian_v_kernel<2, 8, true>(const float *, unsigned long long *, const unsigned long long *, int, VolGeom, HessDv<true>, VessP,
-                                                      VQueue, int, int, int, int, unsigned int *, unsigned long long *);
+                                                      VQueue, int, int, int, int, unsigned int *, unsigned long long *, const float *);
