@@ -216,10 +216,10 @@ def io_figures(pl, hipnative, shape, p, min_area, vol):
     pipe.close()
     for a in (pin_in, pin_fr, pin_lab):
         a.free()
-    # BASELINE config 5 (shortened): a 3-D+T stack of 128 x 512 x 512 frames, host arrays in, host arrays out
+    # BASELINE config 5: a 3-D+T stack of 64 frames of 128 x 512 x 512, host arrays in, host arrays out
     from nellie_amd.streaming import StreamedSegmenter
     from nellie_amd.synthetic import make_volume
-    T, fs = 12, (128, 512, 512)
+    T, fs = int(os.environ.get("NELLIE_BENCH_C5_FRAMES", "64")), (128, 512, 512)
     frames = np.stack([make_volume(fs, 4567 + t) for t in range(T)])
     fr, lab = np.empty(frames.shape, np.float32), np.empty(frames.shape, np.int32)
     seg = StreamedSegmenter(fs, frames.dtype, p)
@@ -373,6 +373,8 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     roofline = roofline_of(groups, shape, args.steps, ms_per_step)
     tr = pipe.trace
+    chain_info = {"enabled": bool(pipe._chain_usable(p, True)), "frames_redone_synchronously": int(pipe.chain_fallbacks),
+                  "last_flags": getattr(pipe, "last_chain_flags", None)}
     fast_div = int(pipe.ctx.info("fast_div"))
     tile_rows = int(pipe.ctx.info("hessian_tile_rows"))
     pipe.close()
@@ -404,6 +406,7 @@ def main():
                 "mask_fraction_per_scale": [round(sc.mask_count / n_local, 4) for sc in tr.scales],
                 "one_pass_scales": int(sum(1 for sc in tr.scales if sc.one_pass)),
                 "host_gen_s": round(t_gen, 1), "h2d_s": round(t_up, 2), "fast_div_proven": fast_div, "hessian_tile_rows": tile_rows,
+                "device_chain": chain_info,
             },
             "roofline": roofline, "cpu_baseline": cpu,
         }
@@ -661,6 +664,8 @@ def zslab_run(dist, rank, world, local_rank, args):
         "mask_fraction_per_scale": [round(sc.mask_count / n_global, 4) for sc in tr.scales],
         "one_pass_scales": int(sum(1 for sc in tr.scales if sc.one_pass)), "host_gen_s": round(t_gen, 1),
         "labels_crc32_rank0": int(crc),
+        "device_chain": {"enabled": bool(pipe._chain_usable(p, True)), "frames_redone_synchronously": int(pipe.chain_fallbacks),
+                         "last_flags": getattr(pipe, "last_chain_flags", None)},
     })
     pipe.close()
     # the same workload on one GPU (rank 0's), after the other ranks are done with theirs
@@ -695,6 +700,8 @@ def zslab_child_main(args):
     if rank == 0:
         print(json.dumps(res), flush=True)
     sys.stdout.flush()
+    if os.environ.get("NELLIE_BENCH_CLEAN_EXIT") == "1":      # under a profiler: let its exit handlers write their files
+        return
     os._exit(0)
 
 

@@ -325,9 +325,6 @@ extern "C" int nl_ctx_destroy(nl_ctx *c) {
     if (c->ev_side) hipEventDestroy(c->ev_side);
     if (c->ev_main) hipEventDestroy(c->ev_main);
     if (c->ev_ahead) hipEventDestroy(c->ev_ahead);
-    if (c->cu_a) { hipStreamSynchronize(c->cu_a); hipStreamDestroy(c->cu_a); }
-    if (c->cu_b) { hipStreamSynchronize(c->cu_b); hipStreamDestroy(c->cu_b); }
-    if (c->ev_cu) hipEventDestroy(c->ev_cu);
     if (c->copy_in) hipStreamDestroy(c->copy_in);
     if (c->copy_out) hipStreamDestroy(c->copy_out);
     if (c->d_blk) hipFree(c->d_blk);
@@ -423,23 +420,6 @@ extern "C" int nl_ctx_create(nl_ctx **out, int device, int64_t nzl, int64_t ny, 
                hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming) != hipSuccess ||
                hipEventCreateWithFlags(&c->ev_ahead, hipEventDisableTiming) != hipSuccess)) {
         rc = nl_fail(err, errlen, NL_EHIP, "stream/event creation failed"); ok = false;
-    }
-    {
-        // bit k of a CU mask is compute unit k / 8 of XCD k % 8 on this part (the driver deals the bits round the XCDs), so
-        // "the first n bits" is n / 8 CUs of every XCD and the complement is the rest of every XCD
-        const char *e = getenv("NELLIE_CU_SPLIT");
-        const int n_b = e ? atoi(e) : 0;
-        hipDeviceProp_t prop;
-        if (ok && n_b > 0 && hipGetDeviceProperties(&prop, device) == hipSuccess && n_b < prop.multiProcessorCount) {
-            const int ncu = prop.multiProcessorCount, words = (ncu + 31) / 32;
-            std::vector<uint32_t> ma(words, 0u), mb(words, 0u);
-            for (int k = 0; k < ncu; ++k) ((k < n_b) ? mb : ma)[k >> 5] |= 1u << (k & 31);
-            if (hipExtStreamCreateWithCUMask(&c->cu_a, (uint32_t)words, ma.data()) != hipSuccess ||
-                hipExtStreamCreateWithCUMask(&c->cu_b, (uint32_t)words, mb.data()) != hipSuccess ||
-                hipEventCreateWithFlags(&c->ev_cu, hipEventDisableTiming) != hipSuccess) {
-                rc = nl_fail(err, errlen, NL_EHIP, "CU-masked stream creation failed (NELLIE_CU_SPLIT)"); ok = false;
-            }
-        }
     }
     if (ok && (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
                hipEventCreate(&c->t0) != hipSuccess || hipEventCreate(&c->t1) != hipSuccess)) {
@@ -733,7 +713,7 @@ extern "C" int nl_gauss_step_ahead(nl_ctx *c, const double *wz, int rz, const do
     NL_ENTER(c);
     if (c->ahead_pending) return nl_fail(err, errlen, NL_ESTATE, "a step enqueued ahead is already pending");
     NL_HIP(hipEventRecord(c->ev_main, c->stream));
-    hipStream_t ahead_stream = c->cu_b ? c->cu_b : c->side;
+    hipStream_t ahead_stream = c->side;
     NL_HIP(hipStreamWaitEvent(ahead_stream, c->ev_main, 0));
     const int cur_idx = c->i_gauss;
     float *cur_ext = c->gauss_ext;
@@ -1211,12 +1191,7 @@ static int spec_enqueue(nl_ctx *c, const double spacing[3], float fsq_lo, float 
         const int nzc = (int)((z1 - z0 + HM_ZCHUNK - 1) / HM_ZCHUNK);
         const unsigned nblocks = (unsigned)(ntx * nty * nzc);
         if (rs) vp.qcap = 2 * HM_SPEC_CAP;              // a wave owns two row segments
-        // a cascade step is running ahead on its share of the compute units: the walk takes the other share
-        hipStream_t hs = (c->ahead_pending && c->cu_a && rs) ? c->cu_a : c->stream;
-        if (hs != c->stream) {
-            NL_HIP(hipEventRecord(c->ev_cu, c->stream));
-            NL_HIP(hipStreamWaitEvent(hs, c->ev_cu, 0));
-        }
+        hipStream_t hs = c->stream;
 #define NL_DEV_LOHI dev_lohi
 #define NL_LAUNCH_SPEC_V(RSV, FASTV, HR)                                                                                  \
         allow_lds(hessian_v_kernel<2, RSV, FASTV>, HVCfg<RSV>::lds_bytes());                                              \
@@ -1233,10 +1208,6 @@ static int spec_enqueue(nl_ctx *c, const double spacing[3], float fsq_lo, float 
 #undef NL_LAUNCH_SPEC_V
 #undef NL_DEV_LOHI
         NL_CHECK_LAUNCH();
-        if (hs != c->stream) {
-            NL_HIP(hipEventRecord(c->ev_cu, hs));
-            NL_HIP(hipStreamWaitEvent(c->stream, c->ev_cu, 0));
-        }
         c->spec_nregions = nblocks * (unsigned)(rs ? rs : ty);
         c->spec_qcap = vp.qcap;
     }
@@ -3452,8 +3423,6 @@ extern "C" int nl_prof_get(nl_ctx *c, const char *name, double *ms, int64_t *lau
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     hipStreamSynchronize(c->side);
-    if (c->cu_a) hipStreamSynchronize(c->cu_a);
-    if (c->cu_b) hipStreamSynchronize(c->cu_b);
     if (c->xstream) hipStreamSynchronize(c->xstream);
     prof_harvest(c, true);
     double tot = 0; int64_t k = 0;

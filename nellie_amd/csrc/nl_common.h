@@ -75,11 +75,6 @@ struct nl_ctx {
     hipEvent_t ev_side = nullptr, ev_main = nullptr;
     hipEvent_t ev_ahead = nullptr;       // a cascade step enqueued ahead on `side` (nl_gauss_step_ahead)
     int ahead_pending = 0, ahead_gauss = 0;
-    // NELLIE_CU_SPLIT=n: while a cascade step runs ahead, it is confined to n compute units (stream cu_b) and the Hessian
-    // walk of the current scale to the other ones (stream cu_a) -- a memory-bound and an issue-bound kernel side by side
-    // on disjoint CUs instead of taking turns on all of them
-    hipStream_t cu_a = nullptr, cu_b = nullptr;
-    hipEvent_t ev_cu = nullptr;
     int side_pending = 0;                // work on `side` the main stream has not been ordered after yet
     int last_spec_overflow = 0;          // the last one-pass walk overflowed a queue region (diagnostics)
     float last_fsq_min = 0;    // the exact mask threshold of the last scale (diagnostics)

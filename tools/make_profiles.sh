@@ -40,7 +40,7 @@ tail -2 /tmp/ks.log; tail -c 600 $R/gpurun_out/r03_bench_n1_1024cube.json
 cd $R
 python bench.py --zslab-on-one-gpu 8 --steps 2 --warmup 1 2>/tmp/z1.err | tail -1 > gpurun_out/r03_c4_as_8_slabs_on_one_gpu.json
 cd /tmp
-rm -rf /tmp/ksz && RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29534 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ksz -- python $R/bench.py --zslab-child --gpus 1 --steps 4 --warmup 2 > /tmp/ksz.log 2>&1
+rm -rf /tmp/ksz && NELLIE_BENCH_CLEAN_EXIT=1 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29534 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ksz -- python $R/bench.py --zslab-child --gpus 1 --steps 4 --warmup 2 > /tmp/ksz.log 2>&1
 python - $(find /tmp/ksz -name '*kernel_stats.csv' | head -1) > $R/gpurun_out/r03_kernel_stats_zslab_world1_128x2048x2048.txt <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))

@@ -1,7 +1,7 @@
 #!/bin/bash
-# A/B of library variants on the GPU box: tools/r3_ab.sh OUTNAME Z Y X REPS variant...   (variants = names under nellie_amd/variants)
+# A/B of library variants on the GPU box: tools/variants_ab.sh OUTNAME Z Y X REPS variant...   (variants = names under nellie_amd/variants)
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
-OUT=gpurun_out/r3/$1.txt; shift; mkdir -p gpurun_out/r3
+OUT=gpurun_out/ab/$1.txt; shift; mkdir -p gpurun_out/ab
 Z=$1; Y=$2; X=$3; REPS=$4; shift 4
 CFG=()
 for v in "$@"; do CFG+=("NELLIE_HIP_LIB=$R/nellie_amd/variants/libnellie_hip_$v.so"); done
