@@ -159,10 +159,12 @@ static bool gyx_tiled() {
     if (on < 0) { const char *e = getenv("NELLIE_GYX_TILE"); on = (e && !atoi(e)) ? 0 : 1; }
     return on != 0;
 }
-// grid of the queue kernels: NELLIE_RESOLVE_GRID caps it (waves then walk several regions each)
+// grid of the queue kernels: NELLIE_RESOLVE_GRID caps it (waves then walk several regions each).  Measured at 512 x 1024 x 1024
+// (ms/step of the resolve group): 1792 workgroups 2.77, 2048 2.69, 4096 2.67, 8192 2.79, 16384 (rounds 1-2) and more 3.16 --
+// a wave that walks 8-16 regions amortises its start-up and evens out the regions' very different entry counts
 static unsigned resolve_grid(unsigned blocks) {
     static long cap = -1;
-    if (cap < 0) { const char *e = getenv("NELLIE_RESOLVE_GRID"); cap = e ? atol(e) : 16384; }
+    if (cap < 0) { const char *e = getenv("NELLIE_RESOLVE_GRID"); cap = e ? atol(e) : 4096; }
     return (cap > 0 && (unsigned)cap < blocks) ? (unsigned)cap : blocks;
 }
 static float *gauss_cur(const nl_ctx *c) { return c->gauss_ext ? c->gauss_ext : c->f[c->i_gauss]; }

@@ -518,29 +518,19 @@ class FramePipeline:
         strides = self._strides(max_samples)
         deltas = list(cascade_deltas(sigmas, zr))
         ctx.chain_begin(len(sigmas))
-        ahead = False
-
-        def cascade_step(k, run_ahead):
-            delta = deltas[k]
-            if not any(s > 0 for s in delta):
-                return False
-            ws = [gaussian_weights(d) for d in delta]
-            z0, z1 = self._gauss_range(0 if ws[0] is None else (len(ws[0]) - 1) // 2)
-            ctx.gauss_step(*ws, z0=z0, z1=z1, **({"ahead": True} if run_ahead else {}))
-            return True
-
+        # No cascade step runs ahead here: that device (sharded.py) fills the GPU while the host waits for a scale's collectives,
+        # and the chain has no such waits -- beside the walk the step only competes with it (measured on a 128 x 2048 x 2048 slab:
+        # 34.1 ms/step with a step running ahead, 29.9 without; the synchronous path: 31.6 / 30.4).
         for k in range(len(sigmas)):
-            if ahead:
-                ctx.gauss_commit()
-            else:
-                cascade_step(k, False)
+            delta = deltas[k]
+            if any(s > 0 for s in delta):
+                ws = [gaussian_weights(d) for d in delta]
+                z0, z1 = self._gauss_range(0 if ws[0] is None else (len(ws[0]) - 1) // 2)
+                ctx.gauss_step(*ws, z0=z0, z1=z1)
             self._after_cascade_step(k)
-            ahead = self._gauss_ahead and k + 1 < len(sigmas) and cascade_step(k + 1, True)
             vz0, vz1 = self._vess_range()
             ctx.chain_scale(spacing, strides, float(p.alpha_sq), float(p.beta_sq), float(p.frob_thresh_division), self.one_pass_margin,
                             self._one_pass_test_scale, z0=vz0, z1=vz1)
-        if ahead:
-            ctx.gauss_commit()
         flags, gamma, max_abs, thr, counts = ctx.chain_finish()
         self.last_chain_flags = [int(f) for f in flags]
         if not self._all_ranks_agree(not flags.any()):
