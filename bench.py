@@ -619,8 +619,11 @@ def zslab_run(dist, rank, world, local_rank, args):
     pipe.ctx.sync()
     dist.barrier()
     t0 = time.perf_counter()
+    each = []
     for _ in range(args.steps):
+        t1 = time.perf_counter()
         n_labels = step()
+        each.append(round((time.perf_counter() - t1) * 1e3, 2))
     pipe.ctx.sync()
     dist.barrier()
     elapsed = time.perf_counter() - t0
@@ -657,7 +660,7 @@ def zslab_run(dist, rank, world, local_rank, args):
                       f"({'raw ghost planes of the input resident with it, ' if (g_lo or g_hi or world == 1) else ''}ghost planes of every computed volume and Label's bit planes exchanged over RCCL in the step); "
                       "5-scale Frangi + Label (no replication), full hot path per step, slabs resident in HBM",
         "voxels": int(n_global), "per_gpu_owned_shape": [planes, gshape[1], gshape[2]], "halo_planes": pipe.halo, "halo_scheme": pipe.halo_mode, "untimed_warmup_steps": n_warm, "raw_ghost_planes_resident_with_input": [int(g_lo), int(g_hi)],
-        "halo_ms": groups.get("halo"), "groups_ms_per_step_rank0": groups,
+        "halo_ms": groups.get("halo"), "groups_ms_per_step_rank0": groups, "ms_of_each_step_rank0": each,
         "groups_ms_per_step_rank0_nothing_ahead": groups_serial, "kernel_sum_ms_per_step_rank0_nothing_ahead": round(sum(groups_serial.values()), 3),
         "labels": int(n_labels),
         "survival_fraction": round(tr.n_positive / n_global, 5),

@@ -123,7 +123,7 @@ def run(file_info, remove_edges=False, otsu_thresh_intensity=False, threshold=No
         print(f"[timeit] Label: {t2 - t1:.3f}s")
     if markers:
         from nellie_amd.segmentation.mocap_marking import Markers
-        Markers(im_info, device=device, low_memory=low_memory).run()
+        Markers(im_info, device=device, low_memory=low_memory, devices=devices, shard=shard).run()
         if timeit:
             print(f"[timeit] Markers: {time.perf_counter() - t2:.3f}s")
     if timeit:

@@ -678,6 +678,40 @@ def test_streamed_stack_equals_per_stage_run(hip, tmp_path):
     assert np.asarray(b.get_memmap(b.pipeline_paths["im_instance_label"], read_mode="r")).max() >= 1
 
 
+@pytest.mark.parametrize("aniso,how", [(False, "force3"), (True, "force4"), (False, "devices00")])
+def test_markers_as_z_slabs_equal_the_whole_volume(hip, aniso, how, monkeypatch):
+    """Markers(...).run() with the frame cut into Z slabs (each slab computed with its halo of labels and intensities from the
+    maps, nothing exchanged: nellie_amd/segmentation/mocap_marking.py) writes the three products of the whole-volume run --
+    and of the oracle.  Tall enough in Z for slabs whose halos do NOT reach the far faces."""
+    from fakes import ArrayImInfo
+    from nellie_amd.segmentation.mocap_marking import Markers
+    from nellie_amd.synthetic import ANISO_03, ISO_01, make_volume
+    dr = ANISO_03 if aniso else ISO_01
+    shape = (150, 40, 48) if not aniso else (96, 48, 56)
+    vol = make_volume(shape, 51)
+    lab = orc.label_frame(orc.filter_frame(vol, dr), dr)
+    assert lab.max() >= 1
+    outs = []
+    for sharded in (False, True):
+        im = ArrayImInfo(vol[None], dr)
+        im.store["labels"] = np.ascontiguousarray(lab[None]).view(type(im.store["im"]))
+        kw = {}
+        if sharded and how.startswith("force"):
+            monkeypatch.setenv("NELLIE_FORCE_SLABS", how[5:])
+        elif sharded:
+            kw["devices"] = [0, 0]
+        mk = Markers(im, device="gpu", **kw)
+        mk.run()
+        if sharded:
+            assert mk._slab_halo() < shape[0] // 2, "the test volume must be taller than two halos"
+        outs.append([np.asarray(im.store[k]) for k in ("marker", "distance", "border")])
+        monkeypatch.delenv("NELLIE_FORCE_SLABS", raising=False)
+    for a, b, name in zip(outs[0], outs[1], ("marker", "distance", "border")):
+        assert a.dtype == b.dtype and np.array_equal(a, b), f"{name}: {int((a != b).sum())} voxels differ"
+    m, d, b = orc.markers_frame(vol, lab, dr)
+    assert np.array_equal(outs[1][0][0], m) and np.array_equal(outs[1][1][0], d) and np.array_equal(outs[1][2][0], b) and m.sum() >= 1
+
+
 def test_streamed_stack_frame_parallel_lanes(hip, tmp_path):
     """run_streamed(devices=[...]): one streamer per GPU, GPU k takes frames k, k + N, ... (here two lanes on device 0) --
     the files of the single-lane run."""

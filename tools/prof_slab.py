@@ -5,6 +5,8 @@ tools/prof_slab.py [Z Y X] [reps]
   NELLIE_PROF_CALLS=0  no per-call timers (for rocprofv3 runs)      NELLIE_PROF_PY=1  cProfile of the timed steps
   NELLIE_PROF_LOG=1    (start, end) of every library call of step NELLIE_PROF_STEP (default: the last): gaps and longest calls"""
 import os, sys, time
+if os.environ.get("NELLIE_PROF_TORCH_FIRST") == "1":      # what bench.py's multi-process path does: torch (and its HIP runtime) before the library
+    import torch  # noqa: F401
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from nellie_amd import hipnative, pipeline as pl, sharded
