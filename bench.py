@@ -547,8 +547,9 @@ def zslab_on_one_gpu(world, planes, yx, device, steps, warmup=2):
 
 
 def zslab_run(dist, rank, world, local_rank, args):
-    """ONE volume over `world` GPUs (nellie_amd/sharded.py).  First a small volume against a single-GPU run of the same
-    volume (bit-for-bit equality of both outputs on every rank), then the timed run at 128 owned planes of 2048 x 2048 per GPU."""
+    """ONE volume over `world` GPUs (nellie_amd/sharded.py).  First the timed run at 128 owned planes of 2048 x 2048 per GPU (a
+    fresh process: see (2) below), then a small volume against a single-GPU run of the same volume (bit-for-bit equality of both
+    outputs on every rank), then -- rank 0 -- the timed workload as `world` slab contexts on one GPU."""
     import torch
     from nellie_amd import hipnative
     from nellie_amd import pipeline as pl
@@ -564,31 +565,7 @@ def zslab_run(dist, rank, world, local_rank, args):
     res = {"world": world, "transport": "RCCL: ncclSend/ncclRecv (ghost planes, bit planes), ncclAllReduce (scalars, histograms), "
                                         "ncclAllGather (threshold samples, slab run tables); the per-step ghost-plane exchanges on a second communicator and stream"}
 
-    # ---- (1) equality on a small volume
-    gshape = (48 * world, 192, 256)
-    o0, o1 = slab_range(gshape[0], world, rank)
-    vol = make_volume(gshape, 4242)
-    uid, uid_x = fresh_uid(), fresh_uid()
-    pipe = ShardedFramePipeline(gshape, rank, world, lambda ctx: RcclComm(ctx, world, rank, uid, uid2=uid_x), p, device=local_rank)
-    ones = pipe.comm.allreduce(np.array([1], np.int64), "sum")
-    res["rccl_ranks"] = int(ones[0])
-    pipe.load_input(vol[o0:o1])
-    pipe.filter(None, p)
-    n_small = pipe.label(pipe.frangi_threshold(), min_area)
-    fr, lab = pipe.download_frangi(), pipe.download_labels()
-    pipe.close()
-    single = pl.FramePipeline(gshape, device=local_rank)
-    single.filter(vol, p)
-    ok_fr = bool(np.array_equal(single.download_frangi()[o0:o1], fr))
-    n_ref = single.label(single.frangi_threshold(), min_area)
-    ok_lab = bool(np.array_equal(single.download_labels()[o0:o1], lab)) and n_ref == n_small
-    single.close()
-    flags = torch.tensor([int(ok_fr), int(ok_lab)], dtype=torch.int64)
-    dist.all_reduce(flags, op=dist.ReduceOp.MIN)
-    res["equality_check"] = {"volume": list(gshape), "labels": int(n_small), "frangi_equal": bool(flags[0]), "labels_equal": bool(flags[1])}
-    res["frangi_equal"], res["labels_equal"] = bool(flags[0]), bool(flags[1])
-
-    # ---- (2) the timed run
+    # ---- (1) the timed run
     planes = int(args.zslab_planes)
     gshape = (planes * world, int(args.zslab_yx[0]), int(args.zslab_yx[1]))
     o0, o1 = slab_range(gshape[0], world, rank)
@@ -671,6 +648,32 @@ def zslab_run(dist, rank, world, local_rank, args):
                          "last_flags": getattr(pipe, "last_chain_flags", None)},
     })
     pipe.close()
+    # ---- (2) equality on a small volume, against a single-GPU run of the same volume.  AFTER the timed run: a process that has
+    # created, used and closed other contexts before runs the same slab step 9 % (synchronous path) to 18 % (device chain) slower
+    # (measured, tools/prof_slab.py NELLIE_PROF_PRELUDE=1: 29.9 -> 32.7 and 30.1 -> 35.4 ms), so the measurement goes first
+    gshape = (48 * world, 192, 256)
+    o0, o1 = slab_range(gshape[0], world, rank)
+    vol = make_volume(gshape, 4242)
+    uid, uid_x = fresh_uid(), fresh_uid()
+    pipe = ShardedFramePipeline(gshape, rank, world, lambda ctx: RcclComm(ctx, world, rank, uid, uid2=uid_x), p, device=local_rank)
+    ones = pipe.comm.allreduce(np.array([1], np.int64), "sum")
+    res["rccl_ranks"] = int(ones[0])
+    pipe.load_input(vol[o0:o1])
+    pipe.filter(None, p)
+    n_small = pipe.label(pipe.frangi_threshold(), min_area)
+    fr, lab = pipe.download_frangi(), pipe.download_labels()
+    pipe.close()
+    single = pl.FramePipeline(gshape, device=local_rank)
+    single.filter(vol, p)
+    ok_fr = bool(np.array_equal(single.download_frangi()[o0:o1], fr))
+    n_ref = single.label(single.frangi_threshold(), min_area)
+    ok_lab = bool(np.array_equal(single.download_labels()[o0:o1], lab)) and n_ref == n_small
+    single.close()
+    flags = torch.tensor([int(ok_fr), int(ok_lab)], dtype=torch.int64)
+    dist.all_reduce(flags, op=dist.ReduceOp.MIN)
+    res["equality_check"] = {"volume": list(gshape), "labels": int(n_small), "frangi_equal": bool(flags[0]), "labels_equal": bool(flags[1])}
+    res["frangi_equal"], res["labels_equal"] = bool(flags[0]), bool(flags[1])
+
     # the same workload on one GPU (rank 0's), after the other ranks are done with theirs
     if rank == 0 and world > 1 and os.environ.get("NELLIE_BENCH_SAME_WORKLOAD", "1") == "1":
         try:

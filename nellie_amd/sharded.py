@@ -325,9 +325,12 @@ class ShardedFramePipeline(FramePipeline):
     def _reduce_sum(self, n):
         return int(self.comm.allreduce(np.array([n], np.int64), "sum")[0])
 
-    # the device-resident threshold chain needs every reduction of a scale on the device, between the kernels
+    # The device-resident threshold chain needs every reduction of a scale on the device, between the kernels (a fused
+    # communicator).  It is exact on slabs (tests/test_hip_sharded.py runs it over the loopback transport) but OFF by default
+    # there: on one rank's 128 x 2048 x 2048 slab it measured level with the synchronous path in one harness (30.0 vs 30.2 ms,
+    # tools/prof_slab.py) and slower in the bench's (38.5 vs 29.8 ms) for a reason not found; NELLIE_DEVICE_CHAIN_SLABS=1 turns it on.
     def _chain_reductions_on_device(self) -> bool:
-        return bool(self._fused_reduce) and self.world >= 1
+        return bool(self._fused_reduce) and os.environ.get("NELLIE_DEVICE_CHAIN_SLABS", "0") == "1"
 
     def _all_ranks_agree(self, ok: bool) -> bool:
         """Every rank decides from the same global histograms and statistics; the reduction only guards the fallback (a

@@ -121,6 +121,7 @@ def test_zslab_over_the_loopback_transport(hip, gshape, aniso, world, halo_mode,
     -- on world contexts of one GPU: Filter and Label equal the single-context result bit for bit."""
     from nellie_amd.synthetic import ANISO_03, ISO_01
     monkeypatch.setenv("NELLIE_FUSE_REDUCE", "1" if fused else "0")
+    monkeypatch.setenv("NELLIE_DEVICE_CHAIN_SLABS", "1")      # fused: the scale loop's thresholds decided on the device, on slabs too
     raw_ghosts = halo_mode.endswith("+raw")
     halo_mode = halo_mode.split("+")[0]
     if halo_mode == "fat" and world == 6:
@@ -146,6 +147,7 @@ def test_zslab_loopback_with_randomised_transfer_delays(hip, world, delay_us, se
     from nellie_amd.synthetic import ISO_01
     monkeypatch.setenv("NELLIE_LOOPBACK_DELAY_US", str(delay_us))
     monkeypatch.setenv("NELLIE_GAUSS_AHEAD", "1")
+    monkeypatch.setenv("NELLIE_DEVICE_CHAIN_SLABS", "1" if seed == 8 else "0")    # once with the device chain, once with the cascade step running ahead
     gshape = (32 * world, 56, 72)
     ref, ref_thr, ref_counts, ref_n, ref_lab = _single_reference(gshape, ISO_01, seed)
     for _ in range(2):

@@ -16,6 +16,24 @@ shape = tuple(int(a) for a in sys.argv[1:4]) if len(sys.argv) > 3 else (128, 204
 reps = int(sys.argv[4]) if len(sys.argv) > 4 else 3
 p = pl.FilterParams(dim_res=ISO_01)
 ma = pl.min_area_pixels_of(ISO_01)
+_pre = os.environ.get("NELLIE_PROF_PRELUDE", "")     # what came before in the process matters: 1 = what bench.py's
+if _pre:                                              # slab run used to do first; a / b / c / d = its parts
+    small = (48, 192, 256)
+    if _pre in ("1", "a", "a1", "a3"):
+        u1, u2 = hipnative.comm_unique_id(), hipnative.comm_unique_id()
+        q = sharded.ShardedFramePipeline(small, 0, 1, lambda ctx: sharded.RcclComm(ctx, 1, 0, u1, uid2=u2), p)
+        if _pre != "a3":                                  # a3: communicators created and destroyed, never used
+            q.load_input(make_volume(small, 4242)); q.filter(None, p); q.label(q.frangi_threshold(), ma); q.download_frangi()
+        if _pre != "a1":                                  # a1: used, kept alive
+            q.close()
+        else:
+            _keep = q
+    if _pre in ("1", "b"):
+        q = pl.FramePipeline(small); q.filter(make_volume(small, 4242), p); q.label(q.frangi_threshold(), ma); q.close()
+    if _pre == "c":
+        q = pl.FramePipeline(small); q.close()
+    if _pre == "d":
+        q = pl.FramePipeline(shape); q.close()
 uid, uid2 = hipnative.comm_unique_id(), hipnative.comm_unique_id()
 pipe = sharded.ShardedFramePipeline(shape, 0, 1, lambda ctx: sharded.RcclComm(ctx, 1, 0, uid, uid2=uid2), p)
 pipe.load_input(make_volume(shape, 3456))
