@@ -685,10 +685,12 @@ class FramePipeline:
 
 
 def log10_min_triangle_otsu(values, nbins=256):
-    """labelling.py:448-455: thresholds in the log10 domain, mapped back, minimum of the two."""
+    """labelling.py:448-455: thresholds in the log10 domain, mapped back, minimum of the two.  The reference histograms the same
+    log values twice (once per threshold); one histogram serves both here -- same counts, same edges, same results."""
+    from nellie_amd.utils.gpu_functions import _host_histogram
     log_values = np.log10(values)
-    triangle = triangle_threshold(log_values, nbins=nbins)
+    counts, edges = _host_histogram(log_values, nbins)
+    triangle, otsu = hipnative.hist_thresholds(counts, edges)
     triangle = 10 ** triangle
-    otsu, _ = otsu_threshold(log_values, nbins=nbins)
     otsu = 10 ** otsu
     return min(triangle, otsu)
