@@ -406,3 +406,54 @@ def test_stage_api_remove_edges_on_local_slabs(hip, monkeypatch):
     monkeypatch.setenv("NELLIE_FORCE_SLABS", "2")
     Filter(b, remove_edges=True, device="gpu").run()
     assert (a.store["frangi"] > 0).any() and np.array_equal(a.store["frangi"], b.store["frangi"])
+
+
+def test_stage_api_rank_slabs_over_loopback_threads(hip, tmp_path):
+    """The multi-process layout of the stage API (engine.RankSlab: one rank per process, rank 0 creates the files, every rank
+    writes its own planes) with the real HIP engine -- the ranks are three threads here, their communicators the library's
+    loopback transport: Filter(...).run() and Label(...).run() per rank == the single-context files."""
+    from nellie_amd import hipnative
+    from nellie_amd.engine import ShardSpec
+    from nellie_amd.im_info import ome_tiff
+    from nellie_amd.im_info.verifier import FileInfo, ImInfo
+    from nellie_amd.run import run
+    from nellie_amd.segmentation.filtering import Filter
+    from nellie_amd.segmentation.labelling import Label
+    from nellie_amd.sharded import RcclComm
+    from nellie_amd.synthetic import ISO_01, make_volume
+    world = 3
+    vols = np.stack([make_volume((78, 40, 56), 60 + t) for t in range(2)])
+    src = str(tmp_path / "stack.ome.tif")
+    ome_tiff.create(src, vols.shape, np.float32, ISO_01, "raw", data=vols)
+    single = run(FileInfo(src, output_dir=str(tmp_path / "single")), device="gpu")
+    out_dir = str(tmp_path / "ranks")
+    ImInfo(src, output_dir=out_dir)                                  # the canonical copy the ranks reuse
+    ids = {stage: (hipnative.comm_unique_id(loopback=True), hipnative.comm_unique_id(loopback=True)) for stage in ("filter", "label")}
+    gate = threading.Barrier(world)
+    infos, errs = [None] * world, []
+
+    def worker(rank):
+        try:
+            im = ImInfo(src, output_dir=out_dir)
+            infos[rank] = im
+            for stage, cls in (("filter", Filter), ("label", Label)):
+                u1, u2 = ids[stage]
+                spec = ShardSpec(rank=rank, world=world, device=0, comm_factory=lambda ctx, a=u1, b=u2: RcclComm(ctx, world, rank, a, uid2=b))
+                cls(im, device="gpu", shard=spec).run()
+                gate.wait()
+        except BaseException as exc:  # noqa: BLE001
+            errs.append(exc)
+            gate.abort()
+
+    ts = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    if errs:
+        raise errs[0]
+    for key in ("im_preprocessed", "im_instance_label"):
+        a = np.asarray(single.get_memmap(single.pipeline_paths[key], read_mode="r"))
+        b = np.asarray(infos[0].get_memmap(infos[0].pipeline_paths[key], read_mode="r"))
+        assert a.dtype == b.dtype and np.array_equal(a, b), f"{key}: {int((a != b).sum())} voxels differ"
+    assert np.asarray(infos[0].get_memmap(infos[0].pipeline_paths["im_instance_label"], read_mode="r")).max() >= 1
