@@ -14,6 +14,7 @@ def child(shape, reps):
     from nellie_amd.synthetic import ISO_01, make_volume
     vol = make_volume(shape, 1234)
     pipe = pl.FramePipeline(shape)
+    pipe._device_chain = False            # the synchronous path calls nl_vesselness_spec, which is what gets repeated
     pipe.load_input(vol)
     p = pl.FilterParams(dim_res=ISO_01)
     ctx = pipe.ctx
