@@ -136,6 +136,11 @@ int nl_sample_gather(nl_ctx *ctx, int field, int64_t sz, int64_t sy, int64_t sx,
    points; *n = number of positives written. */
 int nl_sample_gather_positive(nl_ctx *ctx, int field, int64_t sz, int64_t sy, int64_t sx,
                               float *out, int64_t cap, int64_t *n, char *err, size_t errlen);
+/* The same in two halves: _begin enqueues the compaction (and reports the number of lattice points = the capacity _end
+   needs at most), _end waits and fetches.  Between the two the host is free; the only calls allowed on this context in
+   between are nl_chain_finish / nl_chain_log (which enqueue nothing). */
+int nl_sample_gather_positive_begin(nl_ctx *ctx, int field, int64_t sz, int64_t sy, int64_t sx, int64_t *n_lattice, char *err, size_t errlen);
+int nl_sample_gather_positive_end(nl_ctx *ctx, float *out, int64_t cap, int64_t *n, char *err, size_t errlen);
 
 /* min / max / count of the POSITIVE lattice samples (arr[arr > 0]; filtering.py:357 and the
    range=(min,max) of gpu_functions.py:31-35, 60-64).  npos == 0 leaves mn/mx untouched. */
@@ -224,6 +229,9 @@ int nl_vesselness_spec(nl_ctx *ctx, const double spacing[3], float fsq_lo, float
      nl_chain_scale(...)          everything else of scale k: lattice histograms, thresholds, walk, exact histogram, resolve kernel
                                   (sz, sy, sx: lattice strides; division / margin / test_scale: frob_thresh_division, the relative
                                   half-width of the bracket, a factor on the predicted threshold (1.0; tests force misses with it))
+     nl_chain_flush()             optional: start the download of the records now; kernels enqueued after it (the samples of the
+                                  percentile threshold: nl_sample_gather_positive_begin) run while nl_chain_finish waits for the
+                                  records alone and repeats the decisions on the host
      nl_chain_finish(...)         THE wait: per scale flags[k] (0 = stands), gamma, max |H|, the threshold, this context's h_mask count
    Every histogram and every derived scalar is logged, and nl_chain_finish repeats the arithmetic on the host with the code of
    the synchronous entry points and compares bit for bit: a difference, or any condition the fast path does not handle (no
@@ -233,6 +241,7 @@ int nl_vesselness_spec(nl_ctx *ctx, const double spacing[3], float fsq_lo, float
 int nl_chain_begin(nl_ctx *ctx, int n_scales, char *err, size_t errlen);
 int nl_chain_scale(nl_ctx *ctx, const double spacing[3], int64_t sz, int64_t sy, int64_t sx, double alpha_sq, double beta_sq,
                    double division, double margin, double test_scale, int64_t z0, int64_t z1, char *err, size_t errlen);
+int nl_chain_flush(nl_ctx *ctx, char *err, size_t errlen);
 int nl_chain_finish(nl_ctx *ctx, int *flags, double *gamma, double *max_abs, double *thr, int64_t *mask_count, char *err, size_t errlen);
 int nl_chain_log(nl_ctx *ctx, int k, int which, int64_t *counts, float *edges, float *range, double *scalars, char *err, size_t errlen);
 

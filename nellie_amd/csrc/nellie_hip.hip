@@ -131,6 +131,12 @@ static CommApi &rccl() { static CommApi api; return api; }
 // =================================================================================================
 // workgroups of the lattice reductions (range, histogram): every workgroup ends with atomics on the same few words, which
 // retire ~10 ns apart -- 1024 workgroups spent 10-30 us on that alone (a 1e6-point gather is not longer); NELLIE_SAMPLE_GRID
+// NELLIE_CHAIN_UNFUSED_SAMPLING=1: the chain's first round as two separate range + histogram sequences (A/B, tests)
+static bool chain_unfused_sampling() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("NELLIE_CHAIN_UNFUSED_SAMPLING"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v == 1;
+}
 static i64 sample_grid_cap() {
     static i64 v = 0;
     if (!v) { const char *e = getenv("NELLIE_SAMPLE_GRID"); v = (e && atoll(e) > 0) ? atoll(e) : 256; }
@@ -350,6 +356,7 @@ extern "C" int nl_ctx_destroy(nl_ctx *c) {
     if (c->ev_x_done) hipEventDestroy(c->ev_x_done);
     if (c->d_chain) hipFree(c->d_chain);
     if (c->h_chain) hipHostFree(c->h_chain);
+    if (c->ev_chain) hipEventDestroy(c->ev_chain);
     comm_release(c, c->comm2, 2);
     comm_release(c, c->comm, 1);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -823,35 +830,57 @@ extern "C" int nl_sample_gather(nl_ctx *c, int field, int64_t sz, int64_t sy, in
 
 // The positive samples of the same lattice, compacted on the device: only they cross PCIe (the consumers take
 // arr[arr > 0] first anyway: filtering.py:357, 957-959).  Order unspecified.  cap >= number of lattice points.
-extern "C" int nl_sample_gather_positive(nl_ctx *c, int field, int64_t sz, int64_t sy, int64_t sx, float *out, int64_t cap,
-                                         int64_t *n, char *err, size_t errlen) {
+// The positive lattice samples in two halves, so that the host can do other work (nl_chain_finish: wait for the chain's
+// records, repeat its decisions) while the kernel runs: _begin enqueues the kernel and the download of the count, _end waits and
+// fetches the samples.  No other call on this context in between except nl_chain_finish / nl_chain_log.
+extern "C" int nl_sample_gather_positive_begin(nl_ctx *c, int field, int64_t sz, int64_t sy, int64_t sx, int64_t *n_lattice, char *err, size_t errlen) {
     NL_ENTER(c);
     Lattice L; FieldSrc fs; int rc;
+    c->gp_total = -1;
     if ((rc = make_lattice(c, sz, sy, sx, L, err, errlen))) return rc;
     if ((rc = make_field(c, field, fs, err, errlen))) return rc;
     if ((rc = use_fsq_cache(c, fs, L, err, errlen))) return rc;
     const i64 total = L.cz * L.cy * L.cx;
-    if (n) *n = 0;
+    if (n_lattice) *n_lattice = total;
+    c->gp_total = total;
     if (total == 0) return NL_OK;
-    if (!out || cap < total) return nl_fail(err, errlen, NL_EINVAL, "output capacity %lld < %lld lattice points", (i64)cap, total);
-    if (total > c->n) return nl_fail(err, errlen, NL_EINVAL, "lattice larger than the volume");
-    float *stage = c->f[(c->i_gauss + 1) % 3];
+    if (total > c->n) { c->gp_total = -1; return nl_fail(err, errlen, NL_EINVAL, "lattice larger than the volume"); }
+    c->gp_stage = c->f[(c->i_gauss + 1) % 3];
     unsigned int *d_n = (unsigned int *)c->d_small;
     NL_HIP(zero_small(d_n, 4, c->stream));
     {
         ProfScope ps(c, "sample");
-        sample_gather_pos_kernel<<<(unsigned)((total + 255) / 256), 256, 0, c->stream>>>(fs, geom(c), L, stage, d_n);
+        sample_gather_pos_kernel<<<(unsigned)((total + 255) / 256), 256, 0, c->stream>>>(fs, geom(c), L, c->gp_stage, d_n);
         NL_CHECK_LAUNCH();
     }
     NL_HIP(hipMemcpyAsync(c->h_small, d_n, 4, hipMemcpyDeviceToHost, c->stream));
+    return NL_OK;
+}
+extern "C" int nl_sample_gather_positive_end(nl_ctx *c, float *out, int64_t cap, int64_t *n, char *err, size_t errlen) {
+    NL_ENTER(c);
+    if (c->gp_total < 0) return nl_fail(err, errlen, NL_ESTATE, "nl_sample_gather_positive_end without _begin");
+    const i64 total = c->gp_total;
+    c->gp_total = -1;
+    if (n) *n = 0;
+    if (total == 0) return NL_OK;
     NL_HIP(hipStreamSynchronize(c->stream));
     const i64 k = (i64)(*(unsigned int *)c->h_small);
+    if (k > cap || (k && !out)) return nl_fail(err, errlen, NL_EINVAL, "output capacity %lld < %lld positive samples", (i64)cap, k);
     if (k) {
-        NL_HIP(hipMemcpyAsync(out, stage, (size_t)k * 4, hipMemcpyDeviceToHost, c->stream));
+        NL_HIP(hipMemcpyAsync(out, c->gp_stage, (size_t)k * 4, hipMemcpyDeviceToHost, c->stream));
         NL_HIP(hipStreamSynchronize(c->stream));
     }
     if (n) *n = k;
     return NL_OK;
+}
+extern "C" int nl_sample_gather_positive(nl_ctx *c, int field, int64_t sz, int64_t sy, int64_t sx, float *out, int64_t cap,
+                                         int64_t *n, char *err, size_t errlen) {
+    int64_t total = 0;
+    if (n) *n = 0;
+    int rc = nl_sample_gather_positive_begin(c, field, sz, sy, sx, &total, err, errlen);
+    if (rc) return rc;
+    if (total > 0 && (!out || cap < total)) { c->gp_total = -1; return nl_fail(err, errlen, NL_EINVAL, "output capacity %lld < %lld lattice points", (i64)cap, (i64)total); }
+    return nl_sample_gather_positive_end(c, out, cap, n, err, errlen);
 }
 
 #define NL_NCCL(expr)                                                                                  \
@@ -979,6 +1008,39 @@ static int range_hist_enqueue_at(nl_ctx *c, int field, int64_t sz, int64_t sy, i
         NL_CHECK_LAUNCH();
         if (fused(c) && (rc = reduce_u64_sum(c, d_counts, (size_t)nbins, err, errlen))) return rc;
     }
+    return NL_OK;
+}
+// The Gaussian and the raw-Frobenius records of one scale (chain.inc) in three launches instead of seven: one pass fills the
+// frob_sq cache and both ranges, one builds both edge arrays, one bins both.  Records initialised by the caller; contexts
+// without fused reductions (those interleave collectives between the passes: range_hist_enqueue_at twice).
+static int range_hist_pair_enqueue(nl_ctx *c, int64_t sz, int64_t sy, int64_t sx, int nbins, char *dG, char *dF, char *err, size_t errlen) {
+    Lattice L; FieldSrc fsG, fsF; int rc;
+    if ((rc = make_lattice(c, sz, sy, sx, L, err, errlen))) return rc;
+    if ((rc = make_field(c, NL_FIELD_GAUSS, fsG, err, errlen))) return rc;
+    if ((rc = make_field(c, NL_FIELD_FROB, fsF, err, errlen))) return rc;
+    const i64 total = L.cz * L.cy * L.cx;
+    const size_t off_edges = (size_t)nbins * 8, off_res = off_edges + (((size_t)(nbins + 1) * 4 + 15) & ~(size_t)15);
+    unsigned int *resG = (unsigned int *)(dG + off_res), *resF = (unsigned int *)(dF + off_res);
+    float *edgesG = (float *)(dG + off_edges), *edgesF = (float *)(dF + off_edges);
+    if (total > c->fsq_cache_cap) {
+        if (c->d_fsq_cache) NL_HIP(hipFree(c->d_fsq_cache));
+        c->d_fsq_cache = nullptr; c->fsq_cache_cap = 0;
+        NL_HIP(hipMalloc((void **)&c->d_fsq_cache, (size_t)total * 4));
+        c->fsq_cache_cap = total;
+    }
+    ProfScope ps(c, "sample");
+    if (total > 0) {
+        sample_minmax2_kernel<<<grid1d(total, 256, sample_grid_cap()), 256, 0, c->stream>>>(fsG, fsF, geom(c), L, resG, resF, c->d_fsq_cache);
+        c->fsq_cache_key[0] = L.sz; c->fsq_cache_key[1] = L.sy; c->fsq_cache_key[2] = L.sx;
+        c->fsq_cache_valid = 1;
+        fsF.fsq_cache = c->d_fsq_cache;
+    }
+    sample_edges2_kernel<<<2, 64, 0, c->stream>>>(resG, edgesG, resG + 4, resF, edgesF, resF + 4, nbins);
+    const size_t sh = 2 * ((size_t)(nbins + 2) * 4 + (size_t)nbins * 4);
+    if (total > 0)
+        sample_hist2_kernel<<<grid1d(total, 256, sample_grid_cap()), 256, sh, c->stream>>>(fsG, fsF, geom(c), L, nbins, edgesG, (unsigned long long *)dG, resG + 4,
+                                                                                         edgesF, (unsigned long long *)dF, resF + 4);
+    NL_CHECK_LAUNCH();
     return NL_OK;
 }
 static void range_hist_read(const nl_ctx *c, int nbins, int slot, float *mn, float *mx, int64_t *npos, int64_t *counts, float *edges, int *valid) {
@@ -1385,11 +1447,12 @@ extern "C" int nl_chain_begin(nl_ctx *c, int n_scales, char *err, size_t errlen)
     if (!c->d_chain) {
         NL_HIP(hipMalloc(&c->d_chain, sizeof(ChainScale) * NL_CHAIN_MAX_SCALES));
         NL_HIP(hipHostMalloc(&c->h_chain, sizeof(ChainScale) * NL_CHAIN_MAX_SCALES, hipHostMallocDefault));
+        NL_HIP(hipEventCreateWithFlags(&c->ev_chain, hipEventDisableTiming));
     }
     chain_init_kernel<<<16, 256, 0, c->stream>>>((ChainScale *)c->d_chain, n_scales);
     chain_init2_kernel<<<1, 64, 0, c->stream>>>((ChainScale *)c->d_chain, n_scales);
     NL_CHECK_LAUNCH();
-    c->chain_n = n_scales; c->chain_k = 0;
+    c->chain_n = n_scales; c->chain_k = 0; c->chain_copy_pending = 0;
     return NL_OK;
 }
 
@@ -1405,9 +1468,13 @@ extern "C" int nl_chain_scale(nl_ctx *c, const double spacing[3], int64_t sz, in
     c->chain_par[c->chain_k][0] = division; c->chain_par[c->chain_k][1] = margin; c->chain_par[c->chain_k][2] = test_scale;
     ++c->chain_k;
     c->frob_max_abs = 1.0f; c->frob_max_finite = 0.0f;                    // the bracket round: max_abs := 1 (pipeline.py _fsq_bracket)
-    if ((rc = range_hist_enqueue_at(c, NL_FIELD_GAUSS, sz, sy, sx, NL_CHAIN_BINS, (char *)&cs->h_gauss, nullptr, err, errlen))) return rc;
-    if ((rc = range_hist_enqueue_at(c, NL_FIELD_FROB, sz, sy, sx, NL_CHAIN_BINS, (char *)&cs->h_raw, nullptr, err, errlen))) return rc;
-    chain_thr1_kernel<<<1, 64, 0, c->stream>>>(cs, division, margin, test_scale);
+    if (!fused(c) && !chain_unfused_sampling()) {
+        if ((rc = range_hist_pair_enqueue(c, sz, sy, sx, NL_CHAIN_BINS, (char *)&cs->h_gauss, (char *)&cs->h_raw, err, errlen))) return rc;
+    } else {
+        if ((rc = range_hist_enqueue_at(c, NL_FIELD_GAUSS, sz, sy, sx, NL_CHAIN_BINS, (char *)&cs->h_gauss, nullptr, err, errlen))) return rc;
+        if ((rc = range_hist_enqueue_at(c, NL_FIELD_FROB, sz, sy, sx, NL_CHAIN_BINS, (char *)&cs->h_raw, nullptr, err, errlen))) return rc;
+    }
+    chain_thr1_kernel<<<2, 64, 0, c->stream>>>(cs, division, margin, test_scale);
     NL_CHECK_LAUNCH();
     if ((rc = spec_enqueue(c, spacing, 0.0f, 0.0f, z0, z1, cs->stats, &cs->cnt_walk, &cs->fsq_lo, err, errlen))) return rc;
     chain_post_kernel<<<1, 64, 0, c->stream>>>(cs);
@@ -1435,15 +1502,33 @@ extern "C" int nl_chain_scale(nl_ctx *c, const double spacing[3], int64_t sz, in
     return resolve_enqueue(c, vp, &cs->cnt_resolve, (const float *)cs, err, errlen);
 }
 
+// Optional, before nl_chain_finish: start the download of the records now, so that work enqueued after this call (the samples
+// of the frame's percentile threshold) runs on the device while nl_chain_finish waits for the records only and repeats the
+// decisions on the host.
+extern "C" int nl_chain_flush(nl_ctx *c, char *err, size_t errlen) {
+    NL_ENTER(c);
+    if (!c->d_chain || c->chain_k < 1) return nl_fail(err, errlen, NL_ESTATE, "nl_chain_flush without scales");
+    NL_JOIN_SIDE(c);
+    NL_HIP(hipMemcpyAsync(c->h_chain, c->d_chain, sizeof(ChainScale) * (size_t)c->chain_k, hipMemcpyDeviceToHost, c->stream));
+    NL_HIP(hipEventRecord(c->ev_chain, c->stream));
+    c->chain_copy_pending = 1;
+    return NL_OK;
+}
+
 // The one wait of the frame: per scale flags (0 = the chain's result stands), gamma, max |H|, the Frobenius threshold and this
 // context's h_mask count.  Any non-zero flag: redo the frame the synchronous way.
 extern "C" int nl_chain_finish(nl_ctx *c, int *flags, double *gamma, double *max_abs, double *thr, int64_t *mask_count, char *err, size_t errlen) {
     NL_ENTER(c);
     if (!c->d_chain || c->chain_k < 1) return nl_fail(err, errlen, NL_ESTATE, "nl_chain_finish without scales");
-    NL_JOIN_SIDE(c);
     const int n = c->chain_k;
-    NL_HIP(hipMemcpyAsync(c->h_chain, c->d_chain, sizeof(ChainScale) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-    NL_HIP(hipStreamSynchronize(c->stream));
+    if (c->chain_copy_pending) {
+        NL_HIP(hipEventSynchronize(c->ev_chain));
+        c->chain_copy_pending = 0;
+    } else {
+        NL_JOIN_SIDE(c);
+        NL_HIP(hipMemcpyAsync(c->h_chain, c->d_chain, sizeof(ChainScale) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+        NL_HIP(hipStreamSynchronize(c->stream));
+    }
     const ChainScale *h = (const ChainScale *)c->h_chain;
     for (int k = 0; k < n; ++k) {
         const int f = chain_verify(h[k], c->chain_par[k][0], c->chain_par[k][1], c->chain_par[k][2]);

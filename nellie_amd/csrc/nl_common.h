@@ -98,6 +98,8 @@ struct nl_ctx {
     float frob_max_abs = 1.0f, frob_max_finite = 0.0f;
     int frangi_ready = 0;
     int mask_slots_used = 0;   // per-scale h_mask bit planes written since the frame began
+    hipEvent_t ev_chain = nullptr; int chain_copy_pending = 0;
+    i64 gp_total = -1; float *gp_stage = nullptr;   // nl_sample_gather_positive_begin .. _end
     void *d_chain = nullptr, *h_chain = nullptr;     // device-resident threshold chain (chain.inc): records of a frame's scales, pinned mirror
     int chain_n = 0, chain_k = 0;
     double chain_par[16][3] = {};                    // (division, margin, test scale) each scale was enqueued with

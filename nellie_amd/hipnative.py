@@ -46,6 +46,8 @@ _PROTOS = {
     "nl_gauss_commit": [_p],
     "nl_sample_gather": [_p, _int, _i64, _i64, _i64, _p, _i64, C.POINTER(_i64)],
     "nl_sample_gather_positive": [_p, _int, _i64, _i64, _i64, _p, _i64, C.POINTER(_i64)],
+    "nl_sample_gather_positive_begin": [_p, _int, _i64, _i64, _i64, C.POINTER(_i64)],
+    "nl_sample_gather_positive_end": [_p, _p, _i64, C.POINTER(_i64)],
     "nl_sample_minmax": [_p, _int, _i64, _i64, _i64, C.POINTER(_f32), C.POINTER(_f32), C.POINTER(_i64)],
     "nl_sample_hist": [_p, _int, _i64, _i64, _i64, _p, _int, _p],
     "nl_sample_range_hist": [_p, _int, _i64, _i64, _i64, _int, C.POINTER(_f32), C.POINTER(_f32), C.POINTER(_i64), _p, _p, C.POINTER(_int)],
@@ -118,6 +120,7 @@ _PROTOS = {
     "nl_comm_fuse": [_p, _int],
     "nl_chain_begin": [_p, _int],
     "nl_chain_scale": [_p, _p, _i64, _i64, _i64, _f64, _f64, _f64, _f64, _f64, _i64, _i64],
+    "nl_chain_flush": [_p],
     "nl_chain_finish": [_p, _p, _p, _p, _p, _p],
     "nl_chain_log": [_p, _int, _int, _p, _p, _p, _p],
     "nl_pinned_alloc": [C.POINTER(_p), _i64],
@@ -412,6 +415,19 @@ class Context:
             self._call("nl_sample_gather_positive", field, sz, sy, sx, _ptr(out), out.size, C.byref(n))
         return out[:int(n.value)]
 
+    def sample_gather_positive_begin(self, field, strides):
+        """Enqueue the compaction; sample_gather_positive_end() fetches.  Only chain_finish / chain_log in between."""
+        sz, sy, sx = (int(s) for s in strides)
+        n = _i64(0)
+        self._call("nl_sample_gather_positive_begin", field, sz, sy, sx, C.byref(n))
+        self._gp_cap = int(n.value)
+
+    def sample_gather_positive_end(self):
+        out = np.empty(self._gp_cap, dtype=np.float32)
+        n = _i64(0)
+        self._call("nl_sample_gather_positive_end", _ptr(out), out.size, C.byref(n))
+        return out[:int(n.value)]
+
     def sample_minmax(self, field, strides):
         sz, sy, sx = (int(s) for s in strides)
         mn, mx, n = _f32(0), _f32(0), _i64(0)
@@ -592,6 +608,9 @@ class Context:
         sz, sy, sx = (int(s) for s in strides)
         self._call("nl_chain_scale", sp, sz, sy, sx, float(alpha_sq), float(beta_sq), float(division), float(margin), float(test_scale),
                    int(z0), int(z1))
+
+    def chain_flush(self):
+        self._call("nl_chain_flush")
 
     def chain_finish(self):
         """-> (flags, gamma, max_abs, thr, mask_count) arrays over the scales; flags all zero: the chain's result stands."""

@@ -531,10 +531,19 @@ class FramePipeline:
             vz0, vz1 = self._vess_range()
             ctx.chain_scale(spacing, strides, float(p.alpha_sq), float(p.beta_sq), float(p.frob_thresh_division), self.one_pass_margin,
                             self._one_pass_test_scale, z0=vz0, z1=vz1)
+        # filter()'s percentile threshold reads lattice samples of the result: their compaction is enqueued BEFORE the wait, so it
+        # runs while the host waits for the chain's records and repeats its decisions (one round trip less per frame)
+        tail = self._tail_field is not None and hasattr(ctx, "sample_gather_positive_begin")
+        self._tail_samples = None
+        if tail:
+            ctx.chain_flush()
+            ctx.sample_gather_positive_begin(self._tail_field, strides)
         flags, gamma, max_abs, thr, counts = ctx.chain_finish()
+        samples = ctx.sample_gather_positive_end() if tail else None
         self.last_chain_flags = [int(f) for f in flags]
         if not self._all_ranks_agree(not flags.any()):
             return False
+        self._tail_samples = samples
         if self.check_device_edges:
             for k in range(len(sigmas)):
                 for which in range(3):
@@ -579,6 +588,11 @@ class FramePipeline:
         self.trace.percentile_thr = float(thr)
         return thr
 
+    # the device chain may gather the samples of the percentile threshold under its own wait (a single context: a slab pipeline
+    # gathers them across ranks)
+    _tail_ok = True
+    _tail_field = None
+    _tail_samples = None
     _fused_epilogue = True      # (a Z-slab pipeline on a context without nl_mask_volume_fused keeps the two-step epilogue)
     # Enqueue the cascade step of scale s+1 on the side stream beside the Hessian walk of scale s.  Exact either way.
     # Off by default: at 1024^3 it buys ~1 % (two full-GPU kernels mostly take turns) and it blurs per-kernel timings.
@@ -596,10 +610,16 @@ class FramePipeline:
                 self.mask_volume(p)
             return npos
         if self._fused_epilogue and not self.two_d:
-            self.compute_vesselness(frame, p, mask=mask, finish=False)
+            self._tail_field = FIELD_VESSELNESS if self._tail_ok else None
+            try:
+                self.compute_vesselness(frame, p, mask=mask, finish=False)
+            finally:
+                self._tail_field = None
+            positive, self._tail_samples = self._tail_samples, None
             if any(not sc.skipped for sc in self.trace.scales):
                 strides = self._strides(int(p.max_threshold_samples))
-                positive = self._positive_lattice_samples(FIELD_VESSELNESS, strides)
+                if positive is None:
+                    positive = self._positive_lattice_samples(FIELD_VESSELNESS, strides)
                 if positive.size > 0:
                     thr = np.percentile(positive, 1)
                     self.trace.percentile_thr = float(thr)

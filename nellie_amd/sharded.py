@@ -192,6 +192,8 @@ class RcclComm:
 
 
 class ShardedFramePipeline(FramePipeline):
+    _tail_ok = False            # the percentile samples are gathered across the ranks (pipeline.py: _scales_on_the_device)
+
     def __init__(self, gshape, rank, world, comm_factory, params: FilterParams, device: int = 0, ctx_factory=None, halo=None,
                  halo_mode=None):
         """
