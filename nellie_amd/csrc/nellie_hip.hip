@@ -1010,10 +1010,11 @@ static int range_hist_enqueue_at(nl_ctx *c, int field, int64_t sz, int64_t sy, i
     }
     return NL_OK;
 }
-// The Gaussian and the raw-Frobenius records of one scale (chain.inc) in three launches instead of seven: one pass fills the
-// frob_sq cache and both ranges, one builds both edge arrays, one bins both.  Records initialised by the caller; contexts
-// without fused reductions (those interleave collectives between the passes: range_hist_enqueue_at twice).
-static int range_hist_pair_enqueue(nl_ctx *c, int64_t sz, int64_t sy, int64_t sx, int nbins, char *dG, char *dF, char *err, size_t errlen) {
+// The Gaussian and the raw-Frobenius records of one scale in three launches instead of seven: one pass fills the frob_sq
+// cache and both ranges, one builds both edge arrays, one bins both.  With fused reductions: two grouped collectives instead of
+// four.  hG / hF: pinned mirrors the initial state is uploaded from, or NULL when the caller initialised the records (chain.inc).
+static int range_hist_pair_enqueue(nl_ctx *c, int64_t sz, int64_t sy, int64_t sx, int nbins, char *dG, char *dF, char *hG, char *hF,
+                                   char *err, size_t errlen) {
     Lattice L; FieldSrc fsG, fsF; int rc;
     if ((rc = make_lattice(c, sz, sy, sx, L, err, errlen))) return rc;
     if ((rc = make_field(c, NL_FIELD_GAUSS, fsG, err, errlen))) return rc;
@@ -1022,12 +1023,21 @@ static int range_hist_pair_enqueue(nl_ctx *c, int64_t sz, int64_t sy, int64_t sx
     const size_t off_edges = (size_t)nbins * 8, off_res = off_edges + (((size_t)(nbins + 1) * 4 + 15) & ~(size_t)15);
     unsigned int *resG = (unsigned int *)(dG + off_res), *resF = (unsigned int *)(dF + off_res);
     float *edgesG = (float *)(dG + off_edges), *edgesF = (float *)(dF + off_edges);
+    for (int k = 0; k < 2; ++k) {
+        char *h0 = k ? hF : hG, *d0 = k ? dF : dG;
+        if (!h0) continue;
+        unsigned int *h = (unsigned int *)(h0 + off_res);
+        h[0] = 0xffffffffu; h[1] = 0; h[2] = 0; h[3] = 0; h[4] = 0;
+        NL_HIP(hipMemcpyAsync(d0 + off_res, h, 20, hipMemcpyHostToDevice, c->stream));
+        NL_HIP(zero_small(d0, (size_t)nbins * 8, c->stream));
+    }
     if (total > c->fsq_cache_cap) {
         if (c->d_fsq_cache) NL_HIP(hipFree(c->d_fsq_cache));
         c->d_fsq_cache = nullptr; c->fsq_cache_cap = 0;
         NL_HIP(hipMalloc((void **)&c->d_fsq_cache, (size_t)total * 4));
         c->fsq_cache_cap = total;
     }
+    if (total == 0 && !fused(c)) return NL_OK;
     ProfScope ps(c, "sample");
     if (total > 0) {
         sample_minmax2_kernel<<<grid1d(total, 256, sample_grid_cap()), 256, 0, c->stream>>>(fsG, fsF, geom(c), L, resG, resF, c->d_fsq_cache);
@@ -1035,12 +1045,27 @@ static int range_hist_pair_enqueue(nl_ctx *c, int64_t sz, int64_t sy, int64_t sx
         c->fsq_cache_valid = 1;
         fsF.fsq_cache = c->d_fsq_cache;
     }
+    if (fused(c)) {
+        NL_NCCL(rccl().GroupStart());
+        for (unsigned int *res : {resG, resF}) {
+            NL_NCCL(rccl().AllReduce(res, res, 1, ncclUint32, ncclMin, (ncclComm_t)c->comm, c->stream));
+            NL_NCCL(rccl().AllReduce(res + 1, res + 1, 1, ncclUint32, ncclMax, (ncclComm_t)c->comm, c->stream));
+            NL_NCCL(rccl().AllReduce(res + 2, res + 2, 1, ncclUint64, ncclSum, (ncclComm_t)c->comm, c->stream));
+        }
+        NL_NCCL(rccl().GroupEnd());
+    }
     sample_edges2_kernel<<<2, 64, 0, c->stream>>>(resG, edgesG, resG + 4, resF, edgesF, resF + 4, nbins);
     const size_t sh = 2 * ((size_t)(nbins + 2) * 4 + (size_t)nbins * 4);
     if (total > 0)
         sample_hist2_kernel<<<grid1d(total, 256, sample_grid_cap()), 256, sh, c->stream>>>(fsG, fsF, geom(c), L, nbins, edgesG, (unsigned long long *)dG, resG + 4,
                                                                                          edgesF, (unsigned long long *)dF, resF + 4);
     NL_CHECK_LAUNCH();
+    if (fused(c)) {
+        NL_NCCL(rccl().GroupStart());
+        NL_NCCL(rccl().AllReduce(dG, dG, (size_t)nbins, ncclUint64, ncclSum, (ncclComm_t)c->comm, c->stream));
+        NL_NCCL(rccl().AllReduce(dF, dF, (size_t)nbins, ncclUint64, ncclSum, (ncclComm_t)c->comm, c->stream));
+        NL_NCCL(rccl().GroupEnd());
+    }
     return NL_OK;
 }
 static void range_hist_read(const nl_ctx *c, int nbins, int slot, float *mn, float *mx, int64_t *npos, int64_t *counts, float *edges, int *valid) {
@@ -1078,8 +1103,15 @@ extern "C" int nl_sample_range_hist2(nl_ctx *c, int field_a, int field_b, int64_
     NL_ENTER(c);
     if (!counts || !valid || !mn || !mx || !npos || nbins < 1 || nbins > 2048) return nl_fail(err, errlen, NL_EINVAL, "bad histogram arguments (nbins=%d)", nbins);
     int rc;
-    if ((rc = range_hist_enqueue(c, field_a, sz, sy, sx, nbins, 0, err, errlen))) return rc;
-    if ((rc = range_hist_enqueue(c, field_b, sz, sy, sx, nbins, 1, err, errlen))) return rc;
+    const bool fresh_cache = !(c->fsq_cache_valid && c->fsq_cache_key[0] == sz && c->fsq_cache_key[1] == sy && c->fsq_cache_key[2] == sx);
+    if (field_a == NL_FIELD_GAUSS && field_b == NL_FIELD_FROB && fresh_cache && nbins <= 1024 && !chain_unfused_sampling()) {
+        // the pair of a scale's first round (filtering.py:365-380, 421-444): one pass over the lattice
+        if ((rc = range_hist_pair_enqueue(c, sz, sy, sx, nbins, (char *)c->d_small, (char *)c->d_small + NL_RH_SLOT, (char *)c->h_small,
+                                          (char *)c->h_small + NL_RH_SLOT, err, errlen))) return rc;
+    } else {
+        if ((rc = range_hist_enqueue(c, field_a, sz, sy, sx, nbins, 0, err, errlen))) return rc;
+        if ((rc = range_hist_enqueue(c, field_b, sz, sy, sx, nbins, 1, err, errlen))) return rc;
+    }
     const size_t bytes = (size_t)nbins * 8 + (((size_t)(nbins + 1) * 4 + 15) & ~(size_t)15) + 32;
     for (int k = 0; k < 2; ++k)
         NL_HIP(hipMemcpyAsync((char *)c->h_small + (size_t)k * NL_RH_SLOT, (char *)c->d_small + (size_t)k * NL_RH_SLOT, bytes, hipMemcpyDeviceToHost, c->stream));
@@ -1468,8 +1500,8 @@ extern "C" int nl_chain_scale(nl_ctx *c, const double spacing[3], int64_t sz, in
     c->chain_par[c->chain_k][0] = division; c->chain_par[c->chain_k][1] = margin; c->chain_par[c->chain_k][2] = test_scale;
     ++c->chain_k;
     c->frob_max_abs = 1.0f; c->frob_max_finite = 0.0f;                    // the bracket round: max_abs := 1 (pipeline.py _fsq_bracket)
-    if (!fused(c) && !chain_unfused_sampling()) {
-        if ((rc = range_hist_pair_enqueue(c, sz, sy, sx, NL_CHAIN_BINS, (char *)&cs->h_gauss, (char *)&cs->h_raw, err, errlen))) return rc;
+    if (!chain_unfused_sampling()) {
+        if ((rc = range_hist_pair_enqueue(c, sz, sy, sx, NL_CHAIN_BINS, (char *)&cs->h_gauss, (char *)&cs->h_raw, nullptr, nullptr, err, errlen))) return rc;
     } else {
         if ((rc = range_hist_enqueue_at(c, NL_FIELD_GAUSS, sz, sy, sx, NL_CHAIN_BINS, (char *)&cs->h_gauss, nullptr, err, errlen))) return rc;
         if ((rc = range_hist_enqueue_at(c, NL_FIELD_FROB, sz, sy, sx, NL_CHAIN_BINS, (char *)&cs->h_raw, nullptr, err, errlen))) return rc;
