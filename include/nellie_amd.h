@@ -180,6 +180,12 @@ int nl_hist_thresholds(const int64_t *counts, const float *edges, int nbins, dou
    threshold, the second value of gpu_functions.py:50. */
 int nl_hist_thresholds_ex(const int64_t *counts, const void *edges, int edges_f64, int nbins, double *triangle, double *otsu,
                           double *otsu_var, int *status, char *err, size_t errlen);
+/* Host only: np.histogram(values, bins=nbins) of float32 data (range = its min .. max) and nl_hist_thresholds_ex of it in one
+   call -- Label's log-domain threshold (labelling.py:448-455) on the few 10^4 samples the device compacted.  Same float32
+   arithmetic as the device histogram.  *status: 0 ok, 1 degenerate triangle, 2 range not finite (numpy raises ValueError for
+   both).  counts_out (nbins) / edges_out (nbins + 1): optional copies of the histogram. */
+int nl_host_hist_thresholds_f32(const float *values, int64_t n, int nbins, double *triangle, double *otsu, int *status,
+                                int64_t *counts_out, float *edges_out, char *err, size_t errlen);
 
 /* Hessian by double finite differences of the current Gaussian volume (xp.gradient twice,
    filtering.py:518-536) on the owned planes; returns

@@ -1129,6 +1129,49 @@ extern "C" int nl_hist_thresholds(const int64_t *counts, const float *edges, int
     return NL_OK;
 }
 
+static void host_edges(float first, float last, int nbins, float *edges);
+// np.histogram(values, bins=nbins, range=(min, max)) of float32 host data + the two thresholds of that histogram, in one call
+// (labelling.py:448-455 after the log10: the samples are a few 10^4 values, numpy spends ~0.2-0.6 ms on them while the GPU
+// waits).  Same float32 arithmetic as sample_edges_kernel / sample_hist_kernel, which are pinned against numpy.  *status: 0 ok,
+// 1 degenerate triangle (numpy's ValueError), 2 range not finite (numpy's ValueError).  counts / edges: optional copies.
+extern "C" int nl_host_hist_thresholds_f32(const float *values, int64_t n, int nbins, double *triangle, double *otsu, int *status,
+                                           int64_t *counts_out, float *edges_out, char *err, size_t errlen) {
+    if (!values || n < 1 || !triangle || !otsu || !status || nbins < 1 || nbins > (1 << 20))
+        return nl_fail(err, errlen, NL_EINVAL, "bad histogram arguments (n=%lld, nbins=%d)", (long long)n, nbins);
+    float mn = values[0], mx = values[0];
+    bool nan = false;
+    for (int64_t i = 0; i < n; ++i) {
+        const float a = values[i];
+        if (a != a) nan = true;
+        if (a < mn) mn = a;
+        if (a > mx) mx = a;
+    }
+    *status = 0; *triangle = 0.0; *otsu = 0.0;
+    if (nan || !(fabsf(mn) <= 3.402823466e38f) || !(fabsf(mx) <= 3.402823466e38f)) { *status = 2; return NL_OK; }
+    std::vector<float> edges((size_t)nbins + 1);
+    std::vector<int64_t> counts((size_t)nbins, 0);
+    host_edges(mn, mx, nbins, edges.data());
+    volatile float first = mn, last = mx;
+    if (mn == mx) { first = mn - 0.5f; last = mx + 0.5f; }
+    const float f0 = first, f1 = last;
+    volatile float denom = f1 - f0;
+    const float dn = denom, nb = (float)nbins;
+    for (int64_t i = 0; i < n; ++i) {
+        const float a = values[i];
+        if (!(a >= f0 && a <= f1)) continue;
+        const float t = ((a - f0) / dn) * nb;          // float32 throughout (x86-64 SSE, -ffp-contract=off): numpy's expression
+        int idx = (int)t;
+        if (idx == nbins) idx -= 1;
+        if (a < edges[idx]) idx -= 1;
+        if (a >= edges[idx + 1] && idx != nbins - 1) idx += 1;
+        counts[idx] += 1;
+    }
+    hist_thresholds_host<float>(counts.data(), edges.data(), nbins, triangle, otsu, status, nullptr);
+    if (counts_out) memcpy(counts_out, counts.data(), (size_t)nbins * 8);
+    if (edges_out) memcpy(edges_out, edges.data(), ((size_t)nbins + 1) * 4);
+    return NL_OK;
+}
+
 extern "C" int nl_hist_thresholds_ex(const int64_t *counts, const void *edges, int edges_f64, int nbins, double *triangle, double *otsu,
                                      double *otsu_var, int *status, char *err, size_t errlen) {
     if (!counts || !edges || !triangle || !otsu || !status || nbins < 1 || nbins > (1 << 20))

@@ -54,6 +54,7 @@ _PROTOS = {
     "nl_sample_range_hist2": [_p, _int, _int, _i64, _i64, _i64, _int, _p, _p, _p, _p, _p, _p],
     "nl_hist_thresholds": [_p, _p, _int, C.POINTER(_f64), C.POINTER(_f64), C.POINTER(_int)],
     "nl_hist_thresholds_ex": [_p, _p, _int, _int, C.POINTER(_f64), C.POINTER(_f64), C.POINTER(_f64), C.POINTER(_int)],
+    "nl_host_hist_thresholds_f32": [_p, _i64, _int, C.POINTER(_f64), C.POINTER(_f64), C.POINTER(_int), _p, _p],
     "nl_outputs_pack": [_p, _int, _p],
     "nl_outputs_fetch_packed_async": [_p, _p, _i64],
     "nl_outputs_unpack": [_p, _i64, _p, _p, _i64, _int, _int],
@@ -241,6 +242,23 @@ def hist_thresholds(counts, edges, with_variance=False):
     if with_variance:
         return out_t(tri.value), out_t(otsu.value), np.float64(var.value)
     return out_t(tri.value), out_t(otsu.value)
+
+
+def host_hist_thresholds(values, nbins=256, with_histogram=False):
+    """(triangle, otsu) of np.histogram(values, bins=nbins) for float32 host data, computed by the library in one call
+    (nl_host_hist_thresholds_f32); with_histogram: (triangle, otsu, counts, edges).  Raises ValueError where numpy would."""
+    v = np.ascontiguousarray(values, dtype=np.float32).reshape(-1)
+    tri, otsu, status = _f64(0.0), _f64(0.0), _int(0)
+    counts = np.zeros(nbins, np.int64) if with_histogram else None
+    edges = np.zeros(nbins + 1, np.float32) if with_histogram else None
+    load().call("nl_host_hist_thresholds_f32", _ptr(v), int(v.size), int(nbins), C.byref(tri), C.byref(otsu), C.byref(status),
+                None if counts is None else _ptr(counts), None if edges is None else _ptr(edges))
+    if status.value == 2:
+        raise ValueError("autodetected range of [%s, %s] is not finite" % (v.min(), v.max()))
+    if status.value == 1:
+        raise ValueError("attempt to get argmax of an empty sequence")
+    out = (np.float32(tri.value), np.float32(otsu.value))
+    return out + (counts, edges) if with_histogram else out
 
 
 def outputs_unpack(blob, nbytes, frangi, labels=None, zero_fill=True, threads=8):

@@ -121,3 +121,63 @@ def test_host_parameters_match_oracle():
             assert w is None
         else:
             assert np.array_equal(w, orc.gaussian_kernel1d(sd, orc.gaussian_radius(sd)))
+
+
+def test_host_histogram_thresholds_equal_numpy_then_library():
+    """nl_host_hist_thresholds_f32 = np.histogram of float32 data + nl_hist_thresholds_ex, bit for bit (labelling.py:448-455)."""
+    import numpy as np
+    from nellie_amd import hipnative
+    rng = np.random.default_rng(7)
+    cases = [np.log10(rng.random(n, dtype=np.float32) + np.float32(1e-6)) for n in (2, 3, 17, 1000, 30011, 70001)]
+    cases.append(np.log10(rng.lognormal(0.0, 2.0, 20000).astype(np.float32)))
+    cases.append(np.array([0.25, 0.25, 0.25, 0.5], np.float32))                      # values on bin edges
+    cases.append(np.linspace(-3.0, 2.0, 257, dtype=np.float32))                     # every value on or near an edge
+    cases.append(np.float32(1e-30) * rng.random(5000, dtype=np.float32))            # tiny range
+    for v in cases:
+        counts, edges = np.histogram(v, bins=256, range=(v.min(), v.max()))
+        assert edges.dtype == np.float32
+        try:
+            want = hipnative.hist_thresholds(counts, edges)
+        except ValueError:
+            want = None
+        if want is None:
+            with pytest.raises(ValueError):
+                hipnative.host_hist_thresholds(v, 256)
+            continue
+        tri, otsu, c2, e2 = hipnative.host_hist_thresholds(v, 256, with_histogram=True)
+        assert np.array_equal(c2, counts) and np.array_equal(e2, edges)
+        assert (tri, otsu) == want and type(tri) is type(want[0])
+    same = np.full(100, 0.5, np.float32)                                             # empty range: numpy widens by +-0.5
+    counts, edges = np.histogram(same, bins=256, range=(same.min(), same.max()))
+    _, _, c2, e2 = _with_hist_or_none(hipnative, same)
+    assert np.array_equal(c2, counts) and np.array_equal(e2, edges)
+    with pytest.raises(ValueError):
+        hipnative.host_hist_thresholds(np.array([1.0, np.inf], np.float32), 256)
+
+
+def _with_hist_or_none(hipnative, v):
+    import numpy as np
+    import ctypes as C
+    # the thresholds of a one-bin histogram are degenerate (ValueError): fetch the histogram alone through the C entry point
+    counts, edges = np.zeros(256, np.int64), np.zeros(257, np.float32)
+    tri, otsu, st = C.c_double(0), C.c_double(0), C.c_int(0)
+    hipnative.load().call("nl_host_hist_thresholds_f32", v.ctypes.data_as(C.c_void_p), int(v.size), 256, C.byref(tri), C.byref(otsu),
+                          C.byref(st), counts.ctypes.data_as(C.c_void_p), edges.ctypes.data_as(C.c_void_p))
+    return tri.value, otsu.value, counts, edges
+
+
+def test_percentile_shortcut_is_numpy_percentile():
+    """pipeline.percentile_of_samples: the shortcut passes its own probe with the installed numpy and equals np.percentile."""
+    import numpy as np
+    from nellie_amd import pipeline as pl
+    assert pl._shortcut_matches_numpy()
+    rng = np.random.default_rng(11)
+    for n in (1, 2, 5, 99, 100, 101, 199, 200, 201, 12345, 50000):
+        for make in (lambda: rng.random(n, dtype=np.float32), lambda: np.round(rng.random(n, dtype=np.float32), 1) + np.float32(0.1),
+                     lambda: (rng.random(n, dtype=np.float32) * np.float32(1e-20)).astype(np.float32)):
+            v = make()
+            keep = v.copy()
+            got, want = pl.percentile_of_samples(v, 1), np.percentile(v, 1)
+            assert type(got) is type(want) and got == want, (n, got, want)
+            assert np.array_equal(v, keep)                        # the caller's samples are left alone
+    assert pl.percentile_of_samples(np.arange(10.0), 1) == np.percentile(np.arange(10.0), 1)      # other dtypes: numpy itself
