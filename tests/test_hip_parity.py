@@ -934,3 +934,59 @@ def test_device_chain_on_the_golden_cases(name, hip):
         assert isinstance(frames[0][0], str) and isinstance(frames[1][0], str)
     else:
         assert frames[0][1] == frames[1][1] and np.array_equal(frames[0][0], frames[1][0])
+
+
+def test_positive_gather_in_two_halves_and_under_the_chain_wait(hip):
+    """nl_sample_gather_positive_begin / _end give the one-call result; _end without _begin is a state error; and the frame's
+    percentile threshold is the same whether its samples are compacted under the chain's wait (default) or afterwards."""
+    from nellie_amd import hipnative, pipeline as pl
+    from nellie_amd.synthetic import ISO_01, make_volume
+    vol = make_volume((48, 112, 120), 31)
+    res = []
+    for tail in (True, False):
+        pipe = pl.FramePipeline(vol.shape)
+        pipe._tail_ok = tail
+        pipe.filter(vol, pl.FilterParams(dim_res=ISO_01))
+        assert pipe.chain_fallbacks == 0
+        res.append((pipe.trace.percentile_thr, pipe.trace.n_positive, pipe.download_frangi()))
+        if tail:
+            ctx = pipe.ctx
+            strides = pipe._strides(1_000_000)
+            one = np.sort(ctx.sample_gather_positive(pl.FIELD_FRANGI, strides))
+            ctx.sample_gather_positive_begin(pl.FIELD_FRANGI, strides)
+            two = np.sort(ctx.sample_gather_positive_end())
+            assert one.size > 0 and np.array_equal(one, two)
+            with pytest.raises(hipnative.NellieHipError):
+                ctx.sample_gather_positive_end()
+        pipe.close()
+    assert res[0][0] == res[1][0] and res[0][1] == res[1][1] and np.array_equal(res[0][2], res[1][2])
+
+
+def test_fused_pair_sampling_equals_two_separate_sequences(hip, tmp_path):
+    """sample_minmax2 / edges2 / hist2 (one pass for the Gaussian and the Frobenius samples of a scale) against the two separate
+    range + histogram sequences (NELLIE_CHAIN_UNFUSED_SAMPLING=1, read once per process: a child process), chain and synchronous."""
+    import json, subprocess, sys
+    code = r'''
+import json, sys, zlib
+import numpy as np
+from nellie_amd import pipeline as pl
+from nellie_amd.synthetic import ANISO_03, make_volume
+vol = make_volume((40, 100, 132), 77)
+out = {}
+for chain in (True, False):
+    pipe = pl.FramePipeline(vol.shape)
+    pipe._device_chain = chain
+    pipe.filter(vol, pl.FilterParams(dim_res=ANISO_03))
+    tr = [(s.sigma, s.gamma, s.max_abs, s.frob_thr, s.mask_count) for s in pipe.trace.scales]
+    out[str(chain)] = [tr, pipe.trace.percentile_thr, zlib.crc32(pipe.download_frangi().tobytes()), pipe.chain_fallbacks]
+    pipe.close()
+print(json.dumps(out))
+'''
+    got = []
+    for unfused in ("0", "1"):
+        env = dict(os.environ, NELLIE_CHAIN_UNFUSED_SAMPLING=unfused, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert got[0] == got[1]
+    assert got[0]["True"][:3] == got[0]["False"][:3] and got[0]["True"][3] == 0
