@@ -355,6 +355,10 @@ int nl_label_load_frangi(nl_ctx *ctx, const float *host, int64_t z0, int64_t z1,
    the exactly converted original, `thresh` already rounded by the host as numpy would. */
 int nl_label_intensity_mask(nl_ctx *ctx, const void *host_original, int dtype, double thresh,
                             char *err, size_t errlen);
+/* The same on planes [z0, z1) of the context's frame; `host_original` holds those planes of the original image (a Z slab masks
+   the planes it owns: Label's intensity thresholds on a sharded frame). */
+int nl_label_intensity_mask_planes(nl_ctx *ctx, const void *host_original, int dtype, double thresh, int64_t z0, int64_t z1,
+                                   char *err, size_t errlen);
 
 /* flat[offset::step] of a field (labelling.py:393, 412). */
 int nl_flat_sample_gather(nl_ctx *ctx, int field, int64_t offset, int64_t step,

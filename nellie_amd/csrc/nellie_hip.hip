@@ -2447,33 +2447,41 @@ extern "C" int nl_label_load_frangi(nl_ctx *c, const float *host, int64_t z0, in
     return NL_OK;
 }
 
-extern "C" int nl_label_intensity_mask(nl_ctx *c, const void *host_original, int dtype, double thresh, char *err, size_t errlen) {
+// planes [z0, z1) of the context's frame against `host_original` = those planes of the original image (a Z slab masks the planes it owns)
+extern "C" int nl_label_intensity_mask_planes(nl_ctx *c, const void *host_original, int dtype, double thresh, int64_t z0, int64_t z1,
+                                              char *err, size_t errlen) {
     NL_ENTER(c);
+    if (z0 < 0 || z1 > c->nzl || z0 >= z1) return nl_fail(err, errlen, NL_EINVAL, "bad plane range [%lld,%lld)", (i64)z0, (i64)z1);
+    const i64 count = (z1 - z0) * c->ny * c->nx;
     const size_t es = dtype_size(dtype);
     if (!es || !host_original) return nl_fail(err, errlen, NL_EINVAL, "bad original image (dtype code %d)", dtype);
     void *raw = nullptr;
-    NL_HIP(hipMalloc(&raw, (size_t)c->n * es));
-    hipError_t e = hipMemcpyAsync(raw, host_original, (size_t)c->n * es, hipMemcpyHostToDevice, c->stream);
+    NL_HIP(hipMalloc(&raw, (size_t)count * es));
+    hipError_t e = hipMemcpyAsync(raw, host_original, (size_t)count * es, hipMemcpyHostToDevice, c->stream);
     if (e != hipSuccess) { hipFree(raw); return nl_fail(err, errlen, NL_EHIP, "upload of the original image failed: %s", hipGetErrorString(e)); }
-    float *fr = c->f[c->i_vmax];
-    const unsigned int g = grid1d(c->n);
+    float *fr = c->f[c->i_vmax] + z0 * c->ny * c->nx;
+    const unsigned int g = grid1d(count);
     switch (dtype) {
-        case NL_U8: intensity_mask_kernel<uint8_t><<<g, 256, 0, c->stream>>>((const uint8_t *)raw, fr, thresh, c->n); break;
-        case NL_I8: intensity_mask_kernel<int8_t><<<g, 256, 0, c->stream>>>((const int8_t *)raw, fr, thresh, c->n); break;
-        case NL_U16: intensity_mask_kernel<uint16_t><<<g, 256, 0, c->stream>>>((const uint16_t *)raw, fr, thresh, c->n); break;
-        case NL_I16: intensity_mask_kernel<int16_t><<<g, 256, 0, c->stream>>>((const int16_t *)raw, fr, thresh, c->n); break;
-        case NL_U32: intensity_mask_kernel<uint32_t><<<g, 256, 0, c->stream>>>((const uint32_t *)raw, fr, thresh, c->n); break;
-        case NL_I32: intensity_mask_kernel<int32_t><<<g, 256, 0, c->stream>>>((const int32_t *)raw, fr, thresh, c->n); break;
-        case NL_F32: intensity_mask_kernel<float><<<g, 256, 0, c->stream>>>((const float *)raw, fr, thresh, c->n); break;
-        case NL_F64: intensity_mask_kernel<double><<<g, 256, 0, c->stream>>>((const double *)raw, fr, thresh, c->n); break;
-        case NL_U64: intensity_mask_kernel<uint64_t><<<g, 256, 0, c->stream>>>((const uint64_t *)raw, fr, thresh, c->n); break;
-        case NL_I64: intensity_mask_kernel<int64_t><<<g, 256, 0, c->stream>>>((const int64_t *)raw, fr, thresh, c->n); break;
+        case NL_U8: intensity_mask_kernel<uint8_t><<<g, 256, 0, c->stream>>>((const uint8_t *)raw, fr, thresh, count); break;
+        case NL_I8: intensity_mask_kernel<int8_t><<<g, 256, 0, c->stream>>>((const int8_t *)raw, fr, thresh, count); break;
+        case NL_U16: intensity_mask_kernel<uint16_t><<<g, 256, 0, c->stream>>>((const uint16_t *)raw, fr, thresh, count); break;
+        case NL_I16: intensity_mask_kernel<int16_t><<<g, 256, 0, c->stream>>>((const int16_t *)raw, fr, thresh, count); break;
+        case NL_U32: intensity_mask_kernel<uint32_t><<<g, 256, 0, c->stream>>>((const uint32_t *)raw, fr, thresh, count); break;
+        case NL_I32: intensity_mask_kernel<int32_t><<<g, 256, 0, c->stream>>>((const int32_t *)raw, fr, thresh, count); break;
+        case NL_F32: intensity_mask_kernel<float><<<g, 256, 0, c->stream>>>((const float *)raw, fr, thresh, count); break;
+        case NL_F64: intensity_mask_kernel<double><<<g, 256, 0, c->stream>>>((const double *)raw, fr, thresh, count); break;
+        case NL_U64: intensity_mask_kernel<uint64_t><<<g, 256, 0, c->stream>>>((const uint64_t *)raw, fr, thresh, count); break;
+        case NL_I64: intensity_mask_kernel<int64_t><<<g, 256, 0, c->stream>>>((const int64_t *)raw, fr, thresh, count); break;
     }
     e = hipGetLastError();
     hipStreamSynchronize(c->stream);
     hipFree(raw);
     if (e != hipSuccess) return nl_fail(err, errlen, NL_EHIP, "intensity mask kernel: %s", hipGetErrorString(e));
     return NL_OK;
+}
+extern "C" int nl_label_intensity_mask(nl_ctx *c, const void *host_original, int dtype, double thresh, char *err, size_t errlen) {
+    if (!c) return nl_fail(err, errlen, NL_EINVAL, "ctx is NULL");
+    return nl_label_intensity_mask_planes(c, host_original, dtype, thresh, 0, c->nzl, err, errlen);
 }
 
 extern "C" int nl_flat_sample_gather(nl_ctx *c, int field, int64_t offset, int64_t step, float *out, int64_t cap, int64_t *n,

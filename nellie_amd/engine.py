@@ -88,6 +88,10 @@ class SingleContext:
     def upload_frangi(self, frangi):
         self.pipe.upload_frangi(frangi)
 
+    def intensity_mask(self, original, thresh):
+        """frangi *= (original > thresh) on the uploaded Frangi frame (labelling.py:550-552)."""
+        self.pipe.ctx.label_intensity_mask(np.asarray(original), thresh)
+
     def frangi_threshold(self, max_samples=1_000_000, nbins=256):
         return self.pipe.frangi_threshold(max_samples, nbins)
 
@@ -195,6 +199,9 @@ class LocalSlabs(_SlabBase):
     def upload_frangi(self, frangi):
         self._each(lambda r: self.pipes[r].upload_frangi(_planes(frangi, *self._own(self.pipes[r]))))
 
+    def intensity_mask(self, original, thresh):
+        self._each(lambda r: self.pipes[r].intensity_mask(_planes(original, *self._own(self.pipes[r])), thresh))
+
     def frangi_threshold(self, max_samples=1_000_000, nbins=256):
         return self._each(lambda r: self.pipes[r].frangi_threshold(max_samples, nbins))[0]
 
@@ -275,6 +282,9 @@ class RankSlab(_SlabBase):
 
     def upload_frangi(self, frangi):
         self.pipe.upload_frangi(_planes(frangi, *self._own(self.pipe)))
+
+    def intensity_mask(self, original, thresh):
+        self.pipe.intensity_mask(_planes(original, *self._own(self.pipe)), thresh)
 
     def frangi_threshold(self, max_samples=1_000_000, nbins=256):
         return self.pipe.frangi_threshold(max_samples, nbins)

@@ -95,6 +95,7 @@ _PROTOS = {
     "nl_gauss_store": [_p, _p, _i64, _i64],
     "nl_label_load_frangi": [_p, _p, _i64, _i64],
     "nl_label_intensity_mask": [_p, _p, _int, _f64],
+    "nl_label_intensity_mask_planes": [_p, _p, _int, _f64, _i64, _i64],
     "nl_flat_sample_gather": [_p, _int, _i64, _i64, _p, _i64, C.POINTER(_i64)],
     "nl_flat_sample_gather_positive": [_p, _int, _i64, _i64, _p, _i64, C.POINTER(_i64)],
     "nl_label_run": [_p, _int, _f32, _i64, _int, C.POINTER(_i64)],
@@ -758,12 +759,19 @@ class Context:
         assert a.shape == (z1 - z0, self.shape[1], self.shape[2])
         self._call("nl_label_load_frangi", _ptr(a), z0, z1)
 
-    def label_intensity_mask(self, original: np.ndarray, thresh: float):
+    def label_intensity_mask(self, original: np.ndarray, thresh: float, z0=None, z1=None):
+        """frangi *= (original > thresh); z0, z1: only those planes, `original` holding exactly them."""
         a = np.ascontiguousarray(original)
         if a.dtype not in DTYPE_CODES:
             a = a.astype(np.float64)
-        assert a.shape == self.shape
-        self._call("nl_label_intensity_mask", _ptr(a), DTYPE_CODES[a.dtype], float(thresh))
+        if z0 is None and z1 is None:
+            assert a.shape == self.shape
+            self._call("nl_label_intensity_mask", _ptr(a), DTYPE_CODES[a.dtype], float(thresh))
+            return
+        z0 = 0 if z0 is None else int(z0)
+        z1 = self.shape[0] if z1 is None else int(z1)
+        assert a.shape == (z1 - z0,) + tuple(self.shape[1:])
+        self._call("nl_label_intensity_mask_planes", _ptr(a), DTYPE_CODES[a.dtype], float(thresh), z0, z1)
 
     def flat_sample_gather(self, field, offset, step):
         n = _i64(0)

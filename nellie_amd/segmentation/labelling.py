@@ -270,10 +270,13 @@ class Label:
             shape3 = self._as3d(frangi_view).shape if np.asarray(frangi_view).ndim == 2 else tuple(frangi_view.shape)
             kind = "single" if self.im_info.no_z else plan_engine(shape3, self._engine_params(), self.devices, self._shard_spec(), label_only=True)[0]
             if kind != "single":
-                if self._intensity_threshold(original_view) is not None:
-                    raise NotImplementedError("intensity thresholds (otsu_thresh_intensity / threshold) are not available on Z-slab runs")
+                # the intensity threshold comes from a strided sample of the ORIGINAL image on the host (every rank reads the same
+                # file and finds the same value); each slab then masks the planes it owns (labelling.py:513-520, 550-552)
+                intensity_thresh = self._intensity_threshold(original_view)
                 engine = self._get_engine(shape3)
                 engine.upload_frangi(frangi_view)
+                if intensity_thresh is not None:
+                    engine.intensity_mask(original_view, self._effective_threshold(np.asarray(original_view[:1]), intensity_thresh))
                 frangi_thresh = engine.frangi_threshold(self.threshold_sampling_pixels, self.histogram_nbins)
                 engine.label(frangi_thresh, self.min_area_pixels, fill_holes=True)
                 engine.download_labels(out=self.instance_label_memmap[t, ...])

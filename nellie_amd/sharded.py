@@ -365,6 +365,11 @@ class ShardedFramePipeline(FramePipeline):
         lo, hi = self.own
         self.ctx.label_load_frangi(np.asarray(frangi, dtype=np.float32), z0=lo, z1=hi)
 
+    def intensity_mask(self, original, thresh):
+        """labelling.py:550-552 on this rank's OWN planes (`original` = those planes of the original image)."""
+        lo, hi = self.own
+        self.ctx.label_intensity_mask(np.asarray(original), thresh, z0=lo, z1=hi)
+
     def _gather_list(self, arr):
         f = getattr(self.comm, "allgather_list", None)
         if f is not None:

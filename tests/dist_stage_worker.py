@@ -28,6 +28,13 @@ def main():
     Filter(im_info, shard=spec).run()
     Label(im_info, shard=spec).run()
     dist.barrier()
+    if len(sys.argv) > 3:                                # then once more with a fixed intensity threshold (labelling.py:513-520, 550-552)
+        import numpy as np
+        if rank == 0:
+            np.save(os.path.join(out_dir, "labels_plain.npy"), np.asarray(im_info.get_memmap(im_info.pipeline_paths["im_instance_label"], read_mode="r")))
+        dist.barrier()
+        Label(im_info, threshold=float(sys.argv[3]), shard=spec).run()
+        dist.barrier()
     dist.destroy_process_group()
 
 

@@ -184,6 +184,12 @@ class OracleCtx:
         self.frangi = np.zeros(self.shape, np.float32)
         self.frangi[z0:z1] = frangi
 
+    def label_intensity_mask(self, original, thresh, z0=None, z1=None):
+        z0 = 0 if z0 is None else z0
+        z1 = self.shape[0] if z1 is None else z1
+        keep = np.asarray(original).astype(np.float64) > float(thresh)
+        self.frangi[z0:z1] = np.where(keep, self.frangi[z0:z1], np.float32(0))
+
     def slab_label_pack(self, thr):
         lo, hi = self.own
         self.bits = [np.zeros(self.shape, bool), np.zeros(self.shape, bool)]

@@ -408,6 +408,25 @@ def test_stage_api_remove_edges_on_local_slabs(hip, monkeypatch):
     assert (a.store["frangi"] > 0).any() and np.array_equal(a.store["frangi"], b.store["frangi"])
 
 
+@pytest.mark.parametrize("kw", [dict(threshold=101.5), dict(otsu_thresh_intensity=True)])
+def test_stage_api_label_intensity_thresholds_on_local_slabs(hip, monkeypatch, kw):
+    """Label(threshold=...) / Label(otsu_thresh_intensity=True) through the slab engine (every slab masks the planes it owns with
+    the original image, labelling.py:513-520, 550-552) == the single-context stage; uint16 input."""
+    from fakes import ArrayImInfo
+    from nellie_amd.segmentation.filtering import Filter
+    from nellie_amd.segmentation.labelling import Label
+    from nellie_amd.synthetic import ISO_01, make_volume
+    vols = make_volume((80, 64, 72), 23, dtype=np.uint16)[None]
+    a, b, plain = ArrayImInfo(vols, ISO_01), ArrayImInfo(vols, ISO_01), ArrayImInfo(vols, ISO_01)
+    Filter(a, device="gpu").run(); Label(a, device="gpu", **kw).run()
+    Filter(plain, device="gpu").run(); Label(plain, device="gpu").run()
+    monkeypatch.setenv("NELLIE_FORCE_SLABS", "3")
+    Filter(b, device="gpu").run(); Label(b, device="gpu", **kw).run()
+    assert np.array_equal(a.store["frangi"], b.store["frangi"])
+    assert a.store["labels"].max() >= 1 and np.array_equal(a.store["labels"], b.store["labels"])
+    assert not np.array_equal(a.store["labels"], plain.store["labels"])          # the threshold did something
+
+
 def test_stage_api_rank_slabs_over_loopback_threads(hip, tmp_path):
     """The multi-process layout of the stage API (engine.RankSlab: one rank per process, rank 0 creates the files, every rank
     writes its own planes) with the real HIP engine -- the ranks are three threads here, their communicators the library's

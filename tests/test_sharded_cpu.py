@@ -80,16 +80,20 @@ def test_stage_api_world2_gloo_writes_the_single_rank_files(tmp_path):
     im_info = ImInfo(src, output_dir=out_dir)                      # makes the canonical copy the ranks reuse
     port = 29900 + (os.getpid() % 90)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(REPO, "tests", "dist_stage_worker.py"), src, out_dir]
+           "--master-port", str(port), os.path.join(REPO, "tests", "dist_stage_worker.py"), src, out_dir, "101.5"]
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     fr = np.asarray(im_info.get_memmap(im_info.pipeline_paths["im_preprocessed"], read_mode="r"))
-    lab = np.asarray(im_info.get_memmap(im_info.pipeline_paths["im_instance_label"], read_mode="r"))
-    assert fr.shape == vols.shape == lab.shape and fr.dtype == np.float32 and lab.dtype == np.int32
+    lab = np.load(os.path.join(out_dir, "labels_plain.npy"))
+    lab_thr = np.asarray(im_info.get_memmap(im_info.pipeline_paths["im_instance_label"], read_mode="r"))     # the second Label run
+    assert fr.shape == vols.shape == lab.shape == lab_thr.shape and fr.dtype == np.float32 and lab.dtype == np.int32
     for t in range(2):
         ref = orc.filter_frame(vols[t], ISO_01)
         assert np.array_equal(fr[t], ref), f"t={t}: {int((fr[t] != ref).sum())} voxels differ"
         assert np.array_equal(lab[t], orc.label_frame(ref, ISO_01)) and lab[t].max() >= 1
+        # Label(threshold=101.5) on the slabs: every rank masks the planes it owns with the original image
+        want = orc.label_frame(ref, ISO_01, original=vols[t], threshold=101.5)
+        assert np.array_equal(lab_thr[t], want) and want.max() >= 1 and not np.array_equal(want, lab[t])
     assert np.array_equal(np.asarray(im_info.get_memmap(im_info.im_path, read_mode="r")), vols), "input file was modified"
 
 
