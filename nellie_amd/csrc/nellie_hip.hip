@@ -202,34 +202,45 @@ template <typename K> static void allow_lds(K kernel, int bytes) {
 }
 // the pair kernel addresses the planes of a Z chunk through one buffer resource (32-bit byte offsets)
 static int hv_rs(const nl_ctx *c) { return ((i64)(HM_ZCHUNK + 4) * c->ny * c->nx * 4 < ((i64)1 << 32)) ? hv_rs_env() : 0; }
-static Dv<true> dv_fast(float d) { return Dv<true>{d, (float)(1.0 / (double)d)}; }
-static Dv<false> dv_exact(float d) { return Dv<false>{1.0 / (double)d}; }
-static HessDv<true> hessdv_fast(const nl_ctx *c) {
-    return HessDv<true>{dv_fast(c->hz), dv_fast(c->hy), dv_fast(c->hx), dv_fast(c->hz2), dv_fast(c->hy2), dv_fast(c->hx2)};
+static Dv<1> dv_fast(float d) { return Dv<1>{d, (float)(1.0 / (double)d)}; }
+static Dv<2> dv_two(float d) {              // yh = RN32(1/d), yl = RN32(1/d - yh), both from the float64 quotient
+    const double inv = 1.0 / (double)d;
+    const float yh = (float)inv;
+    return Dv<2>{(float)(inv - (double)yh), yh};
 }
-static HessDv<false> hessdv_exact(const nl_ctx *c) {
-    return HessDv<false>{dv_exact(c->hz), dv_exact(c->hy), dv_exact(c->hx), dv_exact(c->hz2), dv_exact(c->hy2), dv_exact(c->hx2)};
+static Dv<0> dv_exact(float d) { return Dv<0>{1.0 / (double)d}; }
+static HessDv<1> hessdv_fast(const nl_ctx *c) {
+    return HessDv<1>{dv_fast(c->hz), dv_fast(c->hy), dv_fast(c->hx), dv_fast(c->hz2), dv_fast(c->hy2), dv_fast(c->hx2)};
+}
+static HessDv<2> hessdv_two(const nl_ctx *c) {
+    return HessDv<2>{dv_two(c->hz), dv_two(c->hy), dv_two(c->hx), dv_two(c->hz2), dv_two(c->hy2), dv_two(c->hx2)};
+}
+static HessDv<0> hessdv_exact(const nl_ctx *c) {
+    return HessDv<0>{dv_exact(c->hz), dv_exact(c->hy), dv_exact(c->hx), dv_exact(c->hz2), dv_exact(c->hy2), dv_exact(c->hx2)};
 }
 // Exhaustive proof that the 3-instruction division is exact for the six divisors in use.
 static int check_fast_div(nl_ctx *c, char *err, size_t errlen) {
     const float ds[6] = {c->hz, c->hy, c->hx, c->hz2, c->hy2, c->hx2};
     unsigned int *bad = (unsigned int *)c->d_small + 64;
-    NL_HIP(zero_small(bad, 6 * 4, c->stream));
+    NL_HIP(zero_small(bad, 12 * 4, c->stream));
     for (int k = 0; k < 6; ++k) {
-        const Dv<true> dv = dv_fast(ds[k]);
-        divcheck_kernel<<<(1u << 23) / 256, 256, 0, c->stream>>>(dv.d, dv.y, bad + k);
+        divcheck_kernel<1><<<(1u << 23) / 256, 256, 0, c->stream>>>(dv_fast(ds[k]), ds[k], bad + k);
+        divcheck_kernel<2><<<(1u << 23) / 256, 256, 0, c->stream>>>(dv_two(ds[k]), ds[k], bad + 6 + k);
     }
     NL_CHECK_LAUNCH();
     unsigned int *h = (unsigned int *)c->h_small + 64;
-    NL_HIP(hipMemcpyAsync(h, bad, 6 * 4, hipMemcpyDeviceToHost, c->stream));
+    NL_HIP(hipMemcpyAsync(h, bad, 12 * 4, hipMemcpyDeviceToHost, c->stream));
     NL_HIP(hipStreamSynchronize(c->stream));
-    c->fast_div = 1;
+    c->fast_div = 1; c->fast_div2 = 1;
     for (int k = 0; k < 6; ++k) {
         const bool normal = ds[k] > 1e-30f && ds[k] < 1e30f;
         if (h[k] || !normal) c->fast_div = 0;
+        if (h[6 + k] || !normal) c->fast_div2 = 0;
     }
+    // NELLIE_EXACT_DIV=1: the float64 path everywhere; =3: at most the three-instruction sequence (A/B of the two-instruction one)
     const char *e = getenv("NELLIE_EXACT_DIV");
-    if (e && atoi(e)) c->fast_div = 0;
+    if (e && atoi(e) == 1) { c->fast_div = 0; c->fast_div2 = 0; }
+    if (e && atoi(e) == 3) c->fast_div2 = 0;
     return NL_OK;
 }
 static HessP hessp(const nl_ctx *c) { return HessP{c->hz, c->hy, c->hx, c->hz2, c->hy2, c->hx2}; }
@@ -1241,8 +1252,8 @@ extern "C" int nl_hessian_stats(nl_ctx *c, const double spacing[3], float *max_a
                                           HVCfg<RSV>::lds_bytes(), c->stream>>>(                                          \
             gauss_cur(c), nullptr, nullptr, 0, geom(c), HR, vp, VQueue{}, (int)c->own_lo, (int)c->own_hi, ntx,        \
             (int)((c->ny + 2 * RSV - 1) / (2 * RSV)), res, nullptr, nullptr)
-        if (hv_rs(c) == 16) { if (c->fast_div) { NL_LAUNCH_STATS_V(16, true, hessdv_fast(c)); } else { NL_LAUNCH_STATS_V(16, false, hessdv_exact(c)); } }
-        else if (hv_rs(c) == 8) { if (c->fast_div) { NL_LAUNCH_STATS_V(8, true, hessdv_fast(c)); } else { NL_LAUNCH_STATS_V(8, false, hessdv_exact(c)); } }
+        if (hv_rs(c) == 16) { if (c->fast_div2) { NL_LAUNCH_STATS_V(16, 2, hessdv_two(c)); } else if (c->fast_div) { NL_LAUNCH_STATS_V(16, 1, hessdv_fast(c)); } else { NL_LAUNCH_STATS_V(16, 0, hessdv_exact(c)); } }
+        else if (hv_rs(c) == 8) { if (c->fast_div2) { NL_LAUNCH_STATS_V(8, 2, hessdv_two(c)); } else if (c->fast_div) { NL_LAUNCH_STATS_V(8, 1, hessdv_fast(c)); } else { NL_LAUNCH_STATS_V(8, 0, hessdv_exact(c)); } }
         else if (hm_ty() == 8) { if (c->fast_div) NL_LAUNCH_STATS(8, true, hessdv_fast(c)); else NL_LAUNCH_STATS(8, false, hessdv_exact(c)); }
         else { if (c->fast_div) NL_LAUNCH_STATS(16, true, hessdv_fast(c)); else NL_LAUNCH_STATS(16, false, hessdv_exact(c)); }
 #undef NL_LAUNCH_STATS
@@ -1340,8 +1351,8 @@ static int spec_enqueue(nl_ctx *c, const double spacing[3], float fsq_lo, float 
 #define NL_LAUNCH_SPEC(TYV, FASTV, HR)                                                                                    \
         hessian_g_kernel<2, TYV, FASTV><<<nblocks, HGCfg<TYV>::NT, HGCfg<TYV>::lds_bytes(), c->stream>>>(                 \
             gauss_cur(c), cm, pm, wpr, geom(c), HR, vp, vq, (int)z0, (int)z1, ntx, nty, res, d_cnt)
-        if (rs == 16) { if (c->fast_div) { NL_LAUNCH_SPEC_V(16, true, hessdv_fast(c)); } else { NL_LAUNCH_SPEC_V(16, false, hessdv_exact(c)); } }
-        else if (rs == 8) { if (c->fast_div) { NL_LAUNCH_SPEC_V(8, true, hessdv_fast(c)); } else { NL_LAUNCH_SPEC_V(8, false, hessdv_exact(c)); } }
+        if (rs == 16) { if (c->fast_div2) { NL_LAUNCH_SPEC_V(16, 2, hessdv_two(c)); } else if (c->fast_div) { NL_LAUNCH_SPEC_V(16, 1, hessdv_fast(c)); } else { NL_LAUNCH_SPEC_V(16, 0, hessdv_exact(c)); } }
+        else if (rs == 8) { if (c->fast_div2) { NL_LAUNCH_SPEC_V(8, 2, hessdv_two(c)); } else if (c->fast_div) { NL_LAUNCH_SPEC_V(8, 1, hessdv_fast(c)); } else { NL_LAUNCH_SPEC_V(8, 0, hessdv_exact(c)); } }
         else if (ty == 8) { if (c->fast_div) NL_LAUNCH_SPEC(8, true, hessdv_fast(c)); else NL_LAUNCH_SPEC(8, false, hessdv_exact(c)); }
         else { if (c->fast_div) NL_LAUNCH_SPEC(16, true, hessdv_fast(c)); else NL_LAUNCH_SPEC(16, false, hessdv_exact(c)); }
 #undef NL_LAUNCH_SPEC
@@ -1688,8 +1699,8 @@ extern "C" int nl_vesselness_step(nl_ctx *c, float gamma_sq, float alpha_sq, flo
             const i64 zb = za + planes_per_launch < z1 ? za + planes_per_launch : z1;
             const int nzc = (int)((zb - za + HM_ZCHUNK - 1) / HM_ZCHUNK);
             const unsigned nblocks = (unsigned)(ntx * nty * nzc);
-            if (rs == 16) { if (c->fast_div) { NL_LAUNCH_VESS_V(16, true, hessdv_fast(c)); } else { NL_LAUNCH_VESS_V(16, false, hessdv_exact(c)); } }
-            else if (rs == 8) { if (c->fast_div) { NL_LAUNCH_VESS_V(8, true, hessdv_fast(c)); } else { NL_LAUNCH_VESS_V(8, false, hessdv_exact(c)); } }
+            if (rs == 16) { if (c->fast_div2) { NL_LAUNCH_VESS_V(16, 2, hessdv_two(c)); } else if (c->fast_div) { NL_LAUNCH_VESS_V(16, 1, hessdv_fast(c)); } else { NL_LAUNCH_VESS_V(16, 0, hessdv_exact(c)); } }
+            else if (rs == 8) { if (c->fast_div2) { NL_LAUNCH_VESS_V(8, 2, hessdv_two(c)); } else if (c->fast_div) { NL_LAUNCH_VESS_V(8, 1, hessdv_fast(c)); } else { NL_LAUNCH_VESS_V(8, 0, hessdv_exact(c)); } }
             else if (ty == 8) { if (c->fast_div) NL_LAUNCH_VESS(8, true, hessdv_fast(c)); else NL_LAUNCH_VESS(8, false, hessdv_exact(c)); }
             else { if (c->fast_div) NL_LAUNCH_VESS(16, true, hessdv_fast(c)); else NL_LAUNCH_VESS(16, false, hessdv_exact(c)); }
             NL_CHECK_LAUNCH();
@@ -3563,7 +3574,7 @@ extern "C" int nl_outputs_unpack(const void *blob_, int64_t nbytes, float *frang
 // ---------------------------------------------------------------------------------- debug -------
 extern "C" int nl_ctx_info(nl_ctx *c, const char *key, double *value) {
     if (!c || !key || !value) return NL_EINVAL;
-    if (!strcmp(key, "fast_div")) *value = c->fast_div;
+    if (!strcmp(key, "fast_div")) *value = c->fast_div2 ? 2 : c->fast_div;      // 2: two-instruction division proven, 1: three, 0: float64
     else if (!strcmp(key, "hessian_tile_rows")) *value = hv_rs(c) ? 2 * hv_rs(c) : hm_ty();
     else if (!strcmp(key, "vesselness_one_pass")) *value = c->spec_ok;
     else if (!strcmp(key, "last_fsq_min")) *value = c->last_fsq_min;

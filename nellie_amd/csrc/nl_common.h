@@ -94,6 +94,7 @@ struct nl_ctx {
     float hz2 = 2, hy2 = 2, hx2 = 2;         // float32(2.0*h)
     int have_spacing = 0;
     int fast_div = 0;                        // 3-instruction division proven exact for the spacings in use
+    int fast_div2 = 0;                       // 2-instruction division (hessian.inc: Dv<2>) proven exact for them (pair kernel)
     double chk_spacing[3] = {0, 0, 0};
     float frob_max_abs = 1.0f, frob_max_finite = 0.0f;
     int frangi_ready = 0;
