@@ -484,8 +484,8 @@ int nl_outputs_unpack(const void *blob, int64_t nbytes, float *frangi, int32_t *
 int nl_debug_eig_frangi(nl_ctx *ctx, const float *h6, int64_t n, int impl, float alpha_sq, float beta_sq,
                         float gamma_sq, float *out4, char *err, size_t errlen);
 
-/* Introspection: "fast_div" (1 when the 3-instruction constant division was proven exact for the
-   current spacings), "hessian_tile_rows", "device_bytes". */
+/* Introspection: "fast_div" (2 / 1 when the 2- / 3-instruction constant division was proven exact for the
+   current spacings, 0: the float64 form), "hessian_tile_rows", "device_bytes". */
 int nl_ctx_info(nl_ctx *ctx, const char *key, double *value);
 
 /* ------------------------------------------------------------------ timing ------------ */

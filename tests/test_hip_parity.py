@@ -990,3 +990,34 @@ print(json.dumps(out))
         got.append(json.loads(r.stdout.strip().splitlines()[-1]))
     assert got[0] == got[1]
     assert got[0]["True"][:3] == got[0]["False"][:3] and got[0]["True"][3] == 0
+
+
+def test_three_forms_of_the_constant_division_agree(hip):
+    """The walk divides by float32(h) / float32(2h) in one of three ways (csrc/hessian.inc: Dv<2> two instructions, Dv<1> three,
+    Dv<0> through float64), the short ones only after a proof by exhaustion for the divisors in use: same Frangi frame, same
+    trace, on an isotropic and an anisotropic spacing (NELLIE_EXACT_DIV is read per context, a child process per setting)."""
+    import json, subprocess, sys
+    code = r'''
+import json, zlib
+from nellie_amd import pipeline as pl
+from nellie_amd.synthetic import ANISO_03, ISO_01, make_volume
+out = []
+for dr, seed in ((ISO_01, 5), (ANISO_03, 6), ({"X": 0.065, "Y": 0.065, "Z": 0.29, "T": 1.0}, 7)):
+    vol = make_volume((40, 72, 136), seed)
+    pipe = pl.FramePipeline(vol.shape)
+    pipe.filter(vol, pl.FilterParams(dim_res=dr))
+    tr = [(s.gamma, s.max_abs, s.frob_thr, s.mask_count) for s in pipe.trace.scales]
+    out.append([int(pipe.ctx.info("fast_div")), tr, zlib.crc32(pipe.download_frangi().tobytes()), pipe.trace.n_positive])
+    pipe.close()
+print(json.dumps(out))
+'''
+    got = {}
+    for setting in ("0", "3", "1"):
+        env = dict(os.environ, NELLIE_EXACT_DIV=setting, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got[setting] = json.loads(r.stdout.strip().splitlines()[-1])
+    assert [g[0] for g in got["1"]] == [0, 0, 0] and all(g[0] <= 1 for g in got["3"])
+    assert any(g[0] == 2 for g in got["0"]), "the two-instruction division was not selected for any of the spacings"
+    for a, b, c in zip(got["0"], got["3"], got["1"]):
+        assert a[1:] == b[1:] == c[1:] and a[3] > 0
