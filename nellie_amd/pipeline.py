@@ -80,22 +80,33 @@ def sample_strides(shape, max_samples):
     return tuple(strides)
 
 
+_WEIGHTS_CACHE = {}
+
+
 def gaussian_weights(sigma: float):
     """
     scipy.ndimage `gaussian_filter1d` + `_gaussian_kernel1d` (order 0, truncate 3.0):
     lw = int(truncate*sd + 0.5); w = exp(-0.5/sd^2 * x^2) / sum.  None when the axis is
     skipped (scipy `gaussian_filter` skips sigma <= 1e-15).  Computed with numpy exactly as
-    scipy does, so the float64 weights carry scipy's bits.
+    scipy does, so the float64 weights carry scipy's bits.  The (read-only) array of a sigma is kept: a stack's frames
+    ask for the same fifteen kernels again and again, 70 us of numpy per frame with the GPU waiting for the first of them.
     """
     sd = float(sigma)
     if not sd > 1e-15:
         return None
+    got = _WEIGHTS_CACHE.get(sd)
+    if got is not None:
+        return got
     lw = int(_TRUNCATE * sd + 0.5)
     sigma2 = sd * sd
     x = np.arange(-lw, lw + 1)
     phi_x = np.exp(-0.5 / sigma2 * x ** 2)
     phi_x = phi_x / phi_x.sum()
-    return np.ascontiguousarray(phi_x[::-1])
+    w = np.ascontiguousarray(phi_x[::-1])
+    w.setflags(write=False)
+    if len(_WEIGHTS_CACHE) < 4096:
+        _WEIGHTS_CACHE[sd] = w
+    return w
 
 
 def gaussian_derivative_weights(sigma: float, order: int, truncate: float = 4.0):
@@ -135,8 +146,21 @@ def marker_sigmas(dim_res, min_radius_um=0.20, max_radius_um=1, num_sigma=5):
     return (sig if len(sig) else [sigma_min]), max_r
 
 
+_DELTAS_CACHE = {}
+
+
 def cascade_deltas(sigmas, z_ratio):
-    """filtering.py:814-825."""
+    """filtering.py:814-825 (kept per (sigmas, z_ratio): the same for every frame of a stack)."""
+    key = (tuple(float(s) for s in sigmas), float(z_ratio))
+    got = _DELTAS_CACHE.get(key)
+    if got is None:
+        got = _cascade_deltas(sigmas, z_ratio)
+        if len(_DELTAS_CACHE) < 256:
+            _DELTAS_CACHE[key] = got
+    return list(got)
+
+
+def _cascade_deltas(sigmas, z_ratio):
     out = []
     prev = 0.0
     for sigma in sigmas:
