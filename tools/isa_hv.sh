@@ -1,5 +1,5 @@
 #!/bin/bash
-# ISA summary of hessian_v_kernel<2,8,true> compiled alone (tools/ubench/hv_only.hip): tools/isa_hv.sh [TAG] [-D flags]
+# ISA summary of hessian_v_kernel<2,8,2> (the default variant: two-instruction division) compiled alone (tools/ubench/hv_only.hip): tools/isa_hv.sh [TAG] [-D flags]
 TAG=${1:-base}; shift
 OUT=/tmp/isa; mkdir -p $OUT
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -S --cuda-device-only "$@" \

@@ -5,5 +5,5 @@
 #include "../../nellie_amd/csrc/device_math.inc"
 #include "../../nellie_amd/csrc/hessian.inc"
 #include "../../nellie_amd/csrc/hessian_pair.inc"
-template __global__ void hessian_v_kernel<2, 8, true>(const float *, unsigned long long *, const unsigned long long *, int, VolGeom, HessDv<true>, VessP,
+template __global__ void hessian_v_kernel<2, 8, 2>(const float *, unsigned long long *, const unsigned long long *, int, VolGeom, HessDv<2>, VessP,
                                                       VQueue, int, int, int, int, unsigned int *, unsigned long long *, const float *);
