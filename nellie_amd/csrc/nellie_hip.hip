@@ -360,6 +360,7 @@ extern "C" int nl_ctx_destroy(nl_ctx *c) {
     if (c->gbits[1]) hipFree(c->gbits[1]);
     if (c->grows) hipFree(c->grows);
     if (c->h_small) hipHostFree(c->h_small);
+    if (c->h_prefix) hipHostFree(c->h_prefix);
     if (c->t0) hipEventDestroy(c->t0);
     if (c->t1) hipEventDestroy(c->t1);
     if (c->xstream) { hipStreamSynchronize(c->xstream); hipStreamDestroy(c->xstream); }
@@ -841,6 +842,31 @@ extern "C" int nl_sample_gather(nl_ctx *c, int field, int64_t sz, int64_t sy, in
 
 // The positive samples of the same lattice, compacted on the device: only they cross PCIe (the consumers take
 // arr[arr > 0] first anyway: filtering.py:357, 957-959).  Order unspecified.  cap >= number of lattice points.
+// A positive gather leaves its samples in `stage` and their number in *d_n.  Fetching them used to be two round trips (the count,
+// then that many samples); the count and the first NL_PREFIX samples now travel together into pinned memory, and only a longer
+// list costs a second transfer.  *n = the count; out[0 .. n) = the samples.
+#define NL_PREFIX 32768
+static int fetch_counted(nl_ctx *c, const float *stage, const unsigned int *d_n, i64 max_count, float *out, i64 cap, int64_t *n, char *err, size_t errlen) {
+    if (!c->h_prefix) NL_HIP(hipHostMalloc(&c->h_prefix, (size_t)NL_PREFIX * 4 + 64, hipHostMallocDefault));
+    unsigned int *h_n = (unsigned int *)c->h_prefix;
+    float *h_s = (float *)((char *)c->h_prefix + 64);
+    const i64 first = max_count < NL_PREFIX ? max_count : NL_PREFIX;
+    NL_HIP(hipMemcpyAsync(h_n, d_n, 4, hipMemcpyDeviceToHost, c->stream));
+    if (first > 0) NL_HIP(hipMemcpyAsync(h_s, stage, (size_t)first * 4, hipMemcpyDeviceToHost, c->stream));
+    NL_HIP(hipStreamSynchronize(c->stream));
+    const i64 k = (i64)*h_n;
+    if (n) *n = 0;
+    if (k > cap || (k && !out)) return nl_fail(err, errlen, NL_EINVAL, "output capacity %lld < %lld positive samples", (i64)cap, k);
+    if (k > max_count) return nl_fail(err, errlen, NL_ESTATE, "positive gather counted %lld of at most %lld samples", k, max_count);
+    if (k) memcpy(out, h_s, (size_t)(k < first ? k : first) * 4);
+    if (k > first) {
+        NL_HIP(hipMemcpyAsync(out + first, stage + first, (size_t)(k - first) * 4, hipMemcpyDeviceToHost, c->stream));
+        NL_HIP(hipStreamSynchronize(c->stream));
+    }
+    if (n) *n = k;
+    return NL_OK;
+}
+
 // The positive lattice samples in two halves, so that the host can do other work (nl_chain_finish: wait for the chain's
 // records, repeat its decisions) while the kernel runs: _begin enqueues the kernel and the download of the count, _end waits and
 // fetches the samples.  No other call on this context in between except nl_chain_finish / nl_chain_log.
@@ -864,7 +890,6 @@ extern "C" int nl_sample_gather_positive_begin(nl_ctx *c, int field, int64_t sz,
         sample_gather_pos_kernel<<<(unsigned)((total + 255) / 256), 256, 0, c->stream>>>(fs, geom(c), L, c->gp_stage, d_n);
         NL_CHECK_LAUNCH();
     }
-    NL_HIP(hipMemcpyAsync(c->h_small, d_n, 4, hipMemcpyDeviceToHost, c->stream));
     return NL_OK;
 }
 extern "C" int nl_sample_gather_positive_end(nl_ctx *c, float *out, int64_t cap, int64_t *n, char *err, size_t errlen) {
@@ -874,15 +899,7 @@ extern "C" int nl_sample_gather_positive_end(nl_ctx *c, float *out, int64_t cap,
     c->gp_total = -1;
     if (n) *n = 0;
     if (total == 0) return NL_OK;
-    NL_HIP(hipStreamSynchronize(c->stream));
-    const i64 k = (i64)(*(unsigned int *)c->h_small);
-    if (k > cap || (k && !out)) return nl_fail(err, errlen, NL_EINVAL, "output capacity %lld < %lld positive samples", (i64)cap, k);
-    if (k) {
-        NL_HIP(hipMemcpyAsync(out, c->gp_stage, (size_t)k * 4, hipMemcpyDeviceToHost, c->stream));
-        NL_HIP(hipStreamSynchronize(c->stream));
-    }
-    if (n) *n = k;
-    return NL_OK;
+    return fetch_counted(c, c->gp_stage, (const unsigned int *)c->d_small, total, out, cap, n, err, errlen);
 }
 extern "C" int nl_sample_gather_positive(nl_ctx *c, int field, int64_t sz, int64_t sy, int64_t sx, float *out, int64_t cap,
                                          int64_t *n, char *err, size_t errlen) {
@@ -2552,15 +2569,7 @@ extern "C" int nl_flat_sample_gather_positive(nl_ctx *c, int field, int64_t offs
         flat_gather_pos_kernel<<<(unsigned)((count + 255) / 256), 256, 0, c->stream>>>(src, -c->gz0 * plane, offset + k0 * step, step, count, stage, d_n);
         NL_CHECK_LAUNCH();
     }
-    NL_HIP(hipMemcpyAsync(c->h_small, d_n, 4, hipMemcpyDeviceToHost, c->stream));
-    NL_HIP(hipStreamSynchronize(c->stream));
-    const i64 k = (i64)(*(unsigned int *)c->h_small);
-    if (k) {
-        NL_HIP(hipMemcpyAsync(out, stage, (size_t)k * 4, hipMemcpyDeviceToHost, c->stream));
-        NL_HIP(hipStreamSynchronize(c->stream));
-    }
-    if (n) *n = k;
-    return NL_OK;
+    return fetch_counted(c, stage, d_n, count, out, cap, n, err, errlen);
 }
 
 template <int FG, int CONN>

@@ -46,6 +46,7 @@ struct nl_ctx {
     int *d_stage_lab = nullptr;
     void *d_small = nullptr;   // scratch for reductions / histograms / weights (64 KiB)
     void *h_small = nullptr;   // pinned mirror
+    void *h_prefix = nullptr;  // pinned: the count and the first NL_PREFIX samples of a positive gather travel in one transfer
     float *d_vq = nullptr;     // global queue of voxels to eigen-solve (32-byte entries, one region per wave)
     unsigned int *d_vq_count = nullptr;   // entries written per region
     int nw_state = 0;             // Network: 1 after nl_skel_pixel_class (classes + branch bits resident)
