@@ -142,6 +142,15 @@ static i64 sample_grid_cap() {
     if (!v) { const char *e = getenv("NELLIE_SAMPLE_GRID"); v = (e && atoll(e) > 0) ? atoll(e) : 256; }
     return v;
 }
+// 2-D images: 256 columns per workgroup in x, rows by a stride loop in the kernel (~4096 workgroups: the statistics kernels end
+// in one set of atomics per workgroup)
+static inline dim3 grid2d_rows(i64 nx, i64 ny) {
+    const i64 gx = (nx + 255) / 256;
+    i64 gy = (4096 + gx - 1) / gx;
+    if (gy > ny) gy = ny;
+    if (gy < 1) gy = 1;
+    return dim3((unsigned)gx, (unsigned)gy, 1);
+}
 static inline unsigned int grid1d(i64 n, int block = 256, i64 cap = 256 * 32) {
     i64 g = (n + block - 1) / block;
     if (g > cap) g = cap;
@@ -1240,7 +1249,7 @@ extern "C" int nl_hessian_stats(nl_ctx *c, const double spacing[3], float *max_a
         NL_HIP(zero_small(res2, 16, c->stream));
         {
             ProfScope ps(c, "hessian_stats");
-            hessian2d_stats_kernel<<<grid1d(c->n), 256, 0, c->stream>>>(gauss_cur(c), geom(c), hessp(c), res2);
+            hessian2d_stats_kernel<<<grid2d_rows(c->nx, c->ny), 256, 0, c->stream>>>(gauss_cur(c), geom(c), hessp(c), res2);
             NL_CHECK_LAUNCH();
         }
         unsigned int *h2 = (unsigned int *)c->h_small;
@@ -1683,7 +1692,7 @@ extern "C" int nl_vesselness_step(nl_ctx *c, float gamma_sq, float alpha_sq, flo
         unsigned long long *cm = (unsigned long long *)c->m[0] + (i64)(k_scale & 1) * slot_words;
         const unsigned long long *pm = (unsigned long long *)c->m[0] + (i64)((k_scale + 1) & 1) * slot_words;
         if (vp.first) NL_HIP(hipMemsetAsync(c->f[c->i_vmax], 0, (size_t)c->n * 4, c->stream));
-        vesselness2d_kernel<<<grid1d(c->ny * wpr * 64), 256, 0, c->stream>>>(gauss_cur(c), c->f[c->i_vmax], cm, pm, wpr, geom(c), hessp(c), vp, d_cnt);
+        vesselness2d_kernel<<<grid2d_rows((i64)wpr * 64, c->ny), 256, 0, c->stream>>>(gauss_cur(c), c->f[c->i_vmax], cm, pm, wpr, geom(c), hessp(c), vp, d_cnt);
         NL_CHECK_LAUNCH();
     } else {
         ProfScope ps(c, "vesselness");
@@ -1777,7 +1786,7 @@ extern "C" int nl_log2d_step(nl_ctx *c, const double *wy2, const double *wy0, co
     const i64 slot_words = c->nzl * c->ny * wpr;
     const unsigned long long *mask = c->mask_slots_used > 0
         ? (const unsigned long long *)c->m[0] + (i64)((c->mask_slots_used - 1) & 1) * slot_words : nullptr;
-    log2d_combine_kernel<<<grid1d(c->n), 256, 0, c->stream>>>(A, B, s2, use_mask ? mask : nullptr, wpr, v, first, lap);
+    log2d_combine_kernel<<<grid2d_rows(c->nx, c->ny), 256, 0, c->stream>>>(A, B, s2, use_mask ? mask : nullptr, wpr, v, first, lap);
     NL_CHECK_LAUNCH();
     return NL_OK;
 }
