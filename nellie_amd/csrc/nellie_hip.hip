@@ -189,7 +189,8 @@ static VolGeom geom(const nl_ctx *c) {
     // within run-to-run noise) but also halves the number of workgroups, so only where those are plentiful
     static int forced = -1;
     if (forced < 0) { const char *e = getenv("NELLIE_GM_CHUNK"); forced = e ? atoi(e) : 0; }
-    v.chunk = forced > 0 ? forced : (c->n >= ((i64)1 << 29) ? 256 : 128);
+    // (a 2-D image has one plane: 32-row chunks, or its Gaussian passes run on a handful of workgroups)
+    v.chunk = forced > 0 ? forced : (c->two_d ? 32 : (c->n >= ((i64)1 << 29) ? 256 : 128));
     return v;
 }
 // tile height of the Hessian kernels (experiment knob; 8 -> 512-thread workgroups, 16 -> 1024)
@@ -1777,16 +1778,33 @@ extern "C" int nl_log2d_step(nl_ctx *c, const double *wy2, const double *wy0, co
     ProfScope ps(c, "log2d");
     const float *src = gauss_cur(c);
     float *t = c->d_2d[0], *A = c->d_2d[1], *B = c->d_2d[2], *lap = c->d_2d[3];
-    // gaussian_laplace: second derivative along Y (then plain Gaussian along X), plus the one along X
-    gauss_axis_kernel<1><<<grid, blk, 0, c->stream>>>(src, t, v, 0, 1, gy2);
-    gauss_axis_kernel<2><<<grid, blk, 0, c->stream>>>(t, A, v, 0, 1, gx0);
-    gauss_axis_kernel<1><<<grid, blk, 0, c->stream>>>(src, t, v, 0, 1, gy0);
-    gauss_axis_kernel<2><<<grid, blk, 0, c->stream>>>(t, B, v, 0, 1, gx2);
+    // gaussian_laplace: second derivative along Y (then plain Gaussian along X), plus the one along X.  Both terms in one walk over
+    // the image (the pair kernel of Markers' LoG: A = XY(gy2, gx0) + XY(gy0, gx2), the float32 sum the combine kernel forms) when
+    // the radius allows; four one-axis passes otherwise.
+    bool summed = false;
+    if (gyx_tiled() && r >= 1 && r <= GM_MAX_R && r <= c->ny && r <= c->nx) {
+        auto ws_of = [](const GaussW &g) { GaussWS w; for (int k = 0; k <= GM_MAX_R; ++k) w.w[k] = k <= g.r ? g.w[k] : 0.0; return w; };
+        const GaussWS wya = ws_of(gy2), wxa = ws_of(gx0), wyb = ws_of(gy0), wxb = ws_of(gx2);
+        const dim3 g2((unsigned)((c->nx + GYX_COLS - 1) / GYX_COLS), (unsigned)((c->ny + v.chunk - 1) / v.chunk), 1);
+        const int vec4 = (c->nx % 4 == 0) ? 1 : 0;
+        const unsigned nb = g2.x * g2.y;
+        switch (r) {
+#define NL_L2D(RR) case RR: gauss_yx_dual_kernel<RR, false><<<nb, GYX_THREADS, 0, c->stream>>>(src, A, v, 0, 1, wya, wxa, wyb, wxb, vec4, (int)g2.x, (int)g2.y); break;
+            NL_L2D(1) NL_L2D(2) NL_L2D(3) NL_L2D(4) NL_L2D(5) NL_L2D(6) NL_L2D(7) NL_L2D(8) NL_L2D(9) NL_L2D(10) NL_L2D(11) NL_L2D(12)
+#undef NL_L2D
+        }
+        summed = true;
+    } else {
+        gauss_axis_kernel<1><<<grid, blk, 0, c->stream>>>(src, t, v, 0, 1, gy2);
+        gauss_axis_kernel<2><<<grid, blk, 0, c->stream>>>(t, A, v, 0, 1, gx0);
+        gauss_axis_kernel<1><<<grid, blk, 0, c->stream>>>(src, t, v, 0, 1, gy0);
+        gauss_axis_kernel<2><<<grid, blk, 0, c->stream>>>(t, B, v, 0, 1, gx2);
+    }
     const int wpr = (int)((c->nx + 63) / 64);
     const i64 slot_words = c->nzl * c->ny * wpr;
     const unsigned long long *mask = c->mask_slots_used > 0
         ? (const unsigned long long *)c->m[0] + (i64)((c->mask_slots_used - 1) & 1) * slot_words : nullptr;
-    log2d_combine_kernel<<<grid2d_rows(c->nx, c->ny), 256, 0, c->stream>>>(A, B, s2, use_mask ? mask : nullptr, wpr, v, first, lap);
+    log2d_combine_kernel<<<grid2d_rows(c->nx, c->ny), 256, 0, c->stream>>>(A, summed ? nullptr : B, s2, use_mask ? mask : nullptr, wpr, v, first, lap);
     NL_CHECK_LAUNCH();
     return NL_OK;
 }
