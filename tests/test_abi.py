@@ -181,3 +181,15 @@ def test_percentile_shortcut_is_numpy_percentile():
             assert type(got) is type(want) and got == want, (n, got, want)
             assert np.array_equal(v, keep)                        # the caller's samples are left alone
     assert pl.percentile_of_samples(np.arange(10.0), 1) == np.percentile(np.arange(10.0), 1)      # other dtypes: numpy itself
+
+
+def test_percentile_falls_back_to_numpy_when_the_probe_fails(monkeypatch):
+    """A numpy whose percentile the shortcut does not reproduce (the probe says so) gets np.percentile itself."""
+    import numpy as np
+    from nellie_amd import pipeline as pl
+    calls = []
+    monkeypatch.setattr(pl, "_FAST_PERCENTILE", None)
+    monkeypatch.setattr(pl, "_shortcut_matches_numpy", lambda: False)
+    monkeypatch.setattr(pl, "_percentile_shortcut", lambda v, q: calls.append(1) or np.float32(-1))
+    v = np.random.default_rng(3).random(1000, dtype=np.float32)
+    assert pl.percentile_of_samples(v, 1) == np.percentile(v, 1) and not calls and pl._FAST_PERCENTILE is False
