@@ -1366,9 +1366,24 @@ static int spec_enqueue(nl_ctx *c, const double spacing[3], float fsq_lo, float 
         if (dev_lohi && !rs) return nl_fail(err, errlen, NL_ESTATE, "the device-resident chain needs the two-voxel walk");
         const int ty = rs ? 2 * rs : hm_ty();
         const int nty = (int)((c->ny + ty - 1) / ty);
-        const int nzc = (int)((z1 - z0 + HM_ZCHUNK - 1) / HM_ZCHUNK);
+        // Planes per workgroup: 64, or 128 where that still leaves thousands of workgroups (a chunk's prologue -- four planes
+        // staged, the first gradient tile -- is paid half as often: walk -3 % at 1024^3; a 128-plane frame would run on 256
+        // workgroups and lose 30 %).  The queue was sized for 64-plane chunks: twice the planes, twice the entries per region,
+        // half the regions -- the same memory when the chunk count halves exactly or rounds the same way.
+        int zch = HM_ZCHUNK;
+        {
+            static int forced = -1;
+            if (forced < 0) { const char *e = getenv("NELLIE_HV_ZCHUNK"); forced = e ? atoi(e) : 0; }
+            const i64 nz = z1 - z0;
+            const i64 c64 = (nz + HM_ZCHUNK - 1) / HM_ZCHUNK, c128 = (nz + 2 * HM_ZCHUNK - 1) / (2 * HM_ZCHUNK);
+            const bool fits = 2 * c128 <= c64 && (i64)(2 * HM_ZCHUNK + 4) * c->ny * c->nx * 4 < ((i64)1 << 32);
+            if (rs && fits && (forced == 2 * HM_ZCHUNK || (forced == 0 && (i64)ntx * nty * c128 >= 4096))) zch = 2 * HM_ZCHUNK;
+        }
+        vp.zchunk = zch;
+        const int nzc = (int)((z1 - z0 + zch - 1) / zch);
         const unsigned nblocks = (unsigned)(ntx * nty * nzc);
-        if (rs) vp.qcap = 2 * HM_SPEC_CAP;              // a wave owns two row segments
+        vp.qcap = HM_SPEC_CAP * (zch / HM_ZCHUNK);
+        if (rs) vp.qcap *= 2;                           // a wave owns two row segments
         hipStream_t hs = c->stream;
 #define NL_DEV_LOHI dev_lohi
 #define NL_LAUNCH_SPEC_V(RSV, FASTV, HR)                                                                                  \
