@@ -179,7 +179,7 @@ static bool gyx_tiled() {
 // a wave that walks 8-16 regions amortises its start-up and evens out the regions' very different entry counts
 static unsigned resolve_grid(unsigned blocks) {
     static long cap = -1;
-    if (cap < 0) { const char *e = getenv("NELLIE_RESOLVE_GRID"); cap = e ? atol(e) : 4096; }
+    if (cap < 0) { const char *e = getenv("NELLIE_RESOLVE_GRID"); cap = e ? atol(e) : 8192; }
     return (cap > 0 && (unsigned)cap < blocks) ? (unsigned)cap : blocks;
 }
 static float *gauss_cur(const nl_ctx *c) { return c->gauss_ext ? c->gauss_ext : c->f[c->i_gauss]; }
