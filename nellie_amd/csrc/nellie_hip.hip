@@ -2749,13 +2749,23 @@ static int build_components(nl_ctx *c, const LabelGeo &g, const unsigned long lo
     // two levels (see label_runs.inc): planes in LDS, then component pairs across planes; NELLIE_UF_PLANES=0: one level
     static int two_level = -1;
     if (two_level < 0) { const char *e = getenv("NELLIE_UF_PLANES"); two_level = (e && !atoi(e)) ? 0 : 1; }
-    if (two_level && g.nz <= 8192 && rs.proot && rs.link) {
-        uint8_t *plane_done = (uint8_t *)c->d_small + (52 << 10);
+    // segments per plane: at least ~1024 workgroups for the in-LDS level (a 136-plane slab would otherwise use half of the CUs)
+    int seg_shift = 5;
+    {
+        static int seg_target = -1;                                   // NELLIE_UF_SEG_WGS=1: one workgroup per plane (round 3)
+        if (seg_target < 0) { const char *e = getenv("NELLIE_UF_SEG_WGS"); seg_target = (e && atoi(e) > 0) ? atoi(e) : 1024; }
+        const i64 want = (seg_target + g.nz - 1) / g.nz;
+        while (((g.ny + ((i64)1 << seg_shift) - 1) >> seg_shift) > want) ++seg_shift;
+        while (g.nz * ((g.ny + ((i64)1 << seg_shift) - 1) >> seg_shift) > 8192 && ((i64)1 << seg_shift) < g.ny) ++seg_shift;
+    }
+    const int nseg = (int)((g.ny + ((i64)1 << seg_shift) - 1) >> seg_shift);
+    if (two_level && g.nz * nseg <= 8192 && rs.proot && rs.link) {
+        uint8_t *seg_done = (uint8_t *)c->d_small + (52 << 10);
         NL_HIP(hipMemsetAsync(rs.link, 0xff, (size_t)rs.nruns * 4, c->stream));
-        rl_union_plane_kernel<CONN><<<(unsigned)g.nz, 256, 0, c->stream>>>(rs.runs, row_off, rs.parent, rs.proot, (int)g.ny,
-                                                                         CONN == 6 ? 1 : 0, g.zf_lo, g.zf_hi, (int)g.nx, plane_done);
+        rl_union_plane_kernel<CONN><<<(unsigned)(g.nz * nseg), 256, 0, c->stream>>>(rs.runs, row_off, rs.parent, rs.proot, (int)g.ny,
+                                                                         CONN == 6 ? 1 : 0, g.zf_lo, g.zf_hi, (int)g.nx, seg_done, seg_shift, nseg);
         rl_union_cross_kernel<CONN><<<gr, 256, 0, c->stream>>>(rs.runs, row_off, rs.parent, rs.proot, rs.link, rs.nruns, (int)g.ny,
-                                                               CONN == 6 ? 1 : 0, g.zf_lo, g.zf_hi, (int)g.nx, plane_done);
+                                                               CONN == 6 ? 1 : 0, g.zf_lo, g.zf_hi, (int)g.nx, seg_done, seg_shift, nseg);
     } else {
         rl_union_kernel<CONN><<<gr, 256, 0, c->stream>>>(rs.runs, row_off, rs.parent, rs.nruns, (int)g.ny,
                                                          CONN == 6 ? 1 : 0, g.zf_lo, g.zf_hi, (int)g.nx);

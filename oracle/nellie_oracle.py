@@ -483,11 +483,16 @@ def frangi_response(ev, alpha_sq, beta_sq, gamma_sq):
 # =============================================================================
 def compute_vesselness(frame, dim_res, sigmas=None, alpha_sq=0.5, beta_sq=0.5,
                        frob_thresh=None, frob_thresh_division=2,
-                       max_samples=int(1e6), mask=True, trace=None):
+                       max_samples=int(1e6), mask=True, trace=None, given_scales=None):
     """
     filtering.py:806-853 (+ 651-715 for the masked evaluation).
     `trace`, if a list, receives one dict per scale with the intermediates the
     golden vectors pin.
+
+    `given_scales` (crop mode, see `filter_frame_crop`): one dict per scale with the volume-wide quantities of a
+    run over the WHOLE volume -- `gamma`, `max_abs`, `frob_thr` (filtering.py:839, 555-562, 432-441) and `skipped`
+    (the scale's mask was empty everywhere, :843-844) -- used instead of deriving them from `frame`, which is then
+    a crop of that volume.  Everything else is the same per-voxel arithmetic.
     """
     frame = np.asarray(frame, dtype=np.float32)
     zr = z_ratio(dim_res)
@@ -497,13 +502,23 @@ def compute_vesselness(frame, dim_res, sigmas=None, alpha_sq=0.5, beta_sq=0.5,
     vesselness = np.zeros_like(frame, dtype=np.float32)
     masks = np.ones_like(frame, dtype=bool)
     gauss = frame.copy()  # the reference blurs in place (hazard B.1); results are identical
-    for sigma, delta in zip(sigmas, cascade_deltas(sigmas, zr)):
+    for k, (sigma, delta) in enumerate(zip(sigmas, cascade_deltas(sigmas, zr))):
         if any(s > 0 for s in delta):
             gauss = gaussian_filter_f32(gauss, delta, 3.0)
-        gamma = calculate_gamma(gauss, max_samples)
+        giv = None if given_scales is None else given_scales[k]
+        gamma = calculate_gamma(gauss, max_samples) if giv is None else float(giv["gamma"])
         gamma_sq = 2.0 * (float(gamma) ** 2)
         h6 = hessian_components(gauss, spacing)
-        if mask:
+        if mask and giv is not None:
+            # the volume's max|H| and threshold: frob = sqrt(frob_sq) / float32(max_abs), mask = frob > thr / division
+            frob_sq = frobenius(h6)[0]
+            max_abs = float(giv["max_abs"])
+            with np.errstate(invalid="ignore"):
+                frob = np.sqrt(frob_sq) / F32(max_abs)
+            h_mask, thr = frob_mask(frob, giv["frob_thr"] if frob_thresh_division else None, frob_thresh_division, max_samples)
+            if giv.get("skipped"):
+                h_mask = np.zeros_like(frame, dtype=bool)
+        elif mask:
             _, max_abs, frob = frobenius(h6)
             h_mask, thr = frob_mask(frob, frob_thresh, frob_thresh_division, max_samples)
         else:
@@ -609,12 +624,15 @@ def binary_dilation6(m: np.ndarray) -> np.ndarray:
             | p[1:-1, 1:-1, :-2] | p[1:-1, 1:-1, 2:])
 
 
-def mask_volume(frangi_frame, max_samples=int(1e6), return_thr=False):
-    """filtering.py:952-967."""
-    positive = subsample_positive(frangi_frame, max_samples)
-    if positive.size == 0:
-        return (frangi_frame, None) if return_thr else frangi_frame
-    thr = percentile_linear_f32(positive, 1)
+def mask_volume(frangi_frame, max_samples=int(1e6), return_thr=False, given_thr=None):
+    """filtering.py:952-967.  `given_thr`: the percentile threshold of the whole volume (crop mode)."""
+    if given_thr is None:
+        positive = subsample_positive(frangi_frame, max_samples)
+        if positive.size == 0:
+            return (frangi_frame, None) if return_thr else frangi_frame
+        thr = percentile_linear_f32(positive, 1)
+    else:
+        thr = F32(given_thr)
     m = frangi_frame > thr
     m = binary_dilation6(binary_erosion6(m))      # binary_opening, 1 iteration
     out = frangi_frame * m
