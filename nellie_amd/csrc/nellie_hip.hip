@@ -924,7 +924,7 @@ extern "C" int nl_sample_gather_positive(nl_ctx *c, int field, int64_t sz, int64
 #define NL_NCCL(expr)                                                                                  \
     do {                                                                                               \
         ncclResult_t r_ = (expr);                                                                      \
-        if (r_ != ncclSuccess) return nl_fail(err, errlen, NL_ECOMM, "%s: %s", #expr, rccl().GetErrorString(r_)); \
+        if (r_ != ncclSuccess) { c->comm_poisoned = 1; return nl_fail(err, errlen, NL_ECOMM, "%s: %s", #expr, rccl().GetErrorString(r_)); } \
     } while (0)
 
 // ---- reductions across the ranks, on the device (nl_comm_fuse) ---------------------------------------------------------
@@ -2022,7 +2022,10 @@ extern "C" int nl_planes_put(nl_ctx *c, int field, int64_t z0, int64_t z1, const
 extern "C" int nl_comm_unique_id(char *id128, char *err, size_t errlen) {
     if (!id128) return nl_fail(err, errlen, NL_EINVAL, "id buffer is NULL");
     ncclUniqueId id;
-    NL_NCCL(rccl().GetUniqueId(&id));
+    {
+        ncclResult_t r_ = rccl().GetUniqueId(&id);
+        if (r_ != ncclSuccess) return nl_fail(err, errlen, NL_ECOMM, "ncclGetUniqueId: %s", rccl().GetErrorString(r_));
+    }
     static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
     memcpy(id128, &id, 128);
     return NL_OK;
@@ -2038,7 +2041,9 @@ extern "C" int nl_comm_loopback_id(char *id128, char *err, size_t errlen) {
 
 // RCCL communicators outlive their context: a context that closes hands its communicators to a per-process pool, and the next
 // context of the same (device, world, rank, role) takes them from there instead of creating new ones (every rank does the
-// same, so the pool's state is the same everywhere; the id the caller brings is then not used).  Why: a process in which an RCCL
+// same, so the pool's state is the same everywhere; the id the caller brings is then not used -- the CONSTRAINT: the ranks of a
+// job open and close their contexts in the same order, which the SPMD stage classes do; a rank that restarts alone, or a context
+// that failed in a collective (its communicators are destroyed instead, `comm_poisoned`), needs fresh ids on every rank).  Why: a process in which an RCCL
 // communicator has been destroyed -- or created beside an older one -- runs every later slab step 9-18 % slower (measured at
 // world 1 on a 128 x 2048 x 2048 slab: 29.9 -> 32.7 ms synchronous, 30.1 -> 35.3 ms with the device chain; with the earlier
 // communicators neither destroyed nor replaced: 30.1), and the stages of a run (Filter, then Label) each open a context.
@@ -2060,7 +2065,8 @@ static ncclComm_t comm_pool_take(int device, int world, int rank, int role) {
 }
 static void comm_release(nl_ctx *c, void *comm, int role) {
     if (!comm) return;
-    if (lb::is_ours(comm) || getenv("NELLIE_DESTROY_COMMS")) { rccl().CommDestroy((ncclComm_t)comm); return; }
+    // a communicator whose context saw a collective fail may be out of step with its peers: never hand it to a later context
+    if (lb::is_ours(comm) || c->comm_poisoned || getenv("NELLIE_DESTROY_COMMS")) { rccl().CommDestroy((ncclComm_t)comm); return; }
     std::lock_guard<std::mutex> lk(g_comm_pool_mu);
     g_comm_pool.push_back(PooledComm{c->device, c->world, c->rank, role, (ncclComm_t)comm});
 }
@@ -3638,6 +3644,7 @@ extern "C" int nl_ctx_info(nl_ctx *c, const char *key, double *value) {
     if (!strcmp(key, "fast_div")) *value = c->fast_div2 ? 2 : c->fast_div;      // 2: two-instruction division proven, 1: three, 0: float64
     else if (!strcmp(key, "hessian_tile_rows")) *value = hv_rs(c) ? 2 * hv_rs(c) : hm_ty();
     else if (!strcmp(key, "vesselness_one_pass")) *value = c->spec_ok;
+    else if (!strcmp(key, "chain_available")) *value = (!c->two_d && c->spec_ok && hv_rs(c)) ? 1 : 0;   // nl_chain_begin's own precondition
     else if (!strcmp(key, "last_fsq_min")) *value = c->last_fsq_min;
     else if (!strcmp(key, "last_spec_overflow")) *value = c->last_spec_overflow;
     else if (!strcmp(key, "last_label_sparse")) *value = c->last_label_sparse;

@@ -83,6 +83,7 @@ struct nl_ctx {
     unsigned int *d_rows = nullptr;   // per-row run counts and offsets (Label on runs)
     unsigned long long *gbits[2] = {nullptr, nullptr};   // Z-slab Label: GLOBAL bit masks (lazily allocated)
     unsigned int *grows = nullptr;                       // ... and the global per-row arrays
+    int comm_poisoned = 0;     // an RCCL call of this context failed: its communicators are destroyed, not pooled
     i64 blk_cap = 0;
     // Z-slab Label without replication (nl_slab_*): planes [sl_e0, sl_e1) = owned planes + one ghost plane per interior side
     i64 sl_e0 = 0, sl_e1 = 0;

@@ -27,6 +27,7 @@ import numpy as np
 
 from nellie_amd.pipeline import FilterParams, FramePipeline
 
+MAX_LOCAL_SLABS = 16                        # csrc/loopback.inc: ranks of one in-process communicator
 MAX_CONTEXT_VOXELS = (1 << 31) - 1          # nl_ctx_create: int32 voxel indices inside a context
 
 
@@ -224,25 +225,18 @@ class LocalSlabs(_SlabBase):
 
 
 def _exchange_ids(spec: ShardSpec, n_ids: int, make_id, timeout_s=300.0):
-    """Rank 0 creates `n_ids` communicator ids and leaves them in a file of the rendezvous directory; the others pick them up."""
-    d = spec.rendezvous_dir or os.getcwd()
-    os.makedirs(d, exist_ok=True)
+    """Rank 0 creates `n_ids` communicator ids and publishes them through this launch's file rendezvous (nellie_amd/rendezvous.py:
+    the marker carries a nonce the ranks of THIS launch agreed on, so an id left behind by a launch that died is never picked up)."""
+    from nellie_amd.rendezvous import rendezvous_for
+    rdv = rendezvous_for(spec)
     _exchange_ids.counter = getattr(_exchange_ids, "counter", 0) + 1
-    path = os.path.join(d, f".nellie_comm_{spec.tag or 'job'}_{spec.world}_{_exchange_ids.counter}.id")
+    name = f"comm_{_exchange_ids.counter}.id"
     if spec.rank == 0:
         blob = b"".join(make_id() for _ in range(n_ids))
-        tmp = path + f".tmp{os.getpid()}"
-        with open(tmp, "wb") as f:
-            f.write(blob)
-        os.replace(tmp, path)             # the file appears complete or not at all
-        return [blob[i * 128:(i + 1) * 128] for i in range(n_ids)], path
-    t0 = time.time()
-    while not os.path.exists(path):
-        if time.time() - t0 > timeout_s:
-            raise TimeoutError(f"rank {spec.rank}: no communicator id from rank 0 at {path}")
-        time.sleep(0.02)
-    blob = open(path, "rb").read()
-    return [blob[i * 128:(i + 1) * 128] for i in range(n_ids)], path
+        rdv.publish(name, blob)
+    else:
+        blob = rdv.wait(name, timeout_s)
+    return [blob[i * 128:(i + 1) * 128] for i in range(n_ids)], (rdv, name)
 
 
 class RankSlab(_SlabBase):
@@ -261,11 +255,8 @@ class RankSlab(_SlabBase):
         self.pipe = ShardedFramePipeline(self.shape, spec.rank, spec.world, comm_factory, params, device=spec.device,
                                          ctx_factory=spec.ctx_factory, halo=halo, halo_mode=halo_mode)
         self.barrier()
-        if self._id_file and spec.rank == 0:
-            try:
-                os.remove(self._id_file)
-            except OSError:
-                pass
+        if self._id_file and spec.rank == 0:          # every rank holds its communicators (the barrier above ran on them)
+            self._id_file[0].remove(self._id_file[1])
 
     @property
     def trace(self):
@@ -319,6 +310,9 @@ def plan_engine(shape_zyx, params: FilterParams, devices=None, shard: Optional[S
     forced = int(os.environ.get("NELLIE_FORCE_SLABS", "0"))
     if forced > 1:
         w = max(w, forced)
+    if w > MAX_LOCAL_SLABS:
+        raise ValueError(f"a {shape[0]} x {shape[1]} x {shape[2]} frame needs {w} Z slabs in this process, more than the {MAX_LOCAL_SLABS} "
+                         f"the in-process transport carries: run it as one rank per GPU (shard='env') or on more GPUs")
     return ("single", 1) if w == 1 else ("local-slabs", w)
 
 

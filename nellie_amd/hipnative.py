@@ -604,6 +604,11 @@ class Context:
     def one_pass_available(self) -> bool:
         return bool(self.info("vesselness_one_pass"))
 
+    def chain_available(self) -> bool:
+        """nl_chain_begin's precondition: 3-D, the one-pass walk, and the pair kernel (off for planes of >= 2^30 voxels and with
+        NELLIE_HV_RS=0: the synchronous path then runs the one-voxel walk)."""
+        return bool(self.info("chain_available"))
+
     def set_spacing(self, spacing):
         sp = (_f64 * 3)(*[float(s) for s in spacing])
         self._call("nl_set_spacing", sp)

@@ -20,6 +20,7 @@ from __future__ import annotations
 import os
 import re
 import struct
+import uuid
 from xml.sax.saxutils import escape
 
 import numpy as np
@@ -101,6 +102,22 @@ def create(path, shape_tzyx, dtype, dim_res=None, description="", data=None):
     xml = ome_xml(shape_tzyx, dt, dim_res, description, os.path.basename(path)).encode("utf-8") + b"\0"
     software = b"nellie_amd\0"
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    # written under a temporary name and moved into place: a reader (another rank of a multi-process run, a viewer) sees the old
+    # complete file or the new complete file, never a truncated one, and a map of the old file keeps its pages
+    final_path, path = path, f"{path}.tmp{os.getpid()}_{uuid.uuid4().hex[:8]}"
+    try:
+        _write_file(path, t, z, y, x, dt, nplanes, plane_bytes, data_offset, data_bytes, xml, software, data)
+        os.replace(path, final_path)
+    except BaseException:
+        try:
+            os.remove(path)
+        except OSError:
+            pass
+        raise
+    return data_offset
+
+
+def _write_file(path, t, z, y, x, dt, nplanes, plane_bytes, data_offset, data_bytes, xml, software, data):
     with open(path, "wb") as f:
         first_ifd = data_offset + data_bytes
         first_ifd += first_ifd % 2
@@ -133,7 +150,6 @@ def create(path, shape_tzyx, dtype, dim_res=None, description="", data=None):
             if nxt > pos + len(blob):
                 f.write(b"\0")
             pos = nxt
-    return data_offset
 
 
 class TiffLayout:

@@ -525,7 +525,8 @@ class FramePipeline:
 
     def _chain_usable(self, p: FilterParams, mask: bool) -> bool:
         return bool(self._device_chain and self.one_pass and mask and not self.two_d and p.frob_thresh is None and p.frob_thresh_division
-                    and hasattr(self.ctx, "chain_begin") and self._chain_reductions_on_device())
+                    and hasattr(self.ctx, "chain_begin") and getattr(self.ctx, "chain_available", lambda: True)()
+                    and self._chain_reductions_on_device())
 
     def _chain_reductions_on_device(self) -> bool:
         return True            # one GPU: nothing to reduce (a Z-slab pipeline needs its fused communicator)

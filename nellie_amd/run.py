@@ -22,6 +22,32 @@ def _wait_for(path, timeout_s=600.0):
         time.sleep(0.02)
 
 
+def _build_im_info(file_info, shard):
+    """ImInfo(file_info) as run.py:49 -- in a multi-process launch (shard="env") rank 0 first, so that the canonical copy of the
+    input (verifier.py:620-695) is written once; the other ranks then find it complete (ome_tiff.create moves files into place
+    atomically) and reuse it instead of re-creating it under readers."""
+    from nellie_amd.engine import ShardSpec
+    from nellie_amd.im_info.verifier import ImInfo
+    spec = ShardSpec.from_env() if shard == "env" or (shard is None and os.environ.get("NELLIE_SHARD") == "env") else None
+    if spec is None or spec.world <= 1:
+        return ImInfo(file_info)
+    import tempfile
+    from nellie_amd.rendezvous import rendezvous_for
+    src = getattr(file_info, "filepath", None) or (file_info if isinstance(file_info, (str, os.PathLike)) else None)
+    d = getattr(file_info, "output_dir", None) or (os.path.dirname(os.path.abspath(os.fspath(src))) if src else tempfile.gettempdir())
+    rdv = rendezvous_for(spec, d)
+    if spec.rank == 0:
+        im_info = ImInfo(file_info)
+        rdv.publish("im_info_ready")
+    else:
+        rdv.wait("im_info_ready")
+        im_info = ImInfo(file_info)
+    rdv.barrier("im_info_built")
+    if spec.rank == 0:
+        rdv.remove("im_info_ready")
+    return im_info
+
+
 def run_streamed(im_info, viewer=None, device_index=0, devices=None, shard=None):
     """
     Filter + Label of every frame with the three legs overlapped (nellie_amd/streaming.py): same two files as
@@ -41,15 +67,20 @@ def run_streamed(im_info, viewer=None, device_index=0, devices=None, shard=None)
     spec = ShardSpec.from_env() if shard == "env" else shard
     rank, world = (spec.rank, spec.world) if spec is not None else (0, 1)
     fr_path, lab_path = im_info.pipeline_paths["im_preprocessed"], im_info.pipeline_paths["im_instance_label"]
-    marker = f"{lab_path}.ready_{spec.tag}" if spec is not None else None
+    # a multi-process run meets through files that carry this launch's nonce (nellie_amd/rendezvous.py): the markers of a launch
+    # that died on the same MASTER_PORT are never mistaken for this one's
+    rdv = None
+    if spec is not None and world > 1:
+        from nellie_amd.rendezvous import rendezvous_for
+        rdv = rendezvous_for(spec, os.path.dirname(lab_path))
     im = im_info.get_memmap(im_info.im_path)
     if rank == 0:
         fr = im_info.allocate_memory(fr_path, dtype="float32", description="frangi filtered im", return_memmap=True)
         lab = im_info.allocate_memory(lab_path, dtype="int32", description="instance segmentation", return_memmap=True)
-        if marker:
-            open(marker, "w").close()
+        if rdv:
+            rdv.publish("streamed_files_ready")
     else:
-        _wait_for(marker)
+        rdv.wait("streamed_files_ready")
         fr, lab = im_info.get_memmap(fr_path), im_info.get_memmap(lab_path)
     devs = [spec.device] if spec is not None else ([int(d) for d in devices] if devices else [int(device_index)])
     params = FilterParams(dim_res=im_info.dim_res)
@@ -88,14 +119,10 @@ def run_streamed(im_info, viewer=None, device_index=0, devices=None, shard=None)
         if errs:
             raise errs[0]
     fr.flush(); lab.flush()
-    if spec is not None:                                       # every rank done before anyone reads the files
-        open(f"{lab_path}.done_{spec.tag}_{rank}", "w").close()
+    if rdv:                                                    # EVERY rank returns only when every rank has flushed its frames
+        rdv.barrier("streamed_done")
         if rank == 0:
-            for r in range(world):
-                _wait_for(f"{lab_path}.done_{spec.tag}_{r}")
-            for r in range(world):
-                os.remove(f"{lab_path}.done_{spec.tag}_{r}")
-            os.remove(marker)
+            rdv.remove("streamed_files_ready")
     return im_info
 
 
@@ -108,7 +135,10 @@ def run(file_info, remove_edges=False, otsu_thresh_intensity=False, threshold=No
     LOCAL_RANK) of a multi-process Z-slab job over RCCL -- see nellie_amd/engine.py.  Frames beyond one context's size are
     cut into slabs without being asked."""
     from nellie_amd.im_info.verifier import ImInfo
-    im_info = file_info if hasattr(file_info, "pipeline_paths") else ImInfo(file_info)
+    if hasattr(file_info, "pipeline_paths"):
+        im_info = file_info
+    else:
+        im_info = _build_im_info(file_info, shard)
     t0 = time.perf_counter() if timeit else None
     preprocessing = Filter(im_info, remove_edges=remove_edges, device=device, low_memory=low_memory, devices=devices, shard=shard)
     preprocessing.run()

@@ -91,9 +91,12 @@ class Markers:
         paths = self.im_info.pipeline_paths
         _, spec = self._slab_plan(self.shape[1:]) if (len(self.shape) == 4 and self.sigmas) else (1, None)
         self._spec = spec
-        if spec is not None and spec.rank != 0:                # a multi-process run: rank 0 creates the files, the others map them
-            from nellie_amd.run import _wait_for
-            _wait_for(f"{paths['im_border']}.ready_{spec.tag}")
+        self._rdv = None
+        if spec is not None and spec.world > 1:                # a multi-process run meets through this launch's file rendezvous
+            from nellie_amd.rendezvous import rendezvous_for
+            self._rdv = rendezvous_for(spec, os.path.dirname(paths["im_border"]))
+        if spec is not None and spec.rank != 0:                # rank 0 creates the files, the others map them
+            self._rdv.wait("markers_files_ready")
             self.im_marker_memmap = self.im_info.get_memmap(paths["im_marker"])
             self.im_distance_memmap = self.im_info.get_memmap(paths["im_distance"])
             self.im_border_memmap = self.im_info.get_memmap(paths["im_border"])
@@ -102,8 +105,8 @@ class Markers:
         self.im_marker_memmap = alloc(paths["im_marker"], dtype="uint8", description="mocap marker image", return_memmap=True)
         self.im_distance_memmap = alloc(paths["im_distance"], dtype="float32", description="distance transform image", return_memmap=True)
         self.im_border_memmap = alloc(paths["im_border"], dtype="uint8", description="border image", return_memmap=True)
-        if spec is not None:
-            open(f"{paths['im_border']}.ready_{spec.tag}", "w").close()
+        if self._rdv is not None:
+            self._rdv.publish("markers_files_ready")
 
     def _get_pipeline(self, shape) -> FramePipeline:
         key = tuple(int(s) for s in shape)
@@ -258,17 +261,10 @@ class Markers:
         self._allocate_memory()
         try:
             self._run_mocap_marking()
-            spec = getattr(self, "_spec", None)
-            if spec is not None:                               # every rank done before anyone reads the files
-                import os
-                from nellie_amd.run import _wait_for
-                base = self.im_info.pipeline_paths["im_border"]
-                open(f"{base}.done_{spec.tag}_{spec.rank}", "w").close()
-                if spec.rank == 0:
-                    for r in range(spec.world):
-                        _wait_for(f"{base}.done_{spec.tag}_{r}")
-                    for r in range(spec.world):
-                        os.remove(f"{base}.done_{spec.tag}_{r}")
-                    os.remove(f"{base}.ready_{spec.tag}")
+            rdv = getattr(self, "_rdv", None)
+            if rdv is not None:                                # EVERY rank returns only when every rank has flushed its planes
+                rdv.barrier("markers_done")
+                if rdv.rank == 0:
+                    rdv.remove("markers_files_ready")
         finally:
             self.close()

@@ -647,6 +647,38 @@ def filter_frame(frame, dim_res, **kw):
     return fr
 
 
+def filter_frame_crop(crop, dim_res, given_scales, percentile_thr, **kw):
+    """
+    Voxel-level check of a volume too large for this oracle (1024^3 needs ~45 min and ~96 GB): `crop` is a box cut
+    out of the volume, `given_scales` / `percentile_thr` the volume-wide thresholds of the run under test
+    (filtering.py:839, 555-562, 432-441, 843-844, 963 -- everything the algorithm derives from ALL voxels).
+    The result equals the whole-volume result on every voxel farther than
+        sum_s int(3 * delta_sigma_s + 0.5)   (the cascade, filtering.py:816-835)
+        + 2                                   (np.gradient applied twice, :518-536)
+        + 2                                   (binary_opening = erosion + dilation, :965)
+    voxels (per axis, with that axis' sigma) from a face of the crop that is NOT a face of the volume; a face the crop
+    shares with the volume needs no margin: reflect padding, one-sided differences and the opening's zero border are then
+    the volume's own.  `percentile_thr=None`: `_mask_volume` is not applied (the `_run_frame` product).
+    """
+    fr = run_frame(np.asarray(crop, np.float32), dim_res, given_scales=given_scales, **kw)
+    if percentile_thr is not None:
+        fr = mask_volume(fr, given_thr=percentile_thr)
+    return fr
+
+
+def crop_margin(dim_res, sigmas=None, with_mask_volume=True):
+    """Planes / rows / columns of a crop (per axis) that an artificial face invalidates: see `filter_frame_crop`."""
+    zr = z_ratio(dim_res)
+    if sigmas is None:
+        sigmas = default_sigmas(dim_res)
+    reach = [0, 0, 0]
+    for delta in cascade_deltas(sigmas, zr):
+        for a in range(3):
+            if delta[a] > 1e-15:
+                reach[a] += gaussian_radius(delta[a], 3.0)
+    return tuple(r + 2 + (2 if with_mask_volume else 0) for r in reach)
+
+
 # =============================================================================
 # Filter, 2-D images (im_info.no_z): filtering.py:461-490, 675-690, 732-741, 772-796, 927-930
 # =============================================================================

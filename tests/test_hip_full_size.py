@@ -82,9 +82,84 @@ def test_labels_equal_the_oracle_at_1024_cube(full_run):
     assert np.array_equal(ref, full_run["labels"])
 
 
+def given_scales_of(trace):
+    """The volume-wide quantities of a device run, in the form the oracle's crop mode takes them."""
+    return [dict(gamma=sc.gamma, max_abs=sc.max_abs, frob_thr=sc.frob_thr, skipped=sc.skipped) for sc in trace.scales]
+
+
+def crop_valid_slices(box, shape, margin):
+    return tuple(slice(0 if a == 0 else m, (b - a) - (0 if b == n else m)) for (a, b), n, m in zip(box, shape, margin))
+
+
+def check_frangi_crops(vol, frangi, trace, shape, boxes, what):
+    """Voxel-level parity of a Frangi image too large for the oracle, box by box: the oracle recomputes each box from the RAW
+    voxels with the run's volume-wide thresholds (oracle.filter_frame_crop, pinned against the reference's own outputs in
+    tests/test_oracle_golden.py::test_crop_mode_reproduces_the_reference_on_crop_interiors) and the device image must meet
+    the usual bar -- |a - b| <= 1e-4 |ref| + 1e-6 max|ref|, identical support, capped tie zone of the percentile
+    threshold -- on the part of the box no artificial face reaches."""
+    from nellie_amd.synthetic import ISO_01
+    from oracle import nellie_oracle as orc
+    from test_hip_parity import assert_masked_close
+    given = given_scales_of(trace)
+    margin = orc.crop_margin(ISO_01)
+    checked = 0
+    for box in boxes:
+        sl = tuple(slice(a, b) for a, b in box)
+        valid = crop_valid_slices(box, shape, margin)
+        raw = orc.filter_frame_crop(vol[sl], ISO_01, given, None)
+        ref = orc.mask_volume(raw, given_thr=trace.percentile_thr)
+        got = np.ascontiguousarray(frangi[sl][valid])
+        assert_masked_close(got, np.ascontiguousarray(ref[valid]), np.ascontiguousarray(raw[valid]), trace.percentile_thr, f"{what} box {box}")
+        checked += int(np.count_nonzero(ref[valid]))
+    assert checked > 1000, f"{what}: the boxes hold only {checked} non-zero reference voxels"
+    return checked
+
+
+# boxes of 120 x 280 x 280 (valid interiors 72..96 x 232..256 x 232..256): a corner of the volume, a box on the X face, the
+# centre, a box across the seam of the walk's 128-plane chunks (z = 128), the opposite corner in Z
+CUBE_BOXES = [((0, 120), (0, 280), (0, 280)), ((452, 572), (372, 652), (744, 1024)), ((452, 572), (372, 652), (372, 652)),
+              ((68, 188), (700, 980), (100, 380)), ((904, 1024), (744, 1024), (0, 280))]
+
+
+def test_frangi_crops_equal_the_oracle_at_1024_cube(full_run):
+    """filtering.py:806-853 at the headline size, voxel by voxel on five boxes (the walk's 128-plane chunks, the resolve kernel's
+    capped grid and the automatic chunk choice only exist at this size)."""
+    n = check_frangi_crops(full_run["vol"], full_run["frangi"], full_run["trace"], SHAPE, CUBE_BOXES, "1024^3")
+    print(f"1024^3: {n} non-zero reference voxels compared in {len(CUBE_BOXES)} boxes")
+
+
+def test_gaussian_scale_space_and_gamma_at_1024_cube(full_run, hip):
+    """The cascade at the headline size: every scale's Gaussian volume BIT-equal to the oracle's on the interiors of the same
+    boxes (filtering.py:816-835), and gamma = min(triangle, Otsu) of the oracle's own strided sample of the device volume
+    (:365-380, :348-363) equal to the run's trace."""
+    from nellie_amd import pipeline as pl
+    from nellie_amd.synthetic import ISO_01
+    from oracle import nellie_oracle as orc
+    vol = full_run["vol"]
+    margin = orc.crop_margin(ISO_01, with_mask_volume=False)
+    pipe = pl.FramePipeline(SHAPE)
+    try:
+        pipe.ctx.filter_load(vol)
+        sig = pl.default_sigmas(ISO_01)
+        refs = [vol[tuple(slice(a, b) for a, b in box)].astype(np.float32) for box in CUBE_BOXES]
+        for s, delta in enumerate(pl.cascade_deltas(sig, pl.z_ratio_of(ISO_01))):
+            pipe.ctx.gauss_step(*[pl.gaussian_weights(d) for d in delta])
+            gauss = pipe.ctx.gauss_store()
+            assert orc.calculate_gamma(gauss) == full_run["trace"].scales[s].gamma, f"gamma of scale {s}"
+            for k, box in enumerate(CUBE_BOXES):
+                refs[k] = orc.gaussian_filter_f32(refs[k], delta, 3.0)
+                # the cascade's reach grows scale by scale; the final margin covers every scale
+                valid = crop_valid_slices(box, SHAPE, margin)
+                sl = tuple(slice(a, b) for a, b in box)
+                assert np.array_equal(gauss[sl][valid], refs[k][valid]), f"Gaussian of scale {s}, box {box}"
+            del gauss
+    finally:
+        pipe.close()
+
+
 def run_slabs(vol, shape, world, seed_dim_res=None):
     """The volume as `world` Z-slabs, one context and one thread per slab on this GPU (ghost planes and reductions
-    through the host): [(o0, o1, frangi, labels, thr, n)] per rank."""
+    through the host): [(o0, o1, frangi, labels, thr, n, trace)] per rank."""
     from nellie_amd.pipeline import FilterParams, min_area_pixels_of
     from nellie_amd.sharded import ShardedFramePipeline, slab_range
     from nellie_amd.synthetic import ISO_01
@@ -99,7 +174,7 @@ def run_slabs(vol, shape, world, seed_dim_res=None):
             pipe.filter(vol[o0:o1], p)
             thr = pipe.frangi_threshold()
             n = pipe.label(thr, min_area_pixels_of(ISO_01))
-            out[rank] = (o0, o1, pipe.download_frangi(), pipe.download_labels(), thr, n)
+            out[rank] = (o0, o1, pipe.download_frangi(), pipe.download_labels(), thr, n, pipe.trace)
             pipe.close()
         except Exception as exc:  # noqa: BLE001
             errs.append(exc)
@@ -116,7 +191,7 @@ def run_slabs(vol, shape, world, seed_dim_res=None):
 
 
 def test_two_slabs_equal_one_volume_at_1024_cube(full_run):
-    for o0, o1, fr, lab, thr, n in run_slabs(full_run["vol"], SHAPE, 2):
+    for o0, o1, fr, lab, thr, n, _ in run_slabs(full_run["vol"], SHAPE, 2):
         assert thr == full_run["thr"], (thr, full_run["thr"])
         assert n == full_run["n"], (n, full_run["n"])
         ref = full_run["frangi"][o0:o1]
@@ -207,21 +282,27 @@ def test_c4_volume_partition_invariance(hip):
     a = run_slabs(vol, shape, 8)
     t8 = time.perf_counter() - t0
     fr8 = np.concatenate([r[2] for r in a]); lab8 = np.concatenate([r[3] for r in a])
-    thr8, n8 = a[0][4], a[0][5]
+    thr8, n8, trace8 = a[0][4], a[0][5], a[0][6]
     assert all(r[4] == thr8 and r[5] == n8 for r in a)
+    assert all([(sc.gamma, sc.max_abs, sc.frob_thr) for sc in r[6].scales] == [(sc.gamma, sc.max_abs, sc.frob_thr) for sc in trace8.scales]
+               and r[6].percentile_thr == trace8.percentile_thr for r in a)
     del a
+    # voxel-level against the oracle (filtering.py:806-853) where only the slab layout computes: 2048-wide rows, 137-plane
+    # contexts, planes either side of the interfaces at z = 128 and z = 896, the X / Y faces of the wide planes
+    c4_boxes = [((68, 188), (0, 280), (1768, 2048)), ((836, 956), (884, 1164), (884, 1164)), ((0, 120), (1768, 2048), (0, 280))]
+    n_cmp = check_frangi_crops(vol, fr8, trace8, shape, c4_boxes, "C4 as 8 slabs")
     t0 = time.perf_counter()
     b = run_slabs(vol, shape, 4)
     t4 = time.perf_counter() - t0
     assert all(r[4] == thr8 and r[5] == n8 for r in b), ([r[4] for r in b], thr8, [r[5] for r in b], n8)
-    for o0, o1, fr, lab, _, _ in b:
+    for o0, o1, fr, lab, _, _, _ in b:
         assert np.array_equal(fr, fr8[o0:o1]), f"planes [{o0},{o1}): {int((fr != fr8[o0:o1]).sum())} Frangi voxels differ"
         assert np.array_equal(lab, lab8[o0:o1]), f"planes [{o0},{o1}): {int((lab != lab8[o0:o1]).sum())} label voxels differ"
     assert fr8.min() >= 0.0 and np.isfinite(fr8.max()) and n8 >= 10 and int(lab8.max()) == n8
     report = {"shape": list(shape), "voxels": int(np.prod(shape)), "labels": int(n8), "frangi_threshold": float(thr8),
               "survival_fraction": float(np.count_nonzero(fr8) / fr8.size), "labelled_fraction": float(np.count_nonzero(lab8) / lab8.size),
               "wall_s_8_slabs_one_gpu_incl_host_io": round(t8, 2), "wall_s_4_slabs_one_gpu_incl_host_io": round(t4, 2),
-              "equal_bit_for_bit": True}
+              "equal_bit_for_bit": True, "voxels_compared_with_the_oracle_in_boxes": n_cmp}
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/c4_partition_invariance.json", "w") as f:
         json.dump(report, f)

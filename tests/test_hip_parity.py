@@ -1021,3 +1021,30 @@ print(json.dumps(out))
     assert any(g[0] == 2 for g in got["0"]), "the two-instruction division was not selected for any of the spacings"
     for a, b, c in zip(got["0"], got["3"], got["1"]):
         assert a[1:] == b[1:] == c[1:] and a[3] > 0
+
+
+def test_chain_is_skipped_where_the_pair_walk_is_unavailable(hip):
+    """NELLIE_HV_RS=0 (what a plane of >= 2^30 voxels selects by itself) leaves the one-voxel walk and nl_chain_begin's
+    precondition unmet: the default pipeline (chain on) must then take the synchronous path instead of raising, and give the
+    frame the pair walk gives (the switch is read once per process: child processes)."""
+    import json, subprocess, sys
+    code = r'''
+import json, zlib
+from nellie_amd import pipeline as pl
+from nellie_amd.synthetic import ISO_01, make_volume
+vol = make_volume((40, 96, 104), 31)
+pipe = pl.FramePipeline(vol.shape)
+usable = pipe._chain_usable(pl.FilterParams(dim_res=ISO_01), True)
+pipe.filter(vol, pl.FilterParams(dim_res=ISO_01))
+tr = [(s.gamma, s.max_abs, s.frob_thr, s.mask_count) for s in pipe.trace.scales]
+print(json.dumps([bool(pipe.ctx.chain_available()), bool(usable), tr, zlib.crc32(pipe.download_frangi().tobytes()), pipe.trace.n_positive]))
+pipe.close()
+'''
+    got = {}
+    for rs in ("8", "0"):
+        env = dict(os.environ, NELLIE_HV_RS=rs, NELLIE_DEVICE_CHAIN="1", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got[rs] = json.loads(r.stdout.strip().splitlines()[-1])
+    assert got["8"][:2] == [True, True] and got["0"][:2] == [False, False]
+    assert got["8"][2:] == got["0"][2:] and got["8"][4] > 0

@@ -166,3 +166,50 @@ def test_network_steps_match_reference(name):
     assert str(pc.dtype) == str(g["pixel_class_dtype"]) and np.array_equal(pc, g["pixel_class"])
     bl = orc.network_branch_skel_labels(pc)
     assert str(bl.dtype) == str(g["branch_labels_dtype"]) and np.array_equal(bl, g["branch_labels"])
+
+
+def _given_scales(gamma, max_abs, frob_thr, mask_count):
+    return [dict(gamma=float(a), max_abs=float(b), frob_thr=None if np.isnan(c) else float(c), skipped=int(d) == 0)
+            for a, b, c, d in zip(gamma, max_abs, frob_thr, mask_count)]
+
+
+def crop_valid_slices(box, shape, margin):
+    """Within a crop `box` = ((z0, z1), (y0, y1), (x0, x1)) of a volume of `shape`: the part that `filter_frame_crop` reproduces
+    exactly -- `margin` voxels in from every face of the box that is not a face of the volume."""
+    return tuple(slice(0 if a == 0 else m, (b - a) - (0 if b == n else m)) for (a, b), n, m in zip(box, shape, margin))
+
+
+@pytest.mark.parametrize("name,boxes", [
+    ("strided_50x150x141_s5", [((0, 50), (20, 130), (0, 100)), ((0, 50), (0, 150), (30, 141)), ((0, 50), (40, 150), (41, 141))]),
+    ("someempty_24x48x48_s0", [((0, 24), (0, 48), (0, 48))]),
+    ("aniso_20x40x44_s3", [((0, 20), (0, 40), (0, 44))]),
+])
+def test_crop_mode_reproduces_the_reference_on_crop_interiors(name, boxes):
+    """The crop mode of the oracle (`filter_frame_crop`: volume-wide thresholds supplied, per-voxel arithmetic on a box) against the
+    REFERENCE's own outputs: the golden case's thresholds in, the golden `run_frame` / `frangi` arrays on the crop's valid interior
+    out, bit for bit.  This is what licenses the voxel-level checks of 1024^3 and 128x2048x2048 runs in test_hip_full_size.py."""
+    g = load_golden(name)
+    dr = g["dim_res_dict"]
+    kw, sig_kw = _filter_kwargs(g)
+    vol = g["input"]
+    sigmas = orc.default_sigmas(dr, **sig_kw)
+    given = _given_scales(g["gamma"], g["max_abs"], g["frob_thr"], g["mask_count"])
+    margin = orc.crop_margin(dr, sigmas)
+    masked = float(g["run_frame"].sum()) > 0
+    for box in boxes:
+        sl = tuple(slice(a, b) for a, b in box)
+        valid = crop_valid_slices(box, vol.shape, margin)
+        if any(v.stop - v.start <= 0 for v in valid):
+            pytest.fail(f"box {box} has no valid interior with margin {margin}")
+        raw = orc.filter_frame_crop(vol[sl], dr, given, None, sigmas=sigmas, **kw)
+        assert np.array_equal(raw[valid], g["run_frame"][sl][valid])
+        if masked:
+            out = orc.filter_frame_crop(vol[sl], dr, given, float(g["percentile_thr"]), sigmas=sigmas, **kw)
+            assert np.array_equal(out[valid], g["frangi"][sl][valid])
+    # the margin matters: close to an artificial face the box's own reflect padding / one-sided differences show
+    if name.startswith("strided"):
+        box = ((0, 50), (20, 130), (0, 100))
+        sl = tuple(slice(a, b) for a, b in box)
+        valid = crop_valid_slices(box, vol.shape, (3, 3, 3))
+        raw = orc.filter_frame_crop(vol[sl], dr, given, None, sigmas=sigmas, **kw)
+        assert not np.array_equal(raw[valid], g["run_frame"][sl][valid])

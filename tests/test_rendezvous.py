@@ -1,0 +1,72 @@
+"""The file rendezvous of a multi-process launch (nellie_amd/rendezvous.py) on CPU: ranks agree on a nonce no earlier launch can
+have produced, so the leftovers of a launch that died on the same MASTER_PORT -- ready / done markers, a communicator id -- are
+never picked up."""
+import multiprocessing as mp
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+
+def _rank(rank, world, d, tag, delay, q):
+    try:
+        sys.path.insert(0, REPO)
+        from nellie_amd.rendezvous import FileRendezvous
+        time.sleep(delay)
+        rdv = FileRendezvous(rank, world, d, tag, timeout_s=60)
+        if rank == 0:
+            rdv.publish("payload", b"id-of-this-launch")
+        data = rdv.wait("payload", 60)
+        rdv.barrier("end")
+        q.put((rank, rdv.nonce, data))
+    except BaseException as exc:  # noqa: BLE001
+        q.put((rank, "error", repr(exc)))
+
+
+def _launch(world, d, tag, delays):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_rank, args=(r, world, d, tag, delays[r], q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    out = sorted(q.get(timeout=120) for _ in range(world))
+    for p in ps:
+        p.join(30)
+    return out
+
+
+def test_ranks_agree_on_a_fresh_nonce_despite_leftovers(tmp_path):
+    d, tag, world = str(tmp_path), "29500", 3
+    # what a launch that died leaves behind: its handshake files (complete, consistent) and markers under its nonce
+    stale = "deadbeefdeadbeef"
+
+    def leave_a_dead_launch_behind():
+        for r in range(world):
+            open(os.path.join(d, f".nellie_rdv_{tag}_{world}_hello_{r}"), "w").write(f"tok{r}")
+            open(os.path.join(d, f".nellie_rdv_{tag}_{world}_ack_{r}"), "w").write(stale)
+        open(os.path.join(d, f".nellie_rdv_{tag}_{world}_go"), "w").write("\n".join([stale] + [f"tok{r}" for r in range(world)]))
+        open(os.path.join(d, f".nellie_{stale}_payload"), "w").write("id-of-the-dead-launch")
+    # rank 0 late: the others meet the stale `go` first; then rank 2 late: rank 0 meets a stale hello first
+    for delays in ((0.5, 0.0, 0.0), (0.0, 0.0, 0.5)):
+        leave_a_dead_launch_behind()
+        out = _launch(world, d, tag, delays)
+        assert all(o[1] != "error" for o in out), out
+        nonces = {o[1] for o in out}
+        assert len(nonces) == 1 and stale not in nonces
+        assert all(o[2] == b"id-of-this-launch" for o in out)
+    # two launches in a row never share a nonce, and a finished launch leaves no barrier / handshake files behind
+    left = [f for f in os.listdir(d) if "_end_" in f or f.startswith(f".nellie_rdv_{tag}")]
+    assert left == [], left
+
+
+def test_world_one_needs_nobody(tmp_path):
+    from nellie_amd.rendezvous import FileRendezvous
+    rdv = FileRendezvous(0, 1, str(tmp_path), "x", timeout_s=5)
+    rdv.publish("a", b"z")
+    assert rdv.wait("a", 1) == b"z"
+    rdv.barrier("b")
+    rdv.remove("a")
+    assert [f for f in os.listdir(tmp_path) if f.startswith(".nellie")] == []
