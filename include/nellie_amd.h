@@ -392,9 +392,9 @@ int nl_label_run_global(nl_ctx *ctx, int64_t min_area, int fill_holes, int64_t *
    equivalent to the full-volume result -- this is).  Every rank labels its owned planes plus ONE ghost bit plane per
    interior side (exchanged with nl_slab_bits_exchange over RCCL, or nl_slab_bits_get / _put through the host).  A
    component that crosses an interface shows up on both ranks as a tree containing runs of the two planes both ranks see,
-   and the k-th run of such a plane is the same voxels on both sides: `nl_slab_tables` hands those (tree, quantity) pairs
-   to the host, which joins the trees of neighbouring ranks (a graph with a few thousand nodes) and patches the result
-   back.  Three phases, each opened by nl_slab_components(phase):
+   and the k-th SEGMENT COMPONENT of such a plane (a connected piece of the plane's mask inside a band of rows: what the in-LDS
+   level of the union-find joins) is the same voxels on both sides: `nl_slab_phase` hands those (tree, quantity) pairs -- a few
+   hundred per plane -- to the host, which joins the trees of neighbouring ranks and patches the result back.  Three phases:
      phase 0 (fill)   6-connected background; quantity = 1 if the tree touches a face of the GLOBAL volume; after the
                       patch nl_slab_apply sets the enclosed background of the owned planes        (labelling.py:486)
      phase 1 (area)   26-connected foreground; quantity = voxels on the OWNED planes; after the patch (global sums)
@@ -402,24 +402,36 @@ int nl_label_run_global(nl_ctx *ctx, int64_t min_area, int fill_holes, int64_t *
      nl_slab_majority majority filter of the kept-objects mask (its ghost planes exchanged first)  (labelling.py:503-505)
      phase 2 (number) 26-connected foreground; quantity = first run of the tree on the owned planes (INT32_MAX: none).
                       The owner of a component is the lowest rank holding voxels of it; nl_slab_number ranks the trees a
-                      rank owns in raster order, nl_slab_paint adds the rank's base id (exclusive sum of the lower ranks'
-                      counts) and takes the labels of trees owned elsewhere from the host: ids 1..K in raster order of the
-                      first voxel, exactly scipy.ndimage.label's numbering of the whole volume      (labelling.py:507)
-   counts[5] of nl_slab_components: runs in total, then in the low ghost plane, the first owned plane, the last owned plane
-   and the high ghost plane (0 where the slab touches a true face); nl_slab_tables fills roots / values in that order. */
+                      rank owns in raster order (and says which rank each tree of `set` got), nl_slab_paint adds the rank's
+                      base id (exclusive sum of the lower ranks' counts) and takes the labels of trees owned elsewhere from
+                      the host: ids 1..K in raster order of the first voxel, exactly scipy.ndimage.label's numbering of the
+                      whole volume                                                                  (labelling.py:507)
+   nl_slab_phase(phase, gather, block_ints, out, &need_ints, &nruns): one call per phase, one wait.  A rank's tables are a blob
+   of int32: [n0 n1 n2 n3 | ints in the blob | overflow | runs | 0] [roots of plane 0..3] [values of plane 0..3], planes in the
+   order ghost-low, first owned, last owned, ghost-high (n = 0 towards a side without a neighbour).  gather = 0: out receives
+   this rank's blob (one block of block_ints); gather = 1 (needs nl_comm_init): the blobs of ALL ranks, all-gathered over RCCL
+   on the context stream in fixed blocks (no size negotiation), rank r's at out + r * block_ints.  *need_ints: the largest blob;
+   if it exceeds block_ints nothing was copied and the caller repeats with phase = -1 and a larger block (nothing is recomputed). */
 int nl_slab_label_pack(nl_ctx *ctx, int has_thr, float thr, char *err, size_t errlen);
 int nl_slab_bits_get(nl_ctx *ctx, int which, int64_t plane, uint64_t *host, char *err, size_t errlen);
 int nl_slab_bits_put(nl_ctx *ctx, int which, int64_t plane, const uint64_t *host, char *err, size_t errlen);
 int nl_slab_bits_exchange(nl_ctx *ctx, int which, char *err, size_t errlen);
-int nl_slab_components(nl_ctx *ctx, int phase, int64_t *counts, char *err, size_t errlen);
-int nl_slab_tables(nl_ctx *ctx, int32_t *roots, int32_t *values, char *err, size_t errlen);
+int nl_slab_phase(nl_ctx *ctx, int phase, int gather, int64_t block_ints, int32_t *out, int64_t *need_ints, int64_t *nruns,
+                  char *err, size_t errlen);
 int nl_slab_patch(nl_ctx *ctx, int64_t n, const int32_t *roots, const int32_t *values, char *err, size_t errlen);
 int nl_slab_apply(nl_ctx *ctx, int64_t min_area, char *err, size_t errlen);
 int nl_slab_majority(nl_ctx *ctx, char *err, size_t errlen);
 int nl_slab_number(nl_ctx *ctx, int64_t n_clear, const int32_t *clear, int64_t n_set, const int32_t *set, int64_t *n_local,
-                   char *err, size_t errlen);
-int nl_slab_query(nl_ctx *ctx, int64_t n, const int32_t *idx, int32_t *out, char *err, size_t errlen);
+                   int32_t *ids_of_set, char *err, size_t errlen);
 int nl_slab_paint(nl_ctx *ctx, int64_t base, int64_t n, const int32_t *roots, const int32_t *labels, char *err, size_t errlen);
+/* Host only (no device, no context): joins the tables of `world` ranks (blobs as nl_slab_phase writes them, rank r's at
+   blobs + r * block_ints).  One NODE per (rank, tree) that appears in a table, ranks in order, a rank's trees by ascending root;
+   node_rank / node_root / node_val (int64, the tree's quantity) / node_comp receive up to `cap` nodes, *n_nodes their count,
+   *n_comp the number of components after joining rank r's planes 2, 3 with rank r + 1's planes 0, 1 entry by entry; components
+   are numbered in the order of their smallest node.  Returns NL_EINVAL if two ranks disagree about a shared plane.  Every rank
+   calls it on the same gathered blobs and gets the same answer (the reference has no counterpart: SURVEY.md 8(e)). */
+int nl_host_slab_join(int world, const int32_t *blobs, int64_t block_ints, int64_t cap, int64_t *n_nodes, int64_t *n_comp,
+                      int64_t *node_rank, int32_t *node_root, int64_t *node_val, int64_t *node_comp, char *err, size_t errlen);
 
 /* Variable-size all-gather of host bytes over RCCL (ncclAllGather on padded device staging): `recv` receives
    world * max_bytes bytes, rank r's block at r * max_bytes (its first bytes_of[r] bytes are valid; bytes_of has `world`

@@ -364,6 +364,8 @@ extern "C" int nl_ctx_destroy(nl_ctx *c) {
     if (c->d_vq_count) hipFree(c->d_vq_count);
     if (c->d_rows) hipFree(c->d_rows);
     if (c->d_ag) hipFree(c->d_ag);
+    if (c->d_sl) hipFree(c->d_sl);
+    if (c->h_sl) hipHostFree(c->h_sl);
     if (c->d_pack) hipFree(c->d_pack);
     if (c->h_ag) hipHostFree(c->h_ag);
     if (c->gbits[0]) hipFree(c->gbits[0]);
@@ -2708,7 +2710,7 @@ static int scan_excl_u32(nl_ctx *c, const unsigned int *in, unsigned int *out, i
     return NL_OK;
 }
 
-struct RunSet { RunRec *runs; int *parent; unsigned int *row_off; i64 nruns; int *proot = nullptr; int *link = nullptr; };
+struct RunSet { RunRec *runs; int *parent; unsigned int *row_off; i64 nruns; int *proot = nullptr; int *link = nullptr; bool proot_valid = false; };
 
 // Geometry the run-level Label works on: the whole (global) volume as rows of bit-packed words.
 struct LabelGeo {
@@ -2745,6 +2747,7 @@ static int build_components(nl_ctx *c, const LabelGeo &g, const unsigned long lo
     rs.nruns = (i64)(*(unsigned int *)c->h_small);
     rs.row_off = row_off;
     *overflow = rs.nruns > cap;
+    rs.proot_valid = false;
     if (*overflow || rs.nruns == 0) return NL_OK;
     if (g.wpr <= 30)
         rl_emit_kernel<true><<<(unsigned)((g.nrows + 255) / 256), 256, (size_t)256 * (g.wpr + 1) * 8, c->stream>>>(bits, invert, row_off, rs.runs, rs.parent, g.nrows, g.wpr, (int)g.nx);
@@ -2772,6 +2775,7 @@ static int build_components(nl_ctx *c, const LabelGeo &g, const unsigned long lo
                                                                          CONN == 6 ? 1 : 0, g.zf_lo, g.zf_hi, (int)g.nx, seg_done, seg_shift, nseg);
         rl_union_cross_kernel<CONN><<<gr, 256, 0, c->stream>>>(rs.runs, row_off, rs.parent, rs.proot, rs.link, rs.nruns, (int)g.ny,
                                                                CONN == 6 ? 1 : 0, g.zf_lo, g.zf_hi, (int)g.nx, seg_done, seg_shift, nseg);
+        rs.proot_valid = true;
     } else {
         rl_union_kernel<CONN><<<gr, 256, 0, c->stream>>>(rs.runs, row_off, rs.parent, rs.nruns, (int)g.ny,
                                                          CONN == 6 ? 1 : 0, g.zf_lo, g.zf_hi, (int)g.nx);
@@ -3084,95 +3088,127 @@ extern "C" int nl_slab_bits_exchange(nl_ctx *c, int which, char *err, size_t err
     return NL_OK;
 }
 
-/* Components of the owned planes + ghost planes for one phase (SL_FILL: 6-connected background, SL_AREA / SL_NUMBER:
-   26-connected foreground of the working mask) and the phase's per-tree quantity.  counts[5] = runs in total, in the low
-   ghost plane, the first owned plane, the last owned plane, the high ghost plane (0 where the slab has no such plane). */
-extern "C" int nl_slab_components(nl_ctx *c, int phase, int64_t *counts, char *err, size_t errlen) {
-    NL_ENTER(c);
-    if (phase < SL_FILL || phase > SL_NUMBER || !counts) return nl_fail(err, errlen, NL_EINVAL, "bad phase");
-    SlabGeo sg; int rc = slab_geo(c, sg, err, errlen); if (rc) return rc;
-    LabelGeo &g = sg.g; RunSet &rs = sg.rs;
-    ProfScope ps(c, "label");
-    bool overflow = false;
-    if (phase == SL_FILL) rc = build_components<6>(c, g, g.bitsA, 1, rs, sg.cap, &overflow, err, errlen);
-    else rc = build_components<26>(c, g, g.bitsA, 0, rs, sg.cap, &overflow, err, errlen);
-    if (rc) return rc;
-    if (overflow) return nl_fail(err, errlen, NL_ENOMEM, "the slab's mask has more runs than its scratch volumes hold [out of memory]");
-    c->sl_nruns = rs.nruns; c->sl_phase = phase; c->sl_numbered = 0;
-    // run ranges of the four planes the neighbours also see
-    const i64 ny = c->ny;
-    const i64 prow[4] = {0, (c->own_lo - c->sl_e0) * ny, (c->own_hi - 1 - c->sl_e0) * ny, (c->own_hi - c->sl_e0) * ny};
-    unsigned int *h = (unsigned int *)c->h_small;
-    for (int k = 0; k < 8; ++k) h[k] = 0;
-    for (int k = 0; k < 4; ++k) {
-        if ((k == 0 && !sg.has_lo) || (k == 3 && !sg.has_hi)) continue;        // no such plane in this slab
-        NL_HIP(hipMemcpyAsync(h + 2 * k, rs.row_off + prow[k], 4, hipMemcpyDeviceToHost, c->stream));
-        NL_HIP(hipMemcpyAsync(h + 2 * k + 1, rs.row_off + prow[k] + ny, 4, hipMemcpyDeviceToHost, c->stream));
+/* Page-locked staging for the lists the host hands back (patches, selections): they are copied here first, so the H2D copy
+   can stay asynchronous -- the area is rewritten only by a later call, and every phase waits for the stream in between. */
+static int slab_host_stage(nl_ctx *c, size_t ints, char *err, size_t errlen) {
+    if (ints > c->h_sl_ints) {
+        NL_HIP(hipStreamSynchronize(c->stream));
+        if (c->h_sl) hipHostFree(c->h_sl);
+        c->h_sl = nullptr; c->h_sl_ints = 0;
+        const size_t cap = ints + ints / 2 + 4096;
+        NL_HIP(hipHostMalloc((void **)&c->h_sl, cap * 4, hipHostMallocDefault));
+        c->h_sl_ints = cap;
     }
-    NL_HIP(hipStreamSynchronize(c->stream));
-    const int own_first = (int)h[2];                  // first run of the first owned plane
-    if (rs.nruns) {
-        const unsigned gr = (unsigned)((rs.nruns + 255) / 256);
-        if (phase == SL_FILL) {
-            NL_HIP(hipMemsetAsync(c->m[0], 0, (size_t)rs.nruns, c->stream));
-            rl_border_kernel<<<gr, 256, 0, c->stream>>>(rs.runs, rs.parent, c->m[0], rs.nruns, VolGeom{g.nz, g.ny, g.nx, g.gz0, g.gnz});
-        } else if (phase == SL_AREA) {
-            NL_HIP(hipMemsetAsync(sg.aux, 0, (size_t)rs.nruns * 4, c->stream));
-            sl_area_kernel<<<(unsigned)((rs.nruns + RL_CHUNK - 1) / RL_CHUNK), 256, 0, c->stream>>>(rs.runs, rs.parent, sg.aux, rs.nruns, sg.row_lo, sg.row_hi);
-        } else {
-            NL_HIP(hipMemsetD32Async((hipDeviceptr_t)sg.aux, 0x7fffffff, (size_t)rs.nruns, c->stream));
-            sl_first_own_kernel<<<gr, 256, 0, c->stream>>>(rs.runs, rs.parent, sg.aux, rs.nruns, sg.row_lo, sg.row_hi, own_first);
-        }
-        NL_CHECK_LAUNCH();
-    }
-    NL_HIP(hipStreamSynchronize(c->stream));
-    for (int k = 0; k < 4; ++k) { c->sl_first[k] = h[2 * k]; c->sl_count[k] = h[2 * k + 1] - h[2 * k]; }
-    if (!sg.has_lo) c->sl_count[0] = 0;
-    if (!sg.has_hi) c->sl_count[3] = 0;
-    counts[0] = rs.nruns;
-    for (int k = 0; k < 4; ++k) counts[1 + k] = c->sl_count[k];
     return NL_OK;
 }
 
-/* the four tables, concatenated (ghost-low, own-first, own-last, ghost-high): roots[k] = tree of the k-th run of the plane,
-   values[k] = that tree's quantity of the current phase */
-extern "C" int nl_slab_tables(nl_ctx *c, int32_t *roots, int32_t *values, char *err, size_t errlen) {
+/* One phase of the slab protocol up to the tables, in ONE call with one wait of its own (plus the run count inside
+   build_components): components of the owned planes + ghost planes (SL_FILL: 6-connected background, SL_AREA / SL_NUMBER:
+   26-connected foreground of the working mask), the phase's per-tree quantity, and the COMPACT tables of the four planes the
+   neighbours also see (label_runs.inc "the tables the ranks exchange").  gather != 0: the blobs of all ranks, all-gathered over
+   RCCL on the context stream in fixed blocks of block_ints int32 (no size negotiation, no host round trip in between);
+   out receives world (gather) or 1 blocks.  *need_ints = the largest blob of any rank: if it exceeds block_ints the caller calls
+   again with phase = -1 and a larger block (the device tables are still there; nothing is recomputed). */
+extern "C" int nl_slab_phase(nl_ctx *c, int phase, int gather, int64_t block_ints, int32_t *out, int64_t *need_ints, int64_t *nruns,
+                             char *err, size_t errlen) {
     NL_ENTER(c);
-    if (c->sl_phase < 0) return nl_fail(err, errlen, NL_ESTATE, "nl_slab_tables before nl_slab_components");
+    if (phase < -1 || phase > SL_NUMBER || !out || !need_ints || block_ints < 8) return nl_fail(err, errlen, NL_EINVAL, "bad phase / buffers");
+    if (gather && !c->comm) return nl_fail(err, errlen, NL_ESTATE, "nl_slab_phase(gather) before nl_comm_init");
+    if (phase < 0 && c->sl_phase < 0) return nl_fail(err, errlen, NL_ESTATE, "nl_slab_phase(-1) before a phase ran");
     SlabGeo sg; int rc = slab_geo(c, sg, err, errlen); if (rc) return rc;
-    i64 total = 0;
-    for (int k = 0; k < 4; ++k) total += c->sl_count[k];
-    if (total == 0) return NL_OK;
-    if (!roots || !values) return nl_fail(err, errlen, NL_EINVAL, "table buffers are NULL");
-    if (2 * total > c->n) return nl_fail(err, errlen, NL_ENOMEM, "tables larger than the staging volume [out of memory]");
-    int *d_root = sg.stage, *d_val = sg.stage + total;
-    i64 off = 0;
-    for (int k = 0; k < 4; ++k) {
-        if (!c->sl_count[k]) continue;
-        sl_table_kernel<<<(c->sl_count[k] + 255) / 256, 256, 0, c->stream>>>(sg.rs.parent, sg.aux, c->sl_phase == SL_FILL ? c->m[0] : nullptr,
-                                                                          c->sl_first[k], c->sl_count[k], d_root + off, d_val + off);
-        off += c->sl_count[k];
+    LabelGeo &g = sg.g; RunSet &rs = sg.rs;
+    const int W = gather ? c->world : 1;
+    // entries a plane can hold: at most one per run, a row has at most (nx + 1) / 2 runs
+    const i64 max_runs_plane = c->ny * ((c->nx + 1) / 2);
+    const int capE = (int)(max_runs_plane < ((i64)1 << 18) ? max_runs_plane : ((i64)1 << 18));
+    const size_t blob_cap = 8 + (size_t)8 * capE;
+    // [header 16 | entry indices 4 capE | this rank's blob (at least one block: the all-gather sends a whole block) | gathered blocks]
+    const size_t o_bidx = 16, o_blob = o_bidx + (size_t)4 * capE;
+    const size_t o_gath = o_blob + (blob_cap > (size_t)block_ints ? blob_cap : (size_t)block_ints);
+    const size_t need_dev = o_gath + (size_t)W * (size_t)block_ints;
+    if (need_dev > c->d_sl_ints || capE != c->sl_capE) {
+        if (phase < 0 && capE != c->sl_capE) return nl_fail(err, errlen, NL_ESTATE, "slab tables of another geometry");
+        int *nb = nullptr;
+        NL_HIP(hipMalloc((void **)&nb, (need_dev + need_dev / 4) * 4));
+        if (c->d_sl) {
+            const size_t keep = o_blob + blob_cap < c->d_sl_ints ? o_blob + blob_cap : c->d_sl_ints;
+            if (phase < 0) NL_HIP(hipMemcpyAsync(nb, c->d_sl, keep * 4, hipMemcpyDeviceToDevice, c->stream));
+            NL_HIP(hipStreamSynchronize(c->stream));
+            hipFree(c->d_sl);
+        }
+        c->d_sl = nb; c->d_sl_ints = need_dev + need_dev / 4; c->sl_capE = capE;
     }
-    NL_CHECK_LAUNCH();
-    NL_HIP(hipMemcpyAsync(roots, d_root, (size_t)total * 4, hipMemcpyDeviceToHost, c->stream));
-    NL_HIP(hipMemcpyAsync(values, d_val, (size_t)total * 4, hipMemcpyDeviceToHost, c->stream));
+    if ((rc = slab_host_stage(c, (size_t)W * (size_t)block_ints, err, errlen))) return rc;
+    int *hdr = c->d_sl, *bidx = c->d_sl + o_bidx, *blob = c->d_sl + o_blob, *gath = c->d_sl + o_gath;
+    if (phase >= 0) {
+        ProfScope ps(c, "label");
+        bool overflow = false;
+        if (phase == SL_FILL) rc = build_components<6>(c, g, g.bitsA, 1, rs, sg.cap, &overflow, err, errlen);
+        else rc = build_components<26>(c, g, g.bitsA, 0, rs, sg.cap, &overflow, err, errlen);
+        if (rc) return rc;
+        if (overflow) return nl_fail(err, errlen, NL_ENOMEM, "the slab's mask has more runs than its scratch volumes hold [out of memory]");
+        c->sl_nruns = rs.nruns; c->sl_phase = phase; c->sl_numbered = 0;
+        // the four planes the neighbours also see; their segment components BEFORE the per-tree quantity takes proot's memory
+        const i64 ny = c->ny;
+        SlabPlanes pl;
+        // (a plane only matters towards a side that has a neighbour: the ghost plane and the owned plane next to it)
+        pl.row[0] = sg.has_lo ? 0 : -1;
+        pl.row[1] = sg.has_lo ? (int)((c->own_lo - c->sl_e0) * ny) : -1;
+        pl.row[2] = sg.has_hi ? (int)((c->own_hi - 1 - c->sl_e0) * ny) : -1;
+        pl.row[3] = sg.has_hi ? (int)((c->own_hi - c->sl_e0) * ny) : -1;
+        sl_boundary_kernel<<<4, 1024, 0, c->stream>>>(rs.row_off, (rs.nruns && rs.proot_valid) ? rs.proot : nullptr, pl, (int)ny, capE, bidx, hdr);
+        NL_CHECK_LAUNCH();
+        if (rs.nruns) {
+            const unsigned gr = (unsigned)((rs.nruns + 255) / 256);
+            if (phase == SL_FILL) {
+                NL_HIP(hipMemsetAsync(c->m[0], 0, (size_t)rs.nruns, c->stream));
+                rl_border_kernel<<<gr, 256, 0, c->stream>>>(rs.runs, rs.parent, c->m[0], rs.nruns, VolGeom{g.nz, g.ny, g.nx, g.gz0, g.gnz});
+            } else if (phase == SL_AREA) {
+                NL_HIP(hipMemsetAsync(sg.aux, 0, (size_t)rs.nruns * 4, c->stream));
+                sl_area_kernel<<<(unsigned)((rs.nruns + RL_CHUNK - 1) / RL_CHUNK), 256, 0, c->stream>>>(rs.runs, rs.parent, sg.aux, rs.nruns, sg.row_lo, sg.row_hi);
+            } else {
+                NL_HIP(hipMemsetD32Async((hipDeviceptr_t)sg.aux, 0x7fffffff, (size_t)rs.nruns, c->stream));
+                sl_first_own_kernel<<<gr, 256, 0, c->stream>>>(rs.runs, rs.parent, sg.aux, rs.nruns, sg.row_lo, sg.row_hi, rs.row_off + sg.row_lo);
+            }
+            NL_CHECK_LAUNCH();
+        }
+        sl_table2_kernel<<<4, 256, 0, c->stream>>>(rs.parent, sg.aux, phase == SL_FILL ? c->m[0] : nullptr, bidx, capE, hdr, blob, rs.row_off + g.nrows);
+        NL_CHECK_LAUNCH();
+    }
+    const size_t send = (size_t)block_ints < blob_cap ? (size_t)block_ints : blob_cap;
+    if (gather && c->world > 1) {
+        ProfScope ps(c, "halo");
+        NL_NCCL(rccl().AllGather(blob, gath, (size_t)block_ints, ncclInt32, (ncclComm_t)c->comm, c->stream));
+        NL_HIP(hipMemcpyAsync(c->h_sl, gath, (size_t)W * (size_t)block_ints * 4, hipMemcpyDeviceToHost, c->stream));
+    } else {
+        NL_HIP(hipMemcpyAsync(c->h_sl, blob, send * 4, hipMemcpyDeviceToHost, c->stream));
+    }
     NL_HIP(hipStreamSynchronize(c->stream));
+    i64 need = 0;
+    for (int r = 0; r < W; ++r) {
+        const int *b = c->h_sl + (size_t)r * (size_t)block_ints;
+        if (b[5]) return nl_fail(err, errlen, NL_ENOMEM, "rank %d: a boundary plane holds more than %d components [out of memory]", gather ? r : c->rank, capE);
+        if (b[4] > need) need = b[4];
+    }
+    *need_ints = need;
+    if (nruns) *nruns = c->sl_nruns;
+    if (need <= block_ints) memcpy(out, c->h_sl, (size_t)W * (size_t)block_ints * 4);
     return NL_OK;
 }
 
 /* quantity[roots[i]] = values[i]: what the host learned about trees that continue on other ranks */
 extern "C" int nl_slab_patch(nl_ctx *c, int64_t n, const int32_t *roots, const int32_t *values, char *err, size_t errlen) {
     NL_ENTER(c);
-    if (c->sl_phase < 0) return nl_fail(err, errlen, NL_ESTATE, "nl_slab_patch before nl_slab_components");
+    if (c->sl_phase < 0) return nl_fail(err, errlen, NL_ESTATE, "nl_slab_patch before nl_slab_phase");
     if (n == 0) return NL_OK;
     if (n < 0 || !roots || !values || 2 * n > c->n) return nl_fail(err, errlen, NL_EINVAL, "bad patch arguments");
     SlabGeo sg; int rc = slab_geo(c, sg, err, errlen); if (rc) return rc;
+    if ((rc = slab_host_stage(c, (size_t)2 * n, err, errlen))) return rc;
+    memcpy(c->h_sl, roots, (size_t)n * 4); memcpy(c->h_sl + n, values, (size_t)n * 4);
     int *d_idx = sg.stage, *d_val = sg.stage + n;
-    NL_HIP(hipMemcpyAsync(d_idx, roots, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
-    NL_HIP(hipMemcpyAsync(d_val, values, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    NL_HIP(hipMemcpyAsync(d_idx, c->h_sl, (size_t)2 * n * 4, hipMemcpyHostToDevice, c->stream));
     sl_patch_kernel<<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>(sg.aux, c->sl_phase == SL_FILL ? c->m[0] : nullptr, d_idx, d_val, (int)n);
     NL_CHECK_LAUNCH();
-    NL_HIP(hipStreamSynchronize(c->stream));        // the host arrays may go away
     return NL_OK;
 }
 
@@ -3209,56 +3245,46 @@ extern "C" int nl_slab_majority(nl_ctx *c, char *err, size_t errlen) {
 }
 
 /* SL_NUMBER: ranks the trees this rank numbers, in raster order of their first run: the roots on the owned planes, minus
-   `clear` (trees that continue on other ranks), plus `set` (those of them this rank owns).  *n_local = their count. */
+   `clear` (trees that continue on other ranks), plus `set` (those of them this rank owns).  *n_local = their count;
+   ids_of_set[i] = 1-based local rank of set[i] (what the other ranks need to know about the trees this rank owns). */
 extern "C" int nl_slab_number(nl_ctx *c, int64_t n_clear, const int32_t *clear, int64_t n_set, const int32_t *set, int64_t *n_local,
-                              char *err, size_t errlen) {
+                              int32_t *ids_of_set, char *err, size_t errlen) {
     NL_ENTER(c);
     if (c->sl_phase != SL_NUMBER) return nl_fail(err, errlen, NL_ESTATE, "nl_slab_number outside the numbering phase");
-    if (n_clear < 0 || n_set < 0 || (n_clear && !clear) || (n_set && !set) || n_clear + n_set > c->n / 4) return nl_fail(err, errlen, NL_EINVAL, "bad selection lists");
+    if (n_clear < 0 || n_set < 0 || (n_clear && !clear) || (n_set && (!set || !ids_of_set)) || n_clear + n_set > c->n / 4) return nl_fail(err, errlen, NL_EINVAL, "bad selection lists");
     SlabGeo sg; int rc = slab_geo(c, sg, err, errlen); if (rc) return rc;
     RunSet &rs = sg.rs;
     ProfScope ps(c, "label");
     unsigned long long total = 0;
     if (rs.nruns) {
         sl_select_kernel<<<(unsigned)((rs.nruns + 255) / 256), 256, 0, c->stream>>>(rs.runs, rs.parent, sg.sel, rs.nruns, sg.row_lo, sg.row_hi);
-        int *d_idx = (int *)(sg.scan + rs.nruns);                    // behind the scan array (cap >= nruns + the lists: checked above)
-        if (rs.nruns + n_clear + n_set > sg.cap) return nl_fail(err, errlen, NL_ENOMEM, "selection lists do not fit the scratch volume [out of memory]");
-        if (n_clear) {
-            NL_HIP(hipMemcpyAsync(d_idx, clear, (size_t)n_clear * 4, hipMemcpyHostToDevice, c->stream));
-            sl_set_u32_kernel<<<(unsigned)((n_clear + 255) / 256), 256, 0, c->stream>>>(sg.sel, d_idx, (int)n_clear, 0u);
-        }
-        if (n_set) {
-            NL_HIP(hipMemcpyAsync(d_idx + n_clear, set, (size_t)n_set * 4, hipMemcpyHostToDevice, c->stream));
-            sl_set_u32_kernel<<<(unsigned)((n_set + 255) / 256), 256, 0, c->stream>>>(sg.sel, d_idx + n_clear, (int)n_set, 1u);
-        }
+        int *d_idx = (int *)(sg.scan + rs.nruns);                    // behind the scan array (cap >= nruns + the lists: checked below)
+        if (rs.nruns + n_clear + 2 * n_set > sg.cap) return nl_fail(err, errlen, NL_ENOMEM, "selection lists do not fit the scratch volume [out of memory]");
+        if ((rc = slab_host_stage(c, (size_t)(n_clear + n_set) + 2 + (size_t)n_set, err, errlen))) return rc;
+        if (n_clear) memcpy(c->h_sl, clear, (size_t)n_clear * 4);
+        if (n_set) memcpy(c->h_sl + n_clear, set, (size_t)n_set * 4);
+        if (n_clear + n_set) NL_HIP(hipMemcpyAsync(d_idx, c->h_sl, (size_t)(n_clear + n_set) * 4, hipMemcpyHostToDevice, c->stream));
+        if (n_clear) sl_set_u32_kernel<<<(unsigned)((n_clear + 255) / 256), 256, 0, c->stream>>>(sg.sel, d_idx, (int)n_clear, 0u);
+        if (n_set) sl_set_u32_kernel<<<(unsigned)((n_set + 255) / 256), 256, 0, c->stream>>>(sg.sel, d_idx + n_clear, (int)n_set, 1u);
         NL_CHECK_LAUNCH();
-        NL_HIP(hipStreamSynchronize(c->stream));
         if ((rc = scan_excl_u32(c, sg.sel, sg.scan, rs.nruns, err, errlen))) return rc;
-        unsigned int *h = (unsigned int *)c->h_small;
-        NL_HIP(hipMemcpyAsync(h, sg.scan + rs.nruns - 1, 4, hipMemcpyDeviceToHost, c->stream));
-        NL_HIP(hipMemcpyAsync(h + 1, sg.sel + rs.nruns - 1, 4, hipMemcpyDeviceToHost, c->stream));
+        int *h_back = c->h_sl + n_clear + n_set;                     // [scan of the last run, its flag, ids of `set`]
+        int *d_out = d_idx + n_clear + n_set;
+        if (n_set) {
+            sl_gather_kernel<<<(unsigned)((n_set + 255) / 256), 256, 0, c->stream>>>(sg.scan, d_idx + n_clear, d_out, (int)n_set, 1);
+            NL_CHECK_LAUNCH();
+            NL_HIP(hipMemcpyAsync(h_back + 2, d_out, (size_t)n_set * 4, hipMemcpyDeviceToHost, c->stream));
+        }
+        NL_HIP(hipMemcpyAsync(h_back, sg.scan + rs.nruns - 1, 4, hipMemcpyDeviceToHost, c->stream));
+        NL_HIP(hipMemcpyAsync(h_back + 1, sg.sel + rs.nruns - 1, 4, hipMemcpyDeviceToHost, c->stream));
         NL_HIP(hipStreamSynchronize(c->stream));
-        total = (unsigned long long)h[0] + h[1];
+        total = (unsigned long long)(unsigned int)h_back[0] + (unsigned int)h_back[1];
+        if (n_set) memcpy(ids_of_set, h_back + 2, (size_t)n_set * 4);
+    } else if (n_set) {
+        return nl_fail(err, errlen, NL_EINVAL, "selection on an empty run set");
     }
     if (n_local) *n_local = (int64_t)total;
     c->sl_numbered = 1;
-    return NL_OK;
-}
-
-/* out[i] = 1-based local rank of the selected run idx[i] (after nl_slab_number) */
-extern "C" int nl_slab_query(nl_ctx *c, int64_t n, const int32_t *idx, int32_t *out, char *err, size_t errlen) {
-    NL_ENTER(c);
-    if (!c->sl_numbered) return nl_fail(err, errlen, NL_ESTATE, "nl_slab_query before nl_slab_number");
-    if (n == 0) return NL_OK;
-    if (n < 0 || !idx || !out) return nl_fail(err, errlen, NL_EINVAL, "bad query");
-    SlabGeo sg; int rc = slab_geo(c, sg, err, errlen); if (rc) return rc;
-    if (sg.rs.nruns + 2 * n > sg.cap) return nl_fail(err, errlen, NL_ENOMEM, "query does not fit the scratch volume [out of memory]");
-    int *d_idx = (int *)(sg.scan + sg.rs.nruns), *d_out = d_idx + n;
-    NL_HIP(hipMemcpyAsync(d_idx, idx, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
-    sl_gather_kernel<<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>(sg.scan, d_idx, d_out, (int)n, 1);
-    NL_CHECK_LAUNCH();
-    NL_HIP(hipMemcpyAsync(out, d_out, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
-    NL_HIP(hipStreamSynchronize(c->stream));
     return NL_OK;
 }
 
@@ -3276,12 +3302,12 @@ extern "C" int nl_slab_paint(nl_ctx *c, int64_t base, int64_t n, const int32_t *
         if (n) {
             if (rs.nruns + 2 * n > sg.cap) return nl_fail(err, errlen, NL_ENOMEM, "label patch does not fit the scratch volume [out of memory]");
             int *d_idx = (int *)(sg.scan + rs.nruns), *d_val = d_idx + n;
-            NL_HIP(hipMemcpyAsync(d_idx, roots, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
-            NL_HIP(hipMemcpyAsync(d_val, labels, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
-            sl_patch_kernel<<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>(sg.aux, nullptr, d_idx, d_val, (int)n);
+            if ((rc = slab_host_stage(c, (size_t)2 * n, err, errlen))) return rc;
+            memcpy(c->h_sl, roots, (size_t)n * 4); memcpy(c->h_sl + n, labels, (size_t)n * 4);
+            NL_HIP(hipMemcpyAsync(d_idx, c->h_sl, (size_t)2 * n * 4, hipMemcpyHostToDevice, c->stream));
+            sl_patch_kernel<<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>(sg.aux, nullptr, d_idx, d_val, (int)n);   // stream order: before the paint
         }
         NL_CHECK_LAUNCH();
-        NL_HIP(hipStreamSynchronize(c->stream));   // the lists sit in the volume the paint is about to overwrite
     }
     rl_paint_kernel<<<grid1d((g.paint_row1 - g.paint_row0) * 64, 256, (i64)1 << 22), 256, 0, c->stream>>>(
         g.bitsA, rs.row_off, rs.parent, sg.aux, g.paint_out, g.paint_row0, g.paint_row1, g.wpr, (int)g.nx);
@@ -3289,6 +3315,63 @@ extern "C" int nl_slab_paint(nl_ctx *c, int64_t base, int64_t n, const int32_t *
     NL_HIP(hipStreamSynchronize(c->stream));
     c->i_labels = sg.out_idx;
     c->sl_numbered = 0; c->sl_phase = -1;
+    return NL_OK;
+}
+
+// Host side of the slab protocol: the graph of (rank, tree) nodes joined through the shared planes (see include/nellie_amd.h).
+// Plain C++ on a few thousand entries; numpy needed ~1 ms per rank for the same (sharded.join_slab_tables, kept as the model).
+extern "C" int nl_host_slab_join(int world, const int32_t *blobs, int64_t block_ints, int64_t cap, int64_t *n_nodes, int64_t *n_comp,
+                                 int64_t *node_rank, int32_t *node_root, int64_t *node_val, int64_t *node_comp, char *err, size_t errlen) {
+    if (world < 1 || !blobs || block_ints < 8 || !n_nodes || !n_comp) return nl_fail(err, errlen, NL_EINVAL, "bad join arguments");
+    struct Tab { const int32_t *root[4], *val[4]; int n[4]; };
+    std::vector<Tab> tabs((size_t)world);
+    std::vector<std::vector<int32_t>> uniq((size_t)world);          // a rank's trees, ascending root
+    std::vector<i64> base((size_t)world + 1, 0);
+    for (int r = 0; r < world; ++r) {
+        const int32_t *b = blobs + (size_t)r * (size_t)block_ints;
+        i64 total = 0;
+        for (int k = 0; k < 4; ++k) { if (b[k] < 0) return nl_fail(err, errlen, NL_EINVAL, "negative table size"); total += b[k]; }
+        if (8 + 2 * total > block_ints) return nl_fail(err, errlen, NL_EINVAL, "rank %d: table of %lld entries exceeds the block", r, (long long)total);
+        i64 off = 8;
+        for (int k = 0; k < 4; ++k) { tabs[r].n[k] = b[k]; tabs[r].root[k] = b + off; tabs[r].val[k] = b + total + off; off += b[k]; }
+        auto &u = uniq[r];
+        u.assign(b + 8, b + 8 + total);
+        std::sort(u.begin(), u.end());
+        u.erase(std::unique(u.begin(), u.end()), u.end());
+        base[r + 1] = base[r] + (i64)u.size();
+    }
+    const i64 n = base[world];
+    *n_nodes = n;
+    if (n > cap) { *n_comp = 0; return NL_OK; }                     // the caller sizes its arrays from *n_nodes and calls again
+    auto node_of = [&](int r, int32_t root) -> i64 {
+        const auto &u = uniq[r];
+        return base[r] + (i64)(std::lower_bound(u.begin(), u.end(), root) - u.begin());
+    };
+    std::vector<i64> par((size_t)n);
+    for (i64 i = 0; i < n; ++i) par[i] = i;
+    auto find = [&](i64 i) -> i64 { while (par[i] != i) { par[i] = par[par[i]]; i = par[i]; } return i; };
+    std::vector<char> have((size_t)n, 0);
+    for (int r = 0; r < world; ++r)
+        for (int k = 0; k < 4; ++k)
+            for (int e = 0; e < tabs[r].n[k]; ++e) {
+                const i64 v = node_of(r, tabs[r].root[k][e]);
+                if (!have[v]) { have[v] = 1; node_rank[v] = r; node_root[v] = tabs[r].root[k][e]; node_val[v] = tabs[r].val[k][e]; }
+            }
+    for (int r = 0; r + 1 < world; ++r)
+        for (int pair = 0; pair < 2; ++pair) {
+            const int mine = 2 + pair, theirs = pair;
+            if (tabs[r].n[mine] != tabs[r + 1].n[theirs])
+                return nl_fail(err, errlen, NL_EINVAL, "slab tables of ranks %d and %d disagree (%d vs %d entries): the ghost bit planes are stale",
+                               r, r + 1, tabs[r].n[mine], tabs[r + 1].n[theirs]);
+            for (int e = 0; e < tabs[r].n[mine]; ++e) {
+                i64 a = find(node_of(r, tabs[r].root[mine][e])), b = find(node_of(r + 1, tabs[r + 1].root[theirs][e]));
+                if (a != b) { if (a < b) par[b] = a; else par[a] = b; }          // the smaller node stays the root
+            }
+        }
+    i64 nc = 0;
+    std::vector<i64> id((size_t)n, -1);
+    for (i64 i = 0; i < n; ++i) { const i64 rt = find(i); if (id[rt] < 0) id[rt] = nc++; node_comp[i] = id[rt]; }   // rt <= i: numbered by smallest node
+    *n_comp = nc;
     return NL_OK;
 }
 

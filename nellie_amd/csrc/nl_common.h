@@ -89,7 +89,9 @@ struct nl_ctx {
     i64 sl_e0 = 0, sl_e1 = 0;
     i64 sl_nruns = 0;
     int sl_phase = -1;
-    unsigned int sl_first[4] = {0, 0, 0, 0}, sl_count[4] = {0, 0, 0, 0};   // runs of the planes ghost-low, own-first, own-last, ghost-high
+    int *d_sl = nullptr; size_t d_sl_ints = 0;     // tables of the slab protocol: header, entry indices, this rank's blob, the gathered blobs
+    int *h_sl = nullptr; size_t h_sl_ints = 0;     // their page-locked landing area (also stages the host's patch lists)
+    int sl_capE = 0;                               // entries per plane the tables hold
     int sl_numbered = 0;
 
     float hz = 1, hy = 1, hx = 1;            // float32(h)

@@ -55,6 +55,7 @@ _PROTOS = {
     "nl_hist_thresholds": [_p, _p, _int, C.POINTER(_f64), C.POINTER(_f64), C.POINTER(_int)],
     "nl_hist_thresholds_ex": [_p, _p, _int, _int, C.POINTER(_f64), C.POINTER(_f64), C.POINTER(_f64), C.POINTER(_int)],
     "nl_host_hist_thresholds_f32": [_p, _i64, _int, C.POINTER(_f64), C.POINTER(_f64), C.POINTER(_int), _p, _p],
+    "nl_host_slab_join": [_int, _p, _i64, _i64, C.POINTER(_i64), C.POINTER(_i64), _p, _p, _p, _p],
     "nl_outputs_pack": [_p, _int, _p],
     "nl_outputs_fetch_packed_async": [_p, _p, _i64],
     "nl_outputs_unpack": [_p, _i64, _p, _p, _i64, _int, _int],
@@ -109,13 +110,11 @@ _PROTOS = {
     "nl_slab_bits_get": [_p, _int, _i64, _p],
     "nl_slab_bits_put": [_p, _int, _i64, _p],
     "nl_slab_bits_exchange": [_p, _int],
-    "nl_slab_components": [_p, _int, _p],
-    "nl_slab_tables": [_p, _p, _p],
+    "nl_slab_phase": [_p, _int, _int, _i64, _p, C.POINTER(_i64), C.POINTER(_i64)],
     "nl_slab_patch": [_p, _i64, _p, _p],
     "nl_slab_apply": [_p, _i64],
     "nl_slab_majority": [_p],
-    "nl_slab_number": [_p, _i64, _p, _i64, _p, C.POINTER(_i64)],
-    "nl_slab_query": [_p, _i64, _p, _p],
+    "nl_slab_number": [_p, _i64, _p, _i64, _p, C.POINTER(_i64), _p],
     "nl_slab_paint": [_p, _i64, _i64, _p, _p],
     "nl_allgather_bytes": [_p, _p, _i64, _p, _i64, _p],
     "nl_allgather_var": [_p, _p, _i64, _p, _p, _p],
@@ -260,6 +259,22 @@ def host_hist_thresholds(values, nbins=256, with_histogram=False):
         raise ValueError("attempt to get argmax of an empty sequence")
     out = (np.float32(tri.value), np.float32(otsu.value))
     return out + (counts, edges) if with_histogram else out
+
+
+def host_slab_join(blobs):
+    """The joined view of the slab tables of all ranks (nl_host_slab_join; host code, no device): blobs = one int32 array per
+    rank as Context.slab_phase returns them.  -> (rank, root, val, comp, ncomp): one node per (rank, tree)."""
+    world = len(blobs)
+    block = max(8, max(int(b.size) for b in blobs))
+    flat = np.zeros(world * block, np.int32)
+    for r, b in enumerate(blobs):
+        flat[r * block:r * block + b.size] = b
+    cap = max(1, sum(int(b[:4].sum()) for b in blobs))            # nodes <= entries
+    n, nc = _i64(0), _i64(0)
+    rank, root, val, comp = np.empty(cap, np.int64), np.empty(cap, np.int32), np.empty(cap, np.int64), np.empty(cap, np.int64)
+    load().call("nl_host_slab_join", world, _ptr(flat), block, cap, C.byref(n), C.byref(nc), _ptr(rank), _ptr(root), _ptr(val), _ptr(comp))
+    k = int(n.value)
+    return rank[:k], root[:k], val[:k], comp[:k], int(nc.value)
 
 
 def outputs_unpack(blob, nbytes, frangi, labels=None, zero_fill=True, threads=8):
@@ -841,21 +856,22 @@ class Context:
     def slab_bits_exchange(self, which):
         self._call("nl_slab_bits_exchange", int(which))
 
-    def slab_components(self, phase):
-        """-> (runs in total, [runs in the low ghost plane, first owned, last owned, high ghost plane])"""
-        counts = np.zeros(5, np.int64)
-        self._call("nl_slab_components", int(phase), _ptr(counts))
-        self._slab_counts = [int(v) for v in counts[1:]]
-        return int(counts[0]), list(self._slab_counts)
+    SLAB_BLOCK_INTS = 16384
 
-    def slab_tables(self):
-        """-> (roots, values): four int32 arrays each, in the plane order of slab_components"""
-        total = sum(self._slab_counts)
-        roots, vals = np.empty(total, np.int32), np.empty(total, np.int32)
-        if total:
-            self._call("nl_slab_tables", _ptr(roots), _ptr(vals))
-        cuts = np.cumsum([0] + self._slab_counts)
-        return ([roots[cuts[k]:cuts[k + 1]] for k in range(4)], [vals[cuts[k]:cuts[k + 1]] for k in range(4)])
+    def slab_phase(self, phase, gather_world=0):
+        """One phase of the slab protocol up to its tables (nl_slab_phase): -> list of int32 blobs, this rank's only
+        (gather_world = 0) or every rank's, all-gathered on the device (gather_world = the communicator's size)."""
+        nb = int(gather_world) if gather_world else 1
+        block = self.SLAB_BLOCK_INTS
+        need, nruns = _i64(0), _i64(0)
+        out = np.empty(nb * block, np.int32)
+        self._call("nl_slab_phase", int(phase), 1 if gather_world else 0, block, _ptr(out), C.byref(need), C.byref(nruns))
+        if need.value > block:                       # rare: tables beyond 64 KiB -- fetch again in larger blocks, nothing is recomputed
+            block = int(need.value) + 1024
+            out = np.empty(nb * block, np.int32)
+            self._call("nl_slab_phase", -1, 1 if gather_world else 0, block, _ptr(out), C.byref(need), C.byref(nruns))
+        self.slab_nruns = int(nruns.value)
+        return [out[r * block:r * block + int(out[r * block + 4])] for r in range(nb)]
 
     def slab_patch(self, roots, values):
         r = np.ascontiguousarray(roots, dtype=np.int32)
@@ -870,19 +886,15 @@ class Context:
     def slab_majority(self):
         self._call("nl_slab_majority")
 
-    def slab_number(self, clear, select) -> int:
+    def slab_number(self, clear, select):
+        """-> (trees this rank numbers, 1-based local rank of every tree of `select`)"""
         c = np.ascontiguousarray(clear, dtype=np.int32)
         s_ = np.ascontiguousarray(select, dtype=np.int32)
         n = _i64(0)
-        self._call("nl_slab_number", c.size, _ptr(c) if c.size else None, s_.size, _ptr(s_) if s_.size else None, C.byref(n))
-        return int(n.value)
-
-    def slab_query(self, idx):
-        i = np.ascontiguousarray(idx, dtype=np.int32)
-        out = np.empty(i.size, np.int32)
-        if i.size:
-            self._call("nl_slab_query", i.size, _ptr(i), _ptr(out))
-        return out
+        ids = np.empty(s_.size, np.int32)
+        self._call("nl_slab_number", c.size, _ptr(c) if c.size else None, s_.size, _ptr(s_) if s_.size else None, C.byref(n),
+                   _ptr(ids) if s_.size else None)
+        return int(n.value), ids
 
     def slab_paint(self, base, roots, labels):
         r = np.ascontiguousarray(roots, dtype=np.int32)

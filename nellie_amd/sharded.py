@@ -87,13 +87,26 @@ def slab_geometry(gshape, world, rank, halo):
 SLAB_FILL, SLAB_AREA, SLAB_NUMBER = 0, 1, 2
 
 
+SLAB_BLOB_HEADER = 8
+
+
+def pack_slab_tables(roots, values, nruns=0):
+    """The blob a rank publishes per phase (nl_slab_phase's layout): [n0 n1 n2 n3 | ints | overflow | runs | 0] then the roots of
+    the four planes, then their values (int32).  Contexts that build their tables on the host (the CPU double of the tests) use it."""
+    counts = [int(np.asarray(r).size) for r in roots]
+    total = sum(counts)
+    head = np.array(counts + [SLAB_BLOB_HEADER + 2 * total, 0, int(nruns), 0], np.int32)
+    return np.concatenate([head] + [np.asarray(r, np.int32) for r in roots] + [np.asarray(v, np.int32) for v in values])
+
+
 def unpack_slab_tables(blob):
-    """[4 counts | roots of the 4 planes | values of the 4 planes] (int32) -> (roots[4], values[4])."""
+    """A rank's blob -> (roots[4], values[4]), planes in the order ghost-low, own-first, own-last, ghost-high."""
     blob = np.asarray(blob, np.int32)
     counts = [int(c) for c in blob[:4]]
     total = sum(counts)
     cuts = np.cumsum([0] + counts)
-    r, v = blob[4:4 + total], blob[4 + total:4 + 2 * total]
+    h = SLAB_BLOB_HEADER
+    r, v = blob[h:h + total], blob[h + total:h + 2 * total]
     return [r[cuts[k]:cuts[k + 1]] for k in range(4)], [v[cuts[k]:cuts[k + 1]] for k in range(4)]
 
 
@@ -102,10 +115,26 @@ class _Joined:
     __slots__ = ("rank", "root", "val", "comp", "ncomp")
 
 
+def join_slab_blobs(blobs):
+    """The joined view of every rank's tables.  With the library loaded: its host routine (nl_host_slab_join, C++: the numpy
+    model below takes ~1 ms per rank on tables of a 2048 x 2048 plane, which an 8-rank step would pay three times); without it
+    (CPU tests on a machine without the built library) the model itself.  Same nodes, same components, same numbering
+    (tests/test_sharded_cpu.py compares them)."""
+    try:
+        from nellie_amd import hipnative
+        rank, root, val, comp, ncomp = hipnative.host_slab_join([np.ascontiguousarray(b, np.int32) for b in blobs])
+    except (RuntimeError, OSError):
+        return join_slab_tables([unpack_slab_tables(b) for b in blobs])
+    j = _Joined()
+    j.rank, j.root, j.val, j.comp, j.ncomp = rank, root, val, comp, ncomp
+    return j
+
+
 def join_slab_tables(tables):
     """tables[r] = (roots[4], values[4]) of rank r, planes in the order ghost-low, own-first, own-last, ghost-high.
     Rank r's last owned plane is rank r+1's low ghost plane and rank r's high ghost plane is rank r+1's first owned
-    plane: the k-th run of such a plane names the same voxels on both sides, which joins the two trees."""
+    plane: the k-th entry (a run, or a segment component: whatever unit both ranks cut the plane into alike) of such a plane
+    names the same voxels on both sides, which joins the two trees."""
     ranks, roots, vals, ids, n = [], [], [], [], 0
     for r, (rt, vt) in enumerate(tables):
         allr = np.concatenate([np.asarray(x, np.int64) for x in rt]) if rt else np.zeros(0, np.int64)
@@ -180,6 +209,11 @@ class RcclComm:
 
     def allreduce(self, arr, op):
         return self.ctx.allreduce(arr, op)
+
+    def slab_phase_gather(self, ctx, phase):
+        """A Label phase up to the tables of ALL ranks: built, all-gathered (fixed blocks, ncclAllGather on the context stream)
+        and fetched inside one library call -- one wait, no size negotiation through the host."""
+        return ctx.slab_phase(phase, gather_world=self.world)
 
     def allgather_list(self, arr):
         return self.ctx.allgather_var(np.ascontiguousarray(arr), self.world)
@@ -381,11 +415,12 @@ class ShardedFramePipeline(FramePipeline):
         return [flat[cuts[r]:cuts[r + 1]] for r in range(self.world)]
 
     def _slab_phase(self, phase):
-        """Components of this slab for one phase + the joined view of the trees that continue on other ranks."""
-        _, counts = self.ctx.slab_components(phase)
-        roots, vals = self.ctx.slab_tables()
-        blob = np.concatenate([np.asarray(counts, np.int32)] + [np.asarray(r, np.int32) for r in roots] + [np.asarray(v, np.int32) for v in vals])
-        return join_slab_tables([unpack_slab_tables(b) for b in self._gather_list(blob)])
+        """Components of this slab for one phase + the joined view of the trees that continue on other ranks.  Over RCCL the
+        tables are all-gathered on the device inside the context's own call (one wait per phase); other communicators gather
+        the rank's blob through the host."""
+        fused = getattr(self.comm, "slab_phase_gather", None)
+        blobs = fused(self.ctx, phase) if fused is not None else self._gather_list(self.ctx.slab_phase(phase)[0])
+        return join_slab_blobs(blobs)
 
     def label(self, frangi_thresh, min_area, fill_holes=True):
         """labelling.py:467-509 across slabs (see the module docstring); returns the GLOBAL label count."""
@@ -422,8 +457,7 @@ class ShardedFramePipeline(FramePipeline):
         own_nodes = mine & has & (owner[j.comp] == me)
         np.minimum.at(first, j.comp[own_nodes], j.val[own_nodes].astype(np.int64))
         my_comps = np.flatnonzero(first != none)
-        k_local = ctx.slab_number(j.root[mine], first[my_comps].astype(np.int32))
-        local_id = ctx.slab_query(first[my_comps].astype(np.int32))
+        k_local, local_id = ctx.slab_number(j.root[mine], first[my_comps].astype(np.int32))
         parts = self._gather_list(np.concatenate([np.array([k_local], np.int64), my_comps.astype(np.int64), local_id.astype(np.int64)]))
         counts = np.array([int(p[0]) for p in parts], np.int64)
         base = np.concatenate([[0], np.cumsum(counts)])

@@ -208,7 +208,7 @@ class OracleCtx:
         e1 = hi + (1 if self.gz0 + hi < self.gnz else 0)
         return e0, e1
 
-    def slab_components(self, phase):
+    def _slab_components(self, phase):
         from scipy import ndimage as ndi
         lo, hi = self.own
         e0, e1 = self._ext()
@@ -248,10 +248,16 @@ class OracleCtx:
         self._sl["plane_runs"] = [np.flatnonzero(rows // ny == p) if p is not None else np.zeros(0, np.int64) for p in planes]
         return nruns, [int(r.size) for r in self._sl["plane_runs"]]
 
-    def slab_tables(self):
+    def slab_phase(self, phase, gather_world=0):
+        """The rank's tables of one phase as the library's blob (one entry per RUN here: any unit both ranks cut a shared plane
+        into alike will do -- the library uses segment components)."""
+        from nellie_amd.sharded import pack_slab_tables
+        assert not gather_world, "the CPU double gathers through its communicator"
+        self._slab_components(phase)
         sl = self._sl
-        return ([sl["parent"][r].astype(np.int32) for r in sl["plane_runs"]],
-                [sl["aux"][sl["parent"][r]].astype(np.int32) for r in sl["plane_runs"]])
+        roots = [sl["parent"][r].astype(np.int32) for r in sl["plane_runs"]]
+        vals = [sl["aux"][sl["parent"][r]].astype(np.int32) for r in sl["plane_runs"]]
+        return [pack_slab_tables(roots, vals, nruns=sl["parent"].size)]
 
     def slab_patch(self, roots, values):
         self._sl["aux"][np.asarray(roots, np.int64)] = np.asarray(values, np.int64)
@@ -292,10 +298,7 @@ class OracleCtx:
         sel[np.asarray(select, np.int64)] = True
         self._sl["sel"] = sel
         self._sl["rank_of"] = np.cumsum(sel) - sel          # exclusive
-        return int(sel.sum())
-
-    def slab_query(self, idx):
-        return (self._sl["rank_of"][np.asarray(idx, np.int64)] + 1).astype(np.int32)
+        return int(sel.sum()), (self._sl["rank_of"][np.asarray(select, np.int64)] + 1).astype(np.int32)
 
     def slab_paint(self, base, roots, labels):
         sl = self._sl

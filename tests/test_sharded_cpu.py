@@ -184,3 +184,33 @@ def test_zslab_label_protocol_random(world, seed):
     lab, counts = _label_slabs_with_threads(fr, 0.5, 12, world, {"X": 0.1, "Y": 0.1, "Z": 0.1, "T": 1.0})
     assert np.array_equal(lab, ref), f"{int((lab != ref).sum())} voxels differ"
     assert counts == [int(ref.max())] * world
+
+
+def test_library_join_equals_the_numpy_model():
+    """nl_host_slab_join (host C++ inside the library, what every rank runs on the gathered tables) against the numpy model
+    sharded.join_slab_tables: same nodes, values, components and numbering, on random tables of 1..8 ranks with trees that span
+    several planes and several ranks (the library is loaded, no GPU is touched)."""
+    from nellie_amd import hipnative, sharded
+    hipnative.load()
+    rng = np.random.default_rng(7)
+    for world in (1, 2, 3, 8):
+        for trial in range(6):
+            shared = [int(rng.integers(0, 40)) for _ in range(2 * (world - 1))]        # entries of the 2 shared planes per interface
+            blobs = []
+            for r in range(world):
+                n = [shared[2 * (r - 1)] if r > 0 else 0, shared[2 * (r - 1) + 1] if r > 0 else 0,
+                     shared[2 * r] if r + 1 < world else 0, shared[2 * r + 1] if r + 1 < world else 0]
+                trees = rng.integers(0, 5000, size=max(1, sum(n) // 3 + 1))               # few trees: many entries share one
+                val_of = {int(t): int(rng.integers(0, 2 ** 31 - 1)) for t in trees}
+                roots = [rng.choice(trees, size=k).astype(np.int32) for k in n]
+                vals = [np.array([val_of[int(t)] for t in rr], np.int32) for rr in roots]
+                blobs.append(sharded.pack_slab_tables(roots, vals, nruns=5000))
+            ref = sharded.join_slab_tables([sharded.unpack_slab_tables(b) for b in blobs])
+            rank, root, val, comp, ncomp = hipnative.host_slab_join(blobs)
+            assert ncomp == ref.ncomp and np.array_equal(rank, ref.rank) and np.array_equal(root, ref.root)
+            assert np.array_equal(val, ref.val) and np.array_equal(comp, ref.comp)
+    # ranks that disagree about a shared plane are an error, not a silent mis-join
+    a = sharded.pack_slab_tables([[], [], [1, 2], [3]], [[], [], [0, 0], [0]])
+    b = sharded.pack_slab_tables([[5], [6], [], []], [[0], [0], [], []])
+    with pytest.raises(Exception, match="disagree"):
+        hipnative.host_slab_join([a, b])
