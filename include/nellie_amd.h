@@ -433,6 +433,13 @@ int nl_slab_paint(nl_ctx *ctx, int64_t base, int64_t n, const int32_t *roots, co
 int nl_host_slab_join(int world, const int32_t *blobs, int64_t block_ints, int64_t cap, int64_t *n_nodes, int64_t *n_comp,
                       int64_t *node_rank, int32_t *node_root, int64_t *node_val, int64_t *node_comp, char *err, size_t errlen);
 
+/* The positive samples of ALL ranks, compacted on the device, all-gathered over RCCL in fixed blocks and fetched, in one call with
+   one wait: mode 0 = arr[::a, ::b, ::c] of `field` where > 0 (filtering.py:348-363, the samples of gamma / the percentile
+   threshold), mode 1 = flat[a::b] where > 0 (labelling.py:418-433, Label's threshold).  block_items: a bound on the sample POINTS
+   of any one rank, the same number on every rank (the callers derive it from the global shape).  out (cap floats) receives the
+   samples rank by rank (order inside a rank unspecified: the consumers are order-free), counts[world] how many each rank gave. */
+int nl_positive_samples_world(nl_ctx *ctx, int field, int mode, int64_t a, int64_t b, int64_t c, int64_t block_items,
+                              float *out, int64_t cap, int64_t *counts, char *err, size_t errlen);
 /* Variable-size all-gather of host bytes over RCCL (ncclAllGather on padded device staging): `recv` receives
    world * max_bytes bytes, rank r's block at r * max_bytes (its first bytes_of[r] bytes are valid; bytes_of has `world`
    entries and is filled here).  Used for the threshold samples and the slab tables, so that no data of the path

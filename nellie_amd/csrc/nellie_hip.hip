@@ -1966,6 +1966,8 @@ extern "C" int nl_mask_volume_fused(nl_ctx *c, float thr, int64_t *n_positive, c
     float *tmp = c->f[c->i_vmax];
     c->f[c->i_vmax] = c->f[dst];
     c->f[dst] = tmp;
+    // a fused communicator: the count comes back GLOBAL (one collective on the stream instead of a host-level all-reduce behind the call)
+    if (fused(c)) NL_NCCL(rccl().AllReduce(d_cnt, d_cnt, 1, ncclUint64, ncclSum, (ncclComm_t)c->comm, c->stream));
     NL_HIP(hipMemcpyAsync(c->h_small, d_cnt, 8, hipMemcpyDeviceToHost, c->stream));
     NL_HIP(hipStreamSynchronize(c->stream));
     if (n_positive) *n_positive = (int64_t)(*(unsigned long long *)c->h_small);
@@ -2186,6 +2188,84 @@ extern "C" int nl_comm_fuse(nl_ctx *c, int on, char *err, size_t errlen) {
     NL_ENTER(c);
     if (on && !c->comm) return nl_fail(err, errlen, NL_ESTATE, "nl_comm_fuse before nl_comm_init");
     c->fuse_reduce = on ? 1 : 0;
+    return NL_OK;
+}
+
+// The positive samples of ALL ranks in one call with one wait (round 4): every rank compacts its samples into a block
+// [count | samples ...] of block_items + 1 floats (block_items: a bound on any rank's sample points that the callers derive from
+// the global geometry, identical everywhere), the blocks are all-gathered over RCCL on the context stream and land in page-locked
+// memory.  mode 0: the lattice arr[::a, ::b, ::c] of `field` (filtering.py:348-363), mode 1: flat[a::b] (labelling.py:418-433).
+// out receives the samples rank by rank, counts[r] how many rank r contributed.  Before: a download, then nl_allgather_var's two
+// collectives with a wait each.
+extern "C" int nl_positive_samples_world(nl_ctx *c, int field, int mode, int64_t a, int64_t b, int64_t cc, int64_t block_items,
+                                         float *out, int64_t cap, int64_t *counts, char *err, size_t errlen) {
+    NL_ENTER(c);
+    NL_KEEP_SUPPORT(c);
+    if (!c->comm) return nl_fail(err, errlen, NL_ESTATE, "nl_positive_samples_world before nl_comm_init");
+    if (block_items < 0 || !counts || (mode != 0 && mode != 1)) return nl_fail(err, errlen, NL_EINVAL, "bad arguments");
+    const int W = c->world;
+    const size_t blk = (size_t)block_items + 1;                       // floats per rank
+    const size_t need = blk * (size_t)(W + 1) * 4;
+    if (need > c->ag_cap) {
+        if (c->d_ag) hipFree(c->d_ag);
+        c->d_ag = nullptr; c->ag_cap = 0;
+        NL_HIP(hipMalloc(&c->d_ag, need + need / 2));
+        c->ag_cap = need + need / 2;
+    }
+    if (blk * W * 4 > c->h_ag_cap) {
+        if (c->h_ag) hipHostFree(c->h_ag);
+        c->h_ag = nullptr; c->h_ag_cap = 0;
+        NL_HIP(hipHostMalloc(&c->h_ag, blk * W * 4 * 3 / 2, hipHostMallocDefault));
+        c->h_ag_cap = blk * W * 4 * 3 / 2;
+    }
+    float *d_send = (float *)c->d_ag, *d_recv = d_send + blk;
+    NL_HIP(zero_small(d_send, 4, c->stream));
+    int rc;
+    i64 points = 0;
+    if (mode == 0) {
+        Lattice L; FieldSrc fs;
+        if ((rc = make_lattice(c, a, b, cc, L, err, errlen))) return rc;
+        if ((rc = make_field(c, field, fs, err, errlen))) return rc;
+        if ((rc = use_fsq_cache(c, fs, L, err, errlen))) return rc;
+        points = L.cz * L.cy * L.cx;
+        if (points > block_items) return nl_fail(err, errlen, NL_EINVAL, "%lld lattice points in this slab, block of %lld", (long long)points, (long long)block_items);
+        if (points) {
+            ProfScope ps(c, "sample");
+            sample_gather_pos_kernel<<<(unsigned)((points + 255) / 256), 256, 0, c->stream>>>(fs, geom(c), L, d_send + 1, (unsigned int *)d_send);
+            NL_CHECK_LAUNCH();
+        }
+    } else {
+        if (b < 1 || a < 0) return nl_fail(err, errlen, NL_EINVAL, "bad offset/step");
+        if (field != NL_FIELD_FRANGI && field != NL_FIELD_GAUSS) return nl_fail(err, errlen, NL_EINVAL, "flat sampling supports GAUSS/FRANGI");
+        const i64 plane = c->ny * c->nx;
+        const i64 g_begin = (c->gz0 + c->own_lo) * plane, g_end = (c->gz0 + c->own_hi) * plane;
+        const i64 k0 = g_begin > a ? (g_begin - a + b - 1) / b : 0;
+        const i64 k1 = g_end > a ? (g_end - a + b - 1) / b : 0;
+        points = k1 > k0 ? k1 - k0 : 0;
+        if (points > block_items) return nl_fail(err, errlen, NL_EINVAL, "%lld sample points in this slab, block of %lld", (long long)points, (long long)block_items);
+        if (points) {
+            const float *src = (field == NL_FIELD_FRANGI) ? c->f[c->i_vmax] : gauss_cur(c);
+            ProfScope ps(c, "sample");
+            flat_gather_pos_kernel<<<(unsigned)((points + 255) / 256), 256, 0, c->stream>>>(src, -c->gz0 * plane, a + k0 * b, b, points, d_send + 1, (unsigned int *)d_send);
+            NL_CHECK_LAUNCH();
+        }
+    }
+    {
+        ProfScope ps(c, "halo");
+        NL_NCCL(rccl().AllGather(d_send, d_recv, blk, ncclFloat, (ncclComm_t)c->comm, c->stream));
+    }
+    NL_HIP(hipMemcpyAsync(c->h_ag, d_recv, blk * W * 4, hipMemcpyDeviceToHost, c->stream));
+    NL_HIP(hipStreamSynchronize(c->stream));
+    i64 total = 0;
+    const float *h = (const float *)c->h_ag;
+    for (int r = 0; r < W; ++r) {
+        unsigned int k; memcpy(&k, h + (size_t)r * blk, 4);
+        if ((i64)k > block_items) return nl_fail(err, errlen, NL_ESTATE, "rank %d reports %u samples in a block of %lld", r, k, (long long)block_items);
+        counts[r] = (int64_t)k;
+        if (total + (i64)k > cap || (k && !out)) return nl_fail(err, errlen, NL_EINVAL, "output capacity %lld too small", (long long)cap);
+        if (k) memcpy(out + total, h + (size_t)r * blk + 1, (size_t)k * 4);
+        total += (i64)k;
+    }
     return NL_OK;
 }
 

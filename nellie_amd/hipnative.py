@@ -55,6 +55,7 @@ _PROTOS = {
     "nl_hist_thresholds": [_p, _p, _int, C.POINTER(_f64), C.POINTER(_f64), C.POINTER(_int)],
     "nl_hist_thresholds_ex": [_p, _p, _int, _int, C.POINTER(_f64), C.POINTER(_f64), C.POINTER(_f64), C.POINTER(_int)],
     "nl_host_hist_thresholds_f32": [_p, _i64, _int, C.POINTER(_f64), C.POINTER(_f64), C.POINTER(_int), _p, _p],
+    "nl_positive_samples_world": [_p, _int, _int, _i64, _i64, _i64, _i64, _p, _i64, _p],
     "nl_host_slab_join": [_int, _p, _i64, _i64, C.POINTER(_i64), C.POINTER(_i64), _p, _p, _p, _p],
     "nl_outputs_pack": [_p, _int, _p],
     "nl_outputs_fetch_packed_async": [_p, _p, _i64],
@@ -909,6 +910,14 @@ class Context:
         sizes = np.zeros(int(world), np.int64)
         self._call("nl_allgather_bytes", _ptr(send) if send.size else None, send.size, _ptr(recv), int(max_bytes), _ptr(sizes))
         return [recv[r * max_bytes:r * max_bytes + int(sizes[r])].tobytes() for r in range(int(world))]
+
+    def positive_samples_world(self, field, mode, a, b, c, block_items, world):
+        """Every rank's positive samples (mode 0: lattice strides a, b, c; mode 1: flat offset a, step b), gathered on the device."""
+        cap = int(block_items) * int(world)
+        out = np.empty(max(cap, 1), np.float32)
+        counts = np.zeros(int(world), np.int64)
+        self._call("nl_positive_samples_world", int(field), int(mode), int(a), int(b), int(c), int(block_items), _ptr(out), cap, _ptr(counts))
+        return out[:int(counts.sum())]
 
     def allgather_var(self, arr: np.ndarray, world: int):
         """Variable-size all-gather over RCCL of one array per rank (same dtype everywhere): the list of every rank's array."""

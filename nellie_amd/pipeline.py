@@ -318,6 +318,9 @@ class FramePipeline:
     def _gather(self, samples):
         return samples
 
+    def _reduce_fused_count(self, n):
+        return self._reduce_sum(n)      # (a Z-slab pipeline with a fused communicator gets the global count from the call itself)
+
     # ------------------------------------------------------------------ Filter
     def load_input(self, frame):
         """Keep the raw frame resident in HBM; `filter(None, ...)` then starts from device memory."""
@@ -648,7 +651,7 @@ class FramePipeline:
                 if positive.size > 0:
                     thr = percentile_of_samples(positive, 1)
                     self.trace.percentile_thr = float(thr)
-                    self.trace.n_positive = self._reduce_sum(self.ctx.mask_volume_fused(thr))
+                    self.trace.n_positive = self._reduce_fused_count(self.ctx.mask_volume_fused(thr))
                     return self.trace.n_positive
             vz0, vz1 = self._vess_range()
             npos = self.trace.n_positive = self._reduce_sum(self.ctx.filter_finish(vz0, vz1))

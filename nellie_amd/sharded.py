@@ -210,6 +210,9 @@ class RcclComm:
     def allreduce(self, arr, op):
         return self.ctx.allreduce(arr, op)
 
+    def positive_samples_world(self, ctx, field, mode, a, b, c, block_items):
+        return ctx.positive_samples_world(field, mode, a, b, c, block_items, self.world)
+
     def slab_phase_gather(self, ctx, phase):
         """A Label phase up to the tables of ALL ranks: built, all-gathered (fixed blocks, ncclAllGather on the context stream)
         and fetched inside one library call -- one wait, no size negotiation through the host."""
@@ -361,12 +364,17 @@ class ShardedFramePipeline(FramePipeline):
     def _reduce_sum(self, n):
         return int(self.comm.allreduce(np.array([n], np.int64), "sum")[0])
 
+    def _reduce_fused_count(self, n):
+        return int(n) if self._fused_reduce else self._reduce_sum(n)     # nl_mask_volume_fused reduces on the device when fused
+
     # The device-resident threshold chain needs every reduction of a scale on the device, between the kernels (a fused
-    # communicator).  It is exact on slabs (tests/test_hip_sharded.py runs it over the loopback transport) but OFF by default
-    # there: on one rank's 128 x 2048 x 2048 slab it measured level with the synchronous path in one harness (30.0 vs 30.2 ms,
-    # tools/prof_slab.py) and slower in the bench's (38.5 vs 29.8 ms) for a reason not found; NELLIE_DEVICE_CHAIN_SLABS=1 turns it on.
+    # communicator).  Exact on slabs (tests/test_hip_sharded.py runs it over the loopback transport) and ON by default since round 4:
+    # one rank's 128 x 2048 x 2048 step measures 25.3 ms with it against 26.0 ms on the synchronous path (tools/prof_slab.py;
+    # the bench's harness: 26.5 vs 26.7), and what it removes -- ~20 host-synchronous reductions per frame -- is what would each
+    # become a collective plus a wait on 8 ranks.  (Round 3 measured it slower in the bench harness, 38.5 vs 29.8 ms: that was the
+    # cost of communicators destroyed earlier in the process, gone since they are pooled.)  NELLIE_DEVICE_CHAIN_SLABS=0: off.
     def _chain_reductions_on_device(self) -> bool:
-        return bool(self._fused_reduce) and os.environ.get("NELLIE_DEVICE_CHAIN_SLABS", "0") == "1"
+        return bool(self._fused_reduce) and os.environ.get("NELLIE_DEVICE_CHAIN_SLABS", "1") == "1"
 
     def _all_ranks_agree(self, ok: bool) -> bool:
         """Every rank decides from the same global histograms and statistics; the reduction only guards the fallback (a
@@ -387,6 +395,28 @@ class ShardedFramePipeline(FramePipeline):
 
     def _gather(self, samples):
         return self.comm.allgather(np.ascontiguousarray(samples, dtype=np.float32))
+
+    # Over RCCL the positive samples of a threshold never visit the host on their own: compaction, all-gather in fixed blocks
+    # and ONE download happen inside one library call (nl_positive_samples_world).  The block is a bound on any rank's sample
+    # points, derived from the global shape so that every rank passes the same number.
+    def _positive_lattice_samples(self, fld, strides):
+        f = getattr(self.comm, "positive_samples_world", None)
+        if f is None:
+            return super()._positive_lattice_samples(fld, strides)
+        sz, sy, sx = (int(v) for v in strides)
+        gnz, ny, nx = self.shape
+        per_plane = -(-ny // sy) * -(-nx // sx)
+        most = max(-(-o1 // sz) - -(-o0 // sz) for o0, o1 in (slab_range(gnz, self.world, r) for r in range(self.world)))
+        return f(self.ctx, fld, 0, sz, sy, sx, max(1, most * per_plane))
+
+    def _positive_flat_samples(self, fld, offset, step):
+        f = getattr(self.comm, "positive_samples_world", None)
+        if f is None:
+            return super()._positive_flat_samples(fld, offset, step)
+        gnz, ny, nx = self.shape
+        plane = ny * nx
+        most = max(-(-(o1 - o0) * plane // int(step)) + 1 for o0, o1 in (slab_range(gnz, self.world, r) for r in range(self.world)))
+        return f(self.ctx, fld, 1, int(offset), int(step), 0, max(1, most))
 
     # ---- outputs ------------------------------------------------------------------------------------------
     def download_frangi(self, out=None):
@@ -430,18 +460,20 @@ class ShardedFramePipeline(FramePipeline):
         if fill_holes:
             comm.exchange_bits(ctx, 0)
             j = self._slab_phase(SLAB_FILL)
-            mine = j.rank == me
-            outside = np.zeros(j.ncomp, bool)
-            np.logical_or.at(outside, j.comp, j.val != 0)
-            fix = mine & (j.val == 0) & outside[j.comp]
-            ctx.slab_patch(j.root[fix], np.ones(int(fix.sum()), np.int32))
+            if j.ncomp:                                            # (nothing crosses an interface: nothing to learn from the others)
+                mine = j.rank == me
+                outside = np.zeros(j.ncomp, bool)
+                np.logical_or.at(outside, j.comp, j.val != 0)
+                fix = mine & (j.val == 0) & outside[j.comp]
+                ctx.slab_patch(j.root[fix], np.ones(int(fix.sum()), np.int32))
             ctx.slab_apply()
         comm.exchange_bits(ctx, 0)
         j = self._slab_phase(SLAB_AREA)
-        mine = j.rank == me
-        area = np.zeros(j.ncomp, np.int64)
-        np.add.at(area, j.comp, j.val.astype(np.int64))
-        ctx.slab_patch(j.root[mine], np.minimum(area[j.comp[mine]], 2 ** 31 - 1).astype(np.int32))
+        if j.ncomp:
+            mine = j.rank == me
+            area = np.zeros(j.ncomp, np.int64)
+            np.add.at(area, j.comp, j.val.astype(np.int64))
+            ctx.slab_patch(j.root[mine], np.minimum(area[j.comp[mine]], 2 ** 31 - 1).astype(np.int32))
         ctx.slab_apply(int(min_area))
         comm.exchange_bits(ctx, 1)
         ctx.slab_majority()
@@ -458,7 +490,8 @@ class ShardedFramePipeline(FramePipeline):
         np.minimum.at(first, j.comp[own_nodes], j.val[own_nodes].astype(np.int64))
         my_comps = np.flatnonzero(first != none)
         k_local, local_id = ctx.slab_number(j.root[mine], first[my_comps].astype(np.int32))
-        parts = self._gather_list(np.concatenate([np.array([k_local], np.int64), my_comps.astype(np.int64), local_id.astype(np.int64)]))
+        mine_part = np.concatenate([np.array([k_local], np.int64), my_comps.astype(np.int64), local_id.astype(np.int64)])
+        parts = [mine_part] if self.world == 1 else self._gather_list(mine_part)
         counts = np.array([int(p[0]) for p in parts], np.int64)
         base = np.concatenate([[0], np.cumsum(counts)])
         label_of = np.zeros(j.ncomp, np.int64)
