@@ -302,6 +302,18 @@ int nl_mask_volume(nl_ctx *ctx, float thr, char *err, size_t errlen);
    n_positive = OWNED voxels of vesselness * masks that are > 0 (what nl_filter_finish reports).  Requires at least
    one evaluated scale. */
 int nl_mask_volume_fused(nl_ctx *ctx, float thr, int64_t *n_positive, char *err, size_t errlen);
+/* The same epilogue with NO host decision in it (round 4; csrc/percentile.inc): nl_tail_enqueue gathers the positive lattice samples
+   of `vesselness * masks` (strides sz, sy, sx: filtering.py:348-363), selects their q-th percentile on the device with numpy's
+   float32 'linear' rule (filtering.py:963) -- on Z slabs from histograms all-reduced between the kernels, no sample leaves its
+   rank --, and runs the percentile mask, the opening and the product (filtering.py:964-966) with the threshold read from device
+   memory.  Enqueue only.  nl_tail_finish waits and reports (samples, the two order statistics a <= b, the interpolation weight,
+   the threshold, the positive voxels of the product: global on a fused communicator); commit != 0 makes the result the frame
+   (as nl_mask_volume_fused does) unless there was no positive sample -- the caller then takes the plain path. */
+int nl_tail_enqueue(nl_ctx *ctx, int64_t sz, int64_t sy, int64_t sx, double q, char *err, size_t errlen);
+int nl_tail_finish(nl_ctx *ctx, int commit, int64_t *n_samples, float *a, float *b, float *gamma, float *thr, int64_t *n_positive,
+                   char *err, size_t errlen);
+/* tests: numpy.percentile(values, q) of n positive float32 values by the device's selection */
+int nl_debug_percentile(nl_ctx *ctx, const float *values, int64_t n, double q, float *thr, float *a, float *b, char *err, size_t errlen);
 
 /* D2H of NL_FIELD_FRANGI local planes [z0, z1) (filtering.py:1023-1031). */
 int nl_filter_store(nl_ctx *ctx, float *host, int64_t z0, int64_t z1, char *err, size_t errlen);

@@ -125,6 +125,7 @@ static CommApi &rccl() { static CommApi api; return api; }
 #include "network.inc"
 #include "thresholds.inc"
 #include "chain.inc"
+#include "percentile.inc"
 
 // =================================================================================================
 // host side: context, launch helpers, C-ABI
@@ -365,6 +366,8 @@ extern "C" int nl_ctx_destroy(nl_ctx *c) {
     if (c->d_rows) hipFree(c->d_rows);
     if (c->d_ag) hipFree(c->d_ag);
     if (c->d_sl) hipFree(c->d_sl);
+    if (c->d_pct) hipFree(c->d_pct);
+    if (c->h_pct) hipHostFree(c->h_pct);
     if (c->h_sl) hipHostFree(c->h_sl);
     if (c->d_pack) hipFree(c->d_pack);
     if (c->h_ag) hipHostFree(c->h_ag);
@@ -1931,50 +1934,165 @@ extern "C" int nl_mask_volume(nl_ctx *c, float thr, char *err, size_t errlen) {
     return NL_OK;
 }
 
-extern "C" int nl_mask_volume_fused(nl_ctx *c, float thr, int64_t *n_positive, char *err, size_t errlen) {
-    NL_ENTER(c);
-    if (c->mask_slots_used == 0) return nl_fail(err, errlen, NL_ESTATE, "nl_mask_volume_fused before any scale was evaluated");
-    NL_JOIN_SIDE(c);
+// The kernels of the fused epilogue; thr_dev != NULL: the threshold is read from device memory (nl_tail_enqueue).
+// Writes the masked frame into the free volume *dst_out; the caller commits it (swap with i_vmax) or not.
+static int mask_volume_fused_enqueue(nl_ctx *c, float thr, const float *thr_dev, unsigned long long *d_cnt, int *dst_out, char *err, size_t errlen) {
     int dst = -1;
     for (int k = 0; k < 3; ++k) if (k != c->i_gauss) { dst = k; break; }
-    unsigned long long *d_cnt = (unsigned long long *)c->d_small;
+    *dst_out = dst;
     NL_HIP(zero_small(d_cnt, 8, c->stream));
-    {
-        ProfScope ps(c, "mask_volume");
-        const int wpr = (int)((c->nx + 63) / 64);
-        const VolGeom v = geom(c);
-        const i64 slot_words = c->nzl * c->ny * wpr;
-        const int last = (c->mask_slots_used - 1) & 1;
-        const unsigned long long *alive = (const unsigned long long *)c->m[0] + (i64)last * slot_words;
-        // the threshold bits may not overwrite the mask slot they are computed from: m[1] / m[2] hold them, the free
-        // slot of m[0] takes the opened mask
-        const i64 m0 = c->own_lo - 2 > 0 ? c->own_lo - 2 : 0, m1 = c->own_hi + 2 < c->nzl ? c->own_hi + 2 : c->nzl;
-        const i64 e0 = c->own_lo - 1 > 0 ? c->own_lo - 1 : 0, e1 = c->own_hi + 1 < c->nzl ? c->own_hi + 1 : c->nzl;
-        unsigned long long *bM = (unsigned long long *)c->m[1], *bE = (unsigned long long *)c->m[2];
-        unsigned long long *bD = (unsigned long long *)c->m[0] + (i64)(last ^ 1) * slot_words;
-        pack_masked_kernel<<<grid1d((m1 - m0) * c->ny * 64, 256, 256 * 16), 256, 0, c->stream>>>(    // one atomic per workgroup: small grid
-            c->f[c->i_vmax], alive, bM, thr, (int)c->nx, m0 * c->ny, m1 * c->ny, wpr, c->own_lo * c->ny, c->own_hi * c->ny, d_cnt);
-        NL_CHECK_LAUNCH();
-        bits_morph6_kernel<0><<<(unsigned)(((e1 - e0) * c->ny * wpr + 255) / 256), 256, 0, c->stream>>>(bM, bE, v, wpr, e0, e1, c->two_d);
-        NL_CHECK_LAUNCH();
-        bits_morph6_kernel<1><<<(unsigned)(((c->own_hi - c->own_lo) * c->ny * wpr + 255) / 256), 256, 0, c->stream>>>(bE, bD, v, wpr, c->own_lo, c->own_hi, c->two_d);
-        NL_CHECK_LAUNCH();
-        apply_bits_pos_kernel<<<grid1d((c->own_hi - c->own_lo) * c->ny * 64, 256, (i64)1 << 22), 256, 0, c->stream>>>(
-            c->f[c->i_vmax], bD, c->f[dst], v, wpr, c->own_lo, c->own_hi);
-        NL_CHECK_LAUNCH();
-    }
+    ProfScope ps(c, "mask_volume");
+    const int wpr = (int)((c->nx + 63) / 64);
+    const VolGeom v = geom(c);
+    const i64 slot_words = c->nzl * c->ny * wpr;
+    const int last = (c->mask_slots_used - 1) & 1;
+    const unsigned long long *alive = (const unsigned long long *)c->m[0] + (i64)last * slot_words;
+    // the threshold bits may not overwrite the mask slot they are computed from: m[1] / m[2] hold them, the free
+    // slot of m[0] takes the opened mask
+    const i64 m0 = c->own_lo - 2 > 0 ? c->own_lo - 2 : 0, m1 = c->own_hi + 2 < c->nzl ? c->own_hi + 2 : c->nzl;
+    const i64 e0 = c->own_lo - 1 > 0 ? c->own_lo - 1 : 0, e1 = c->own_hi + 1 < c->nzl ? c->own_hi + 1 : c->nzl;
+    unsigned long long *bM = (unsigned long long *)c->m[1], *bE = (unsigned long long *)c->m[2];
+    unsigned long long *bD = (unsigned long long *)c->m[0] + (i64)(last ^ 1) * slot_words;
+    pack_masked_kernel<<<grid1d((m1 - m0) * c->ny * 64, 256, 256 * 16), 256, 0, c->stream>>>(    // one atomic per workgroup: small grid
+        c->f[c->i_vmax], alive, bM, thr, thr_dev, (int)c->nx, m0 * c->ny, m1 * c->ny, wpr, c->own_lo * c->ny, c->own_hi * c->ny, d_cnt);
+    NL_CHECK_LAUNCH();
+    bits_morph6_kernel<0><<<(unsigned)(((e1 - e0) * c->ny * wpr + 255) / 256), 256, 0, c->stream>>>(bM, bE, v, wpr, e0, e1, c->two_d);
+    NL_CHECK_LAUNCH();
+    bits_morph6_kernel<1><<<(unsigned)(((c->own_hi - c->own_lo) * c->ny * wpr + 255) / 256), 256, 0, c->stream>>>(bE, bD, v, wpr, c->own_lo, c->own_hi, c->two_d);
+    NL_CHECK_LAUNCH();
+    apply_bits_pos_kernel<<<grid1d((c->own_hi - c->own_lo) * c->ny * 64, 256, (i64)1 << 22), 256, 0, c->stream>>>(
+        c->f[c->i_vmax], bD, c->f[dst], v, wpr, c->own_lo, c->own_hi);
+    NL_CHECK_LAUNCH();
+    // a fused communicator: the count comes back GLOBAL (one collective on the stream instead of a host-level all-reduce behind the call)
+    if (fused(c)) NL_NCCL(rccl().AllReduce(d_cnt, d_cnt, 1, ncclUint64, ncclSum, (ncclComm_t)c->comm, c->stream));
+    return NL_OK;
+}
+static void mask_volume_fused_commit(nl_ctx *c, int dst) {
     float *tmp = c->f[c->i_vmax];
     c->f[c->i_vmax] = c->f[dst];
     c->f[dst] = tmp;
-    // a fused communicator: the count comes back GLOBAL (one collective on the stream instead of a host-level all-reduce behind the call)
-    if (fused(c)) NL_NCCL(rccl().AllReduce(d_cnt, d_cnt, 1, ncclUint64, ncclSum, (ncclComm_t)c->comm, c->stream));
-    NL_HIP(hipMemcpyAsync(c->h_small, d_cnt, 8, hipMemcpyDeviceToHost, c->stream));
-    NL_HIP(hipStreamSynchronize(c->stream));
-    if (n_positive) *n_positive = (int64_t)(*(unsigned long long *)c->h_small);
     c->frangi_ready = 1;
     // valid as long as only NL_KEEP_SUPPORT entry points follow; on a slab it describes the OWNED planes (all nl_slab_label_pack reads)
     c->d_support = (const unsigned long long *)c->m[0] + (i64)(((c->mask_slots_used - 1) & 1) ^ 1) * (c->nzl * c->ny * (i64)((c->nx + 63) / 64));
     c->support_epoch = c->epoch.load();
+}
+
+extern "C" int nl_mask_volume_fused(nl_ctx *c, float thr, int64_t *n_positive, char *err, size_t errlen) {
+    NL_ENTER(c);
+    if (c->mask_slots_used == 0) return nl_fail(err, errlen, NL_ESTATE, "nl_mask_volume_fused before any scale was evaluated");
+    NL_JOIN_SIDE(c);
+    unsigned long long *d_cnt = (unsigned long long *)c->d_small;
+    int dst, rc;
+    if ((rc = mask_volume_fused_enqueue(c, thr, nullptr, d_cnt, &dst, err, errlen))) return rc;
+    NL_HIP(hipMemcpyAsync(c->h_small, d_cnt, 8, hipMemcpyDeviceToHost, c->stream));
+    NL_HIP(hipStreamSynchronize(c->stream));
+    if (n_positive) *n_positive = (int64_t)(*(unsigned long long *)c->h_small);
+    mask_volume_fused_commit(c, dst);
+    return NL_OK;
+}
+
+// ---- the frame's epilogue without a host decision in it (percentile.inc) ------------------------------------------------------
+// layout of d_pct: [PctRec 64 B][sample counter 4 B, pad][voxel counter 8 B][hist 2 x PCT_BINS u32]
+static int pct_buffers(nl_ctx *c, char *err, size_t errlen) {
+    if (!c->d_pct) {
+        NL_HIP(hipMalloc(&c->d_pct, 128 + (size_t)2 * PCT_BINS * 4));
+        NL_HIP(hipHostMalloc(&c->h_pct, 128, hipHostMallocDefault));
+    }
+    return NL_OK;
+}
+// numpy.percentile(samples[0 .. *d_n), q) -> rec->thr, selected on the device (all-reduced across a fused communicator)
+static int pct_enqueue(nl_ctx *c, const float *samples, const unsigned int *d_n, i64 max_n, float q, char *err, size_t errlen) {
+    PctRec *rec = (PctRec *)c->d_pct;
+    unsigned int *hist = (unsigned int *)((char *)c->d_pct + 128);
+    NL_HIP(hipMemcpyAsync(&rec->n, d_n, 4, hipMemcpyDeviceToDevice, c->stream));
+    NL_HIP(hipMemcpyAsync(&rec->n_local, d_n, 4, hipMemcpyDeviceToDevice, c->stream));
+    if (fused(c)) NL_NCCL(rccl().AllReduce(&rec->n, &rec->n, 1, ncclUint32, ncclSum, (ncclComm_t)c->comm, c->stream));
+    ProfScope ps(c, "sample");
+    pct_begin_kernel<<<1, 64, 0, c->stream>>>(rec, q);
+    const unsigned grid = grid1d(max_n > 0 ? max_n : 1, 256, 256 * 256);
+#define NL_PCT_LEVEL(L)                                                                                            \
+    NL_HIP(hipMemsetAsync(hist, 0, (size_t)2 * PCT_BINS * 4, c->stream));                                           \
+    pct_hist_kernel<L><<<grid, 256, 0, c->stream>>>(samples, d_n, rec, hist);                                       \
+    if (fused(c)) NL_NCCL(rccl().AllReduce(hist, hist, (size_t)2 * PCT_BINS, ncclUint32, ncclSum, (ncclComm_t)c->comm, c->stream)); \
+    pct_select_kernel<L><<<1, 256, 0, c->stream>>>(rec, hist);
+    NL_PCT_LEVEL(0) NL_PCT_LEVEL(1) NL_PCT_LEVEL(2)
+#undef NL_PCT_LEVEL
+    NL_CHECK_LAUNCH();
+    return NL_OK;
+}
+
+/* filtering.py:926 + 952-967 in one enqueue, no host decision inside: the positive lattice samples of `vesselness * masks`
+   (strides sz, sy, sx), their q-th percentile (numpy's float32 'linear' rule, selected on the device), the percentile mask, its
+   opening and the product.  Nothing is committed yet: nl_tail_finish waits, reports and (commit != 0) makes the result the frame. */
+extern "C" int nl_tail_enqueue(nl_ctx *c, int64_t sz, int64_t sy, int64_t sx, double q, char *err, size_t errlen) {
+    NL_ENTER(c);
+    if (c->mask_slots_used == 0) return nl_fail(err, errlen, NL_ESTATE, "nl_tail_enqueue before any scale was evaluated");
+    if (c->two_d) return nl_fail(err, errlen, NL_EINVAL, "nl_tail_enqueue is the 3-D epilogue");
+    int rc;
+    if ((rc = pct_buffers(c, err, errlen))) return rc;
+    Lattice L; FieldSrc fs;
+    if ((rc = make_lattice(c, sz, sy, sx, L, err, errlen))) return rc;
+    if ((rc = make_field(c, NL_FIELD_VESSELNESS, fs, err, errlen))) return rc;       // (joins the side stream)
+    const i64 total = L.cz * L.cy * L.cx;
+    if (total > c->n) return nl_fail(err, errlen, NL_EINVAL, "lattice larger than the volume");
+    float *stage = c->f[(c->i_gauss + 1) % 3];
+    if (stage == c->f[c->i_vmax]) return nl_fail(err, errlen, NL_ESTATE, "no free volume for the samples");
+    unsigned int *d_n = (unsigned int *)((char *)c->d_pct + 64);
+    unsigned long long *d_cnt = (unsigned long long *)((char *)c->d_pct + 72);
+    NL_HIP(zero_small(d_n, 4, c->stream));
+    if (total > 0) {
+        ProfScope ps(c, "sample");
+        sample_gather_pos_kernel<<<(unsigned)((total + 255) / 256), 256, 0, c->stream>>>(fs, geom(c), L, stage, d_n);
+        NL_CHECK_LAUNCH();
+    }
+    if ((rc = pct_enqueue(c, stage, d_n, total, (float)q, err, errlen))) return rc;
+    // the samples sit in a volume the epilogue may write (dst): the selection above is complete before it does (stream order)
+    int dst;
+    if ((rc = mask_volume_fused_enqueue(c, 0.0f, &((PctRec *)c->d_pct)->thr, d_cnt, &dst, err, errlen))) return rc;
+    NL_HIP(hipMemcpyAsync(c->h_pct, c->d_pct, 80, hipMemcpyDeviceToHost, c->stream));
+    c->tail_pending = 1; c->tail_dst = dst;
+    return NL_OK;
+}
+
+extern "C" int nl_tail_finish(nl_ctx *c, int commit, int64_t *n_samples, float *a, float *b, float *gamma, float *thr, int64_t *n_positive,
+                              char *err, size_t errlen) {
+    NL_ENTER(c);
+    if (!c->tail_pending) return nl_fail(err, errlen, NL_ESTATE, "nl_tail_finish without nl_tail_enqueue");
+    NL_HIP(hipStreamSynchronize(c->stream));
+    c->tail_pending = 0;
+    const PctRec *rec = (const PctRec *)c->h_pct;
+    if (n_samples) *n_samples = rec->n;
+    if (a) *a = rec->a;
+    if (b) *b = rec->b;
+    if (gamma) *gamma = rec->gamma;
+    if (thr) *thr = rec->thr;
+    if (n_positive) *n_positive = (int64_t)(*(const unsigned long long *)((const char *)c->h_pct + 72));
+    if (commit && rec->n > 0) mask_volume_fused_commit(c, c->tail_dst);
+    return NL_OK;
+}
+
+/* numpy.percentile(values, q) by the device's selection (tests): values > 0, n < the context's voxel count */
+extern "C" int nl_debug_percentile(nl_ctx *c, const float *values, int64_t n, double q, float *thr, float *a, float *b, char *err, size_t errlen) {
+    NL_ENTER(c);
+    if (!values || n < 1 || n > c->n) return nl_fail(err, errlen, NL_EINVAL, "bad sample array");
+    int rc;
+    if ((rc = pct_buffers(c, err, errlen))) return rc;
+    float *stage = c->f[(c->i_gauss + 1) % 3];
+    unsigned int *d_n = (unsigned int *)((char *)c->d_pct + 64);
+    const unsigned int un = (unsigned int)n;
+    NL_HIP(hipMemcpyAsync(stage, values, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    NL_HIP(hipMemcpyAsync(d_n, &un, 4, hipMemcpyHostToDevice, c->stream));
+    NL_HIP(hipStreamSynchronize(c->stream));
+    const int keep = c->fuse_reduce; c->fuse_reduce = 0;                 // a local array: no collective
+    rc = pct_enqueue(c, stage, d_n, n, (float)q, err, errlen);
+    c->fuse_reduce = keep;
+    if (rc) return rc;
+    NL_HIP(hipMemcpyAsync(c->h_pct, c->d_pct, 64, hipMemcpyDeviceToHost, c->stream));
+    NL_HIP(hipStreamSynchronize(c->stream));
+    const PctRec *rec = (const PctRec *)c->h_pct;
+    if (thr) *thr = rec->thr;
+    if (a) *a = rec->a;
+    if (b) *b = rec->b;
     return NL_OK;
 }
 

@@ -105,6 +105,10 @@ struct nl_ctx {
     int mask_slots_used = 0;   // per-scale h_mask bit planes written since the frame began
     hipEvent_t ev_chain = nullptr; int chain_copy_pending = 0;
     i64 gp_total = -1; float *gp_stage = nullptr;   // nl_sample_gather_positive_begin .. _end
+    // nl_tail_enqueue .. nl_tail_finish: percentile threshold + _mask_volume decided on the device (percentile.inc)
+    void *d_pct = nullptr;      // PctRec, sample counter, voxel counter, two histograms
+    void *h_pct = nullptr;      // pinned landing area of the record and the count
+    int tail_pending = 0, tail_dst = -1;
     void *d_chain = nullptr, *h_chain = nullptr;     // device-resident threshold chain (chain.inc): records of a frame's scales, pinned mirror
     int chain_n = 0, chain_k = 0;
     double chain_par[16][3] = {};                    // (division, margin, test scale) each scale was enqueued with

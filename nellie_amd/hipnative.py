@@ -55,6 +55,9 @@ _PROTOS = {
     "nl_hist_thresholds": [_p, _p, _int, C.POINTER(_f64), C.POINTER(_f64), C.POINTER(_int)],
     "nl_hist_thresholds_ex": [_p, _p, _int, _int, C.POINTER(_f64), C.POINTER(_f64), C.POINTER(_f64), C.POINTER(_int)],
     "nl_host_hist_thresholds_f32": [_p, _i64, _int, C.POINTER(_f64), C.POINTER(_f64), C.POINTER(_int), _p, _p],
+    "nl_tail_enqueue": [_p, _i64, _i64, _i64, _f64],
+    "nl_tail_finish": [_p, _int, C.POINTER(_i64), C.POINTER(_f32), C.POINTER(_f32), C.POINTER(_f32), C.POINTER(_f32), C.POINTER(_i64)],
+    "nl_debug_percentile": [_p, _p, _i64, _f64, C.POINTER(_f32), C.POINTER(_f32), C.POINTER(_f32)],
     "nl_positive_samples_world": [_p, _int, _int, _i64, _i64, _i64, _i64, _p, _i64, _p],
     "nl_host_slab_join": [_int, _p, _i64, _i64, C.POINTER(_i64), C.POINTER(_i64), _p, _p, _p, _p],
     "nl_outputs_pack": [_p, _int, _p],
@@ -520,6 +523,24 @@ class Context:
         return int(n.value)
 
     # ---------------------------------------------------------------- Markers stage
+    def tail_enqueue(self, strides, q=1.0):
+        """The frame's epilogue (percentile threshold selected on the device, mask, opening, product), enqueued without a wait."""
+        self._call("nl_tail_enqueue", int(strides[0]), int(strides[1]), int(strides[2]), float(q))
+
+    def tail_finish(self, commit=True):
+        """-> dict(n_samples, a, b, gamma, thr, n_positive) of the epilogue nl_tail_enqueue started; commit: it becomes the frame."""
+        n, npos = _i64(0), _i64(0)
+        a, b, g, t = _f32(0), _f32(0), _f32(0), _f32(0)
+        self._call("nl_tail_finish", 1 if commit else 0, C.byref(n), C.byref(a), C.byref(b), C.byref(g), C.byref(t), C.byref(npos))
+        return dict(n_samples=int(n.value), a=np.float32(a.value), b=np.float32(b.value), gamma=np.float32(g.value),
+                    thr=np.float32(t.value), n_positive=int(npos.value))
+
+    def debug_percentile(self, values, q=1.0):
+        v = np.ascontiguousarray(values, dtype=np.float32).reshape(-1)
+        a, b, t = _f32(0), _f32(0), _f32(0)
+        self._call("nl_debug_percentile", _ptr(v), v.size, float(q), C.byref(t), C.byref(a), C.byref(b))
+        return np.float32(t.value), np.float32(a.value), np.float32(b.value)
+
     def markers_begin(self, labels=None, intensity=None):
         """labels: int32 (Z, Y, X) host array or None (device labels of label_run); intensity: host array of any
         supported dtype or None (the resident input)."""

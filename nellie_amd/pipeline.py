@@ -561,17 +561,27 @@ class FramePipeline:
                             self._one_pass_test_scale, z0=vz0, z1=vz1)
         # filter()'s percentile threshold reads lattice samples of the result: their compaction is enqueued BEFORE the wait, so it
         # runs while the host waits for the chain's records and repeats its decisions (one round trip less per frame)
-        tail = self._tail_field is not None and hasattr(ctx, "sample_gather_positive_begin")
+        # Round 4: with the percentile selected on the device (nl_tail_enqueue) the WHOLE epilogue is enqueued before the wait -- the
+        # host repeats the chain's decisions while the GPU masks the frame -- and no sample ever travels.
+        dev_tail = self._tail_field is not None and self._device_tail_usable()
+        tail = not dev_tail and self._tail_ok and self._tail_field is not None and hasattr(ctx, "sample_gather_positive_begin")
         self._tail_samples = None
-        if tail:
+        self._tail_dev_pending = False
+        if dev_tail:
+            ctx.chain_flush()
+            ctx.tail_enqueue(strides, 1.0)
+        elif tail:
             ctx.chain_flush()
             ctx.sample_gather_positive_begin(self._tail_field, strides)
         flags, gamma, max_abs, thr, counts = ctx.chain_finish()
         samples = ctx.sample_gather_positive_end() if tail else None
         self.last_chain_flags = [int(f) for f in flags]
         if not self._all_ranks_agree(not flags.any()):
+            if dev_tail:
+                ctx.tail_finish(commit=False)              # the frame is redone: what the epilogue computed from it is dropped
             return False
         self._tail_samples = samples
+        self._tail_dev_pending = dev_tail
         if self.check_device_edges:
             for k in range(len(sigmas)):
                 for which in range(3):
@@ -621,6 +631,33 @@ class FramePipeline:
     _tail_ok = True
     _tail_field = None
     _tail_samples = None
+    _tail_dev_pending = False
+    _device_tail = os.environ.get("NELLIE_DEVICE_TAIL", "1") == "1"      # 0: the percentile threshold on the host (round 3)
+
+    def _device_tail_usable(self) -> bool:
+        """The epilogue with the percentile selected on the device: needs the entry points, a 3-D frame, and the host's repetition
+        of numpy's interpolation to be the installed numpy's (percentile_of_samples checks that once per process)."""
+        global _FAST_PERCENTILE
+        if _FAST_PERCENTILE is None:
+            percentile_of_samples(np.array([1.0, 2.0], np.float32), 1)
+        return bool(self._device_tail and _FAST_PERCENTILE and not self.two_d and hasattr(self.ctx, "tail_enqueue")
+                    and self._tail_reductions_on_device())
+
+    def _tail_reductions_on_device(self) -> bool:
+        return True            # one GPU: nothing to reduce (a Z-slab pipeline needs its fused communicator)
+
+    def _finish_device_tail(self):
+        """Waits for the epilogue nl_tail_enqueue started, checks the device's interpolation against numpy's rule, fills the trace.
+        -> positive voxels, or None when there was no positive sample (the caller takes the plain path)."""
+        rec = self.ctx.tail_finish(commit=True)
+        if rec["n_samples"] == 0:
+            return None
+        thr, gamma = percentile_from_order_statistics(rec["n_samples"], rec["a"], rec["b"], 1)
+        if not (np.float32(thr) == rec["thr"] and np.float32(gamma) == rec["gamma"] and rec["a"] <= rec["b"]):
+            raise RuntimeError(f"device percentile {rec} differs from numpy's rule ({thr}, {gamma})")
+        self.trace.percentile_thr = float(rec["thr"])
+        self.trace.n_positive = self._reduce_fused_count(rec["n_positive"])
+        return self.trace.n_positive
     _fused_epilogue = True      # (a Z-slab pipeline on a context without nl_mask_volume_fused keeps the two-step epilogue)
     # Enqueue the cascade step of scale s+1 on the side stream beside the Hessian walk of scale s.  Exact either way.
     # Off by default: at 1024^3 it buys ~1 % (two full-GPU kernels mostly take turns) and it blurs per-kernel timings.
@@ -638,14 +675,24 @@ class FramePipeline:
                 self.mask_volume(p)
             return npos
         if self._fused_epilogue and not self.two_d:
-            self._tail_field = FIELD_VESSELNESS if self._tail_ok else None
+            self._tail_field = FIELD_VESSELNESS if (self._tail_ok or self._device_tail_usable()) else None
+            self._tail_dev_pending = False
             try:
                 self.compute_vesselness(frame, p, mask=mask, finish=False)
             finally:
                 self._tail_field = None
             positive, self._tail_samples = self._tail_samples, None
+            pending, self._tail_dev_pending = self._tail_dev_pending, False
             if any(not sc.skipped for sc in self.trace.scales):
                 strides = self._strides(int(p.max_threshold_samples))
+                if pending or (positive is None and self._device_tail_usable()):
+                    if not pending:
+                        self.ctx.tail_enqueue(strides, 1.0)
+                    npos = self._finish_device_tail()
+                    if npos is not None:
+                        return npos
+                    positive = np.zeros(0, np.float32)          # no positive sample: the plain path below
+                    pending = False
                 if positive is None:
                     positive = self._positive_lattice_samples(FIELD_VESSELNESS, strides)
                 if positive.size > 0:
@@ -653,6 +700,8 @@ class FramePipeline:
                     self.trace.percentile_thr = float(thr)
                     self.trace.n_positive = self._reduce_fused_count(self.ctx.mask_volume_fused(thr))
                     return self.trace.n_positive
+            if pending:                                         # every scale was skipped: nothing to commit
+                self.ctx.tail_finish(commit=False)
             vz0, vz1 = self._vess_range()
             npos = self.trace.n_positive = self._reduce_sum(self.ctx.filter_finish(vz0, vz1))
         else:
@@ -755,6 +804,18 @@ def _percentile_shortcut(values, q):
     if gamma >= 0.5:
         return b - diff * (1 - gamma)
     return a + diff * gamma
+
+
+def percentile_from_order_statistics(n, a, b, q):
+    """np.percentile of n float32 values whose order statistics at floor((n - 1) q / 100) and the next index are a and b: the
+    interpolation of _percentile_shortcut (numpy's float32 'linear' rule).  -> (thr, gamma); the host's check of the device's."""
+    qf = np.true_divide(q, np.float32(100))
+    vi = (n - 1) * qf
+    lo = n - 1 if vi >= n - 1 else int(np.floor(vi))
+    gamma = np.float32(np.float64(vi) - lo)
+    a, b = np.float32(a), np.float32(b)
+    diff = b - a
+    return (b - diff * (1 - gamma) if gamma >= 0.5 else a + diff * gamma), gamma
 
 
 def _shortcut_matches_numpy():

@@ -364,6 +364,9 @@ class ShardedFramePipeline(FramePipeline):
     def _reduce_sum(self, n):
         return int(self.comm.allreduce(np.array([n], np.int64), "sum")[0])
 
+    def _tail_reductions_on_device(self) -> bool:
+        return bool(self._fused_reduce)      # the percentile's histograms are all-reduced between the kernels (nl_tail_enqueue)
+
     def _reduce_fused_count(self, n):
         return int(n) if self._fused_reduce else self._reduce_sum(n)     # nl_mask_volume_fused reduces on the device when fused
 

@@ -1048,3 +1048,48 @@ pipe.close()
         got[rs] = json.loads(r.stdout.strip().splitlines()[-1])
     assert got["8"][:2] == [True, True] and got["0"][:2] == [False, False]
     assert got["8"][2:] == got["0"][2:] and got["8"][4] > 0
+
+
+def test_device_percentile_equals_numpy(hip):
+    """The radix select of csrc/percentile.inc (three levels, both order statistics at once, numpy's float32 'linear'
+    interpolation on the device) against np.percentile itself -- filtering.py:963 takes the 1st percentile; other q, tiny arrays,
+    ties and values spread over many binades are covered too."""
+    from nellie_amd import pipeline as pl
+    rng = np.random.default_rng(99)
+    pipe = pl.FramePipeline((16, 256, 256))
+    try:
+        cases = []
+        for n in (1, 2, 3, 7, 100, 101, 4097, 65536, 830584):
+            cases.append((rng.random(n, dtype=np.float32) * np.float32(1e-3) + np.float32(1e-9)).astype(np.float32))
+        cases.append(np.exp(rng.normal(0, 8, 50000)).astype(np.float32))                    # many binades
+        cases.append(np.repeat(np.float32([0.25, 0.5, 0.75]), 3333))                        # ties
+        cases.append(np.full(1000, np.float32(3.0e-5)))                                     # all equal
+        cases.append(np.float32([1e-38, 1e-38, 3.4e38, 1.0]))                               # extremes
+        for v in cases:
+            for q in (1, 50, 99, 100, 0):
+                want = np.percentile(v, q)
+                thr, a, b = pipe.ctx.debug_percentile(v, q)
+                assert type(want) is np.float32 and thr == want, (v.size, q, thr, want, a, b)
+    finally:
+        pipe.close()
+
+
+def test_device_tail_equals_the_host_epilogue(hip):
+    """filter() with the epilogue enqueued on the device (nl_tail_enqueue: percentile selected by kernels, threshold read from
+    device memory) against the round-3 epilogue (samples to the host, np.partition there): same threshold, same count, same frame,
+    with the chain and on the synchronous path."""
+    from nellie_amd import pipeline as pl
+    from nellie_amd.synthetic import ANISO_03, ISO_01, make_volume
+    for shape, seed, dr in (((40, 96, 104), 41, ISO_01), ((33, 70, 130), 42, ANISO_03), ((64, 128, 136), 43, ISO_01)):
+        vol = make_volume(shape, seed)
+        res = []
+        for chain in (True, False):
+            for dev in (True, False):
+                pipe = pl.FramePipeline(shape)
+                pipe._device_chain, pipe._device_tail = chain, dev
+                assert pipe._device_tail_usable() == dev
+                pipe.filter(vol, pl.FilterParams(dim_res=dr))
+                res.append((pipe.trace.percentile_thr, pipe.trace.n_positive, zlib.crc32(pipe.download_frangi().tobytes())))
+                pipe.close()
+        assert all(r == res[0] for r in res), res
+        assert res[0][1] > 0
