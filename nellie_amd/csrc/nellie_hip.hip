@@ -2878,11 +2878,11 @@ static int label_run_voxels(nl_ctx *c, int has_thr, float thr, int64_t min_area,
     const i64 nblk = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
     unsigned int *blk = (unsigned int *)c->d_blk;
     unsigned long long *d_total = (unsigned long long *)c->d_small;
-    root_count_kernel<<<(unsigned)nblk, 256, 0, c->stream>>>(L, n, blk);
+    root_count_kernel<<<(unsigned)nblk, 256, 0, c->stream>>>(L, n, nullptr, n, blk);
     NL_CHECK_LAUNCH();
     blk_scan_kernel<<<1, 1024, 0, c->stream>>>(blk, nblk, d_total);
     NL_CHECK_LAUNCH();
-    root_assign_kernel<<<(unsigned)nblk, 256, 0, c->stream>>>(L, n, blk, aux);
+    root_assign_kernel<<<(unsigned)nblk, 256, 0, c->stream>>>(L, n, nullptr, n, blk, aux);
     NL_CHECK_LAUNCH();
     relabel_kernel<<<grid1d(n), 256, 0, c->stream>>>(L, aux, out, n);
     NL_CHECK_LAUNCH();
@@ -2908,7 +2908,19 @@ static int scan_excl_u32(nl_ctx *c, const unsigned int *in, unsigned int *out, i
     return NL_OK;
 }
 
-struct RunSet { RunRec *runs; int *parent; unsigned int *row_off; i64 nruns; int *proot = nullptr; int *link = nullptr; bool proot_valid = false; };
+struct RunSet { RunRec *runs; int *parent; unsigned int *row_off; i64 nruns; int *proot = nullptr; int *link = nullptr; bool proot_valid = false;
+                // nruns < 0: the host did not wait for the count (it lies at row_off[nrows]); kernels then read it there
+                bool host_count = true; i64 cap = 0;
+                RunN rn() const { return RunN{host_count ? nullptr : n_ptr, nruns, cap}; }
+                const unsigned int *n_ptr = nullptr; };
+// workgroups of a kernel that walks the runs: exact when the host knows the count, else a grid the kernels stride over
+static unsigned run_blocks(const RunSet &rs, i64 nrows, int per_block = 256) {
+    if (rs.host_count) return (unsigned)((rs.nruns + per_block - 1) / per_block > 0 ? (rs.nruns + per_block - 1) / per_block : 1);
+    i64 b = nrows / 64;                                   // ~4 runs per row at one thread per run: more only means grid-stride trips
+    if (b < 256) b = 256;
+    if (b > 8192) b = 8192;
+    return (unsigned)b;
+}
 
 // Geometry the run-level Label works on: the whole (global) volume as rows of bit-packed words.
 struct LabelGeo {
@@ -2940,19 +2952,19 @@ static int build_components(nl_ctx *c, const LabelGeo &g, const unsigned long lo
     NL_CHECK_LAUNCH();
     int rc = scan_excl_u32(c, counts, row_off, g.nrows + 1, err, errlen);
     if (rc) return rc;
-    NL_HIP(hipMemcpyAsync(c->h_small, row_off + g.nrows, 4, hipMemcpyDeviceToHost, c->stream));
-    NL_HIP(hipStreamSynchronize(c->stream));
-    rs.nruns = (i64)(*(unsigned int *)c->h_small);
-    rs.row_off = row_off;
-    *overflow = rs.nruns > cap;
+    rs.row_off = row_off; rs.n_ptr = row_off + g.nrows; rs.cap = cap;
     rs.proot_valid = false;
-    if (*overflow || rs.nruns == 0) return NL_OK;
-    if (g.wpr <= 30)
-        rl_emit_kernel<true><<<(unsigned)((g.nrows + 255) / 256), 256, (size_t)256 * (g.wpr + 1) * 8, c->stream>>>(bits, invert, row_off, rs.runs, rs.parent, g.nrows, g.wpr, (int)g.nx);
-    else
-        rl_emit_kernel<false><<<(unsigned)((g.nrows + 255) / 256), 256, 0, c->stream>>>(bits, invert, row_off, rs.runs, rs.parent, g.nrows, g.wpr, (int)g.nx);
-    NL_CHECK_LAUNCH();
-    const unsigned gr = (unsigned)((rs.nruns + 255) / 256);
+    *overflow = false;
+    unsigned int *d_ovf = (unsigned int *)c->d_small + 60;           // sticky within a labelling: zeroed by the caller, read at its end
+    if (rs.host_count) {
+        NL_HIP(hipMemcpyAsync(c->h_small, row_off + g.nrows, 4, hipMemcpyDeviceToHost, c->stream));
+        NL_HIP(hipStreamSynchronize(c->stream));
+        rs.nruns = (i64)(*(unsigned int *)c->h_small);
+        *overflow = rs.nruns > cap;
+        if (*overflow || rs.nruns == 0) return NL_OK;
+    } else {
+        rs.nruns = -1;                                                 // kernels read row_off[nrows]; beyond `cap` they are no-ops
+    }
     // two levels (see label_runs.inc): planes in LDS, then component pairs across planes; NELLIE_UF_PLANES=0: one level
     static int two_level = -1;
     if (two_level < 0) { const char *e = getenv("NELLIE_UF_PLANES"); two_level = (e && !atoi(e)) ? 0 : 1; }
@@ -2966,44 +2978,57 @@ static int build_components(nl_ctx *c, const LabelGeo &g, const unsigned long lo
         while (g.nz * ((g.ny + ((i64)1 << seg_shift) - 1) >> seg_shift) > 8192 && ((i64)1 << seg_shift) < g.ny) ++seg_shift;
     }
     const int nseg = (int)((g.ny + ((i64)1 << seg_shift) - 1) >> seg_shift);
-    if (two_level && g.nz * nseg <= 8192 && rs.proot && rs.link) {
+    const bool lvl2 = two_level && g.nz * nseg <= 8192 && rs.proot && rs.link;
+    int *link = lvl2 ? rs.link : nullptr;                            // rl_emit_kernel fills the pair filter's slots with -1
+    if (g.wpr <= 30)
+        rl_emit_kernel<true><<<(unsigned)((g.nrows + 255) / 256), 256, (size_t)256 * (g.wpr + 1) * 8, c->stream>>>(bits, invert, row_off, rs.runs, rs.parent, g.nrows, g.wpr, (int)g.nx, link, cap, d_ovf);
+    else
+        rl_emit_kernel<false><<<(unsigned)((g.nrows + 255) / 256), 256, 0, c->stream>>>(bits, invert, row_off, rs.runs, rs.parent, g.nrows, g.wpr, (int)g.nx, link, cap, d_ovf);
+    NL_CHECK_LAUNCH();
+    const unsigned gr = run_blocks(rs, g.nrows);
+    const RunN rn = rs.rn();
+    if (lvl2) {
         uint8_t *seg_done = (uint8_t *)c->d_small + (52 << 10);
-        NL_HIP(hipMemsetAsync(rs.link, 0xff, (size_t)rs.nruns * 4, c->stream));
         rl_union_plane_kernel<CONN><<<(unsigned)(g.nz * nseg), 256, 0, c->stream>>>(rs.runs, row_off, rs.parent, rs.proot, (int)g.ny,
-                                                                         CONN == 6 ? 1 : 0, g.zf_lo, g.zf_hi, (int)g.nx, seg_done, seg_shift, nseg);
-        rl_union_cross_kernel<CONN><<<gr, 256, 0, c->stream>>>(rs.runs, row_off, rs.parent, rs.proot, rs.link, rs.nruns, (int)g.ny,
+                                                                         CONN == 6 ? 1 : 0, g.zf_lo, g.zf_hi, (int)g.nx, seg_done, seg_shift, nseg, rn);
+        rl_union_cross_kernel<CONN><<<gr, 256, 0, c->stream>>>(rs.runs, row_off, rs.parent, rs.proot, rs.link, rn, (int)g.ny,
                                                                CONN == 6 ? 1 : 0, g.zf_lo, g.zf_hi, (int)g.nx, seg_done, seg_shift, nseg);
         rs.proot_valid = true;
     } else {
-        rl_union_kernel<CONN><<<gr, 256, 0, c->stream>>>(rs.runs, row_off, rs.parent, rs.nruns, (int)g.ny,
+        rl_union_kernel<CONN><<<gr, 256, 0, c->stream>>>(rs.runs, row_off, rs.parent, rn, (int)g.ny,
                                                          CONN == 6 ? 1 : 0, g.zf_lo, g.zf_hi, (int)g.nx);
     }
     NL_CHECK_LAUNCH();
-    ccl_flatten_kernel<<<grid1d(rs.nruns), 256, 0, c->stream>>>(rs.parent, rs.nruns);
+    ccl_flatten_kernel<<<gr, 256, 0, c->stream>>>(rs.parent, rs.nruns, rn.p, cap);
     NL_CHECK_LAUNCH();
     return NL_OK;
 }
 
 // ids 1..K in raster order of each component's first voxel (scipy.ndimage.label numbering), painted as int32
-static int number_and_paint(nl_ctx *c, const LabelGeo &g, const RunSet &rs, int *aux, int64_t *n_labels, char *err, size_t errlen) {
+static int number_and_paint(nl_ctx *c, const LabelGeo &g, const RunSet &rs, int *aux, int64_t *n_labels, char *err, size_t errlen,
+                            bool *overflow = nullptr) {
     unsigned long long total = 0;
-    if (rs.nruns) {
-        const i64 nblk = (rs.nruns + SCAN_CHUNK - 1) / SCAN_CHUNK;
-        unsigned int *blk = (unsigned int *)c->d_blk;
-        unsigned long long *d_total = (unsigned long long *)c->d_small;
-        root_count_kernel<<<(unsigned)nblk, 256, 0, c->stream>>>(rs.parent, rs.nruns, blk);
+    unsigned int *blk = (unsigned int *)c->d_blk;
+    unsigned long long *d_total = (unsigned long long *)c->d_small;
+    const bool any = !rs.host_count || rs.nruns > 0;
+    if (any) {
+        const RunN rn = rs.rn();
+        const unsigned nb = rs.host_count ? (unsigned)((rs.nruns + SCAN_CHUNK - 1) / SCAN_CHUNK) : run_blocks(rs, g.nrows / 16 + 1);
+        root_count_kernel<<<nb, 256, 0, c->stream>>>(rs.parent, rs.nruns, rn.p, rs.cap, blk);
         NL_CHECK_LAUNCH();
-        blk_scan_kernel<<<1, 1024, 0, c->stream>>>(blk, nblk, d_total);
+        blk_scan_kernel<<<1, 1024, 0, c->stream>>>(blk, rs.host_count ? (rs.nruns + SCAN_CHUNK - 1) / SCAN_CHUNK : 0, d_total, rn.p, rs.cap);
         NL_CHECK_LAUNCH();
-        root_assign_kernel<<<(unsigned)nblk, 256, 0, c->stream>>>(rs.parent, rs.nruns, blk, aux);
+        root_assign_kernel<<<nb, 256, 0, c->stream>>>(rs.parent, rs.nruns, rn.p, rs.cap, blk, aux);
         NL_CHECK_LAUNCH();
         NL_HIP(hipMemcpyAsync(c->h_small, d_total, 8, hipMemcpyDeviceToHost, c->stream));
+        NL_HIP(hipMemcpyAsync((char *)c->h_small + 8, (unsigned int *)c->d_small + 60, 4, hipMemcpyDeviceToHost, c->stream));   // the overflow flag
     }
     rl_paint_kernel<<<grid1d((g.paint_row1 - g.paint_row0) * 64, 256, (i64)1 << 22), 256, 0, c->stream>>>(
         g.bitsA, rs.row_off, rs.parent, aux, g.paint_out, g.paint_row0, g.paint_row1, g.wpr, (int)g.nx);
     NL_CHECK_LAUNCH();
     NL_HIP(hipStreamSynchronize(c->stream));
-    if (rs.nruns) total = *(unsigned long long *)c->h_small;
+    if (any) total = *(unsigned long long *)c->h_small;
+    if (overflow) *overflow = any && !rs.host_count && *(unsigned int *)((char *)c->h_small + 8) != 0;
     if (n_labels) *n_labels = (int64_t)total;
     return NL_OK;
 }
@@ -3024,16 +3049,23 @@ static int label_core(nl_ctx *c, const LabelGeo &g, int64_t min_area, int fill_h
     const VolGeom vg{g.nz, g.ny, g.nx, g.gz0, g.gnz};        // boundary rules: true faces of the global volume only
     int rc;
     *overflow = false;
+    // No launch below waits for a run count (round 4): the kernels read it from device memory and stride over the runs; a run
+    // set beyond the scratch volumes makes them no-ops and raises a flag that the single wait at the end returns.
+    static int dev_count = -1;
+    if (dev_count < 0) { const char *e = getenv("NELLIE_LABEL_HOST_COUNTS"); dev_count = (e && atoi(e)) ? 0 : 1; }
+    rs.host_count = !dev_count;
+    NL_HIP(zero_small((unsigned int *)c->d_small + 60, 4, c->stream));
+    auto known_empty = [&]() { return rs.host_count && rs.nruns == 0; };
     if (fill_holes) {
         // binary_fill_holes: 6-connected background components that reach no face become foreground
         if ((rc = build_components<6>(c, g, g.bitsA, 1, rs, cap, overflow, err, errlen))) return rc;
         if (*overflow) return NL_OK;
-        if (rs.nruns) {
-            const unsigned gr = (unsigned)((rs.nruns + 255) / 256);
-            NL_HIP(hipMemsetAsync(flag, 0, (size_t)rs.nruns, c->stream));
-            rl_border_kernel<<<gr, 256, 0, c->stream>>>(rs.runs, rs.parent, flag, rs.nruns, vg);
+        if (!known_empty()) {
+            const unsigned gr = run_blocks(rs, g.nrows);
+            rl_fill_u8_kernel<<<gr, 256, 0, c->stream>>>(flag, rs.rn());
+            rl_border_kernel<<<gr, 256, 0, c->stream>>>(rs.runs, rs.parent, flag, rs.rn(), vg);
             NL_CHECK_LAUNCH();
-            rl_fill_kernel<<<gr, 256, 0, c->stream>>>(rs.runs, rs.parent, flag, g.bitsA, rs.nruns, g.wpr);
+            rl_fill_kernel<<<gr, 256, 0, c->stream>>>(rs.runs, rs.parent, flag, g.bitsA, rs.rn(), g.wpr);
             NL_CHECK_LAUNCH();
         }
     }
@@ -3041,13 +3073,13 @@ static int label_core(nl_ctx *c, const LabelGeo &g, int64_t min_area, int fill_h
     if ((rc = build_components<26>(c, g, g.bitsA, 0, rs, cap, overflow, err, errlen))) return rc;
     if (*overflow) return NL_OK;
     NL_HIP(hipMemsetAsync(g.bitsB, 0, (size_t)g.nwords * 8, c->stream));
-    if (rs.nruns) {
-        const unsigned gr = (unsigned)((rs.nruns + 255) / 256);
-        NL_HIP(hipMemsetAsync(aux, 0, (size_t)rs.nruns * 4, c->stream));
-        rl_area_kernel<<<(unsigned)((rs.nruns + RL_CHUNK - 1) / RL_CHUNK), 256, 0, c->stream>>>(rs.runs, rs.parent, aux, rs.nruns);
+    if (!known_empty()) {
+        const unsigned gr = run_blocks(rs, g.nrows);
+        rl_fill_u32_kernel<<<gr, 256, 0, c->stream>>>((unsigned int *)aux, 0u, rs.rn());
+        rl_area_kernel<<<run_blocks(rs, g.nrows / 16 + 1, RL_CHUNK), 256, 0, c->stream>>>(rs.runs, rs.parent, aux, rs.rn());
         NL_CHECK_LAUNCH();
         const int ma = (int)(min_area > 0x7fffffff ? 0x7fffffff : min_area);
-        rl_keep_kernel<<<gr, 256, 0, c->stream>>>(rs.runs, rs.parent, aux, ma, g.bitsB, rs.nruns, g.wpr);
+        rl_keep_kernel<<<gr, 256, 0, c->stream>>>(rs.runs, rs.parent, aux, ma, g.bitsB, rs.rn(), g.wpr);
         NL_CHECK_LAUNCH();
     }
     // majority smoothing, second labelling
@@ -3055,7 +3087,8 @@ static int label_core(nl_ctx *c, const LabelGeo &g, int64_t min_area, int fill_h
     NL_CHECK_LAUNCH();
     if ((rc = build_components<26>(c, g, g.bitsA, 0, rs, cap, overflow, err, errlen))) return rc;
     if (*overflow) return NL_OK;
-    if ((rc = number_and_paint(c, g, rs, aux, n_labels, err, errlen))) return rc;
+    if ((rc = number_and_paint(c, g, rs, aux, n_labels, err, errlen, overflow))) return rc;
+    if (*overflow) return NL_OK;
     c->i_labels = free_idx[2];
     return NL_OK;
 }
@@ -3212,7 +3245,7 @@ static int slab_geo(nl_ctx *c, SlabGeo &sg, char *err, size_t errlen) {
     sg.rs.proot = sg.aux;
     sg.rs.link = (int *)c->f[free_idx[2]];
     sg.rs.row_off = g.rows + (g.nrows + 2);
-    sg.rs.nruns = c->sl_nruns;
+    sg.rs.nruns = c->sl_nruns; sg.rs.cap = sg.cap;
     sg.sel = (unsigned int *)c->f[free_idx[2]]; sg.scan = sg.sel + sg.cap;
     sg.stage = (int *)c->f[free_idx[2]];
     sg.out_idx = free_idx[2];
@@ -3360,7 +3393,7 @@ extern "C" int nl_slab_phase(nl_ctx *c, int phase, int gather, int64_t block_int
             const unsigned gr = (unsigned)((rs.nruns + 255) / 256);
             if (phase == SL_FILL) {
                 NL_HIP(hipMemsetAsync(c->m[0], 0, (size_t)rs.nruns, c->stream));
-                rl_border_kernel<<<gr, 256, 0, c->stream>>>(rs.runs, rs.parent, c->m[0], rs.nruns, VolGeom{g.nz, g.ny, g.nx, g.gz0, g.gnz});
+                rl_border_kernel<<<gr, 256, 0, c->stream>>>(rs.runs, rs.parent, c->m[0], rs.rn(), VolGeom{g.nz, g.ny, g.nx, g.gz0, g.gnz});
             } else if (phase == SL_AREA) {
                 NL_HIP(hipMemsetAsync(sg.aux, 0, (size_t)rs.nruns * 4, c->stream));
                 sl_area_kernel<<<(unsigned)((rs.nruns + RL_CHUNK - 1) / RL_CHUNK), 256, 0, c->stream>>>(rs.runs, rs.parent, sg.aux, rs.nruns, sg.row_lo, sg.row_hi);
