@@ -100,7 +100,9 @@ def parse_args():
     ap.add_argument("--no-io", action="store_true", help="skip the host-to-host and streamed figures")
     ap.add_argument("--no-cpu-all-cores", action="store_true", help="skip the frame-parallel all-cores CPU baseline")
     ap.add_argument("--cpu-all-cores-child", action="store_true", help="internal: the all-cores CPU baseline (a process that never loads HIP)")
-    ap.add_argument("--cpu-all-cores-shape", type=int, nargs=3, default=[128, 512, 512], help="frame of the all-cores baseline (default: a BASELINE config 5 frame)")
+    ap.add_argument("--cpu-all-cores-shape", type=int, nargs=3, default=[64, 256, 256],
+                    help="frame per worker of the all-cores baseline (default: an eighth of a BASELINE config 5 frame -- 256 workers on full frames "
+                         "need ~1 TB of host RAM and took the GPU box down in round 4)")
     ap.add_argument("--no-zslab", action="store_true", help="N > 1: frame replicas only")
     ap.add_argument("--zslab-timeout", type=float, default=420.0)
     ap.add_argument("--zslab-child", action="store_true", help="internal: the Z-slab run (spawned by the bench)")
@@ -163,18 +165,25 @@ def cpu_all_cores_child(args):
         avail = psutil.virtual_memory().available / 1e9
     except ImportError:
         avail = 64.0
-    per_proc_gb = 24.0 * float(np.prod(shape)) * 4 / 1e9 + 0.3        # ~22 float32 volume equivalents at the peak
-    workers = max(1, min(cores, int((budget_gb or 0.6 * avail) / per_proc_gb)))
+    try:                                                                # a container's limit may be far below what the host reports
+        lim = open("/sys/fs/cgroup/memory.max").read().strip()
+        if lim != "max":
+            avail = min(avail, float(lim) / 1e9)
+    except OSError:
+        pass
+    per_proc_gb = 30.0 * float(np.prod(shape)) * 4 / 1e9 + 0.4        # ~22 float32 volume equivalents at the peak, + margin
+    workers = max(1, min(cores, int((budget_gb or min(0.25 * avail, 160.0)) / per_proc_gb)))
     with mp.get_context("fork").Pool(workers) as pool:
         pool.map(_oracle_frame, [((8, 32, 32), 1)] * workers)           # imports done, pool warm
         t0 = time.perf_counter()
         res = pool.map(_oracle_frame, [(shape, 4567 + i) for i in range(workers)], chunksize=1)
         wall = time.perf_counter() - t0
     n = float(np.prod(shape)) * workers
+    what = {(128, 512, 512): "a BASELINE config 5 frame", (64, 256, 256): "the generator of BASELINE config 5, an eighth of its frame"}.get(shape, "same generator")
     print(json.dumps({
         "value": round(n / wall / 1e6, 3), "unit": "Mvoxel/s", "cores": workers, "host_cores": cores, "kind": "port",
         "sample": f"oracle Filter+Label, frame-parallel: {workers} worker processes (one per core{'' if workers == cores else ', capped by free RAM'}), "
-                  f"one synthetic {shape[0]}x{shape[1]}x{shape[2]} float32 frame each ({'a BASELINE config 5 frame' if shape == (128, 512, 512) else 'same generator'}, seeds 4567+i); "
+                  f"one synthetic {shape[0]}x{shape[1]}x{shape[2]} float32 frame each ({what}, seeds 4567+i); "
                   f"wall {wall:.1f} s, slowest worker {max(r[0] for r in res):.1f} s, fastest {min(r[0] for r in res):.1f} s, "
                   f"labels per frame {min(r[1] for r in res)}..{max(r[1] for r in res)}",
         "per_core_mvoxel_s": round(n / wall / 1e6 / workers, 4),
