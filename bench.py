@@ -426,6 +426,11 @@ def main():
     pipe.ctx.prof_enable(True)      # the event pairs of the per-group timers exist (and have been used) before the timed region
     for _ in range(args.warmup):
         step()
+    if os.environ.get("NELLIE_BENCH_GC", "freeze") == "freeze":
+        # the interpreter's cyclic collector stays out of the timed region, as in timeit: with torch imported (N > 1) a full
+        # collection takes 50-100 ms and used to land in one step of a run (round 3's "one-off stall of the queue": found in round 4)
+        import gc
+        gc.collect(); gc.freeze()
     pipe.ctx.prof_reset()
     barrier()
     t0 = time.perf_counter()
@@ -677,6 +682,9 @@ def zslab_run(dist, rank, world, local_rank, args):
     n_warm = max(2, args.warmup)
     for _ in range(n_warm):
         step()
+    if os.environ.get("NELLIE_BENCH_GC", "freeze") == "freeze":
+        import gc
+        gc.collect(); gc.freeze()      # the interpreter's cyclic collector out of the timed region (as timeit does): see DESIGN.md section 5
     pipe.ctx.prof_reset()
     pipe.ctx.sync()
     dist.barrier()

@@ -8,7 +8,7 @@
 #                                    world 1 over a real one-rank RCCL communicator): what a rank costs before any neighbour exists
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
-python $R/bench.py --steps 10 --warmup 2 > /tmp/bench.out 2>/tmp/bench.err; tail -1 /tmp/bench.out > $R/gpurun_out/r04_bench_n1_1024cube.json
+if [ "$1" != "nobench" ]; then python $R/bench.py --steps 10 --warmup 2 > /tmp/bench.out 2>/tmp/bench.err; tail -1 /tmp/bench.out > $R/gpurun_out/r04_bench_n1_1024cube.json; fi
 rm -rf /tmp/ks && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-io > /tmp/ks.log 2>&1
 cp $(find /tmp/ks -name '*kernel_stats.csv' | head -1) $R/gpurun_out/r04_kernel_stats_1024cube.csv
 for C in FETCH_SIZE WRITE_SIZE; do
