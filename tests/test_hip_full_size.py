@@ -200,14 +200,18 @@ def test_two_slabs_equal_one_volume_at_1024_cube(full_run):
         assert np.array_equal(lab, ref), f"slab [{o0},{o1}): {int((lab != ref).sum())} label voxels differ, first at {np.argwhere(lab != ref)[:4].tolist()}"
 
 
-def test_c2_parity_at_its_own_size(hip):
-    """BASELINE config 2 (256 x 512 x 512, seed 1234) against the oracle at its own size: Frangi within
+@pytest.mark.parametrize("aniso", [False, True], ids=["iso_0.1um", "aniso_z0.3um"])
+def test_c2_parity_at_its_own_size(hip, aniso):
+    """BASELINE config 2 (256 x 512 x 512, seed 1234) against the oracle at its own size -- at the isotropic 0.1 um of the
+    configs and, since round 4, at SURVEY 8(d)'s secondary anisotropic set (Z = 0.3 um: cascade radii 1, 1, 1, 1, 2 along Z against
+    4, 3, 4, 4, 5 in the plane, min_area_pixels 22) --: Frangi within
     |a - b| <= 1e-4 |ref| + 1e-6 max|ref| with identical support (the threshold-tie relaxation of the golden tests is
     available but capped), labels bit-exact given the oracle's Frangi frame, thresholds equal."""
     from nellie_amd import pipeline as pl
-    from nellie_amd.synthetic import ISO_01, make_volume
+    from nellie_amd.synthetic import ANISO_03, ISO_01 as ISO, make_volume
     from oracle import nellie_oracle as orc
     from test_hip_parity import assert_masked_close
+    ISO_01 = ANISO_03 if aniso else ISO
     shape = (256, 512, 512)
     vol = make_volume(shape, 1234)
     run_ref = orc.run_frame(vol, ISO_01)
@@ -217,7 +221,7 @@ def test_c2_parity_at_its_own_size(hip):
     pipe.filter(vol, p)
     fr = pipe.download_frangi()
     assert abs(pipe.trace.percentile_thr - float(thr_ref)) <= 2e-4 * float(thr_ref)
-    assert_masked_close(fr, ref, run_ref, thr_ref, "C2 256x512x512")
+    assert_masked_close(fr, ref, run_ref, thr_ref, "C2 256x512x512" + (" aniso" if aniso else ""))
     ref_lab, ref_lthr = orc.label_frame(ref, ISO_01, return_thr=True)
     pipe.upload_frangi(ref)
     lthr = pipe.frangi_threshold()
@@ -230,7 +234,10 @@ def test_c2_parity_at_its_own_size(hip):
     lab_e2e = pipe.download_labels()
     n_diff = int((lab_e2e != ref_lab).sum())
     print(f"C2 end to end: {n_diff} label voxels differ, {n_e2e} vs {int(ref_lab.max())} labels")
-    assert n_diff == 0 and n_e2e == int(ref_lab.max())
+    if aniso:        # (exact equality end to end is a property of the seeded isotropic volumes; here: all but a tie zone's worth)
+        assert n_diff <= 1e-5 * lab_e2e.size and abs(n_e2e - int(ref_lab.max())) <= 1
+    else:
+        assert n_diff == 0 and n_e2e == int(ref_lab.max())
     pipe.close()
 
 
