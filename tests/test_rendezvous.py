@@ -70,3 +70,38 @@ def test_world_one_needs_nobody(tmp_path):
     rdv.barrier("b")
     rdv.remove("a")
     assert [f for f in os.listdir(tmp_path) if f.startswith(".nellie")] == []
+
+
+def _build_rank(rank, world, src, out_dir, port, q):
+    try:
+        sys.path.insert(0, REPO)
+        os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank), MASTER_PORT=str(port))
+        from nellie_amd.im_info.verifier import FileInfo
+        from nellie_amd.run import _build_im_info
+        im = _build_im_info(FileInfo(src, output_dir=out_dir), "env")
+        import numpy as np
+        q.put((rank, im.im_path, int(np.asarray(im.im).sum()), os.stat(im.im_path).st_ino))
+    except BaseException as exc:  # noqa: BLE001
+        q.put((rank, "error", repr(exc), 0))
+
+
+def test_ranks_build_the_im_info_in_order(tmp_path):
+    """run(file_info, shard="env"): every rank constructs ImInfo (run.py:49), which re-saves the input as the canonical copy
+    (verifier.py:620-695).  Rank 0 goes first and the others reuse its file: one inode, never a half-written header."""
+    import numpy as np
+    from nellie_amd.im_info import ome_tiff
+    vols = np.arange(2 * 6 * 10 * 12, dtype=np.uint16).reshape(2, 6, 10, 12)
+    src = str(tmp_path / "stack.ome.tif")
+    ome_tiff.create(src, vols.shape, np.uint16, {"X": 0.1, "Y": 0.1, "Z": 0.2, "T": 1.0}, "raw", data=vols)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world = 3
+    ps = [ctx.Process(target=_build_rank, args=(r, world, src, str(tmp_path / "out"), 29611, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    out = sorted(q.get(timeout=120) for _ in range(world))
+    for p in ps:
+        p.join(30)
+    assert all(o[1] != "error" for o in out), out
+    assert len({o[1] for o in out}) == 1 and len({o[3] for o in out}) == 1, out      # same path, same inode: written once
+    assert all(o[2] == int(vols.sum()) for o in out)
