@@ -476,3 +476,28 @@ def test_stage_api_rank_slabs_over_loopback_threads(hip, tmp_path):
         b = np.asarray(infos[0].get_memmap(infos[0].pipeline_paths[key], read_mode="r"))
         assert a.dtype == b.dtype and np.array_equal(a, b), f"{key}: {int((a != b).sum())} voxels differ"
     assert np.asarray(infos[0].get_memmap(infos[0].pipeline_paths["im_instance_label"], read_mode="r")).max() >= 1
+
+
+@pytest.mark.parametrize("transport", ["host", "loopback"])
+def test_slab_tables_beyond_one_block_are_fetched_again(hip, transport, monkeypatch):
+    """nl_slab_phase ships a rank's tables in fixed blocks (64 KiB by default; all-gathered without a size negotiation over RCCL).
+    Tables that do not fit report their size, and the caller fetches them again in larger blocks without recomputing anything:
+    forced here with 24-int blocks (header 8 + room for 8 entries), through the host gather and through the gathered device path."""
+    from nellie_amd import hipnative
+    from nellie_amd.synthetic import ISO_01
+    monkeypatch.setattr(hipnative.Context, "SLAB_BLOCK_INTS", 24)
+    calls = []
+    orig = hipnative.Context._call
+
+    def spy(self, name, *a):
+        if name == "nl_slab_phase":
+            calls.append(int(a[0]))
+        return orig(self, name, *a)
+    monkeypatch.setattr(hipnative.Context, "_call", spy)
+    gshape, world = (96, 64, 80), 3
+    ref, ref_thr, ref_counts, ref_n, ref_lab = _single_reference(gshape, ISO_01, 91)
+    parts = _run_sharded(gshape, ISO_01, 91, world, "steps", False, transport=transport)
+    assert -1 in calls, "no phase needed a second fetch: the test volume has too few boundary components"
+    lab = np.concatenate([p_[3] for p_ in parts])
+    assert np.array_equal(lab, ref_lab) and all(p_[4] == ref_n for p_ in parts) and ref_n >= 1
+    assert np.array_equal(np.concatenate([p_[0] for p_ in parts]), ref)
