@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Soak: N different frames through the default path (device chain) and through the synchronous path on a second context;
-Frangi frames, labels and traces must agree frame by frame; counts the frames the chain handed back.
+"""Soak: N different frames through the default path (device chain, percentile threshold selected on the device) and through the
+synchronous path with the percentile on the host (round 3's) on a second context; Frangi frames, labels and traces must agree frame
+by frame; counts the frames the chain handed back.
     tools/soak_chain.py [Z Y X] [N]"""
 import json, os, sys, time, zlib
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,6 +13,7 @@ shape = tuple(int(a) for a in sys.argv[1:4]) if len(sys.argv) >= 4 else (64, 160
 n = int(sys.argv[4]) if len(sys.argv) >= 5 else 300
 a, b = pl.FramePipeline(shape), pl.FramePipeline(shape)
 b._device_chain = False
+b._device_tail = False
 bad, t0 = [], time.time()
 rng = np.random.default_rng(1)
 for k in range(n):
