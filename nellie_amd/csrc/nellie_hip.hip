@@ -1438,6 +1438,7 @@ extern "C" int nl_vesselness_spec(nl_ctx *c, const double spacing[3], float fsq_
     return NL_OK;
 }
 
+static bool resolve_on_side();
 // *hit = 1: the exact threshold lies in the bracket of the pass, the scale is complete (mask_count as
 // nl_vesselness_step reports it); *hit = 0: nothing was changed, run nl_vesselness_step.
 // h_mask count of the scale completed by the last nl_vesselness_resolve hit (waits for its kernel).
@@ -1446,22 +1447,37 @@ extern "C" int nl_vesselness_count(nl_ctx *c, int64_t *mask_count, char *err, si
     if (!mask_count) return nl_fail(err, errlen, NL_EINVAL, "mask_count is NULL");
     unsigned long long *d_cnt = (unsigned long long *)((char *)c->d_small + (48 << 10));
     unsigned long long *h_cnt = (unsigned long long *)((char *)c->h_small + (48 << 10));
-    NL_HIP(hipMemcpyAsync(h_cnt, d_cnt, 8, hipMemcpyDeviceToHost, c->side));
-    NL_HIP(hipStreamSynchronize(c->side));
+    hipStream_t st = resolve_on_side() ? c->side : c->stream;        // the stream the resolve kernel ran on
+    NL_HIP(hipMemcpyAsync(h_cnt, d_cnt, 8, hipMemcpyDeviceToHost, st));
+    NL_HIP(hipStreamSynchronize(st));
     *mask_count = (int64_t)(*h_cnt + c->spec_count);
     return NL_OK;
 }
 
 // The resolve kernel of a scale, enqueued on the side stream (ordered after everything submitted to the main stream so far);
 // commits the scale's mask slot.  dev_params != NULL: gamma_sq, fsq_min and m_inf are read from device memory (chain.inc).
+// The resolve kernel runs on the MAIN stream by default (round 4): since the two-voxel walk and the cheaper resolve kernel,
+// running it beside the next scale's Gaussian buys nothing (48.8 vs 49.0 ms/step at 1024^3: the Z pass slows from 1.77 to 2.55 ms
+// per launch while it shares the GPU) -- and sending it to the side stream only to make the main stream wait for it cost two
+// cross-queue dependencies of ~13 us per scale (0.13 ms of a 3.3 ms config-5 frame).  NELLIE_RESOLVE_OVERLAP=1: the side stream,
+// beside the next cascade step (every entry point that needs its result joins it: NL_JOIN_SIDE).
+static bool resolve_on_side() {
+    static int overlap = -1;
+    if (overlap < 0) { const char *e = getenv("NELLIE_RESOLVE_OVERLAP"); overlap = (e && atoi(e)) ? 1 : 0; }
+    return overlap != 0;
+}
 static int resolve_enqueue(nl_ctx *c, VessP vp, unsigned long long *d_cnt, const float *dev_params, char *err, size_t errlen) {
     const i64 plane = c->ny * c->nx, z0 = c->spec_z0, z1 = c->spec_z1;
-    NL_HIP(hipEventRecord(c->ev_main, c->stream));
-    NL_HIP(hipStreamWaitEvent(c->side, c->ev_main, 0));
+    const bool side = resolve_on_side();
+    hipStream_t st = side ? c->side : c->stream;
+    if (side) {
+        NL_HIP(hipEventRecord(c->ev_main, c->stream));
+        NL_HIP(hipStreamWaitEvent(c->side, c->ev_main, 0));
+    }
     vp.qcap = c->spec_qcap;
     vp.idx_lo = (c->own_lo - z0) * plane; vp.idx_hi = (c->own_hi - z0) * plane;
     {
-        ProfScope ps(c, "vesselness_resolve", c->side);
+        ProfScope ps(c, "vesselness_resolve", st);
         const int wpr = (int)((c->nx + 63) / 64);
         const i64 slot_words = c->nzl * c->ny * wpr;
         const int k_scale = c->mask_slots_used++;
@@ -1469,21 +1485,16 @@ static int resolve_enqueue(nl_ctx *c, VessP vp, unsigned long long *d_cnt, const
         unsigned long long *cm = (unsigned long long *)c->m[0] + (i64)(k_scale & 1) * slot_words;
         const unsigned long long *pm = (unsigned long long *)c->m[0] + (i64)((k_scale + 1) & 1) * slot_words;
         if (vp.first)
-            NL_HIP(hipMemsetAsync(c->f[c->i_vmax] + z0 * plane, 0, (size_t)(z1 - z0) * plane * 4, c->side));
-        vesselness_queue_kernel<true><<<resolve_grid((c->spec_nregions + 3) / 4), 256, 0, c->side>>>(
+            NL_HIP(hipMemsetAsync(c->f[c->i_vmax] + z0 * plane, 0, (size_t)(z1 - z0) * plane * 4, st));
+        vesselness_queue_kernel<true><<<resolve_grid((c->spec_nregions + 3) / 4), 256, 0, st>>>(
             (const float4 *)c->d_vq, c->d_vq_count, c->spec_nregions, c->f[c->i_vmax], z0 * plane, vp, cm, pm, wpr, (int)c->ny, (int)c->nx, z0, d_cnt,
             dev_params);
         NL_CHECK_LAUNCH();
     }
-    NL_HIP(hipEventRecord(c->ev_side, c->side));
-    // The kernel runs on the side stream, but the main stream waits for it by default: since the two-voxel walk and the
-    // cheaper resolve kernel, running it beside the next scale's Gaussian buys nothing (48.8 vs 49.0 ms/step at 1024^3:
-    // the Z pass slows from 1.77 to 2.55 ms per launch while it shares the GPU) and it blurs every per-kernel figure.
-    // NELLIE_RESOLVE_OVERLAP=1 lets the two overlap again.
-    static int serial = -1;
-    if (serial < 0) { const char *e = getenv("NELLIE_RESOLVE_OVERLAP"); serial = (e && atoi(e)) ? 0 : 1; }
-    if (serial) NL_HIP(hipStreamWaitEvent(c->stream, c->ev_side, 0));
-    c->side_pending = 1;
+    if (side) {
+        NL_HIP(hipEventRecord(c->ev_side, c->side));
+        c->side_pending = 1;
+    }
     c->spec_valid = 0;
     return NL_OK;
 }
@@ -1498,9 +1509,13 @@ extern "C" int nl_vesselness_resolve(nl_ctx *c, float gamma_sq, float alpha_sq, 
     if (!(vp.fsq_min >= c->spec_lo && vp.fsq_min <= c->spec_hi)) { c->spec_valid = 0; return NL_OK; }
     // The kernel's counter lives outside the sampling scratch.
     unsigned long long *d_cnt = (unsigned long long *)((char *)c->d_small + (48 << 10));
-    NL_HIP(hipEventRecord(c->ev_main, c->stream));
-    NL_HIP(hipStreamWaitEvent(c->side, c->ev_main, 0));
-    NL_HIP(zero_small(d_cnt, 8, c->side));
+    if (resolve_on_side()) {
+        NL_HIP(hipEventRecord(c->ev_main, c->stream));
+        NL_HIP(hipStreamWaitEvent(c->side, c->ev_main, 0));
+        NL_HIP(zero_small(d_cnt, 8, c->side));
+    } else {
+        NL_HIP(zero_small(d_cnt, 8, c->stream));
+    }
     { int rc = resolve_enqueue(c, vp, d_cnt, nullptr, err, errlen); if (rc) return rc; }
     *hit = 1;
     if (mask_count) {        // asking for the count here waits for the kernel; nl_vesselness_count can be called later instead
