@@ -312,6 +312,11 @@ int nl_mask_volume_fused(nl_ctx *ctx, float thr, int64_t *n_positive, char *err,
 int nl_tail_enqueue(nl_ctx *ctx, int64_t sz, int64_t sy, int64_t sx, double q, char *err, size_t errlen);
 int nl_tail_finish(nl_ctx *ctx, int commit, int64_t *n_samples, float *a, float *b, float *gamma, float *thr, int64_t *n_positive,
                    char *err, size_t errlen);
+/* _mask_volume (filtering.py:952-967) on the finished Frangi frame with the percentile selected on the device (samples, selection,
+   `frame > thr`, opening, product; one wait): the epilogue of 2-D images, of remove_edges runs and of slabs without the fused
+   epilogue.  Reports (n, a, b, gamma, thr) for the host's check; n = 0: the frame was left as it is. */
+int nl_mask_volume_dev(nl_ctx *ctx, int64_t sz, int64_t sy, int64_t sx, double q, int64_t *n_samples, float *a, float *b, float *gamma,
+                       float *thr, char *err, size_t errlen);
 /* tests: numpy.percentile(values, q) of n positive float32 values by the device's selection */
 int nl_debug_percentile(nl_ctx *ctx, const float *values, int64_t n, double q, float *thr, float *a, float *b, char *err, size_t errlen);
 

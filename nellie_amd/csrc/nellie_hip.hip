@@ -1918,34 +1918,42 @@ extern "C" int nl_remove_edges(nl_ctx *c, int margin, int64_t *n_positive, char 
     return NL_OK;
 }
 
-extern "C" int nl_mask_volume(nl_ctx *c, float thr, char *err, size_t errlen) {
-    NL_ENTER(c);
+// filtering.py:964-966 on the finished frame; thr_dev != NULL: the threshold is read from device memory (nl_mask_volume_dev)
+static int mask_volume_enqueue(nl_ctx *c, float thr, const float *thr_dev, int *dst_out, char *err, size_t errlen) {
     // result goes to a free gauss volume, which then becomes the Frangi volume
     int dst = -1;
     for (int k = 0; k < 3; ++k) if (k != c->i_gauss) { dst = k; break; }
-    {
-        ProfScope ps(c, "mask_volume");
-        const int wpr = (int)((c->nx + 63) / 64);
-        const VolGeom v = geom(c);
-        // planes whose bits exist: own +-2 clipped to the slab (ghost planes beyond a true face do not exist)
-        const i64 m0 = c->own_lo - 2 > 0 ? c->own_lo - 2 : 0, m1 = c->own_hi + 2 < c->nzl ? c->own_hi + 2 : c->nzl;
-        const i64 e0 = c->own_lo - 1 > 0 ? c->own_lo - 1 : 0, e1 = c->own_hi + 1 < c->nzl ? c->own_hi + 1 : c->nzl;
-        unsigned long long *bM = (unsigned long long *)c->m[1], *bE = (unsigned long long *)c->m[2], *bD = (unsigned long long *)c->m[0];
-        rl_threshold_pack_kernel<<<grid1d((m1 - m0) * c->ny * 64, 256, (i64)1 << 22), 256, 0, c->stream>>>(
-            c->f[c->i_vmax] + m0 * c->ny * c->nx, nullptr, bM + m0 * c->ny * wpr, 1, thr, (int)c->nx, (m1 - m0) * c->ny, wpr);
-        NL_CHECK_LAUNCH();
-        bits_morph6_kernel<0><<<(unsigned)(((e1 - e0) * c->ny * wpr + 255) / 256), 256, 0, c->stream>>>(bM, bE, v, wpr, e0, e1, c->two_d);
-        NL_CHECK_LAUNCH();
-        bits_morph6_kernel<1><<<(unsigned)(((c->own_hi - c->own_lo) * c->ny * wpr + 255) / 256), 256, 0, c->stream>>>(bE, bD, v, wpr, c->own_lo, c->own_hi, c->two_d);
-        NL_CHECK_LAUNCH();
-        apply_bits_kernel<<<grid1d((c->own_hi - c->own_lo) * c->ny * ((c->nx + 3) / 4), 256, 256 * 32), 256, 0, c->stream>>>(
-            c->f[c->i_vmax], bD, c->f[dst], v, wpr, c->own_lo, c->own_hi);
-        NL_CHECK_LAUNCH();
-    }
-    // swap roles: old vmax volume joins the gauss ping-pong set
+    *dst_out = dst;
+    ProfScope ps(c, "mask_volume");
+    const int wpr = (int)((c->nx + 63) / 64);
+    const VolGeom v = geom(c);
+    // planes whose bits exist: own +-2 clipped to the slab (ghost planes beyond a true face do not exist)
+    const i64 m0 = c->own_lo - 2 > 0 ? c->own_lo - 2 : 0, m1 = c->own_hi + 2 < c->nzl ? c->own_hi + 2 : c->nzl;
+    const i64 e0 = c->own_lo - 1 > 0 ? c->own_lo - 1 : 0, e1 = c->own_hi + 1 < c->nzl ? c->own_hi + 1 : c->nzl;
+    unsigned long long *bM = (unsigned long long *)c->m[1], *bE = (unsigned long long *)c->m[2], *bD = (unsigned long long *)c->m[0];
+    rl_threshold_pack_kernel<<<grid1d((m1 - m0) * c->ny * 64, 256, (i64)1 << 22), 256, 0, c->stream>>>(
+        c->f[c->i_vmax] + m0 * c->ny * c->nx, nullptr, bM + m0 * c->ny * wpr, 1, thr, (int)c->nx, (m1 - m0) * c->ny, wpr, thr_dev);
+    NL_CHECK_LAUNCH();
+    bits_morph6_kernel<0><<<(unsigned)(((e1 - e0) * c->ny * wpr + 255) / 256), 256, 0, c->stream>>>(bM, bE, v, wpr, e0, e1, c->two_d);
+    NL_CHECK_LAUNCH();
+    bits_morph6_kernel<1><<<(unsigned)(((c->own_hi - c->own_lo) * c->ny * wpr + 255) / 256), 256, 0, c->stream>>>(bE, bD, v, wpr, c->own_lo, c->own_hi, c->two_d);
+    NL_CHECK_LAUNCH();
+    apply_bits_kernel<<<grid1d((c->own_hi - c->own_lo) * c->ny * ((c->nx + 3) / 4), 256, 256 * 32), 256, 0, c->stream>>>(
+        c->f[c->i_vmax], bD, c->f[dst], v, wpr, c->own_lo, c->own_hi);
+    NL_CHECK_LAUNCH();
+    return NL_OK;
+}
+static void mask_volume_commit(nl_ctx *c, int dst) {       // swap roles: the old vmax volume joins the gauss ping-pong set
     float *tmp = c->f[c->i_vmax];
     c->f[c->i_vmax] = c->f[dst];
     c->f[dst] = tmp;
+}
+
+extern "C" int nl_mask_volume(nl_ctx *c, float thr, char *err, size_t errlen) {
+    NL_ENTER(c);
+    int dst, rc;
+    if ((rc = mask_volume_enqueue(c, thr, nullptr, &dst, err, errlen))) return rc;
+    mask_volume_commit(c, dst);
     return NL_OK;
 }
 
@@ -2083,6 +2091,45 @@ extern "C" int nl_tail_finish(nl_ctx *c, int commit, int64_t *n_samples, float *
     if (thr) *thr = rec->thr;
     if (n_positive) *n_positive = (int64_t)(*(const unsigned long long *)((const char *)c->h_pct + 72));
     if (commit && rec->n > 0) mask_volume_fused_commit(c, c->tail_dst);
+    return NL_OK;
+}
+
+/* _mask_volume (filtering.py:952-967) on the finished frame with the percentile selected on the device: the positive lattice samples
+   of the Frangi frame, their q-th percentile, `frame > thr`, the opening and the product, one wait.  n_samples = 0: nothing was
+   changed (the reference returns the frame as it is).  The epilogue of 2-D images, of remove_edges runs, of slabs without the
+   fused epilogue; 3-D frames normally take nl_tail_enqueue. */
+extern "C" int nl_mask_volume_dev(nl_ctx *c, int64_t sz, int64_t sy, int64_t sx, double q, int64_t *n_samples, float *a, float *b, float *gamma,
+                                  float *thr, char *err, size_t errlen) {
+    NL_ENTER(c);
+    int rc;
+    if ((rc = pct_buffers(c, err, errlen))) return rc;
+    Lattice L; FieldSrc fs;
+    if ((rc = make_lattice(c, sz, sy, sx, L, err, errlen))) return rc;
+    if ((rc = make_field(c, NL_FIELD_FRANGI, fs, err, errlen))) return rc;
+    const i64 total = L.cz * L.cy * L.cx;
+    if (total > c->n) return nl_fail(err, errlen, NL_EINVAL, "lattice larger than the volume");
+    float *stage = nullptr;                                  // a free volume: neither the frame nor the current Gaussian
+    for (int k = 0; k < 3; ++k) if (k != c->i_gauss && c->f[k] != c->f[c->i_vmax]) stage = c->f[k];
+    if (!stage) return nl_fail(err, errlen, NL_ESTATE, "no free volume for the samples");
+    unsigned int *d_n = (unsigned int *)((char *)c->d_pct + 64);
+    NL_HIP(zero_small(d_n, 4, c->stream));
+    if (total > 0) {
+        ProfScope ps(c, "sample");
+        sample_gather_pos_kernel<<<(unsigned)((total + 255) / 256), 256, 0, c->stream>>>(fs, geom(c), L, stage, d_n);
+        NL_CHECK_LAUNCH();
+    }
+    if ((rc = pct_enqueue(c, stage, d_n, total, (float)q, err, errlen))) return rc;
+    int dst;
+    if ((rc = mask_volume_enqueue(c, 0.0f, &((PctRec *)c->d_pct)->thr, &dst, err, errlen))) return rc;
+    NL_HIP(hipMemcpyAsync(c->h_pct, c->d_pct, 64, hipMemcpyDeviceToHost, c->stream));
+    NL_HIP(hipStreamSynchronize(c->stream));
+    const PctRec *rec = (const PctRec *)c->h_pct;
+    if (n_samples) *n_samples = rec->n;
+    if (a) *a = rec->a;
+    if (b) *b = rec->b;
+    if (gamma) *gamma = rec->gamma;
+    if (thr) *thr = rec->thr;
+    if (rec->n > 0) mask_volume_commit(c, dst);
     return NL_OK;
 }
 

@@ -57,6 +57,7 @@ _PROTOS = {
     "nl_host_hist_thresholds_f32": [_p, _i64, _int, C.POINTER(_f64), C.POINTER(_f64), C.POINTER(_int), _p, _p],
     "nl_tail_enqueue": [_p, _i64, _i64, _i64, _f64],
     "nl_tail_finish": [_p, _int, C.POINTER(_i64), C.POINTER(_f32), C.POINTER(_f32), C.POINTER(_f32), C.POINTER(_f32), C.POINTER(_i64)],
+    "nl_mask_volume_dev": [_p, _i64, _i64, _i64, _f64, C.POINTER(_i64), C.POINTER(_f32), C.POINTER(_f32), C.POINTER(_f32), C.POINTER(_f32)],
     "nl_debug_percentile": [_p, _p, _i64, _f64, C.POINTER(_f32), C.POINTER(_f32), C.POINTER(_f32)],
     "nl_positive_samples_world": [_p, _int, _int, _i64, _i64, _i64, _i64, _p, _i64, _p],
     "nl_host_slab_join": [_int, _p, _i64, _i64, C.POINTER(_i64), C.POINTER(_i64), _p, _p, _p, _p],
@@ -534,6 +535,14 @@ class Context:
         self._call("nl_tail_finish", 1 if commit else 0, C.byref(n), C.byref(a), C.byref(b), C.byref(g), C.byref(t), C.byref(npos))
         return dict(n_samples=int(n.value), a=np.float32(a.value), b=np.float32(b.value), gamma=np.float32(g.value),
                     thr=np.float32(t.value), n_positive=int(npos.value))
+
+    def mask_volume_dev(self, strides, q=1.0):
+        """_mask_volume with the percentile selected on the device -> dict(n_samples, a, b, gamma, thr); n_samples = 0: frame unchanged."""
+        n = _i64(0)
+        a, b, g, t = _f32(0), _f32(0), _f32(0), _f32(0)
+        self._call("nl_mask_volume_dev", int(strides[0]), int(strides[1]), int(strides[2]), float(q), C.byref(n), C.byref(a), C.byref(b),
+                   C.byref(g), C.byref(t))
+        return dict(n_samples=int(n.value), a=np.float32(a.value), b=np.float32(b.value), gamma=np.float32(g.value), thr=np.float32(t.value))
 
     def debug_percentile(self, values, q=1.0):
         v = np.ascontiguousarray(values, dtype=np.float32).reshape(-1)

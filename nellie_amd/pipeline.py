@@ -618,6 +618,13 @@ class FramePipeline:
     def mask_volume(self, p: FilterParams):
         """filtering.py:952-967 on the device-resident frame."""
         strides = self._strides(int(p.max_threshold_samples))
+        if self._device_percentile_usable():
+            rec = self.ctx.mask_volume_dev(strides, 1.0)
+            if rec["n_samples"] == 0:
+                return None
+            self._check_device_percentile(rec)
+            self.trace.percentile_thr = float(rec["thr"])
+            return rec["thr"]
         positive = self._positive_lattice_samples(FIELD_FRANGI, strides)
         if positive.size == 0:
             return None
@@ -634,14 +641,22 @@ class FramePipeline:
     _tail_dev_pending = False
     _device_tail = os.environ.get("NELLIE_DEVICE_TAIL", "1") == "1"      # 0: the percentile threshold on the host (round 3)
 
-    def _device_tail_usable(self) -> bool:
-        """The epilogue with the percentile selected on the device: needs the entry points, a 3-D frame, and the host's repetition
-        of numpy's interpolation to be the installed numpy's (percentile_of_samples checks that once per process)."""
+    def _device_percentile_usable(self) -> bool:
+        """The percentile selected on the device: needs the entry points and the host's repetition of numpy's interpolation to be
+        the installed numpy's (percentile_of_samples checks that once per process)."""
         global _FAST_PERCENTILE
         if _FAST_PERCENTILE is None:
             percentile_of_samples(np.array([1.0, 2.0], np.float32), 1)
-        return bool(self._device_tail and _FAST_PERCENTILE and not self.two_d and hasattr(self.ctx, "tail_enqueue")
-                    and self._tail_reductions_on_device())
+        return bool(self._device_tail and _FAST_PERCENTILE and hasattr(self.ctx, "mask_volume_dev") and self._tail_reductions_on_device())
+
+    def _device_tail_usable(self) -> bool:
+        """... and the whole fused epilogue enqueued without a wait (nl_tail_enqueue): 3-D frames."""
+        return bool(self._device_percentile_usable() and not self.two_d and hasattr(self.ctx, "tail_enqueue"))
+
+    def _check_device_percentile(self, rec):
+        thr, gamma = percentile_from_order_statistics(rec["n_samples"], rec["a"], rec["b"], 1)
+        if not (np.float32(thr) == rec["thr"] and np.float32(gamma) == rec["gamma"] and rec["a"] <= rec["b"]):
+            raise RuntimeError(f"device percentile {rec} differs from numpy's rule ({thr}, {gamma})")
 
     def _tail_reductions_on_device(self) -> bool:
         return True            # one GPU: nothing to reduce (a Z-slab pipeline needs its fused communicator)
@@ -652,9 +667,7 @@ class FramePipeline:
         rec = self.ctx.tail_finish(commit=True)
         if rec["n_samples"] == 0:
             return None
-        thr, gamma = percentile_from_order_statistics(rec["n_samples"], rec["a"], rec["b"], 1)
-        if not (np.float32(thr) == rec["thr"] and np.float32(gamma) == rec["gamma"] and rec["a"] <= rec["b"]):
-            raise RuntimeError(f"device percentile {rec} differs from numpy's rule ({thr}, {gamma})")
+        self._check_device_percentile(rec)
         self.trace.percentile_thr = float(rec["thr"])
         self.trace.n_positive = self._reduce_fused_count(rec["n_positive"])
         return self.trace.n_positive

@@ -482,26 +482,35 @@ class ShardedFramePipeline(FramePipeline):
         ctx.slab_majority()
         comm.exchange_bits(ctx, 0)
         j = self._slab_phase(SLAB_NUMBER)
-        mine = j.rank == me
-        none = np.int64(2 ** 31 - 1)
-        # the owner of a component: the lowest rank holding voxels of it; its defining run there: the first one
-        owner = np.full(j.ncomp, self.world, np.int64)
-        has = j.val != none
-        np.minimum.at(owner, j.comp[has], j.rank[has])
-        first = np.full(j.ncomp, none, np.int64)
-        own_nodes = mine & has & (owner[j.comp] == me)
-        np.minimum.at(first, j.comp[own_nodes], j.val[own_nodes].astype(np.int64))
-        my_comps = np.flatnonzero(first != none)
-        k_local, local_id = ctx.slab_number(j.root[mine], first[my_comps].astype(np.int32))
+        empty = np.zeros(0, np.int32)
+        if j.ncomp == 0:                                        # no tree crosses an interface: every rank numbers its own, ids offset
+            k_local, _ = ctx.slab_number(empty, empty)
+            my_comps = local_id = np.zeros(0, np.int64)
+            mine = np.zeros(0, bool)
+        else:
+            mine = j.rank == me
+            none = np.int64(2 ** 31 - 1)
+            # the owner of a component: the lowest rank holding voxels of it; its defining run there: the first one
+            owner = np.full(j.ncomp, self.world, np.int64)
+            has = j.val != none
+            np.minimum.at(owner, j.comp[has], j.rank[has])
+            first = np.full(j.ncomp, none, np.int64)
+            own_nodes = mine & has & (owner[j.comp] == me)
+            np.minimum.at(first, j.comp[own_nodes], j.val[own_nodes].astype(np.int64))
+            my_comps = np.flatnonzero(first != none)
+            k_local, local_id = ctx.slab_number(j.root[mine], first[my_comps].astype(np.int32))
         mine_part = np.concatenate([np.array([k_local], np.int64), my_comps.astype(np.int64), local_id.astype(np.int64)])
         parts = [mine_part] if self.world == 1 else self._gather_list(mine_part)
         counts = np.array([int(p[0]) for p in parts], np.int64)
         base = np.concatenate([[0], np.cumsum(counts)])
-        label_of = np.zeros(j.ncomp, np.int64)
-        for r, p in enumerate(parts):
-            m = (p.size - 1) // 2
-            label_of[p[1:1 + m]] = base[r] + p[1 + m:]
-        ctx.slab_paint(int(base[me]), j.root[mine], label_of[j.comp[mine]].astype(np.int32))
+        if j.ncomp == 0:
+            ctx.slab_paint(int(base[me]), empty, empty)
+        else:
+            label_of = np.zeros(j.ncomp, np.int64)
+            for r, p in enumerate(parts):
+                m = (p.size - 1) // 2
+                label_of[p[1:1 + m]] = base[r] + p[1 + m:]
+            ctx.slab_paint(int(base[me]), j.root[mine], label_of[j.comp[mine]].astype(np.int32))
         self.trace.n_labels = int(base[-1])
         return self.trace.n_labels
 
