@@ -1983,7 +1983,7 @@ static int mask_volume_fused_enqueue(nl_ctx *c, float thr, const float *thr_dev,
     NL_CHECK_LAUNCH();
     bits_morph6_kernel<1><<<(unsigned)(((c->own_hi - c->own_lo) * c->ny * wpr + 255) / 256), 256, 0, c->stream>>>(bE, bD, v, wpr, c->own_lo, c->own_hi, c->two_d);
     NL_CHECK_LAUNCH();
-    apply_bits_pos_kernel<<<grid1d((c->own_hi - c->own_lo) * c->ny * 64, 256, (i64)1 << 22), 256, 0, c->stream>>>(
+    apply_bits_pos_kernel<<<grid1d(((c->own_hi - c->own_lo) * c->ny + APPLY_ROWS - 1) / APPLY_ROWS * 64, 256, (i64)1 << 22), 256, 0, c->stream>>>(    // a wave takes APPLY_ROWS rows
         c->f[c->i_vmax], bD, c->f[dst], v, wpr, c->own_lo, c->own_hi);
     NL_CHECK_LAUNCH();
     // a fused communicator: the count comes back GLOBAL (one collective on the stream instead of a host-level all-reduce behind the call)
