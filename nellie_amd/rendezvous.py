@@ -78,10 +78,11 @@ class FileRendezvous:
                 os.remove(self._hs("go"))
             except OSError:
                 pass
-            # leftovers of launches that died: markers of any other nonce with this tag's prefix older than a day are litter
+            # leftovers of launches that died: markers of any other nonce older than a week are litter (a launch that is still running
+            # after a week keeps working: its ranks only read markers while a stage starts or ends, minutes after they were written)
             for p in glob.glob(os.path.join(self.dir, ".nellie_*")):
                 try:
-                    if f"_{job}_" not in p and time.time() - os.path.getmtime(p) > 86400:
+                    if f"_{job}_" not in p and time.time() - os.path.getmtime(p) > 7 * 86400:
                         os.remove(p)
                 except OSError:
                     pass
