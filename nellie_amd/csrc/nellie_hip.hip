@@ -117,6 +117,7 @@ static CommApi &rccl() { static CommApi api; return api; }
 #include "sampling.inc"
 #include "hessian.inc"
 #include "hessian_pair.inc"
+#include "hv_launch.h"
 #include "filter2d.inc"
 #include "markers.inc"
 #include "label_voxels.inc"
@@ -207,28 +208,13 @@ static int hv_rs_env() {
     if (v < 0) { const char *e = getenv("NELLIE_HV_RS"); v = e ? atoi(e) : 8; if (v != 0 && v != 8 && v != 16) v = 8; }
     return v;
 }
-// dynamic LDS beyond 64 KiB has to be allowed per kernel (the RS = 16 tile of the pair kernel takes 121 KiB)
-template <typename K> static void allow_lds(K kernel, int bytes) {
-    if (bytes > (64 << 10)) (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-}
 // the pair kernel addresses the planes of a Z chunk through one buffer resource (32-bit byte offsets)
 static int hv_rs(const nl_ctx *c) { return ((i64)(HM_ZCHUNK + 4) * c->ny * c->nx * 4 < ((i64)1 << 32)) ? hv_rs_env() : 0; }
-static Dv<1> dv_fast(float d) { return Dv<1>{d, (float)(1.0 / (double)d)}; }
-static Dv<2> dv_two(float d) {              // yh = RN32(1/d), yl = RN32(1/d - yh), both from the float64 quotient
-    const double inv = 1.0 / (double)d;
-    const float yh = (float)inv;
-    return Dv<2>{(float)(inv - (double)yh), yh};
-}
-static Dv<0> dv_exact(float d) { return Dv<0>{1.0 / (double)d}; }
-static HessDv<1> hessdv_fast(const nl_ctx *c) {
-    return HessDv<1>{dv_fast(c->hz), dv_fast(c->hy), dv_fast(c->hx), dv_fast(c->hz2), dv_fast(c->hy2), dv_fast(c->hx2)};
-}
-static HessDv<2> hessdv_two(const nl_ctx *c) {
-    return HessDv<2>{dv_two(c->hz), dv_two(c->hy), dv_two(c->hx), dv_two(c->hz2), dv_two(c->hy2), dv_two(c->hx2)};
-}
-static HessDv<0> hessdv_exact(const nl_ctx *c) {
-    return HessDv<0>{dv_exact(c->hz), dv_exact(c->hy), dv_exact(c->hx), dv_exact(c->hz2), dv_exact(c->hy2), dv_exact(c->hx2)};
-}
+static HessP hessp(const nl_ctx *c);
+static HessDv<1> hessdv_fast(const nl_ctx *c) { return hessdv_fast(hessp(c)); }      // (dv_* and the HessP forms: hv_launch.h)
+static HessDv<0> hessdv_exact(const nl_ctx *c) { return hessdv_exact(hessp(c)); }
+// the pair walk (its own translation unit, hv_launch.h): division variant as proven for this context's divisors
+static int hv_fastv(const nl_ctx *c) { return c->fast_div2 ? 2 : (c->fast_div ? 1 : 0); }
 // Exhaustive proof that the 3-instruction division is exact for the six divisors in use.
 static int check_fast_div(nl_ctx *c, char *err, size_t errlen) {
     const float ds[6] = {c->hz, c->hy, c->hx, c->hz2, c->hy2, c->hx2};
@@ -1278,18 +1264,14 @@ extern "C" int nl_hessian_stats(nl_ctx *c, const double spacing[3], float *max_a
                                           HGCfg<TYV>::lds_bytes(), c->stream>>>(                                          \
             gauss_cur(c), nullptr, nullptr, 0, geom(c), HR, vp, VQueue{}, (int)c->own_lo, (int)c->own_hi, ntx,        \
             (int)((c->ny + TYV - 1) / TYV), res, nullptr)
-#define NL_LAUNCH_STATS_V(RSV, FASTV, HR)                                                                                 \
-        allow_lds(hessian_v_kernel<0, RSV, FASTV>, HVCfg<RSV>::lds_bytes());                                              \
-        hessian_v_kernel<0, RSV, FASTV><<<(unsigned)(ntx * (int)((c->ny + 2 * RSV - 1) / (2 * RSV)) * nzc), HVCfg<RSV>::NT, \
-                                          HVCfg<RSV>::lds_bytes(), c->stream>>>(                                          \
-            gauss_cur(c), nullptr, nullptr, 0, geom(c), HR, vp, VQueue{}, (int)c->own_lo, (int)c->own_hi, ntx,        \
-            (int)((c->ny + 2 * RSV - 1) / (2 * RSV)), res, nullptr, nullptr)
-        if (hv_rs(c) == 16) { if (c->fast_div2) { NL_LAUNCH_STATS_V(16, 2, hessdv_two(c)); } else if (c->fast_div) { NL_LAUNCH_STATS_V(16, 1, hessdv_fast(c)); } else { NL_LAUNCH_STATS_V(16, 0, hessdv_exact(c)); } }
-        else if (hv_rs(c) == 8) { if (c->fast_div2) { NL_LAUNCH_STATS_V(8, 2, hessdv_two(c)); } else if (c->fast_div) { NL_LAUNCH_STATS_V(8, 1, hessdv_fast(c)); } else { NL_LAUNCH_STATS_V(8, 0, hessdv_exact(c)); } }
+        if (hv_rs(c)) {
+            const int rsv = hv_rs(c), ntyv = (int)((c->ny + 2 * rsv - 1) / (2 * rsv));
+            NL_HIP(nl_hv_launch(HvLaunch{0, rsv, hv_fastv(c), (unsigned)(ntx * ntyv * nzc), c->stream, gauss_cur(c), nullptr, nullptr, 0, geom(c),
+                                         hessp(c), vp, VQueue{}, (int)c->own_lo, (int)c->own_hi, ntx, ntyv, res, nullptr, nullptr}));
+        }
         else if (hm_ty() == 8) { if (c->fast_div) NL_LAUNCH_STATS(8, true, hessdv_fast(c)); else NL_LAUNCH_STATS(8, false, hessdv_exact(c)); }
         else { if (c->fast_div) NL_LAUNCH_STATS(16, true, hessdv_fast(c)); else NL_LAUNCH_STATS(16, false, hessdv_exact(c)); }
 #undef NL_LAUNCH_STATS
-#undef NL_LAUNCH_STATS_V
         NL_CHECK_LAUNCH();
     }
     unsigned int *h = (unsigned int *)c->h_small;
@@ -1391,19 +1373,14 @@ static int spec_enqueue(nl_ctx *c, const double spacing[3], float fsq_lo, float 
         if (rs) vp.qcap *= 2;                           // a wave owns two row segments
         hipStream_t hs = c->stream;
 #define NL_DEV_LOHI dev_lohi
-#define NL_LAUNCH_SPEC_V(RSV, FASTV, HR)                                                                                  \
-        allow_lds(hessian_v_kernel<2, RSV, FASTV>, HVCfg<RSV>::lds_bytes());                                              \
-        hessian_v_kernel<2, RSV, FASTV><<<nblocks, HVCfg<RSV>::NT, HVCfg<RSV>::lds_bytes(), hs>>>(                        \
-            gauss_cur(c), cm, pm, wpr, geom(c), HR, vp, vq, (int)z0, (int)z1, ntx, nty, res, d_cnt, NL_DEV_LOHI)
 #define NL_LAUNCH_SPEC(TYV, FASTV, HR)                                                                                    \
         hessian_g_kernel<2, TYV, FASTV><<<nblocks, HGCfg<TYV>::NT, HGCfg<TYV>::lds_bytes(), c->stream>>>(                 \
             gauss_cur(c), cm, pm, wpr, geom(c), HR, vp, vq, (int)z0, (int)z1, ntx, nty, res, d_cnt)
-        if (rs == 16) { if (c->fast_div2) { NL_LAUNCH_SPEC_V(16, 2, hessdv_two(c)); } else if (c->fast_div) { NL_LAUNCH_SPEC_V(16, 1, hessdv_fast(c)); } else { NL_LAUNCH_SPEC_V(16, 0, hessdv_exact(c)); } }
-        else if (rs == 8) { if (c->fast_div2) { NL_LAUNCH_SPEC_V(8, 2, hessdv_two(c)); } else if (c->fast_div) { NL_LAUNCH_SPEC_V(8, 1, hessdv_fast(c)); } else { NL_LAUNCH_SPEC_V(8, 0, hessdv_exact(c)); } }
+        if (rs) NL_HIP(nl_hv_launch(HvLaunch{2, rs, hv_fastv(c), nblocks, hs, gauss_cur(c), cm, pm, wpr, geom(c), hessp(c), vp, vq, (int)z0, (int)z1,
+                                             ntx, nty, res, d_cnt, NL_DEV_LOHI}));
         else if (ty == 8) { if (c->fast_div) NL_LAUNCH_SPEC(8, true, hessdv_fast(c)); else NL_LAUNCH_SPEC(8, false, hessdv_exact(c)); }
         else { if (c->fast_div) NL_LAUNCH_SPEC(16, true, hessdv_fast(c)); else NL_LAUNCH_SPEC(16, false, hessdv_exact(c)); }
 #undef NL_LAUNCH_SPEC
-#undef NL_LAUNCH_SPEC_V
 #undef NL_DEV_LOHI
         NL_CHECK_LAUNCH();
         c->spec_nregions = nblocks * (unsigned)(rs ? rs : ty);
@@ -1750,10 +1727,6 @@ extern "C" int nl_vesselness_step(nl_ctx *c, float gamma_sq, float alpha_sq, flo
         const int ty = rs ? 2 * rs : hm_ty();
         const int nty = (int)((c->ny + ty - 1) / ty);
         if (rs) vp.qcap = 2 * HM_REGION;
-#define NL_LAUNCH_VESS_V(RSV, FASTV, HR)                                                                                  \
-        allow_lds(hessian_v_kernel<1, RSV, FASTV>, HVCfg<RSV>::lds_bytes());                                              \
-        hessian_v_kernel<1, RSV, FASTV><<<nblocks, HVCfg<RSV>::NT, HVCfg<RSV>::lds_bytes(), c->stream>>>(                 \
-            gauss_cur(c), cm, pm, wpr, geom(c), HR, vp, vq, (int)za, (int)zb, ntx, nty, nullptr, d_cnt, nullptr)
 #define NL_LAUNCH_VESS(TYV, FASTV, HR)                                                                                    \
         hessian_g_kernel<1, TYV, FASTV><<<nblocks, HGCfg<TYV>::NT, HGCfg<TYV>::lds_bytes(), c->stream>>>(                 \
             gauss_cur(c), cm, pm, wpr, geom(c), HR, vp, vq, (int)za, (int)zb, ntx, nty, nullptr, d_cnt)
@@ -1761,8 +1734,8 @@ extern "C" int nl_vesselness_step(nl_ctx *c, float gamma_sq, float alpha_sq, flo
             const i64 zb = za + planes_per_launch < z1 ? za + planes_per_launch : z1;
             const int nzc = (int)((zb - za + HM_ZCHUNK - 1) / HM_ZCHUNK);
             const unsigned nblocks = (unsigned)(ntx * nty * nzc);
-            if (rs == 16) { if (c->fast_div2) { NL_LAUNCH_VESS_V(16, 2, hessdv_two(c)); } else if (c->fast_div) { NL_LAUNCH_VESS_V(16, 1, hessdv_fast(c)); } else { NL_LAUNCH_VESS_V(16, 0, hessdv_exact(c)); } }
-            else if (rs == 8) { if (c->fast_div2) { NL_LAUNCH_VESS_V(8, 2, hessdv_two(c)); } else if (c->fast_div) { NL_LAUNCH_VESS_V(8, 1, hessdv_fast(c)); } else { NL_LAUNCH_VESS_V(8, 0, hessdv_exact(c)); } }
+            if (rs) NL_HIP(nl_hv_launch(HvLaunch{1, rs, hv_fastv(c), nblocks, c->stream, gauss_cur(c), cm, pm, wpr, geom(c), hessp(c), vp, vq, (int)za, (int)zb,
+                                                 ntx, nty, nullptr, d_cnt, nullptr}));
             else if (ty == 8) { if (c->fast_div) NL_LAUNCH_VESS(8, true, hessdv_fast(c)); else NL_LAUNCH_VESS(8, false, hessdv_exact(c)); }
             else { if (c->fast_div) NL_LAUNCH_VESS(16, true, hessdv_fast(c)); else NL_LAUNCH_VESS(16, false, hessdv_exact(c)); }
             NL_CHECK_LAUNCH();
@@ -1772,7 +1745,6 @@ extern "C" int nl_vesselness_step(nl_ctx *c, float gamma_sq, float alpha_sq, flo
             NL_CHECK_LAUNCH();
         }
 #undef NL_LAUNCH_VESS
-#undef NL_LAUNCH_VESS_V
         NL_CHECK_LAUNCH();
     }
     if (mask_count) {

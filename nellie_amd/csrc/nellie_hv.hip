@@ -1,0 +1,44 @@
+// Second translation unit of libnellie_hip.so (gfx950): the pair walk, compiled with the ILP-first scheduler (see hv_launch.h and
+// nellie_amd/build.py).  Only the kernel and its launch live here.
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include <type_traits>
+#define NL_HV_UNIT 1
+#include "nl_common.h"
+#include "device_math.inc"
+#include "hessian.inc"
+#include "hessian_pair.inc"
+#include "hv_launch.h"
+
+// dynamic LDS beyond 64 KiB has to be allowed per kernel (the RS = 16 tile of the pair kernel takes 121 KiB)
+template <typename K> static void allow_lds(K kernel, int bytes) {
+    if (bytes > (64 << 10)) (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
+template <int MODE, int RS, int FAST>
+static void launch_one(const HvLaunch &a, const HessDv<FAST> &hr) {
+    allow_lds(hessian_v_kernel<MODE, RS, FAST>, HVCfg<RS>::lds_bytes());
+    hessian_v_kernel<MODE, RS, FAST><<<a.nblocks, HVCfg<RS>::NT, HVCfg<RS>::lds_bytes(), a.stream>>>(
+        a.g, a.cmask, a.pmask, a.wpr, a.geom, hr, a.vp, a.vq, a.z0, a.z1, a.ntx, a.nty, a.res, a.d_cnt, a.dev_lohi);
+}
+template <int MODE, int RS>
+static void launch_div(const HvLaunch &a) {
+    if (a.fastv == 2) launch_one<MODE, RS, 2>(a, hessdv_two(a.hp));
+    else if (a.fastv == 1) launch_one<MODE, RS, 1>(a, hessdv_fast(a.hp));
+    else launch_one<MODE, RS, 0>(a, hessdv_exact(a.hp));
+}
+template <int MODE>
+static void launch_rs(const HvLaunch &a) {
+    if (a.rs == 16) launch_div<MODE, 16>(a); else launch_div<MODE, 8>(a);
+}
+
+hipError_t nl_hv_launch(const HvLaunch &a) {
+    if (a.rs != 8 && a.rs != 16) return hipErrorInvalidValue;
+    switch (a.mode) {
+        case 0: launch_rs<0>(a); break;
+        case 1: launch_rs<1>(a); break;
+        case 2: launch_rs<2>(a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
