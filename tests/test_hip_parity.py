@@ -895,6 +895,8 @@ def test_device_chain_equals_the_synchronous_path(hip, shape, seed, aniso):
     from nellie_amd.synthetic import ANISO_03, ISO_01, make_volume
     vol = make_volume(shape, seed)
     (fr_c, tr_c, np_c, pt_c, fb_c, flags), (fr_s, tr_s, np_s, pt_s, fb_s, _) = _run_both_ways(vol, ANISO_03 if aniso else ISO_01)
+    if flags is None and fb_c == 0:
+        pytest.skip("the device chain is not offered in this configuration (NELLIE_HV_RS=0 / NELLIE_DEVICE_CHAIN=0)")
     assert fb_c == 0 and flags == [0] * len(tr_c), f"the chain fell back: flags {flags}"
     assert fb_s == 0
     assert tr_c == tr_s
@@ -908,6 +910,8 @@ def test_device_chain_falls_back_on_a_bracket_miss(hip):
     from nellie_amd.synthetic import ISO_01, make_volume
     vol = make_volume((40, 96, 96), 21)
     (fr_c, tr_c, _, _, fb_c, flags), (fr_s, tr_s, _, _, _, _) = _run_both_ways(vol, ISO_01, _one_pass_test_scale=1.5)
+    if flags is None and fb_c == 0:
+        pytest.skip("the device chain is not offered in this configuration (NELLIE_HV_RS=0 / NELLIE_DEVICE_CHAIN=0)")
     assert fb_c == 1 and all(f & 128 for f in flags), flags
     assert tr_c == tr_s and np.array_equal(fr_c, fr_s)
     ref = _run_both_ways(vol, ISO_01)[0][0]
