@@ -176,6 +176,28 @@ def test_one_pass_queue_overflow_falls_back(hip):
     assert np.array_equal(out[True][0].view(np.uint32), out[False][0].view(np.uint32))
 
 
+@pytest.mark.parametrize("scale", [1e15, 1e16, 3e16, 1e17, 3e17])
+def test_hessians_whose_frob_sq_overflows_float32(hip, scale):
+    """Intensities of 1e17 ... 1e19: from 1e16 on the squared Frobenius norm of some Hessians is +inf in float32 (filtering.py:421-426
+    handles that), the one-pass walk hands those scales to the two-pass path, and the eigenvalues -- float64 from finite components --
+    still give responses > 0.  The walk's queue test (trace |trace| + 0.30 frob_sq < 0) must not drop such a voxel: round 4's first
+    form did, and only this probe showed it."""
+    from nellie_amd.pipeline import FilterParams, FramePipeline
+    from nellie_amd.synthetic import ISO_01, make_volume
+    shape = (40, 96, 96)
+    vol = (make_volume(shape, 5).astype(np.float64) * scale).astype(np.float32)
+    with np.errstate(all="ignore"):
+        ref = orc.run_frame(vol, ISO_01)
+    pipe = FramePipeline(shape)
+    pipe.compute_vesselness(vol, FilterParams(dim_res=ISO_01))
+    got = pipe.download_frangi()
+    two_pass = [not s.one_pass for s in pipe.trace.scales]
+    pipe.close()
+    if scale >= 1e16:
+        assert any(two_pass), "these intensities were meant to overflow frob_sq"
+    assert_frangi_close(got, ref, f"scale {scale:g}")
+
+
 def test_two_pass_vesselness_in_several_launches(hip):
     """The two-pass path launches the Hessian kernel per block of Z chunks when the eigen queue is small
     (NELLIE_VQ_CAP is read once per process, hence the child processes): same bits as one launch."""
