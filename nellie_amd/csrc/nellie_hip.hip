@@ -348,6 +348,7 @@ extern "C" int nl_ctx_destroy(nl_ctx *c) {
     for (int k = 0; k < 4; ++k) if (c->d_2d[k]) hipFree(c->d_2d[k]);
     if (c->d_fsq_cache) hipFree(c->d_fsq_cache);
     if (c->d_vq) hipFree(c->d_vq);
+    if (c->mk_scratch) hipFree(c->mk_scratch);
     if (c->d_vq_count) hipFree(c->d_vq_count);
     if (c->d_rows) hipFree(c->d_rows);
     if (c->d_ag) hipFree(c->d_ag);
@@ -2606,7 +2607,12 @@ extern "C" int nl_markers_log_step(nl_ctx *c, const double *wz2, const double *w
     const bool flat = !wz2 && !wz0;                    // 2-D image: sigma_vec = (s, s), no Z terms (mocap_marking.py:323-324)
     if (flat && c->nzl != 1) return nl_fail(err, errlen, NL_EINVAL, "Z weights are NULL on a 3-D context");
     if ((!flat && (!wz2 || !wz0)) || !wy2 || !wy0 || !wx2 || !wx0) return nl_fail(err, errlen, NL_EINVAL, "weights are NULL");
-    if ((!flat && rz < 1) || ryx < 1 || ryx > GM_MAX_R || ryx > c->ny) return nl_fail(err, errlen, NL_EINVAL, "LoG radii (%d, %d) outside the supported range [1, %d]", rz, ryx, GM_MAX_R);
+    if ((!flat && rz < 1) || ryx < 1 || rz > NL_MAX_RADIUS || ryx > NL_MAX_RADIUS) return nl_fail(err, errlen, NL_EINVAL, "LoG radii (%d, %d) outside the supported range [1, %d]", rz, ryx, NL_MAX_RADIUS);
+    // The tiled in-plane kernels hold 2R+1 values per thread (R <= GM_MAX_R) and reflect at most once (R <= ny).  Finer pixels
+    // (0.065 um: sigma up to 5.1 px, radius 21) and images thinner than a kernel take the one-thread-per-voxel passes: any radius,
+    // scipy's multiple reflection, the same summation order; the volume between the Y and the X pass is allocated on first use.
+    const bool generic = ryx > GM_MAX_R || ryx > c->ny;
+    if (generic && !c->mk_scratch) NL_HIP(hipMalloc((void **)&c->mk_scratch, (size_t)c->n * 4));
     GaussW gz2, gz0, gy2, gy0, gx2, gx0;
     int rc;
     if ((!flat && ((rc = fill_gw(gz2, wz2, rz, err, errlen)) || (rc = fill_gw(gz0, wz0, rz, err, errlen)))) || (rc = fill_gw(gy2, wy2, ryx, err, errlen)) ||
@@ -2675,10 +2681,18 @@ extern "C" int nl_markers_log_step(nl_ctx *c, const double *wz2, const double *w
         }
     };
     const bool use_dual = dual && gyx_tiled();
+    auto yx_generic = [&](const GaussW &gy, const GaussW &gx, bool acc) {
+        gauss_axis_kernel<1><<<grid, blk, 0, c->stream>>>(yx_src, c->mk_scratch, v, z0, z1, gy);
+        if (acc) gauss_axis_kernel<2, true><<<grid, blk, 0, c->stream>>>(c->mk_scratch, lap, v, z0, z1, gx);
+        else gauss_axis_kernel<2><<<grid, blk, 0, c->stream>>>(c->mk_scratch, lap, v, z0, z1, gx);
+    };
     {
         ProfScope ps(c, "markers_log");
         // generic_laplace: output = d2/dz2 term; output += d2/dy2 term; output += d2/dx2 term (float32 adds, in this order)
-        if (flat) {
+        if (generic) {
+            if (flat) { yx_generic(gy2, gx0, false); yx_generic(gy0, gx2, true); }
+            else { zpass(gz2); yx_generic(gy0, gx0, false); zpass(gz0); yx_generic(gy2, gx0, true); yx_generic(gy0, gx2, true); }
+        } else if (flat) {
             if (use_dual) yx_dual(false);
             else { yx(gy2, gx0, false); yx(gy0, gx2, true); }
         } else {

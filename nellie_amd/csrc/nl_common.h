@@ -51,6 +51,7 @@ struct nl_ctx {
     unsigned int *d_vq_count = nullptr;   // entries written per region
     int nw_state = 0;             // Network: 1 after nl_skel_pixel_class (classes + branch bits resident)
     float *mk_use = nullptr;      // Markers: LoG source when use_im = 'frangi' (inside d_vq), else the distance image
+    float *mk_scratch = nullptr;  // Markers: volume between the Y and the X pass of the any-radius LoG path, allocated on first use
     std::atomic<unsigned long long> epoch{0};      // C-ABI calls made on this context (see NL_KEEP_SUPPORT)
     unsigned long long support_epoch = ~0ull - 8;   // epoch at which d_support described the Frangi frame
     const unsigned long long *d_support = nullptr;

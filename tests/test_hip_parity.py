@@ -388,6 +388,28 @@ def test_markers_golden_bitexact(name, hip):
         pipe.close()
 
 
+@pytest.mark.parametrize("shape,dr", [((20, 60, 70), {"X": 0.065, "Y": 0.065, "Z": 0.25, "T": 1.0}),      # LoG radii up to 21 in-plane
+                                      ((30, 9, 140), {"X": 0.1, "Y": 0.1, "Z": 0.1, "T": 1.0}),           # Y shorter than the kernel radius
+                                      ((24, 50, 66), {"X": 0.05, "Y": 0.05, "Z": 0.05, "T": 1.0})])       # radii 27 on all three axes
+def test_markers_any_radius_vs_oracle(hip, shape, dr):
+    """Pixel sizes below 0.1 um make LoG kernels wider than the tiled in-plane kernels hold (GM_MAX_R = 12), thin images make them
+    longer than an axis (scipy reflects several times): nl_markers_log_step then takes the one-thread-per-voxel passes.  Found by
+    tools/fuzz_stages.py (the library used to refuse such radii).  All three products equal the oracle's."""
+    from nellie_amd import pipeline as pl
+    from nellie_amd.synthetic import make_volume
+    vol = make_volume(shape, 77)
+    lab = (vol > np.percentile(vol, 97)).astype(np.int32)
+    ref = orc.markers_frame(vol, lab, dr)
+    pipe = pl.FramePipeline(shape)
+    try:
+        n = pipe.markers(dr, labels=lab, intensity=vol)
+        marker, dist, border = (a.reshape(shape) for a in pipe.download_markers())
+        assert np.array_equal(dist, ref[1]) and np.array_equal(border, ref[2])
+        assert np.array_equal(marker, ref[0]) and n == int(ref[0].sum()) and n > 0
+    finally:
+        pipe.close()
+
+
 def test_stage_api_markers(hip):
     """Filter -> Label -> Markers through the drop-in stage classes; products equal the oracle's on the same labels."""
     from fakes import ArrayImInfo

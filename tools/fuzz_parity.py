@@ -35,11 +35,14 @@ ULP1 = 2.0 ** -24                               # float32 spacing just below 1.0
 # The response is (1 - exp(-a)) * exp(-b) * (1 - exp(-c)) in float32 (filtering.py:744-766).  numpy's float32 exp (its own
 # SIMD routine, documented at <= 2.52 ulp) and the device's differ by an ulp or two, and one ulp of exp(-a) next to 1.0 is an
 # ABSOLUTE 2^-24 in 1 - exp(-a): whatever the image, two correct implementations differ by a few times 2^-24 + rtol * |ref|
-# (the largest difference seen in the first 5781 cases: 1.1919e-07 = 2 * 2^-24 to four digits, on 304 frames).  The suite's
-# absolute term, 1e-6 * max|ref|, covers that whenever the frame's largest response exceeds ~0.12 (every golden, every synthetic
-# volume); the random low-contrast textures here also produce frames whose largest response is 1e-3, where the 1st percentile
-# (the smallest responses of all) moves by 1e-2 relative for the same reason.  A case is first held to the suite's bar
-# ("equal") and, failing that, to the floor ("equal_at_exp_floor", counted separately); a defect fails both.
+# (the largest difference seen in the first 5781 cases: 1.1919e-07 = 2 * 2^-24 to four digits, on 304 frames).  Two
+# quantities inherit that absolute error unscaled: the smallest responses of a frame (their support included) and the 1st
+# percentile of the positive responses (filtering.py:963), which is one of them by construction.  The suite's bars -- absolute
+# term 1e-6 * max|ref|, percentile within 2e-4 relative -- suit the goldens and the synthetic volumes (noisy backgrounds:
+# percentile thresholds of 1e-3 ... 1e-1, largest response 0.155); the random textures here also give frames whose percentile
+# threshold is 1e-6 (an absolute 6e-8 is then 1e-2 of it) or whose largest response is 1e-3.  A case is first held to the
+# suite's bars ("equal") and, failing that, to the same bars with the absolute terms floored at 4 * 2^-24
+# ("equal_at_exp_floor", counted separately); a defect fails both.  Labels are compared bit for bit in either case.
 FLOOR = 4 * ULP1
 
 
@@ -164,6 +167,9 @@ def one_case(rng, idx):
         kw["frob_thresh_division"] = int(rng.choice([2, 3, 4, 8]))
     if rng.integers(0, 6) == 0:
         kw["alpha_sq"], kw["beta_sq"] = float(rng.choice([0.25, 0.5, 1.0])), float(rng.choice([0.25, 0.5, 2.0]))
+    if rng.integers(0, 4) == 0:                      # an explicit sigma list: cascade radii up to ~25 (beyond the specialised kernels' 12,
+        k = int(rng.integers(1, 6))                  # and beyond the length of a thin axis: the generic reflecting kernel)
+        kw["sigmas"] = [float(v) for v in np.sort(np.round(rng.uniform(0.7, float(rng.choice([3.0, 5.0, 9.0])), size=k), 3))]
     info = {"case": idx, "shape": list(shape), "dtype": str(vol.dtype), "z_um": dr["Z"], "x_um": dr["X"], "kw": kw}
     ref_err = None
     try:
