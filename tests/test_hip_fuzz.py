@@ -39,3 +39,12 @@ def test_fuzz_slice_slabs_vs_one_context(hip):
     bad = [r for r in results if not r["ok"]]
     assert not bad, bad[:3]
     assert sum(r["result"] == "identical" for r in results) >= 6
+
+
+def test_fuzz_slice_stage_classes_vs_oracle(hip):
+    """Filter / Label / Markers classes with random keywords, stacks of 1-3 frames, one context or `devices=[0, 0(, 0)]`."""
+    import fuzz_api as A
+    rng = np.random.default_rng(2027)
+    results = [A.one_case(rng, i) for i in range(10)]
+    bad = [r for r in results if not r["ok"]]
+    assert not bad, bad[:3]

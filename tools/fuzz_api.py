@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""Randomised differential run THROUGH THE DROP-IN STAGE CLASSES (Filter, Label, Markers over a duck-typed ImInfo, as the
+reference's own tests drive them) against the oracle: T stacks of 1-3 frames, random shapes / dtypes / spacings, the
+reference's keywords drawn at random -- remove_edges, min / max radius, alpha / beta, frob_thresh fixed or by division,
+max_threshold_samples small enough to stride; Label with threshold= / otsu_thresh_intensity / min_radius_um / few sampling
+pixels; Markers with use_im, num_sigma, peak_min_distance -- and where a frame runs: one context, or `devices=[0, 0(, 0)]`
+(the frame as Z slabs of one GPU through nellie_amd/engine.py).  Bars: as tools/fuzz_parity.py for the Filter output; labels
+(on the oracle's Filter output) and the three Markers products (on the oracle's labels) bit for bit.
+
+  tools/fuzz_api.py SECONDS [SEED] [OUT]
+"""
+import json
+import os
+import sys
+import time
+import traceback
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import fuzz_parity as F  # noqa: E402
+
+
+def one_case(rng, idx):
+    from fakes import ArrayImInfo
+    from nellie_amd.segmentation.filtering import Filter
+    from nellie_amd.segmentation.labelling import Label
+    from nellie_amd.segmentation.mocap_marking import Markers
+    from oracle import nellie_oracle as orc
+    nt = int(rng.integers(1, 4))
+    nslab = int(rng.choice([1, 1, 2, 3]))
+    if nslab > 1:
+        shape = (int(rng.integers(30, 70)) * nslab, int(rng.choice(F.PRIMES[8:26])), int(rng.choice(F.PRIMES[8:28])))
+    else:
+        shape = F.draw_shape(rng)
+    dr = F.SPACINGS[int(rng.integers(0, len(F.SPACINGS)))]
+    vols = [F.draw_volume(rng, shape) for _ in range(nt)]
+    vols = np.stack([v.astype(vols[0].dtype) for v in vols])
+    fkw, okw = {}, {}
+    if rng.integers(0, 3) == 0:
+        fkw["remove_edges"] = True
+        okw["remove_edges_flag"] = True
+    if rng.integers(0, 4) == 0:
+        fkw["min_radius_um"], fkw["max_radius_um"] = float(rng.choice([0.2, 0.25, 0.4])), float(rng.choice([0.6, 1.0, 1.5]))
+        okw["sigmas"] = orc.default_sigmas(dr, fkw["min_radius_um"], fkw["max_radius_um"])
+    if rng.integers(0, 5) == 0:
+        fkw["alpha_sq"], fkw["beta_sq"] = float(rng.choice([0.25, 0.5, 1.0])), float(rng.choice([0.25, 0.5, 2.0]))
+        okw.update(alpha_sq=fkw["alpha_sq"], beta_sq=fkw["beta_sq"])
+    r = int(rng.integers(0, 6))
+    if r == 0:
+        fkw["frob_thresh"] = float(rng.choice([0.01, 0.05, 0.2]))
+        okw["frob_thresh"] = fkw["frob_thresh"]
+    elif r == 1:
+        fkw["frob_thresh_division"] = int(rng.choice([3, 4, 8]))
+        okw["frob_thresh_division"] = fkw["frob_thresh_division"]
+    if rng.integers(0, 4) == 0:
+        fkw["max_threshold_samples"] = int(rng.choice([500, 5000, 50000]))
+        okw["max_samples"] = fkw["max_threshold_samples"]
+    devices = [0] * nslab if nslab > 1 else None
+    lkw, olkw = {}, {}
+    r = int(rng.integers(0, 4))
+    if r == 0:
+        lkw["otsu_thresh_intensity"] = True
+        olkw["otsu_thresh_intensity"] = True
+    elif r == 1:
+        lkw["threshold"] = float(np.percentile(vols[0].astype(np.float64), float(rng.uniform(20, 90))))
+        olkw["threshold"] = lkw["threshold"]
+    if rng.integers(0, 4) == 0:
+        lkw["min_radius_um"] = float(rng.choice([0.1, 0.25, 0.5]))
+        olkw["min_radius_um"] = lkw["min_radius_um"]
+    if rng.integers(0, 4) == 0:
+        lkw["threshold_sampling_pixels"] = int(rng.choice([300, 3000, 30000]))
+        olkw["max_samples"] = lkw["threshold_sampling_pixels"]
+    mkw, omkw = {}, {}
+    if rng.integers(0, 3) == 0:
+        mkw["peak_min_distance"] = int(rng.integers(1, 4))
+        omkw["peak_min_distance"] = mkw["peak_min_distance"]
+    if rng.integers(0, 4) == 0:
+        mkw["num_sigma"] = int(rng.integers(2, 7))
+        omkw["num_sigma"] = mkw["num_sigma"]
+    use_fr = bool(rng.integers(0, 3) == 0)
+    info = {"case": idx, "shape": [nt] + list(shape), "dtype": str(vols.dtype), "z_um": dr["Z"], "x_um": dr["X"], "slabs": nslab,
+            "filter": {k: (v if not isinstance(v, float) else round(v, 4)) for k, v in fkw.items()}, "label": {k: (round(v, 3) if isinstance(v, float) else v) for k, v in lkw.items()},
+            "markers": dict(mkw, use_im="frangi" if use_fr else "distance")}
+    im = ArrayImInfo(vols, dr)
+    # ---- the oracle, frame by frame
+    refs, err = [], None
+    try:
+        for t in range(nt):
+            run = orc.run_frame(vols[t], dr, **okw)
+            if float(np.sum(run)) > 0.0:
+                fr, thr = orc.mask_volume(run, okw.get("max_samples", int(1e6)), return_thr=True)
+            else:
+                fr, thr = run, None
+            refs.append((run, fr, thr))
+    except ValueError as exc:
+        err = str(exc)
+    level = "equal"
+    try:
+        if err is not None:
+            try:
+                Filter(im, devices=devices, **fkw).run()
+            except ValueError as exc:
+                info.update(ok=True, result="both raise", message=str(exc)[:60])
+                return info
+            raise AssertionError(f"oracle raised ({err}), Filter did not")
+        Filter(im, devices=devices, **fkw).run()
+        for t in range(nt):
+            run, fr, thr = refs[t]
+            got = np.asarray(im.store["frangi"][t])
+            last = None
+            for floor, name in ((0.0, "equal"), (F.FLOOR, "equal_at_exp_floor")):
+                try:
+                    if thr is None:
+                        F.frangi_close(got, fr, floor, f"frangi[{t}]")
+                    else:
+                        F.masked_close(orc, got, fr, run, thr, floor, f"frangi[{t}]")
+                    last = None
+                    if name != "equal":
+                        level = name
+                    break
+                except AssertionError as exc:
+                    last = exc
+            if last is not None:
+                raise last
+        # ---- Label on the oracle's Filter output: bit-exact
+        im.store["frangi"] = np.stack([r_[1] for r_ in refs]).view(type(im.store["im"]))
+        lab_ref, lab_err = [], None
+        try:
+            for t in range(nt):
+                lab_ref.append(orc.label_frame(refs[t][1], dr, original=vols[t], **olkw))
+        except ValueError as exc:
+            lab_err = str(exc)
+        if lab_err is not None:
+            try:
+                Label(im, devices=devices, **lkw).run()
+            except ValueError:
+                info.update(ok=True, result=level + ", Label: both raise")
+                return info
+            raise AssertionError(f"oracle's Label raised ({lab_err}), Label did not")
+        Label(im, devices=devices, **lkw).run()
+        for t in range(nt):
+            got = np.asarray(im.store["labels"][t])
+            assert np.array_equal(got, lab_ref[t]), f"labels[{t}] differ on {int((got != lab_ref[t]).sum())} voxels"
+        info["labels"] = [int(l.max()) for l in lab_ref]
+        # ---- Markers on those labels: bit-exact
+        Markers(im, use_im="frangi" if use_fr else "distance", devices=devices, **mkw).run()
+        for t in range(nt):
+            m, d, b = orc.markers_frame(vols[t], lab_ref[t], dr, frangi=refs[t][1] if use_fr else None, **omkw)
+            for name, ref in (("distance", d), ("border", b), ("marker", m)):
+                got = np.asarray(im.store[name][t])
+                assert np.array_equal(got, ref), f"{name}[{t}] differs on {int((got != ref).sum())} voxels"
+        info.update(ok=True, result=level)
+    except AssertionError as exc:
+        info.update(ok=False, result="MISMATCH: " + str(exc)[:300])
+    except Exception as exc:  # noqa: BLE001
+        info.update(ok=False, result="ERROR: " + repr(exc)[:200] + " | " + " / ".join(traceback.format_exc().splitlines()[-4:])[:400])
+    return info
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+    out = sys.argv[3] if len(sys.argv) > 3 else None
+    rng = np.random.default_rng(seed)
+    t0 = time.time()
+    lines, bad, idx, res = [], 0, 0, {}
+    while time.time() - t0 < budget:
+        info = one_case(rng, idx)
+        idx += 1
+        bad += 0 if info["ok"] else 1
+        key = info["result"].split(":")[0][:40] if not info["ok"] else info["result"]
+        res[key] = res.get(key, 0) + 1
+        lines.append(json.dumps(info))
+        print(lines[-1], flush=True)
+    summary = {"summary": True, "cases": idx, "failed": bad, "results": res, "seed": seed, "seconds": round(time.time() - t0, 1)}
+    lines.append(json.dumps(summary))
+    print(lines[-1], flush=True)
+    if out:
+        with open(out, "w") as f:
+            f.write("# tools/fuzz_api.py: Filter / Label / Markers stage classes with random keywords (one context or Z slabs) vs the oracle\n")
+            f.write("\n".join(lines) + "\n")
+    os._exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()

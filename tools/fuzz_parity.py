@@ -171,6 +171,9 @@ def one_case(rng, idx):
         k = int(rng.integers(1, 6))                  # and beyond the length of a thin axis: the generic reflecting kernel)
         kw["sigmas"] = [float(v) for v in np.sort(np.round(rng.uniform(0.7, float(rng.choice([3.0, 5.0, 9.0])), size=k), 3))]
     info = {"case": idx, "shape": list(shape), "dtype": str(vol.dtype), "z_um": dr["Z"], "x_um": dr["X"], "kw": kw}
+    if idx < int(os.environ.get("FUZZ_SKIP", "0")):      # replay the draws of the earlier cases without running them
+        info.update(ok=True, result="skipped")
+        return info
     ref_err = None
     try:
         ref_run = orc.run_frame(vol, dr, **kw)
@@ -200,10 +203,19 @@ def one_case(rng, idx):
         else:
             ref_fr, ref_thr, thr, fr = ref_run, None, None, run
         level = None
-        for floor, name in ((0.0, "equal"), (FLOOR, "equal_at_exp_floor")):
+        # third level: a frame with FEW positive voxels spread over decades (1 176 voxels from 1e-8 to 0.5 in the case that
+        # prompted it) has order statistics a decade apart at its low end; a handful of voxels at 6e-8 that are 0 on the other
+        # side then shift the 1st percentile by one rank = a factor of two.  Both sides are right about their own frame: the
+        # device's run_frame is held to the floored bar, and its threshold and masked frame must EQUAL what the oracle's
+        # _mask_volume makes of the device's own run_frame, bit for bit.
+        for floor, name in ((0.0, "equal"), (FLOOR, "equal_at_exp_floor"), (FLOOR, "equal_mask_volume_of_own_run_frame")):
             try:
                 frangi_close(run, ref_run, floor, "run_frame")
-                if has_signal:
+                if has_signal and name == "equal_mask_volume_of_own_run_frame":
+                    own_fr, own_thr = orc.mask_volume(run, return_thr=True)
+                    assert thr is not None and float(thr) == float(own_thr), f"percentile {thr} vs {own_thr} on the device's own run_frame"
+                    assert np.array_equal(fr, own_fr), f"masked frame differs from the oracle's _mask_volume of the device's run_frame on {int((fr != own_fr).sum())} voxels"
+                elif has_signal:
                     assert thr is not None, "device found no positive voxel"
                     assert abs(float(thr) - float(ref_thr)) <= 2e-4 * float(ref_thr) + max(1e-12, floor), f"percentile {thr} vs {ref_thr}"
                     masked_close(orc, fr, ref_fr, ref_run, ref_thr, floor)
@@ -275,7 +287,8 @@ def main():
     levels = {}
     for l in lines:
         r = json.loads(l)["result"]
-        levels[r if r in ("equal", "equal_at_exp_floor") or r.startswith(("both raise", "Label: both")) else "FAILED"] = levels.get(r if r in ("equal", "equal_at_exp_floor") or r.startswith(("both raise", "Label: both")) else "FAILED", 0) + 1
+        k = r if r.startswith(("equal", "both raise", "Label: both", "skipped")) else "FAILED"
+        levels[k] = levels.get(k, 0) + 1
     summary = {"summary": True, "cases": idx, "failed": bad, "results": levels, "seed": seed, "seconds": round(time.time() - t0, 1), "voxels": voxels}
     print(json.dumps(summary), flush=True)
     lines.append(json.dumps(summary))

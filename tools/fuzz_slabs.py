@@ -4,7 +4,7 @@ join) against the single-context HIP run of the same volume, on ONE GPU over the
 slab counts 2..6, halo schemes, spacings, textures and dtypes of tools/fuzz_parity.py.  Bar: Filter output, every threshold,
 mask counts, label volume and label count IDENTICAL (the single context is what tools/fuzz_parity.py holds against the oracle).
 
-  tools/fuzz_slabs.py SECONDS [SEED] [OUT]
+  tools/fuzz_slabs.py SECONDS [SEED] [OUT] [big]
 """
 import json
 import os
@@ -55,14 +55,26 @@ def run_slabs(vol, dr, world, halo_mode, raw_ghosts, kw):
     return out
 
 
+BIG = False      # argv[4] == "big": 20 - 250 Mvoxel volumes of the synthetic generator (several Z chunks of the walk, thousands of tiles,
+                 # slab tables of several blocks) -- too large for the oracle, so the bar is slabs == one context, bit for bit
+
+
 def one_case(rng, idx):
     from nellie_amd import pipeline as pl
     world = int(rng.integers(2, 7))
-    per = int(rng.integers(9, 40))
-    extra = int(rng.integers(0, world))                  # uneven split
-    gshape = (per * world + extra, int(rng.choice(F.PRIMES[8:28])), int(rng.choice(F.PRIMES[8:30])))
-    dr = F.SPACINGS[int(rng.integers(0, len(F.SPACINGS)))]
-    vol = F.draw_volume(rng, gshape)
+    if BIG:
+        from nellie_amd.synthetic import make_volume
+        per = int(rng.integers(30, 90))
+        extra = int(rng.integers(0, world))
+        gshape = (per * world + extra, int(rng.integers(250, 800)), int(rng.integers(250, 900)))
+        dr = F.SPACINGS[int(rng.integers(0, 2))]
+        vol = make_volume(gshape, int(rng.integers(0, 1 << 30)), dtype=[np.float32, np.uint16][int(rng.integers(0, 2))])
+    else:
+        per = int(rng.integers(9, 40))
+        extra = int(rng.integers(0, world))                  # uneven split
+        gshape = (per * world + extra, int(rng.choice(F.PRIMES[8:28])), int(rng.choice(F.PRIMES[8:30])))
+        dr = F.SPACINGS[int(rng.integers(0, len(F.SPACINGS)))]
+        vol = F.draw_volume(rng, gshape)
     halo_mode = ["steps", "fat"][int(rng.integers(0, 2))]
     raw = bool(rng.integers(0, 2))
     kw = {}
@@ -126,6 +138,8 @@ def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 7
     out = sys.argv[3] if len(sys.argv) > 3 else None
+    global BIG
+    BIG = len(sys.argv) > 4 and sys.argv[4] == "big"
     rng = np.random.default_rng(seed)
     t0 = time.time()
     lines, bad, idx, res = [], 0, 0, {}
