@@ -74,6 +74,9 @@ def one_case(rng, idx):
     if rng.integers(0, 4) == 0:
         lkw["threshold_sampling_pixels"] = int(rng.choice([300, 3000, 30000]))
         olkw["max_samples"] = lkw["threshold_sampling_pixels"]
+    if rng.integers(0, 5) == 0:
+        lkw["histogram_nbins"] = int(rng.choice([64, 128, 512]))
+        olkw["nbins"] = lkw["histogram_nbins"]
     mkw, omkw = {}, {}
     if rng.integers(0, 3) == 0:
         mkw["peak_min_distance"] = int(rng.integers(1, 4))
