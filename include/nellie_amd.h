@@ -547,6 +547,8 @@ int nl_prof_reset(nl_ctx *ctx);
                       clamped at 0; a valid voxel (mask & distance > 0) whose response equals the maximum of its 3x3x3
                       neighbourhood (mode 'nearest') and beats every earlier scale becomes a peak.  Weights: scipy's
                       `_gaussian_kernel1d` of order 2 / 0, truncate 4.0, 2r+1 float64 values each, s2 = float32(s**2).
+                      Radii 1 ... 63 on every axis (a 0.065 um pixel gives 21); in-plane radii above 12, or above ny, take
+                      one-thread-per-voxel passes with scipy's multiple reflection (one more float32 volume, allocated then).
                       2-D image (context of shape (1, ny, nx)): wz2 = wz0 = NULL, sigma_vec = (s, s) (:323-324) -- the two
                       in-plane terms only; distance transform, border, 3x3 maxima and the suppression window are the
                       nz = 1 cases of the 3-D kernels.

@@ -27,8 +27,8 @@ def test_fuzz_slice_hot_path_vs_oracle(hip):
 def test_fuzz_slice_stages_vs_oracle(hip):
     import fuzz_stages as S
     rng = np.random.default_rng(2025)
-    for i in range(45):
-        info = (S.case_markers, S.case_network, S.case_2d)[i % 3](rng, i)      # an AssertionError names the stage and the count
+    for i in range(60):
+        info = (S.case_markers, S.case_network, S.case_2d, S.case_label)[i % 4](rng, i)      # an AssertionError names the stage and the count
         assert info["ok"], info
 
 

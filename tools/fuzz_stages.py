@@ -145,6 +145,51 @@ def case_2d(rng, idx):
     return info
 
 
+def case_label(rng, idx):
+    """Label on dense random structure (fill 2 - 80 %, blobs with cavities, shells, single voxels): hole filling, both
+    26-connected labellings, area filter, majority smoothing and numbering, bit for bit (labelling.py:467-509)."""
+    from nellie_amd import pipeline as pl
+    from oracle import nellie_oracle as orc
+    shape = F.draw_shape(rng)
+    dr = F.SPACINGS[int(rng.integers(0, len(F.SPACINGS)))]
+    nz, ny, nx = shape
+    f = rng.random(shape).astype(np.float32)
+    for ax in range(3):                                  # a few box-filter passes: structure at a random scale
+        for _ in range(int(rng.integers(0, 3))):
+            f = (f + np.roll(f, 1, ax) + np.roll(f, -1, ax)) / np.float32(3)
+    fill = float(rng.uniform(0.02, 0.8))
+    cut = np.quantile(f, 1.0 - fill)
+    fr = np.where(f > cut, f - np.float32(cut) + np.float32(1e-3), 0).astype(np.float32)
+    for _ in range(int(rng.integers(0, 4))):             # hollow boxes: cavities for the hole filling, shells for the area filter
+        lo = [int(rng.integers(0, max(1, s_ - 3))) for s_ in shape]
+        hi = [min(s_, l + int(rng.integers(3, 14))) for s_, l in zip(shape, lo)]
+        sl = tuple(slice(a, b) for a, b in zip(lo, hi))
+        inner = tuple(slice(a + 1, max(a + 1, b - 1)) for a, b in zip(lo, hi))
+        fr[sl] = np.float32(rng.uniform(0.5, 2.0))
+        if rng.integers(0, 2):
+            fr[inner] = 0
+    if rng.integers(0, 3) == 0:
+        fr[rng.random(shape) < 0.01] = np.float32(0.7)   # isolated voxels
+    kw = {}
+    if rng.integers(0, 3) == 0:
+        kw["min_radius_um"] = float(rng.choice([0.05, 0.1, 0.25, 0.5]))
+    info = {"stage": "label", "case": idx, "shape": list(shape), "fill": round(float((fr > 0).mean()), 3), "kw": kw}
+    ref_lab, ref_thr = orc.label_frame(fr, dr, return_thr=True, **kw)
+    pipe = pl.FramePipeline(shape)
+    try:
+        pipe.upload_frangi(fr)
+        thr = pipe.frangi_threshold()
+        assert (thr is None and ref_thr is None) or float(thr) == float(ref_thr), f"label threshold {thr} vs {ref_thr}"
+        n = pipe.label(thr, pl.min_area_pixels_of(dr, **({"min_radius_um": kw["min_radius_um"]} if kw else {})))
+        lab = pipe.download_labels()
+        assert np.array_equal(lab, ref_lab), f"labels differ on {int((lab != ref_lab).sum())} voxels"
+        assert n == int(ref_lab.max())
+        info.update(ok=True, result="equal", labels=int(n))
+    finally:
+        pipe.close()
+    return info
+
+
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 8
@@ -152,9 +197,9 @@ def main():
     rng = np.random.default_rng(seed)
     t0 = time.time()
     lines, bad, idx, res = [], 0, 0, {}
-    cases = [case_markers, case_network, case_2d]
+    cases = [case_markers, case_network, case_2d, case_label]
     while time.time() - t0 < budget:
-        fn = cases[idx % 3]
+        fn = cases[idx % len(cases)]
         try:
             info = fn(rng, idx)
         except AssertionError as exc:
