@@ -48,3 +48,12 @@ def test_fuzz_slice_stage_classes_vs_oracle(hip):
     results = [A.one_case(rng, i) for i in range(10)]
     bad = [r for r in results if not r["ok"]]
     assert not bad, bad[:3]
+
+
+def test_fuzz_slice_through_files(hip, tmp_path):
+    """OME-TIFF -> FileInfo / ImInfo -> run(markers=True) and run_streamed() -> every product reopened from its file."""
+    import fuzz_files as FF
+    rng = np.random.default_rng(2028)
+    results = [FF.one_case(rng, i, str(tmp_path)) for i in range(6)]
+    bad = [r for r in results if not r["ok"]]
+    assert not bad, bad[:3]
