@@ -24,6 +24,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import fuzz_parity as F  # noqa: E402
 
 
+TWO_D = os.environ.get("FUZZ_API_2D", "1") == "1"     # every fourth case: the no_z branch (TYX stacks)
+
+
 def one_case(rng, idx):
     from fakes import ArrayImInfo
     from nellie_amd.segmentation.filtering import Filter
@@ -164,6 +167,111 @@ def one_case(rng, idx):
     return info
 
 
+def one_case_2d(rng, idx):
+    """The `no_z` branch of the three stage classes: a TYX stack of 2-D images."""
+    from fakes import ArrayImInfo
+    from nellie_amd.segmentation.filtering import Filter
+    from nellie_amd.segmentation.labelling import Label
+    from nellie_amd.segmentation.mocap_marking import Markers
+    from oracle import nellie_oracle as orc
+    nt = int(rng.integers(1, 4))
+    shape = (int(rng.choice(F.PRIMES[8:])), int(rng.choice(F.PRIMES[8:])))
+    x = float(rng.choice([0.065, 0.1, 0.2]))
+    dr = {"X": x, "Y": x, "Z": None, "T": 1.0}
+    vols = np.stack([np.ascontiguousarray(F.draw_volume(rng, (5,) + shape)[2]).astype(np.float32) for _ in range(nt)])
+    if rng.integers(0, 2):
+        vols = np.clip(vols * 30, 0, 65535).astype(np.uint16)
+    fkw, okw = {}, {}
+    if rng.integers(0, 3) == 0:
+        fkw["remove_edges"] = True
+        okw["remove_edges_flag"] = True
+    r = int(rng.integers(0, 5))
+    if r == 0:
+        fkw["frob_thresh"] = okw["frob_thresh"] = float(rng.choice([0.01, 0.05, 0.2]))
+    elif r == 1:
+        fkw["frob_thresh_division"] = okw["frob_thresh_division"] = int(rng.choice([3, 4, 8]))
+    lkw, olkw = {}, {}
+    if rng.integers(0, 3) == 0:
+        lkw["min_radius_um"] = olkw["min_radius_um"] = float(rng.choice([0.1, 0.25, 0.5]))
+    mkw = {}
+    if rng.integers(0, 3) == 0:
+        mkw["peak_min_distance"] = int(rng.integers(1, 4))
+    info = {"case": idx, "shape": [nt] + list(shape), "dtype": str(vols.dtype), "z_um": None, "x_um": x, "slabs": 1, "filter": fkw, "label": lkw, "markers": dict(mkw, use_im="distance")}
+    im = ArrayImInfo(vols, dr, no_z=True)
+    level = "equal"
+    try:
+        refs, err = [], None
+        try:
+            for t in range(nt):
+                run = orc.run_frame_2d(vols[t], dr, **okw)
+                fr = orc.mask_volume_2d(run) if float(np.sum(run)) > 0.0 else run
+                refs.append((run, fr))
+        except ValueError as exc:
+            err = str(exc)
+        if err is not None:
+            try:
+                Filter(im, **fkw).run()
+            except ValueError:
+                info.update(ok=True, result="both raise")
+                return info
+            raise AssertionError(f"oracle raised ({err}), Filter did not")
+        Filter(im, **fkw).run()
+        for t in range(nt):
+            got = np.asarray(im.store["frangi"][t])
+            thr = orc.mask_volume_2d(refs[t][0], return_thr=True)[1] if float(np.sum(refs[t][0])) > 0.0 else None
+            last = None
+            for floor, name in ((0.0, "equal"), (F.FLOOR, "equal_at_exp_floor")):
+                try:
+                    if thr is None:
+                        F.frangi_close(got, refs[t][1], floor, f"frangi2d[{t}]")
+                    else:                                # 2-D tie zone: the same relaxation with the 4-connected opening's reach
+                        F.masked_close(_Orc2D(orc), got, refs[t][1], refs[t][0], thr, floor, f"frangi2d[{t}]")
+                    last = None
+                    if name != "equal":
+                        level = name
+                    break
+                except AssertionError as exc:
+                    last = exc
+            if last is not None:
+                raise last
+        im.store["frangi"] = np.stack([r_[1] for r_ in refs]).view(type(im.store["im"]))
+        try:
+            lab_ref = [orc.label_frame_2d(refs[t][1], dr, **olkw) for t in range(nt)]
+        except ValueError:
+            try:
+                Label(im, **lkw).run()
+            except ValueError:
+                info.update(ok=True, result=level + ", Label: both raise")
+                return info
+            raise AssertionError("oracle's Label raised, Label did not")
+        Label(im, **lkw).run()
+        for t in range(nt):
+            got = np.asarray(im.store["labels"][t])
+            assert np.array_equal(got, lab_ref[t]), f"labels2d[{t}] differ on {int((got != lab_ref[t]).sum())} pixels"
+        Markers(im, **mkw).run()
+        for t in range(nt):
+            m, d, b = orc.markers_frame(vols[t], lab_ref[t], dr, **mkw)
+            for name, ref in (("distance", d), ("border", b), ("marker", m)):
+                got = np.asarray(im.store[name][t])
+                assert np.array_equal(got, ref), f"{name}2d[{t}] differs on {int((got != ref).sum())} pixels"
+        info.update(ok=True, result=level, labels=[int(l.max()) for l in lab_ref])
+    except AssertionError as exc:
+        info.update(ok=False, result="MISMATCH: " + str(exc)[:300])
+    except Exception as exc:  # noqa: BLE001
+        info.update(ok=False, result="ERROR: " + repr(exc)[:200] + " | " + " / ".join(traceback.format_exc().splitlines()[-4:])[:400])
+    return info
+
+
+class _Orc2D:
+    """binary_dilation6 of a 2-D mask = the 4-connected cross (what F.masked_close grows its tie zone with)."""
+    def __init__(self, orc):
+        self.orc = orc
+
+    def binary_dilation6(self, m):
+        p = np.pad(m, 1, mode="constant", constant_values=False)
+        return p[1:-1, 1:-1] | p[:-2, 1:-1] | p[2:, 1:-1] | p[1:-1, :-2] | p[1:-1, 2:]
+
+
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 10
@@ -172,7 +280,7 @@ def main():
     t0 = time.time()
     lines, bad, idx, res = [], 0, 0, {}
     while time.time() - t0 < budget:
-        info = one_case(rng, idx)
+        info = one_case_2d(rng, idx) if (TWO_D and idx % 4 == 3) else one_case(rng, idx)
         idx += 1
         bad += 0 if info["ok"] else 1
         key = info["result"].split(":")[0][:40] if not info["ok"] else info["result"]
