@@ -52,7 +52,11 @@ def frangi_close(got, ref, floor, what):
     tol = RTOL * np.abs(ref) + max(ATOL_REL * scale, floor)
     d = np.abs(got.astype(np.float64) - ref.astype(np.float64))
     bad = d > tol
-    assert not bad.any(), f"{what}: {int(bad.sum())} voxels outside tolerance, max|d|={d.max():.3e}, max|ref|={scale:.3e}"
+    if bad.any():
+        w = np.argwhere(bad)
+        ex = "; ".join(f"{tuple(int(v) for v in q)}: got {float(got[tuple(q)]):.4g} ref {float(ref[tuple(q)]):.4g}" for q in w[:6])
+        lo, hi = w.min(0), w.max(0)
+        raise AssertionError(f"{what}: {int(bad.sum())} voxels outside tolerance, max|d|={d.max():.3e}, max|ref|={scale:.3e}; box {lo.tolist()}..{hi.tolist()}; {ex}")
     sup = (got > 0) != (ref > 0)
     if sup.any():
         assert floor > 0 and float(np.maximum(np.abs(got), np.abs(ref))[sup].max()) <= floor, f"{what}: support differs on {int(sup.sum())} voxels"
