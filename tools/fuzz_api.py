@@ -138,7 +138,24 @@ def one_case(rng, idx):
                 except AssertionError as exc:
                     last = exc
             if last is not None:
-                raise last
+                # third level (as in tools/fuzz_parity.py): filtering.py:969-1000 zeroes 15 rows at both ends of the bounding box of ANY
+                # non-zero value of a plane, so one response of 2^-24 that is 0 on the other side (one ulp of the float32 exp) moves
+                # the box by a row and whole rows of large responses with it (case 128 of seed 17, tools/diag_remove_edges.py).  Both
+                # sides are then right about their own frame: the device's run_frame (same library, pipeline level) is held to the
+                # floored bar, and the stage class's output must EQUAL the oracle's remove_edges + _mask_volume of that frame.
+                from nellie_amd import pipeline as pl
+                pp = pl.FilterParams(dim_res=dr, **{k: v for k, v in fkw.items() if k != "remove_edges"})
+                pipe = pl.FramePipeline(shape)
+                try:
+                    pipe.compute_vesselness(vols[t], pp)
+                    run_dev = pipe.download_frangi()
+                finally:
+                    pipe.close()
+                F.frangi_close(run_dev, orc.run_frame(vols[t], dr, **{k: v for k, v in okw.items() if k != "remove_edges_flag"}), F.FLOOR, f"run_frame[{t}]")
+                own = orc.remove_edges(run_dev) if fkw.get("remove_edges") else run_dev
+                own_fr = orc.mask_volume(own, okw.get("max_samples", int(1e6))) if float(np.sum(own)) > 0.0 else own
+                assert np.array_equal(got, own_fr), str(last)[:700] + f" | and differs from the oracle's chain on the device's own run_frame on {int((got != own_fr).sum())} voxels"
+                level = "equal_chain_on_own_run_frame"
         # ---- Label on the oracle's Filter output: bit-exact
         im.store["frangi"] = np.stack([r_[1] for r_ in refs]).view(type(im.store["im"]))
         lab_ref, lab_err = [], None
