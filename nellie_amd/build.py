@@ -17,9 +17,11 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libnellie_hip.so")
-# translation unit -> extra flags.  The pair walk has its own unit because it wants the ILP-first instruction scheduler, which costs the
-# fused Gaussian pass 15 % (csrc/hv_launch.h); everything else is nellie_hip.hip.
-SOURCES = {"nellie_hip.hip": [], "nellie_hv.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
+# translation unit -> extra flags, compiled side by side.  The pair walk has its own unit because it wants the ILP-first instruction
+# scheduler, which costs the fused Gaussian pass 15 % (csrc/hv_launch.h); Filter + comm (nellie_hip.hip), Label / Network / streaming
+# (nellie_label.hip) and Markers (nellie_markers.hip) are separate so that an edit rebuilds one of them (nl_host.h holds what they share).
+SOURCES = {"nellie_hip.hip": [], "nellie_gauss.hip": [], "nellie_label.hip": [], "nellie_markers.hip": [],
+           "nellie_hv.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
 # every include of the translation units: a stale library after editing one of them would silently test old kernels
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith((".inc", ".h"))) + [os.path.join("..", "..", "include", "nellie_amd.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
@@ -42,20 +44,39 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
+def _unit_fresh(obj: str, cmd) -> bool:
+    """An object is reused when it is newer than every file its compiler-written dependency list (-MD) names and was made by the same
+    command: an edit recompiles the translation units that include the edited file, nothing else."""
+    dep, cmdf = obj + ".d", obj + ".cmd"
+    if not (os.path.exists(obj) and os.path.exists(dep) and os.path.exists(cmdf)):
+        return False
+    if open(cmdf).read() != " ".join(cmd):
+        return False
+    t = os.path.getmtime(obj)
+    words = open(dep).read().replace("\\\n", " ").split()
+    files = [w for w in words[1:] if not w.endswith(":")]
+    return all(os.path.exists(f) and os.path.getmtime(f) <= t for f in files)
+
+
 def build(force: bool = False, verbose: bool = True, extra_flags=(), out: str = None) -> str:
     """Compiles the translation units side by side (objects under csrc/.obj, git-ignored) and links them.  extra_flags / out: A/B builds
     (tools/build_variant.sh)."""
     out = out or LIB
     if not force and out == LIB and not needs_build():
         return LIB
-    objdir = os.path.join(CSRC, ".obj" if out == LIB else ".obj_" + os.path.basename(out))
+    objdir = os.path.join(CSRC, ".obj") if out == LIB else os.path.join(os.path.dirname(out), ".obj_" + os.path.basename(out))
     os.makedirs(objdir, exist_ok=True)
-    procs = []
+    procs, objs_all = [], []
     for src, flags in SOURCES.items():
         obj = os.path.join(objdir, src + ".o")
-        cmd = [hipcc_path()] + FLAGS + list(flags) + list(extra_flags) + ["-c", os.path.join(CSRC, src), "-o", obj]
+        objs_all.append(obj)
+        cmd = [hipcc_path()] + FLAGS + list(flags) + list(extra_flags) + ["-MD", "-MF", obj + ".d", "-c", os.path.join(CSRC, src), "-o", obj]
+        if not force and _unit_fresh(obj, cmd):
+            continue
         if verbose:
             print("[nellie_amd.build]", " ".join(cmd), flush=True)
+        with open(obj + ".cmd", "w") as f:
+            f.write(" ".join(cmd))
         procs.append((cmd, obj, subprocess.Popen(cmd)))
     objs = []
     for cmd, obj, proc in procs:
@@ -63,8 +84,10 @@ def build(force: bool = False, verbose: bool = True, extra_flags=(), out: str = 
             for _, _, other in procs:
                 if other.poll() is None:
                     other.wait()
+            if os.path.exists(obj):
+                os.remove(obj)
             raise subprocess.CalledProcessError(proc.returncode, cmd)
-        objs.append(obj)
+    objs = objs_all
     link = [hipcc_path(), "--offload-arch=gfx950", "-fPIC", "-shared", "-o", out] + objs + ["-ldl"]   # RCCL is dlopen()ed on first use, never linked
     if verbose:
         print("[nellie_amd.build]", " ".join(link), flush=True)

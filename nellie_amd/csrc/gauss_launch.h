@@ -1,0 +1,34 @@
+// Internal: the Gaussian passes of libnellie_hip.so live in their own translation unit (nellie_gauss.hip: ~70 unrolled kernel
+// instantiations, a minute of compile time); the cascade (nellie_hip.hip), the 2-D blob filter and the LoG of Markers (nellie_markers.hip)
+// reach them through these launchers.  Every launcher enqueues on c->stream and returns false when the radius has no specialised kernel.
+#pragma once
+#define NL_MAX_RADIUS 63
+struct GaussW { double w[NL_MAX_RADIUS + 1]; int r; };   // w[k] = weight at distance k from the centre
+#define GM_MAX_R 12       // Filter's cascade needs <= 5 at 0.1 um; the LoG kernels of Markers (truncate 4.0) reach 11
+struct GaussWS { double w[GM_MAX_R + 1]; };
+#define GYX_COLS 256      // fused Y+X pass: output columns per workgroup
+#define GYX_THREADS 320
+#define GX_SEG 1024       // stand-alone X pass: row segment per workgroup
+
+static int fill_gw(GaussW &gw, const double *w, int r, char *err, size_t errlen) {
+    if (r < 0 || r > NL_MAX_RADIUS) return nl_fail(err, errlen, NL_EINVAL, "Gaussian radius %d outside [0,%d]", r, NL_MAX_RADIUS);
+    gw.r = r;
+    for (int k = 0; k <= r; ++k) gw.w[k] = w[r + k];   // w[] has 2r+1 entries centred at r (symmetric)
+    return NL_OK;
+}
+
+static inline GaussWS gauss_ws_of(const GaussW &g) { GaussWS w; for (int k = 0; k <= GM_MAX_R; ++k) w.w[k] = k <= g.r ? g.w[k] : 0.0; return w; }
+
+// marching Z / Y pass or the LDS X pass of radius gw.r <= GM_MAX_R (axis 0, 1, 2)
+bool gl_fast(int axis, nl_ctx *c, const float *src, float *dst, const VolGeom &v, i64 z0, i64 z1, const GaussW &gw);
+// one thread per voxel, any radius, scipy's multiple reflection; acc: dst += result
+void gl_axis(int axis, bool acc, nl_ctx *c, dim3 grid, const float *src, float *dst, const VolGeom &v, i64 z0, i64 z1, const GaussW &gw);
+// fused Y+X pass (tiled: the register-blocked X pass; else one row at a time), radius r on both axes; g2 = (x tiles, y chunks, planes)
+bool gl_yx(nl_ctx *c, bool tiled, bool acc, int r, const float *src, float *dst, const VolGeom &v, i64 z0, i64 z1, const GaussWS &wy,
+           const GaussWS &wx, dim3 g2);
+// dst (+)= XY(wya, wxa)(src) + XY(wyb, wxb)(src) in one walk (the two in-plane terms of generic_laplace)
+bool gl_yx_dual(nl_ctx *c, bool acc, int r, const float *src, float *dst, const VolGeom &v, i64 z0, i64 z1, const GaussWS &wya,
+                const GaussWS &wxa, const GaussWS &wyb, const GaussWS &wxb, dim3 g2);
+// marching Y pass into tmp, then the stand-alone X pass into dst (acc: dst += result): large radii of Markers' LoG
+bool gl_y_then_x(nl_ctx *c, bool acc, int r, const float *src, float *tmp, float *dst, const VolGeom &v, i64 z0, i64 z1, const GaussWS &wy,
+                 const GaussWS &wx);
