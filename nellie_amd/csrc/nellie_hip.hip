@@ -287,6 +287,7 @@ extern "C" int nl_ctx_destroy(nl_ctx *c) {
     if (c->d_rows) hipFree(c->d_rows);
     if (c->d_ag) hipFree(c->d_ag);
     if (c->d_sl) hipFree(c->d_sl);
+    if (c->d_seg_done) hipFree(c->d_seg_done);
     if (c->d_pct) hipFree(c->d_pct);
     if (c->h_pct) hipHostFree(c->h_pct);
     if (c->h_sl) hipHostFree(c->h_sl);

@@ -168,6 +168,7 @@ struct LabelGeo {
     int *link_scratch = nullptr;  // >= one int per possible run, free until the paint (enables the two-level union-find)
     int zf_lo = 0, zf_hi = -2;    // planes of this run set that are true Z faces of the volume (-1: none; set by label_geo_faces)
     i64 gz0 = 0, gnz = 0;         // placement of plane 0 of the run set in the global volume (boundary rules)
+    bool rank_independent_bands = false;   // Z slab: the row bands of the in-LDS union level are a function of ny alone (build_components)
 };
 static void label_geo_whole(LabelGeo &g) { g.zf_lo = 0; g.zf_hi = (int)g.nz - 1; g.gz0 = 0; g.gnz = g.nz; }
 
@@ -203,17 +204,30 @@ static int build_components(nl_ctx *c, const LabelGeo &g, const unsigned long lo
     // two levels (see label_runs.inc): planes in LDS, then component pairs across planes; NELLIE_UF_PLANES=0: one level
     static int two_level = -1;
     if (two_level < 0) { const char *e = getenv("NELLIE_UF_PLANES"); two_level = (e && !atoi(e)) ? 0 : 1; }
-    // segments per plane: at least ~1024 workgroups for the in-LDS level (a 136-plane slab would otherwise use half of the CUs)
+    // segments per plane: at least ~1024 workgroups for the in-LDS level (a 136-plane slab would otherwise use half of the CUs).
+    // On a Z slab the banding must NOT depend on the rank: the tables the ranks exchange hold one entry per segment component of a
+    // shared plane, so both ranks that see a plane have to cut it into the same row bands -- and a rank's plane count differs from its
+    // neighbour's (uneven splits, one or two ghost planes).  There the rule reads ny alone: at most 8 bands of >= 32 rows.
+    static int seg_target = -1;                                       // NELLIE_UF_SEG_WGS=1: one workgroup per plane (round 3)
+    if (seg_target < 0) { const char *e = getenv("NELLIE_UF_SEG_WGS"); seg_target = (e && atoi(e) > 0) ? atoi(e) : 1024; }
     int seg_shift = 5;
-    {
-        static int seg_target = -1;                                   // NELLIE_UF_SEG_WGS=1: one workgroup per plane (round 3)
-        if (seg_target < 0) { const char *e = getenv("NELLIE_UF_SEG_WGS"); seg_target = (e && atoi(e) > 0) ? atoi(e) : 1024; }
+    if (g.rank_independent_bands) {
+        const i64 want = seg_target == 1 ? 1 : 8;
+        while (((g.ny + ((i64)1 << seg_shift) - 1) >> seg_shift) > want) ++seg_shift;
+    } else {
         const i64 want = (seg_target + g.nz - 1) / g.nz;
         while (((g.ny + ((i64)1 << seg_shift) - 1) >> seg_shift) > want) ++seg_shift;
-        while (g.nz * ((g.ny + ((i64)1 << seg_shift) - 1) >> seg_shift) > 8192 && ((i64)1 << seg_shift) < g.ny) ++seg_shift;
     }
     const int nseg = (int)((g.ny + ((i64)1 << seg_shift) - 1) >> seg_shift);
-    const bool lvl2 = two_level && g.nz * nseg <= 8192 && rs.proot && rs.link;
+    // one "done in LDS" byte per (plane, band)
+    const size_t seg_bytes = (size_t)g.nz * nseg;
+    if (two_level && rs.proot && rs.link && seg_bytes > c->seg_done_cap) {
+        if (c->d_seg_done) { NL_HIP(hipStreamSynchronize(c->stream)); NL_HIP(hipFree(c->d_seg_done)); c->d_seg_done = nullptr; c->seg_done_cap = 0; }
+        const size_t want_bytes = seg_bytes < 8192 ? 8192 : seg_bytes;
+        NL_HIP(hipMalloc((void **)&c->d_seg_done, want_bytes));
+        c->seg_done_cap = want_bytes;
+    }
+    const bool lvl2 = two_level && rs.proot && rs.link;
     int *link = lvl2 ? rs.link : nullptr;                            // rl_emit_kernel fills the pair filter's slots with -1
     if (g.wpr <= 30)
         rl_emit_kernel<true><<<(unsigned)((g.nrows + 255) / 256), 256, (size_t)256 * (g.wpr + 1) * 8, c->stream>>>(bits, invert, row_off, rs.runs, rs.parent, g.nrows, g.wpr, (int)g.nx, link, cap, d_ovf);
@@ -223,7 +237,7 @@ static int build_components(nl_ctx *c, const LabelGeo &g, const unsigned long lo
     const unsigned gr = run_blocks(rs, g.nrows);
     const RunN rn = rs.rn();
     if (lvl2) {
-        uint8_t *seg_done = (uint8_t *)c->d_small + (52 << 10);
+        uint8_t *seg_done = c->d_seg_done;
         rl_union_plane_kernel<CONN><<<(unsigned)(g.nz * nseg), 256, 0, c->stream>>>(rs.runs, row_off, rs.parent, rs.proot, (int)g.ny,
                                                                          CONN == 6 ? 1 : 0, g.zf_lo, g.zf_hi, (int)g.nx, seg_done, seg_shift, nseg, rn);
         rl_union_cross_kernel<CONN><<<gr, 256, 0, c->stream>>>(rs.runs, row_off, rs.parent, rs.proot, rs.link, rn, (int)g.ny,
@@ -470,6 +484,7 @@ static int slab_geo(nl_ctx *c, SlabGeo &sg, char *err, size_t errlen) {
     g.bitsA = (unsigned long long *)c->m[1] + c->sl_e0 * c->ny * wpr;
     g.bitsB = (unsigned long long *)c->m[2] + c->sl_e0 * c->ny * wpr;
     g.gz0 = c->gz0 + c->sl_e0; g.gnz = c->gnz;
+    g.rank_independent_bands = true;
     g.zf_lo = (g.gz0 == 0) ? 0 : -1; g.zf_hi = (g.gz0 + g.nz == c->gnz) ? (int)g.nz - 1 : -1;
     int free_idx[3], nf = 0;
     for (int k = 0; k < 4; ++k) if (k != c->i_vmax) free_idx[nf++] = k;
@@ -808,7 +823,7 @@ extern "C" int nl_host_slab_join(int world, const int32_t *blobs, int64_t block_
     }
     const i64 n = base[world];
     *n_nodes = n;
-    if (n > cap) { *n_comp = 0; return NL_OK; }                     // the caller sizes its arrays from *n_nodes and calls again
+    if (n > cap) { *n_comp = 0; return nl_fail(err, errlen, NL_EINVAL, "the output arrays hold %lld nodes, the tables name %lld (n_nodes says how many to allocate)", (long long)cap, (long long)n); }
     auto node_of = [&](int r, int32_t root) -> i64 {
         const auto &u = uniq[r];
         return base[r] + (i64)(std::lower_bound(u.begin(), u.end(), root) - u.begin());

@@ -94,6 +94,7 @@ struct nl_ctx {
     int *h_sl = nullptr; size_t h_sl_ints = 0;     // their page-locked landing area (also stages the host's patch lists)
     int sl_capE = 0;                               // entries per plane the tables hold
     int sl_numbered = 0;
+    uint8_t *d_seg_done = nullptr; size_t seg_done_cap = 0;   // Label's two-level union-find: one "joined in LDS" byte per (plane, row band)
 
     float hz = 1, hy = 1, hx = 1;            // float32(h)
     float hz2 = 2, hy2 = 2, hx2 = 2;         // float32(2.0*h)

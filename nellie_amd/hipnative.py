@@ -161,6 +161,10 @@ class NellieHipError(RuntimeError):
         self.code = code
 
 
+class LibraryUnavailable(RuntimeError):
+    """libnellie_hip.so is not built or cannot be loaded (as opposed to an error the loaded library reports)."""
+
+
 def _raise(code: int, msg: str):
     if code == NL_ENODEV:
         if "GPU backend requested" not in msg:
@@ -220,10 +224,13 @@ def load() -> _Lib:
     global _LIB
     if _LIB is None:
         if not os.path.exists(LIB_PATH):
-            raise RuntimeError(
+            raise LibraryUnavailable(
                 f"GPU backend requested but {LIB_PATH} is not built "
                 "(run `python -m nellie_amd.build`); nellie_amd has no CPU fallback")
-        _LIB = _Lib(LIB_PATH)
+        try:
+            _LIB = _Lib(LIB_PATH)
+        except OSError as e:
+            raise LibraryUnavailable(f"GPU backend requested but {LIB_PATH} cannot be loaded: {e}") from e
     return _LIB
 
 
@@ -279,6 +286,8 @@ def host_slab_join(blobs):
     rank, root, val, comp = np.empty(cap, np.int64), np.empty(cap, np.int32), np.empty(cap, np.int64), np.empty(cap, np.int64)
     load().call("nl_host_slab_join", world, _ptr(flat), block, cap, C.byref(n), C.byref(nc), _ptr(rank), _ptr(root), _ptr(val), _ptr(comp))
     k = int(n.value)
+    if k > cap:          # (the library reports this as an error: the arrays above are sized from the entry counts, which bound the nodes)
+        raise NellieHipError(NL_EINVAL, f"nl_host_slab_join: {k} nodes for arrays of {cap}")
     return rank[:k], root[:k], val[:k], comp[:k], int(nc.value)
 
 

@@ -105,6 +105,7 @@ def create(path, shape_tzyx, dtype, dim_res=None, description="", data=None):
     # written under a temporary name and moved into place: a reader (another rank of a multi-process run, a viewer) sees the old
     # complete file or the new complete file, never a truncated one, and a map of the old file keeps its pages
     final_path, path = path, f"{path}.tmp{os.getpid()}_{uuid.uuid4().hex[:8]}"
+    _sweep_stale_tmp(final_path)
     try:
         _write_file(path, t, z, y, x, dt, nplanes, plane_bytes, data_offset, data_bytes, xml, software, data)
         os.replace(path, final_path)
@@ -115,6 +116,31 @@ def create(path, shape_tzyx, dtype, dim_res=None, description="", data=None):
             pass
         raise
     return data_offset
+
+
+def _sweep_stale_tmp(final_path, max_age_s=3600.0):
+    """A process killed inside create() leaves `<path>.tmp<pid>_<hex>` behind (possibly a full-size sparse file next to the
+    outputs): the next create() of the same path removes such siblings once their writer is gone (pid not alive) or they are an
+    hour old."""
+    import glob
+    import re
+    import time
+    for p in glob.glob(glob.escape(final_path) + ".tmp*"):
+        m = re.fullmatch(r"\.tmp(\d+)_[0-9a-f]{8}", p[len(final_path):])
+        if not m:
+            continue
+        try:
+            alive = True
+            try:
+                os.kill(int(m.group(1)), 0)
+            except ProcessLookupError:
+                alive = False
+            except PermissionError:
+                pass
+            if not alive or time.time() - os.path.getmtime(p) > max_age_s:
+                os.remove(p)
+        except OSError:
+            pass
 
 
 def _write_file(path, t, z, y, x, dt, nplanes, plane_bytes, data_offset, data_bytes, xml, software, data):

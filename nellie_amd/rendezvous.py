@@ -18,11 +18,13 @@ from __future__ import annotations
 
 import glob
 import os
+import re
 import time
 import uuid
 
 _CACHE = {}
 _POLL_S = 0.01
+_OURS = re.compile(r"^\.nellie_(rdv_.+|[0-9a-f]{16}_.+)$")
 
 
 def _atomic_write(path: str, data: bytes):
@@ -46,6 +48,12 @@ class FileRendezvous:
         os.makedirs(self.dir, exist_ok=True)
         self.nonce = self._handshake()
         self._mine = []
+        # A name may be used again within one launch (a process that runs several files through `run()` reuses "im_info_built",
+        # "streamed_done", ...): every use of a name gets the next GENERATION, counted per name on every rank alike -- each rank either
+        # publishes or waits for a marker once per use, and takes part in every barrier -- so a marker or barrier file of use k is
+        # never mistaken for one of use k+1, and rank 0's late clean-up of use k cannot delete a file of use k+1.
+        self._gen = {}
+        self._unwaited = set()             # names this rank published in their current generation and has not waited for itself
 
     # ------------------------------------------------------------------ the handshake
     def _hs(self, name):
@@ -80,9 +88,11 @@ class FileRendezvous:
                 pass
             # leftovers of launches that died: markers of any other nonce older than a week are litter (a launch that is still running
             # after a week keeps working: its ranks only read markers while a stage starts or ends, minutes after they were written)
+            # (only names this module writes: `.nellie_<16 hex>_...` markers and `.nellie_rdv_...` handshake files -- the directory is
+            # usually the user's data directory)
             for p in glob.glob(os.path.join(self.dir, ".nellie_*")):
                 try:
-                    if f"_{job}_" not in p and time.time() - os.path.getmtime(p) > 7 * 86400:
+                    if _OURS.match(os.path.basename(p)) and f"_{job}_" not in p and time.time() - os.path.getmtime(p) > 7 * 86400:
                         os.remove(p)
                 except OSError:
                     pass
@@ -98,23 +108,43 @@ class FileRendezvous:
 
     # ------------------------------------------------------------------ markers of this launch
     def path(self, name: str) -> str:
-        return os.path.join(self.dir, f".nellie_{self.nonce}_{name}")
+        """The marker file of `name` in its current generation (what the last publish / wait of this rank used)."""
+        return self._path_g(name, self._gen.get(name, 0))
+
+    def _path_g(self, name: str, gen: int) -> str:
+        return os.path.join(self.dir, f".nellie_{self.nonce}_{name}.g{gen}")
+
+    def _next(self, name: str) -> int:
+        self._gen[name] = self._gen.get(name, 0) + 1
+        return self._gen[name]
 
     def publish(self, name: str, payload: bytes = b"1"):
-        _atomic_write(self.path(name), payload)
-        self._mine.append(self.path(name))
+        p = self._path_g(name, self._next(name))
+        self._unwaited.add(name)
+        _atomic_write(p, payload)
+        self._mine.append(p)
 
-    def wait(self, name: str, timeout_s: float = None) -> bytes:
+    def _wait_path(self, p: str, timeout_s: float = None) -> bytes:
         t0, limit = time.time(), self.timeout_s if timeout_s is None else timeout_s
         while True:
-            data = _read(self.path(name))
+            data = _read(p)
             if data is not None:
                 return data
             if time.time() - t0 > limit:
-                raise TimeoutError(f"rank {self.rank}: timed out waiting for {self.path(name)}")
+                raise TimeoutError(f"rank {self.rank}: timed out waiting for {p}")
             time.sleep(_POLL_S)
 
+    def wait(self, name: str, timeout_s: float = None) -> bytes:
+        if name in self._unwaited:         # the publisher reading its own marker: the same use
+            self._unwaited.discard(name)
+            gen = self._gen[name]
+        else:
+            gen = self._next(name)
+        return self._wait_path(self._path_g(name, gen), timeout_s)
+
     def remove(self, name: str):
+        """Removes the marker of `name`'s current generation (the publisher's job, after a barrier)."""
+        self._unwaited.discard(name)
         try:
             os.remove(self.path(name))
         except OSError:
@@ -122,17 +152,23 @@ class FileRendezvous:
 
     def barrier(self, name: str):
         """Every rank has reached this point when any rank returns.  Two rounds, so that rank 0 can clean up: the `a` files stay
-        until every rank has written its `b` file, i.e. has finished looking at the `a` files."""
-        self.publish(f"{name}_a_{self.rank}")
+        until every rank has written its `b` file, i.e. has finished looking at the `a` files.  The files carry the generation of
+        this use of `name`, so the next barrier of the same name starts from files nobody has written yet."""
+        gen = self._next("barrier:" + name)
+        f = lambda ab, r: os.path.join(self.dir, f".nellie_{self.nonce}_{name}.g{gen}_{ab}_{r}")
+        _atomic_write(f("a", self.rank), b"1")
         for r in range(self.world):
-            self.wait(f"{name}_a_{r}")
-        self.publish(f"{name}_b_{self.rank}")
+            self._wait_path(f("a", r))
+        _atomic_write(f("b", self.rank), b"1")
         if self.rank == 0:
             for r in range(self.world):
-                self.wait(f"{name}_b_{r}")
+                self._wait_path(f("b", r))
             for r in range(self.world):
-                self.remove(f"{name}_a_{r}")
-                self.remove(f"{name}_b_{r}")
+                for ab in ("a", "b"):
+                    try:
+                        os.remove(f(ab, r))
+                    except OSError:
+                        pass
 
 
 def rendezvous_for(spec, directory=None) -> FileRendezvous:

@@ -120,11 +120,12 @@ def join_slab_blobs(blobs):
     model below takes ~1 ms per rank on tables of a 2048 x 2048 plane, which an 8-rank step would pay three times); without it
     (CPU tests on a machine without the built library) the model itself.  Same nodes, same components, same numbering
     (tests/test_sharded_cpu.py compares them)."""
+    from nellie_amd import hipnative
     try:
-        from nellie_amd import hipnative
-        rank, root, val, comp, ncomp = hipnative.host_slab_join([np.ascontiguousarray(b, np.int32) for b in blobs])
-    except (RuntimeError, OSError):
-        return join_slab_tables([unpack_slab_tables(b) for b in blobs])
+        hipnative.load()
+    except (hipnative.LibraryUnavailable, OSError):      # only "there is no library": an error the library REPORTS (tables that
+        return join_slab_tables([unpack_slab_tables(b) for b in blobs])      # disagree, a table beyond its block) propagates
+    rank, root, val, comp, ncomp = hipnative.host_slab_join([np.ascontiguousarray(b, np.int32) for b in blobs])
     j = _Joined()
     j.rank, j.root, j.val, j.comp, j.ncomp = rank, root, val, comp, ncomp
     return j

@@ -522,7 +522,9 @@ def compute_vesselness(frame, dim_res, sigmas=None, alpha_sq=0.5, beta_sq=0.5,
             _, max_abs, frob = frobenius(h6)
             h_mask, thr = frob_mask(frob, frob_thresh, frob_thresh_division, max_samples)
         else:
-            max_abs, thr = None, None
+            # filtering.py:555-567: the normalisation is still computed, then h_mask = ones_like(image)
+            max_abs = (frobenius(h6)[1] if giv is None else float(giv["max_abs"]))
+            thr = None
             h_mask = np.ones_like(frame, dtype=bool)
         rec = dict(sigma=float(sigma), delta=delta, gamma=gamma, gamma_sq=gamma_sq,
                    max_abs=max_abs, frob_thr=thr, mask_count=int(h_mask.sum()))
@@ -807,7 +809,9 @@ def compute_vesselness_2d(frame, dim_res, sigmas=None, beta_sq=0.5, frob_thresh=
             _, max_abs, frob = frobenius_2d(h3)
             h_mask, thr = frob_mask(frob, frob_thresh, frob_thresh_division, max_samples)
         else:
-            max_abs, thr = None, None
+            # filtering.py:555-567: the normalisation is still computed, then h_mask = ones_like(image)
+            max_abs = (frobenius(h6)[1] if giv is None else float(giv["max_abs"]))
+            thr = None
             h_mask = np.ones_like(frame, dtype=bool)
         rec = dict(sigma=float(sigma), delta=delta, gamma=gamma, gamma_sq=gamma_sq, max_abs=max_abs, frob_thr=thr,
                    mask_count=int(h_mask.sum()))

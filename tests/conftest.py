@@ -70,6 +70,8 @@ def load_golden(name):
                 g["kwargs"][name_] = int(v)
             else:
                 g["kwargs"][name_] = v
+    # the `mask` argument of Filter.run() (filtering.py:1033) is a property of the run, not of the constructor: kept apart
+    g["run_mask"] = bool(g["kwargs"].pop("mask", 1.0))
     return g
 
 

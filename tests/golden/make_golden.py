@@ -59,8 +59,9 @@ def im_info(shape, dim_res):
                            dim_res=dict(dim_res))
 
 
-def run_filter_case(Filter, vol, dim_res, **kw):
-    """Reference Filter on one frame, recording the per-scale intermediates."""
+def run_filter_case(Filter, vol, dim_res, run_mask=True, **kw):
+    """Reference Filter on one frame, recording the per-scale intermediates.  run_mask: the `mask` argument of Filter.run()
+    (filtering.py:1033 -> :841 -> :566-567: False makes every h_mask all ones)."""
     f = Filter(im_info(vol.shape, dim_res), device="cpu", **kw)
     f._get_t()
     f._set_default_sigmas()
@@ -106,7 +107,7 @@ def run_filter_case(Filter, vol, dim_res, **kw):
     f._calculate_gamma = gamma_hook
     f._get_frob_mask = frob_hook
     f._compute_hessian = hess_hook
-    fr = f._run_frame(0)
+    fr = f._run_frame(0, mask=run_mask)
     total = float(np.sum(fr))
     if total > 0.0:
         pos = f._subsample_for_thresholds(fr)
@@ -139,7 +140,7 @@ def image_2d(shape, seed, dtype=np.float32):
     return make_image_2d(shape, seed, dtype=dtype)
 
 
-def run_filter_case_2d(Filter, img, dim_res, **kw):
+def run_filter_case_2d(Filter, img, dim_res, run_mask=True, **kw):
     """Reference Filter on one (Y, X) frame (im_info.no_z), recording the per-scale intermediates."""
     f = Filter(im_info_2d(img.shape, dim_res), device="cpu", **kw)
     f._get_t()
@@ -179,7 +180,7 @@ def run_filter_case_2d(Filter, img, dim_res, **kw):
         return h_mask, comps
 
     f._calculate_gamma, f._get_frob_mask, f._compute_hessian = gamma_hook, frob_hook, hess_hook
-    fr = f._run_frame(0)
+    fr = f._run_frame(0, mask=run_mask)
     if float(np.sum(fr)) > 0.0:
         pos = f._subsample_for_thresholds(fr)
         pthr = float(np.percentile(pos, 1)) if pos.size else np.nan
@@ -200,13 +201,15 @@ def run_label_case_2d(Label, img, frangi, dim_res, **kw):
                 labels=np.asarray(labels, dtype=np.int32))
 
 
-def twod_cases(Filter, Label):
+def twod_cases(Filter, Label, only_nomask=False):
     """2-D images (im_info.no_z): filtering.py:461-490, 675-690, 732-741, 772-796, 927-930; labelling.py:191-216."""
     iso = {"X": 0.1, "Y": 0.1, "Z": None, "T": 1.0}
     aniso = {"X": 0.2, "Y": 0.15, "Z": None, "T": 1.0}
 
-    def case(name, img, dim_res, gen=None, **kw):
+    def case(name, img, dim_res, gen=None, run_mask=True, **kw):
         meta = dict(dim_res=np.array([np.nan, dim_res["Y"], dim_res["X"]], dtype=np.float64))
+        if not run_mask:
+            meta["kw_mask"] = np.float64(0.0)
         if gen is None:
             meta["input"] = img
         else:   # large input: regenerate with nellie_amd.synthetic.make_image_2d(shape, seed); CRC pins it
@@ -216,13 +219,17 @@ def twod_cases(Filter, Label):
         for k, val in kw.items():
             meta["kw_" + k] = np.float64(np.nan if val is None else val)
         try:
-            out = run_filter_case_2d(Filter, img, dim_res, **kw)
+            out = run_filter_case_2d(Filter, img, dim_res, run_mask=run_mask, **kw)
         except Exception as exc:
             save(name, error_type=np.array(type(exc).__name__), error_msg=np.array(str(exc)), **meta)
             return
         lab = run_label_case_2d(Label, img, out["frangi"], dim_res)
         save(name, **meta, **out, **lab)
 
+    # Filter.run(mask=False) on a 2-D image: the blob response is then unmasked too (filtering.py:927-929)
+    case("twod_nomask_80x72_s26", image_2d((80, 72), 26), iso, run_mask=False)
+    if only_nomask:
+        return
     case("twod_iso_96x128_s20", image_2d((96, 128), 20), iso)
     case("twod_aniso_61x77_s21", image_2d((61, 77), 21), aniso)
     case("twod_u16_64x64_s22", image_2d((64, 64), 22, dtype=np.uint16), iso)
@@ -466,8 +473,10 @@ def main():
         return
     from nellie_amd.synthetic import make_volume, ISO_01, ANISO_03
 
-    def full_case(name, vol, dim_res, gen=None, **kw):
+    def full_case(name, vol, dim_res, gen=None, run_mask=True, **kw):
         meta = dict(dim_res=np.array([dim_res["Z"], dim_res["Y"], dim_res["X"]], dtype=np.float64))
+        if not run_mask:
+            meta["kw_mask"] = np.float64(0.0)
         for k, val in kw.items():
             meta["kw_" + k] = np.float64(np.nan if val is None else val)
         if gen is None:
@@ -477,13 +486,20 @@ def main():
             meta["input_seed"] = np.int64(gen)
             meta["input_crc"] = crc(vol)
         try:
-            out = run_filter_case(Filter, vol, dim_res, **kw)
+            out = run_filter_case(Filter, vol, dim_res, run_mask=run_mask, **kw)
         except Exception as exc:  # the reference itself raises on this input: pin the error
             save(name, error_type=np.array(type(exc).__name__), error_msg=np.array(str(exc)), **meta)
             return
         lab = run_label_case(Label, vol, out["frangi"], dim_res)
         save(name, **meta, **out, **lab)
 
+    # Filter.run(mask=False) (filtering.py:1033 -> 841 -> 566-567): every h_mask is all ones, every voxel of every scale is
+    # eigen-solved, masks stay all ones -- the response is the plain multiscale maximum
+    full_case("nomask_20x40x40_s9", make_volume((20, 40, 40), 9), ISO_01, run_mask=False)
+    full_case("nomask_aniso_16x36x44_s10", make_volume((16, 36, 44), 10), ANISO_03, run_mask=False)
+    if "--only-nomask" in sys.argv:
+        twod_cases(Filter, Label, only_nomask=True)
+        return
     # (i) isotropic 24x48x48, 3 seeds
     for seed in (0, 1, 2):
         full_case(f"iso_24x48x48_s{seed}", make_volume((24, 48, 48), seed), ISO_01)

@@ -100,9 +100,14 @@ def test_filter_golden(name, one_pass, pipes):
             pipe.filter(vol, p)
         return
     assert np.array_equal(np.array(p.resolved_sigmas()), g["sigmas"])
-    pipe.compute_vesselness(vol, p)
+    pipe.compute_vesselness(vol, p, mask=g["run_mask"])
     tr = pipe.trace
     assert len(tr.scales) == len(g["gamma"])
+    if not g["run_mask"]:
+        # Filter.run(mask=False) (filtering.py:566-567): every voxel of every scale goes to the eigen queue.  No bracket exists to
+        # speculate on, so neither the one-pass walk nor the device chain may have been used -- the known-threshold walk queues at
+        # full capacity (one entry per voxel of a wave's region), which cannot overflow
+        assert not any(sc.one_pass for sc in tr.scales) and all(sc.mask_count == vol.size for sc in tr.scales)
     for s, sc in enumerate(tr.scales):
         assert sc.gamma == g["gamma"][s], f"gamma scale {s}"
         assert sc.max_abs == g["max_abs"][s], f"max_abs scale {s}"
@@ -303,7 +308,7 @@ def test_filter_and_label_2d_golden(name, hip):
     pipe = pl.FramePipeline(img.shape)
     try:
         assert pipe.two_d and np.array_equal(np.array(p.resolved_sigmas()), g["sigmas"])
-        pipe.compute_vesselness(img, p)
+        pipe.compute_vesselness(img, p, mask=g["run_mask"])
         tr = pipe.trace
         assert len(tr.scales) == len(g["gamma"])
         for s, sc in enumerate(tr.scales):
@@ -585,6 +590,24 @@ def test_stage_api_filter_then_label(hip):
         ref_lab = orc.label_frame(np.asarray(im_info.store["frangi"][t]), ISO_01)
         assert np.array_equal(np.asarray(im_info.store["labels"][t]), ref_lab)
         assert im_info.store["labels"].dtype == np.int32
+
+
+def test_stage_api_filter_run_mask_false(hip):
+    """Filter.run(mask=False) (filtering.py:1033 -> 841 -> 566-567) through the drop-in class: every voxel of every scale is
+    eigen-solved, the product with the (all-ones) masks changes nothing, _mask_volume still applies."""
+    from fakes import ArrayImInfo
+    from nellie_amd.segmentation.filtering import Filter
+    from nellie_amd.synthetic import ANISO_03, make_volume
+    vols = np.stack([make_volume((18, 40, 52), 40 + t) for t in range(2)])
+    im_info = ArrayImInfo(vols, ANISO_03)
+    Filter(im_info).run(mask=False)
+    for t in range(2):
+        vess, masks = orc.compute_vesselness(vols[t], ANISO_03, mask=False)
+        assert masks.all()
+        ref_run = vess * masks
+        assert float(ref_run.sum()) > 0
+        ref, thr = orc.mask_volume(ref_run, return_thr=True)
+        assert_masked_close(np.asarray(im_info.store["frangi"][t]), ref, ref_run, thr)
 
 
 def test_reference_label_tests_on_the_hip_backend(hip):
@@ -974,7 +997,7 @@ def test_device_chain_on_the_golden_cases(name, hip):
         pipe = pl.FramePipeline(vol.shape)
         pipe._device_chain = chain
         try:
-            pipe.filter(vol, pl.FilterParams(dim_res=dr, **kw))
+            pipe.filter(vol, pl.FilterParams(dim_res=dr, **kw), mask=g["run_mask"])
             frames.append((pipe.download_frangi(), [(s.gamma, s.max_abs, s.frob_thr, s.mask_count, s.skipped) for s in pipe.trace.scales]))
         except ValueError as exc:
             frames.append(("raised", str(exc)))

@@ -275,57 +275,69 @@ def test_zslab_label_golden_on_hip_slabs(hip, world):
             assert [o[1] for o in out] == [int(g["labels"].max())] * world
 
 
-def test_zslab_label_random_on_hip_slabs(hip):
-    """Shells, tubes and specks across up to 6 interfaces: slabs == one context, bit for bit."""
+def _label_as_slabs_vs_one_context(shape, world, seed, n_shells=40):
     from nellie_amd import pipeline as pl
     from nellie_amd.pipeline import FilterParams
     from nellie_amd.sharded import ShardedFramePipeline, slab_range
     dr = {"X": 0.1, "Y": 0.1, "Z": 0.1, "T": 1.0}
+    rng = np.random.default_rng(seed)
+    zz, yy, xx = np.meshgrid(*[np.arange(s, dtype=np.float32) for s in shape], indexing="ij")
+    fr = np.zeros(shape, np.float32)
+    for _ in range(n_shells):
+        c = [rng.uniform(0, s) for s in shape]
+        r = rng.uniform(2.0, 9.0)
+        d = np.sqrt((zz - c[0]) ** 2 + (yy - c[1]) ** 2 + (xx - c[2]) ** 2)
+        fr[(d < r) & (d > r - rng.uniform(1.2, 3.0))] = 1.0
+    for _ in range(30):
+        y0, x0 = rng.integers(0, shape[1]), rng.integers(0, shape[2])
+        z0, z1 = sorted(rng.integers(0, shape[0], 2))
+        fr[z0:z1 + 1, y0:y0 + 2, x0:x0 + 2] = 1.0
+    fr[rng.random(shape) < 0.02] = 1.0
+    single = pl.FramePipeline(shape)
+    single.upload_frangi(fr)
+    ref_n = single.label(0.5, 12)
+    ref = single.download_labels()
+    single.close()
+    group = ThreadGroup(world)
+    out, errs = [None] * world, []
+
+    def worker(rank):
+        try:
+            o0, o1 = slab_range(shape[0], world, rank)
+            pipe = ShardedFramePipeline(shape, rank, world, lambda ctx: ThreadComm(group, rank), FilterParams(dim_res=dr), halo=2)
+            pipe.upload_frangi(fr[o0:o1])
+            n = pipe.label(0.5, 12)
+            out[rank] = (pipe.download_labels(), n)
+            pipe.close()
+        except Exception as exc:  # noqa: BLE001
+            errs.append(exc)
+            group.barrier.abort()
+
+    ts = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    if errs:
+        raise errs[0]
+    lab = np.concatenate([o[0] for o in out])
+    assert np.array_equal(lab, ref), f"world {world}: {int((lab != ref).sum())} voxels differ"
+    assert [o[1] for o in out] == [ref_n] * world and ref_n > 5
+
+
+def test_zslab_label_random_on_hip_slabs(hip):
+    """Shells, tubes and specks across up to 6 interfaces: slabs == one context, bit for bit."""
     for world, seed in ((2, 0), (5, 1), (7, 2)):
-        rng = np.random.default_rng(seed)
-        shape = (9 * world + 2, 70, 130)
-        zz, yy, xx = np.meshgrid(*[np.arange(s) for s in shape], indexing="ij")
-        fr = np.zeros(shape, np.float32)
-        for _ in range(40):
-            c = [rng.uniform(0, s) for s in shape]
-            r = rng.uniform(2.0, 9.0)
-            d = np.sqrt((zz - c[0]) ** 2 + (yy - c[1]) ** 2 + (xx - c[2]) ** 2)
-            fr[(d < r) & (d > r - rng.uniform(1.2, 3.0))] = 1.0
-        for _ in range(30):
-            y0, x0 = rng.integers(0, shape[1]), rng.integers(0, shape[2])
-            z0, z1 = sorted(rng.integers(0, shape[0], 2))
-            fr[z0:z1 + 1, y0:y0 + 2, x0:x0 + 2] = 1.0
-        fr[rng.random(shape) < 0.02] = 1.0
-        single = pl.FramePipeline(shape)
-        single.upload_frangi(fr)
-        ref_n = single.label(0.5, 12)
-        ref = single.download_labels()
-        single.close()
-        group = ThreadGroup(world)
-        out, errs = [None] * world, []
+        _label_as_slabs_vs_one_context((9 * world + 2, 70, 130), world, seed)
 
-        def worker(rank):
-            try:
-                o0, o1 = slab_range(shape[0], world, rank)
-                pipe = ShardedFramePipeline(shape, rank, world, lambda ctx: ThreadComm(group, rank), FilterParams(dim_res=dr), halo=2)
-                pipe.upload_frangi(fr[o0:o1])
-                n = pipe.label(0.5, 12)
-                out[rank] = (pipe.download_labels(), n)
-                pipe.close()
-            except Exception as exc:  # noqa: BLE001
-                errs.append(exc)
-                group.barrier.abort()
 
-        ts = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
-        for t in ts:
-            t.start()
-        for t in ts:
-            t.join()
-        if errs:
-            raise errs[0]
-        lab = np.concatenate([o[0] for o in out])
-        assert np.array_equal(lab, ref), f"world {world}: {int((lab != ref).sum())} voxels differ"
-        assert [o[1] for o in out] == [ref_n] * world and ref_n > 5
+@pytest.mark.parametrize("shape,world", [((291, 256, 72), 2), ((293, 256, 40), 3), ((131, 520, 64), 2)])
+def test_zslab_label_uneven_slabs_cut_shared_planes_alike(hip, shape, world):
+    """the tables the ranks exchange hold one entry per SEGMENT component of a shared plane, so both ranks have to
+    cut the plane into the same row bands.  Round 4 derived the bands from the rank's own plane count: 291 planes on 2 ranks are 147 +
+    146 (+ ghosts), which gave bands of 64 rows on one side and 32 on the other -- "slab tables disagree".  The bands of a slab are a
+    function of ny alone now."""
+    _label_as_slabs_vs_one_context(shape, world, seed=3, n_shells=60)
 
 
 def test_zslab_remove_edges_equals_single_gpu(hip):

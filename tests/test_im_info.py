@@ -42,6 +42,23 @@ def test_zero_filled_allocation_is_writable(tmp_path):
     assert again[1, 2, 3, 3] == 7.5 and again[0].sum() == 0
 
 
+def test_create_removes_the_temporaries_of_writers_that_died(tmp_path):
+    """create() writes under `<path>.tmp<pid>_<hex>` and moves the file into place; a process killed in between leaves the
+    temporary behind.  The next create() of the same path removes those whose writer is gone, and nothing else."""
+    import subprocess
+    import sys
+    path = str(tmp_path / "o.ome.tif")
+    dead = subprocess.Popen([sys.executable, "-c", "pass"])
+    dead.wait()
+    stale = f"{path}.tmp{dead.pid}_0123abcd"
+    mine = f"{path}.tmp{os.getpid()}_89abcdef"                 # a writer that is alive (this process) and recent: kept
+    other = f"{path}.tmpnotes"
+    for p in (stale, mine, other):
+        open(p, "wb").write(b"x")
+    ome_tiff.create(path, (1, 2, 4, 4), np.uint8, {"X": 1.0, "Y": 1.0, "Z": 1.0, "T": 1.0}, "d")
+    assert not os.path.exists(stale) and os.path.exists(mine) and os.path.exists(other) and os.path.exists(path)
+
+
 def test_iminfo_layout_matches_nellie_convention(tmp_path):
     vol = np.arange(2 * 3 * 4 * 5, dtype=np.float32).reshape(2, 3, 4, 5)
     im = ImInfo(vol, dim_res={"X": 0.1, "Y": 0.1, "Z": 0.25, "T": 1.5}, output_dir=str(tmp_path), name="cell")

@@ -32,7 +32,7 @@ def test_filter_matches_reference(name):
     sigmas = orc.default_sigmas(dr, **sig_kw)
     assert np.array_equal(np.array(sigmas), g["sigmas"])
     trace = []
-    vess, masks = orc.compute_vesselness(vol, dr, sigmas=sigmas, trace=trace, **kw)
+    vess, masks = orc.compute_vesselness(vol, dr, sigmas=sigmas, trace=trace, mask=g["run_mask"], **kw)
     assert len(trace) == len(g["gamma"])
     for s, rec in enumerate(trace):
         assert rec["gamma"] == g["gamma"][s]
@@ -42,6 +42,8 @@ def test_filter_matches_reference(name):
         if not np.isnan(g["frob_thr"][s]):
             assert rec["frob_thr"] == g["frob_thr"][s]
         assert rec["mask_count"] == g["mask_count"][s]
+        if not g["run_mask"]:
+            assert rec["mask_count"] == vol.size          # h_mask = ones_like(image) (filtering.py:566-567)
     fr = vess * masks
     assert np.array_equal(fr, g["run_frame"])
     if float(fr.sum()) > 0:
@@ -81,7 +83,7 @@ def test_filter_and_label_2d_match_reference(name):
     sigmas = orc.default_sigmas_2d(dr)
     assert np.array_equal(np.array(sigmas), g["sigmas"])
     trace = []
-    orc.compute_vesselness_2d(img, dr, sigmas=sigmas, trace=trace, **kw)
+    orc.compute_vesselness_2d(img, dr, sigmas=sigmas, trace=trace, mask=g["run_mask"], **kw)
     assert len(trace) == len(g["gamma"])
     for s, rec in enumerate(trace):
         assert rec["gamma"] == g["gamma"][s]
@@ -90,7 +92,7 @@ def test_filter_and_label_2d_match_reference(name):
         if not np.isnan(g["frob_thr"][s]):
             assert rec["frob_thr"] == g["frob_thr"][s]
         assert rec["mask_count"] == g["mask_count"][s]
-    fr = orc.run_frame_2d(img, dr, remove_edges_flag=rm, **kw)
+    fr = orc.run_frame_2d(img, dr, remove_edges_flag=rm, mask=g["run_mask"], **kw)
     assert np.array_equal(fr, g["run_frame"])
     if float(fr.sum()) > 0:
         out, thr = orc.mask_volume_2d(fr, return_thr=True)

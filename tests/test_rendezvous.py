@@ -58,7 +58,7 @@ def test_ranks_agree_on_a_fresh_nonce_despite_leftovers(tmp_path):
         assert len(nonces) == 1 and stale not in nonces
         assert all(o[2] == b"id-of-this-launch" for o in out)
     # two launches in a row never share a nonce, and a finished launch leaves no barrier / handshake files behind
-    left = [f for f in os.listdir(d) if "_end_" in f or f.startswith(f".nellie_rdv_{tag}")]
+    left = [f for f in os.listdir(d) if "_end." in f or f.startswith(f".nellie_rdv_{tag}")]
     assert left == [], left
 
 
@@ -70,6 +70,56 @@ def test_world_one_needs_nobody(tmp_path):
     rdv.barrier("b")
     rdv.remove("a")
     assert [f for f in os.listdir(tmp_path) if f.startswith(".nellie")] == []
+
+
+def test_a_name_can_be_used_again_within_one_launch(tmp_path):
+    """a process that runs several files through run() / run_streamed() / Markers.run() reuses the fixed names
+    ("im_info_built", "streamed_done", "markers_files_ready", ...).  Non-zero ranks leave a barrier right after their `b` file while
+    rank 0 deletes the files later: without a generation per use, rank 1 passes the second barrier on rank 0's stale `a` file and
+    rank 0 then deletes rank 1's new files -- both time out.  Also the publish / wait / remove cycle of a marker."""
+    import threading
+    from nellie_amd.rendezvous import FileRendezvous
+    world, errs, made = 3, [], {}
+
+    def rank(r):
+        try:
+            rdv = FileRendezvous(r, world, str(tmp_path), "again", timeout_s=20)
+            made[r] = rdv
+            for k in range(25):
+                if r == 0:
+                    rdv.publish("files_ready", str(k).encode())
+                else:
+                    assert rdv.wait("files_ready") == str(k).encode(), "a marker of an earlier use was picked up"
+                rdv.barrier("same")
+                if r == 0:
+                    rdv.remove("files_ready")
+                rdv.barrier("same")
+        except BaseException as exc:  # noqa: BLE001
+            errs.append((r, repr(exc)))
+
+    ts = [threading.Thread(target=rank, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(120)
+    assert not errs, errs
+    assert len({m.nonce for m in made.values()}) == 1
+    assert [f for f in os.listdir(tmp_path) if f.startswith(".nellie")] == []
+
+
+def test_the_litter_sweep_only_touches_this_modules_files(tmp_path):
+    """Rank 0 deletes week-old leftovers of dead launches -- and nothing else that happens to start with `.nellie_`."""
+    from nellie_amd.rendezvous import FileRendezvous
+    old = time.time() - 8 * 86400
+    names = {".nellie_deadbeefdeadbeef_payload.g1": False, ".nellie_rdv_29500_2_hello_1": False,       # ours, stale: swept
+             ".nellie_notes.txt": True, ".nellie_settings": True, ".nellie_DEADBEEFDEADBEEF_x": True}   # somebody else's: kept
+    for n in names:
+        p = os.path.join(str(tmp_path), n)
+        open(p, "w").write("x")
+        os.utime(p, (old, old))
+    FileRendezvous(0, 1, str(tmp_path), "sweep", timeout_s=5)
+    for n, kept in names.items():
+        assert os.path.exists(os.path.join(str(tmp_path), n)) == kept, n
 
 
 def _build_rank(rank, world, src, out_dir, port, q):
