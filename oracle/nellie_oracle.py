@@ -810,7 +810,7 @@ def compute_vesselness_2d(frame, dim_res, sigmas=None, beta_sq=0.5, frob_thresh=
             h_mask, thr = frob_mask(frob, frob_thresh, frob_thresh_division, max_samples)
         else:
             # filtering.py:555-567: the normalisation is still computed, then h_mask = ones_like(image)
-            max_abs = (frobenius(h6)[1] if giv is None else float(giv["max_abs"]))
+            max_abs = frobenius_2d(h3)[1]
             thr = None
             h_mask = np.ones_like(frame, dtype=bool)
         rec = dict(sigma=float(sigma), delta=delta, gamma=gamma, gamma_sq=gamma_sq, max_abs=max_abs, frob_thr=thr,

@@ -111,7 +111,7 @@ def test_filter_golden(name, one_pass, pipes):
     for s, sc in enumerate(tr.scales):
         assert sc.gamma == g["gamma"][s], f"gamma scale {s}"
         assert sc.max_abs == g["max_abs"][s], f"max_abs scale {s}"
-        if not np.isnan(g["frob_thr"][s]):
+        if g["run_mask"] and not np.isnan(g["frob_thr"][s]):      # (mask=False never derives a threshold)
             assert sc.frob_thr == g["frob_thr"][s], f"frob threshold scale {s}"
         assert sc.mask_count == (0 if sc.skipped else g["mask_count"][s]), f"mask count scale {s}"
         assert sc.skipped == (g["mask_count"][s] == 0)
@@ -313,7 +313,7 @@ def test_filter_and_label_2d_golden(name, hip):
         assert len(tr.scales) == len(g["gamma"])
         for s, sc in enumerate(tr.scales):
             assert sc.gamma == g["gamma"][s] and sc.max_abs == g["max_abs"][s]
-            if not np.isnan(g["frob_thr"][s]):
+            if g["run_mask"] and not np.isnan(g["frob_thr"][s]):      # (mask=False never derives a threshold)
                 assert sc.frob_thr == g["frob_thr"][s]
             assert sc.mask_count == (0 if sc.skipped else g["mask_count"][s])
         run_frame = pipe.download_frangi()[0]

@@ -39,7 +39,7 @@ def test_filter_matches_reference(name):
         assert np.uint32(zlib.crc32(rec["gauss"].tobytes())) == g["gauss_crc"][s], f"gauss scale {s}"
         assert np.array_equal(rec["gauss"][vol.shape[0] // 2], g["gauss_mid_planes"][s])
         assert rec["max_abs"] == g["max_abs"][s]
-        if not np.isnan(g["frob_thr"][s]):
+        if g["run_mask"] and not np.isnan(g["frob_thr"][s]):      # (mask=False never derives a threshold)
             assert rec["frob_thr"] == g["frob_thr"][s]
         assert rec["mask_count"] == g["mask_count"][s]
         if not g["run_mask"]:
@@ -89,7 +89,7 @@ def test_filter_and_label_2d_match_reference(name):
         assert rec["gamma"] == g["gamma"][s]
         assert np.uint32(zlib.crc32(rec["gauss"].tobytes())) == g["gauss_crc"][s], f"gauss scale {s}"
         assert rec["max_abs"] == g["max_abs"][s]
-        if not np.isnan(g["frob_thr"][s]):
+        if g["run_mask"] and not np.isnan(g["frob_thr"][s]):      # (mask=False never derives a threshold)
             assert rec["frob_thr"] == g["frob_thr"][s]
         assert rec["mask_count"] == g["mask_count"][s]
     fr = orc.run_frame_2d(img, dr, remove_edges_flag=rm, mask=g["run_mask"], **kw)
