@@ -42,20 +42,22 @@ HBM_COPY_GBS = 6290.0
 MEASURED_COPY_GBS = 5000.0     # what a read + write stream reaches on these boxes (profiles/r02_stream_patterns_*.txt: 4.7-5.65 TB/s)
 B_ALG_TOTAL = 301.0            # Filter 257 + Label 44 bytes/voxel
 # SURVEY.md 8(d)'s pass-structured bytes per voxel, split over the kernel groups of this build (one launch each):
-#   per scale: Z pass 8 + fused Y+X pass 16 (the model's two axis passes) = 24;
+#   per scale: the cascade step 24 (the model's three axis passes; one fused kernel since round 5 -- gauss_zyx -- or the Z pass 8 +
+#              the fused Y+X pass 16 where the radii have no fused instantiation);
 #              Hessian/eigen/Frangi pass 16 + mask pass 6 = 22, of which the walk (Gaussian read 4, frob_sq 4, mask pass 6)
 #              does 14 and the resolve kernel (running maximum 4 r + 4 w) 8;
 #   frame: product 9 + _mask_volume 18 = 27 (one fused epilogue here); Label 44.        5 (24 + 22) + 27 + 44 = 301
 B_ALG_KERNEL = {
-    "load": 8.0, "gauss_z": 8.0, "gauss_yx": 16.0, "gauss_y": 8.0, "gauss_x": 8.0,
+    "load": 8.0, "gauss_zyx": 24.0, "gauss_z": 8.0, "gauss_yx": 16.0, "gauss_y": 8.0, "gauss_x": 8.0,
     "hessian_stats": 4.0, "vesselness": 14.0, "vesselness_resolve": 8.0,
     "finish": 9.0, "mask_volume": 27.0, "label": 44.0,
 }
 B_ALG_PASS = 22.0              # walk + resolve: what SURVEY 8(d) calls the Hessian/eigen/Frangi + mask passes of a scale
 PMC_KERNEL_OF_GROUP = {"vesselness": ("hessian_v_kernel<2", "hessian_g_kernel<2"), "vesselness_resolve": ("vesselness_queue_kernel<true",),
                        "hessian_stats": ("hessian_v_kernel<0", "hessian_g_kernel<0"), "gauss_yx": ("gauss_yx_tile_kernel<4",),
+                       "gauss_zyx": ("gauss_zyx_kernel<4, 4",),
                        "gauss_z": ("gauss_march_z2_kernel<4", "gauss_march_kernel<0, 4")}
-GROUPS = ("load", "gauss_z", "gauss_yx", "gauss_y", "gauss_x", "sample", "hessian_stats", "vesselness", "vesselness_resolve",
+GROUPS = ("load", "gauss_zyx", "gauss_z", "gauss_yx", "gauss_y", "gauss_x", "sample", "hessian_stats", "vesselness", "vesselness_resolve",
           "finish", "mask_volume", "label", "halo")
 SLAB_PLANES = 128              # owned planes per GPU of the Z-slab run: BASELINE config 4 / 8
 SLAB_YX = (2048, 2048)

@@ -20,7 +20,7 @@ LIB = os.path.join(HERE, "libnellie_hip.so")
 # translation unit -> extra flags, compiled side by side.  The pair walk has its own unit because it wants the ILP-first instruction
 # scheduler, which costs the fused Gaussian pass 15 % (csrc/hv_launch.h); Filter + comm (nellie_hip.hip), Label / Network / streaming
 # (nellie_label.hip) and Markers (nellie_markers.hip) are separate so that an edit rebuilds one of them (nl_host.h holds what they share).
-SOURCES = {"nellie_hip.hip": [], "nellie_gauss.hip": [], "nellie_label.hip": [], "nellie_markers.hip": [],
+SOURCES = {"nellie_hip.hip": [], "nellie_gauss.hip": [], "nellie_gzyx.hip": [], "nellie_label.hip": [], "nellie_markers.hip": [],
            "nellie_hv.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
 # every include of the translation units: a stale library after editing one of them would silently test old kernels
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith((".inc", ".h"))) + [os.path.join("..", "..", "include", "nellie_amd.h")]

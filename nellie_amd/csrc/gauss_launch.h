@@ -32,3 +32,7 @@ bool gl_yx_dual(nl_ctx *c, bool acc, int r, const float *src, float *dst, const 
 // marching Y pass into tmp, then the stand-alone X pass into dst (acc: dst += result): large radii of Markers' LoG
 bool gl_y_then_x(nl_ctx *c, bool acc, int r, const float *src, float *tmp, float *dst, const VolGeom &v, i64 z0, i64 z1, const GaussWS &wy,
                  const GaussWS &wx);
+// the whole cascade step in one kernel (gauss_zyx.inc, nellie_gzyx.hip): Z radius rz with weights gz, Y and X radius r with the SAME
+// weights gyx (sigma_vec = (s / z_ratio, s, s), filtering.py:816-825); false: no instantiation for these radii / this shape
+bool gl_zyx_ok(const nl_ctx *c, int rz, int r, const float *dst);
+bool gl_zyx(nl_ctx *c, int rz, int r, const float *src, float *dst, const VolGeom &v, i64 z0, i64 z1, const GaussWS &gz, const GaussWS &gyx);

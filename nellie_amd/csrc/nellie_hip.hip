@@ -443,6 +443,7 @@ extern "C" int nl_filter_load(nl_ctx *c, const void *host, int dtype, int64_t z0
     c->gauss_ext = nullptr;
     c->ahead_pending = 0;
     c->fsq_cache_valid = 0;
+    NL_HIP(zero_small((char *)c->d_small + (52 << 10), 4, c->stream));
     const i64 plane = c->ny * c->nx;
     int rc = upload_convert(c, host, dtype, c->f[0] + z0 * plane, (z1 - z0) * plane, err, errlen);
     if (rc) return rc;
@@ -479,6 +480,7 @@ extern "C" int nl_filter_begin(nl_ctx *c, char *err, size_t errlen) {
     c->gauss_ext = nullptr;
     c->ahead_pending = 0;
     c->fsq_cache_valid = 0;
+    NL_HIP(zero_small((char *)c->d_small + (52 << 10), 4, c->stream));
     if (c->input_dtype == NL_F32 && !getenv("NELLIE_COPY_INPUT")) {
         // float32 frames are used where they lie: the cascade never writes its source (ping-pong volumes), so the
         // first Gaussian pass reads the resident input directly (the reference's gauss = frame view, filtering.py:811)
@@ -523,6 +525,26 @@ extern "C" int nl_gauss_step(nl_ctx *c, const double *wz, int rz, const double *
     const float *srcp = gauss_cur(c);       // the source of the next pass (the borrowed input before the first one)
     GaussW gw;
     int rc;
+    const bool can_yx = wy && wx && ry == rx && ry >= 1 && ry <= GM_MAX_R && ry <= c->ny && !getenv("NELLIE_NO_FUSED_YX");
+    bool fused_yx = false;
+    // the whole step in one kernel (gauss_zyx.inc) when the radii have an instantiation and Y and X share their weights, which is
+    // what Filter asks for (sigma_vec = (s / z_ratio, s, s)); NELLIE_GAUSS_FUSED=0: the Z march and the Y+X pass as two kernels
+    static int fused_zyx = -1;
+    if (fused_zyx < 0) { const char *e = getenv("NELLIE_GAUSS_FUSED"); fused_zyx = (e && !atoi(e)) ? 0 : 1; }
+    if (fused_zyx && wz && can_yx && gyx_tiled() && gl_zyx_ok(c, rz, ry, c->f[(src + 1) % 3]) &&
+        memcmp(wy, wx, (size_t)(2 * ry + 1) * sizeof(double)) == 0) {
+        GaussW gy;
+        if ((rc = fill_gw(gw, wz, rz, err, errlen)) || (rc = fill_gw(gy, wy, ry, err, errlen))) return rc;
+        if ((z0 - rz < 0 && c->gz0 > 0) || (z1 - 1 + rz >= c->nzl && c->gz0 + c->nzl < c->gnz))
+            return nl_fail(err, errlen, NL_EINVAL, "Z pass of radius %d on planes [%lld,%lld) reaches outside the local slab", rz, (i64)z0, (i64)z1);
+        const int dst = (src + 1) % 3;
+        ProfScope ps(c, "gauss_zyx");
+        (void)gl_zyx(c, rz, ry, srcp, c->f[dst], v, z0, z1, gauss_ws_of(gw), gauss_ws_of(gy));
+        NL_CHECK_LAUNCH();
+        src = dst; srcp = c->f[dst];
+        fused_yx = true;
+        wz = nullptr;
+    }
     if (wz) {
         if ((rc = fill_gw(gw, wz, rz, err, errlen))) return rc;
         // every tap must land inside the local slab unless it reflects at a true face
@@ -534,8 +556,7 @@ extern "C" int nl_gauss_step(nl_ctx *c, const double *wz, int rz, const double *
         NL_CHECK_LAUNCH();
         src = dst; srcp = c->f[dst];
     }
-    bool fused_yx = false;
-    if (wy && wx && ry == rx && ry >= 1 && ry <= GM_MAX_R && ry <= c->ny && !getenv("NELLIE_NO_FUSED_YX")) {
+    if (!fused_yx && can_yx) {
         GaussW gy, gx;
         if ((rc = fill_gw(gy, wy, ry, err, errlen))) return rc;
         if ((rc = fill_gw(gx, wx, rx, err, errlen))) return rc;
@@ -1145,6 +1166,7 @@ static float mask_threshold_on_fsq(float max_abs, int use_thr, float thr) {
     return r;
 }
 
+#define NL_NAN_FLAG_OFF (52 << 10)      // byte offset in d_small of the "NaN Hessian solved" word (VessP::nan_flag), zeroed per frame
 static VessP make_vessp(nl_ctx *c, float gamma_sq, float alpha_sq, float beta_sq, int use_thr, float thr) {
     VessP vp{};
     vp.gamma_sq = gamma_sq; vp.alpha_sq = alpha_sq; vp.beta_sq = beta_sq; vp.use_thr = use_thr; vp.thr = thr;
@@ -1153,6 +1175,8 @@ static VessP make_vessp(nl_ctx *c, float gamma_sq, float alpha_sq, float beta_sq
     vp.first = c->mask_slots_used == 0 ? 1 : 0;
     vp.fsq_min = mask_threshold_on_fsq(c->frob_max_abs, use_thr, thr);
     vp.m_inf = use_thr ? (c->frob_max_finite > thr) : (c->frob_max_finite > 0.0f);
+    vp.all_ones = (use_thr && thr == -INFINITY) ? 1 : 0;       // the host's way of saying mask=False (pipeline.py: thr_cmp = -inf)
+    vp.nan_flag = (unsigned int *)((char *)c->d_small + NL_NAN_FLAG_OFF);
     c->last_fsq_min = vp.fsq_min;
     return vp;
 }
@@ -2394,6 +2418,15 @@ extern "C" int nl_ctx_info(nl_ctx *c, const char *key, double *value) {
     else if (!strcmp(key, "last_spec_overflow")) *value = c->last_spec_overflow;
     else if (!strcmp(key, "last_label_sparse")) *value = c->last_label_sparse;
     else if (!strcmp(key, "device_bytes")) *value = (double)nl_ctx_bytes(c->nzl, c->ny, c->nx);
+    else if (!strcmp(key, "nan_hessian")) {
+        // Filter.run(mask=False) only: 1 if a Hessian with a NaN entry reached the eigen-solver since the frame began (waits for the stream)
+        if (hipSetDevice(c->device) != hipSuccess) return NL_EHIP;
+        unsigned int flag = 0;
+        if (c->side_pending && hipStreamSynchronize(c->side) != hipSuccess) return NL_EHIP;
+        if (hipMemcpyAsync(&flag, (char *)c->d_small + NL_NAN_FLAG_OFF, 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+            hipStreamSynchronize(c->stream) != hipSuccess) return NL_EHIP;
+        *value = flag ? 1.0 : 0.0;
+    }
     else return NL_EINVAL;
     return NL_OK;
 }

@@ -520,6 +520,12 @@ class FramePipeline:
                 settle()
                 pending = self.trace.scales[-1]      # its kernel overlaps the next scale's Gaussian; count read later
         settle()
+        if not mask and not self.two_d:
+            # filtering.py:581: with h_mask all ones EVERY Hessian goes to numpy.linalg.eigvalsh, and LAPACK gives up on a matrix with a
+            # NaN entry -- the reference's run ends in LinAlgError("Eigenvalues did not converge") (pinned: tests/golden nomask_nan_*).
+            # The device solves in closed form and would return 0 there; it reports such a voxel instead and the same exception is raised.
+            if self._reduce_sum(int(ctx.info("nan_hessian"))):
+                raise np.linalg.LinAlgError("Eigenvalues did not converge")
         return self._finish_frame(finish, p, mask)
 
     # Device-resident threshold chain (csrc/chain.inc): the scale loop without a host round trip; NELLIE_DEVICE_CHAIN=0: off

@@ -534,6 +534,11 @@ def compute_vesselness(frame, dim_res, sigmas=None, alpha_sq=0.5, beta_sq=0.5,
         if not np.any(h_mask):
             continue
         coords = np.where(h_mask)
+        if not mask and any(np.isnan(c[coords]).any() for c in h6):
+            # filtering.py:581 calls numpy.linalg.eigvalsh on every masked Hessian; with mask=False that includes the ones holding a NaN,
+            # on which LAPACK does not converge (observed with the reference itself: tests/golden/nomask_nan_*.npz pins the exception).
+            # With mask=True a NaN Hessian has a NaN Frobenius norm and never passes `frobenius_norm > threshold`.
+            raise np.linalg.LinAlgError("Eigenvalues did not converge")
         ev = eigvalsh3_f32(*[c[coords] for c in h6])
         ev = sort_by_abs(ev)
         v = frangi_response(ev, alpha_sq, beta_sq, gamma_sq).astype(np.float32, copy=False)

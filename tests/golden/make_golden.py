@@ -497,6 +497,11 @@ def main():
     # eigen-solved, masks stay all ones -- the response is the plain multiscale maximum
     full_case("nomask_20x40x40_s9", make_volume((20, 40, 40), 9), ISO_01, run_mask=False)
     full_case("nomask_aniso_16x36x44_s10", make_volume((16, 36, 44), 10), ANISO_03, run_mask=False)
+    # ... and what the reference does when a NaN (or a -Inf, whose differences are NaN) meets mask=False: LAPACK gives up
+    for tag, val in (("nan", np.nan), ("neginf", -np.inf)):
+        bad = make_volume((20, 40, 40), 9)
+        bad[10, 20, 20] = val
+        full_case(f"nomask_{tag}_20x40x40_s9", bad, ISO_01, run_mask=False)
     if "--only-nomask" in sys.argv:
         twod_cases(Filter, Label, only_nomask=True)
         return

@@ -96,8 +96,9 @@ def test_filter_golden(name, one_pass, pipes):
     pipe.one_pass = one_pass and pipe.ctx.one_pass_available()
     p = _params(g)
     if "error_type" in g:
-        with pytest.raises(ValueError, match=str(g["error_msg"])[:30]):
-            pipe.filter(vol, p)
+        with pytest.raises(ValueError, match=str(g["error_msg"])[:30]) as ei:       # (numpy.linalg.LinAlgError is a ValueError)
+            pipe.filter(vol, p, mask=g["run_mask"])
+        assert type(ei.value).__name__ == str(g["error_type"])
         return
     assert np.array_equal(np.array(p.resolved_sigmas()), g["sigmas"])
     pipe.compute_vesselness(vol, p, mask=g["run_mask"])
@@ -608,6 +609,61 @@ def test_stage_api_filter_run_mask_false(hip):
         assert float(ref_run.sum()) > 0
         ref, thr = orc.mask_volume(ref_run, return_thr=True)
         assert_masked_close(np.asarray(im_info.store["frangi"][t]), ref, ref_run, thr)
+
+
+@pytest.mark.parametrize("mask", [True, False], ids=["mask", "nomask"])
+@pytest.mark.parametrize("shape", [(20, 40, 40), (40, 96, 80)])
+def test_nonfinite_voxels_follow_the_reference(hip, shape, mask):
+    """NaN / -Inf / +Inf voxels in the input.  The reference has defined behaviour there: NaN > 0 is False, so such voxels leave the
+    threshold samples; an infinite Frobenius norm is replaced by the largest finite one (filtering.py:421-426); NaN / Inf responses
+    become 0 (:764-766); a +Inf that reaches a histogram makes numpy raise ValueError("... range ... is not finite"), which the
+    reference lets through; with mask=False a NaN Hessian reaches LAPACK, which raises LinAlgError.  The device follows all of it:
+    same support, responses within the Frangi tolerance, the same exceptions -- and it neither hangs nor leaves a NaN / Inf in the
+    frame (the device chain hands such frames to the synchronous path)."""
+    import warnings
+    from nellie_amd import pipeline as pl
+    from nellie_amd.synthetic import ISO_01, make_volume
+    pipe = pl.FramePipeline(shape)
+    try:
+        for val, where in ((np.nan, "one"), (-np.inf, "one"), (np.nan, "plane"), (np.nan, "all"), (np.inf, "one")):
+            vol = make_volume(shape, 9)
+            if where == "one":
+                vol[shape[0] // 2, shape[1] // 2, shape[2] // 2] = val
+            elif where == "plane":
+                vol[shape[0] // 2] = val
+            else:
+                vol[:] = val
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                if val == np.inf:
+                    with pytest.raises(ValueError):
+                        orc.filter_frame(vol.copy(), ISO_01, mask=mask)
+                    with pytest.raises(ValueError, match="is not finite"):
+                        pipe.filter(vol.copy(), pl.FilterParams(dim_res=ISO_01), mask=mask)
+                    continue
+                if not mask:
+                    # every Hessian goes to numpy.linalg.eigvalsh then, and LAPACK gives up on one with a NaN entry: the reference's
+                    # run ends in LinAlgError (pinned by the goldens nomask_nan_* / nomask_neginf_*); oracle and device raise the same
+                    with pytest.raises(np.linalg.LinAlgError, match="did not converge"):
+                        orc.filter_frame(vol.copy(), ISO_01, mask=False)
+                    with pytest.raises(np.linalg.LinAlgError, match="did not converge"):
+                        pipe.filter(vol.copy(), pl.FilterParams(dim_res=ISO_01), mask=False)
+                    continue
+                ref_run = orc.run_frame(vol.copy(), ISO_01, mask=mask)
+                pipe.filter(vol.copy(), pl.FilterParams(dim_res=ISO_01), mask=mask)
+            out = pipe.download_frangi()
+            assert np.isfinite(out).all(), f"{val} {where}: the frame holds NaN / Inf"
+            if float(ref_run.sum()) > 0:
+                ref, thr = orc.mask_volume(ref_run, return_thr=True)
+                assert_masked_close(out, ref, ref_run, thr)
+            else:
+                assert not out.any()
+        # the context is usable afterwards
+        vol = make_volume(shape, 10)
+        pipe.filter(vol, pl.FilterParams(dim_res=ISO_01), mask=mask)
+        assert_frangi_close(pipe.download_frangi(), orc.filter_frame(vol, ISO_01, mask=mask), "after the non-finite frames")
+    finally:
+        pipe.close()
 
 
 def test_reference_label_tests_on_the_hip_backend(hip):

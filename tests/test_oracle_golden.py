@@ -26,8 +26,9 @@ def test_filter_matches_reference(name):
     kw, sig_kw = _filter_kwargs(g)
     vol = g["input"]
     if "error_type" in g:
-        with pytest.raises(ValueError, match=str(g["error_msg"])[:30]):
-            orc.filter_frame(vol, dr, **kw)
+        with pytest.raises(ValueError, match=str(g["error_msg"])[:30]) as ei:       # (numpy.linalg.LinAlgError is a ValueError)
+            orc.filter_frame(vol, dr, mask=g["run_mask"], **kw)
+        assert type(ei.value).__name__ == str(g["error_type"])
         return
     sigmas = orc.default_sigmas(dr, **sig_kw)
     assert np.array_equal(np.array(sigmas), g["sigmas"])
