@@ -48,19 +48,43 @@ B_ALG_TOTAL = 301.0            # Filter 257 + Label 44 bytes/vox
 #              does 14 and the resolve kernel (running maximum 4 r + 4 w) 8;
 #   frame: product 9 + _mask_volume 18 = 27 (one fused epilogue here); Label 44.        5 (24 + 22) + 27 + 44 = 301
 B_ALG_KERNEL = {
-    "load": 8.0, "gauss_zyx": 24.0, "gauss_z": 8.0, "gauss_yx": 16.0, "gauss_y": 8.0, "gauss_x": 8.0,
+    "load": 8.0, "gauss_z": 8.0, "gauss_yx": 16.0, "gauss_y": 8.0, "gauss_x": 8.0,
     "hessian_stats": 4.0, "vesselness": 14.0, "vesselness_resolve": 8.0,
     "finish": 9.0, "mask_volume": 27.0, "label": 44.0,
 }
+GAUSS_ZYX = tuple(f"gauss_zyx<{rz},{r}>" for rz in range(1, 6) for r in range(3, 6))     # the fused cascade step, one group per instantiation
+B_ALG_KERNEL.update({g: 24.0 for g in GAUSS_ZYX})
 B_ALG_PASS = 22.0              # walk + resolve: what SURVEY 8(d) calls the Hessian/eigen/Frangi + mask passes of a scale
 PMC_KERNEL_OF_GROUP = {"vesselness": ("hessian_v_kernel<2", "hessian_g_kernel<2"), "vesselness_resolve": ("vesselness_queue_kernel<true",),
                        "hessian_stats": ("hessian_v_kernel<0", "hessian_g_kernel<0"), "gauss_yx": ("gauss_yx_tile_kernel<4",),
-                       "gauss_zyx": ("gauss_zyx_kernel<4, 4",),
+                       "gauss_zyx<4,4>": ("gauss_zyx_kernel<4, 4>",), "gauss_zyx<3,3>": ("gauss_zyx_kernel<3, 3>",),
+                       "gauss_zyx<5,5>": ("gauss_zyx_kernel<5, 5>",),
                        "gauss_z": ("gauss_march_z2_kernel<4", "gauss_march_kernel<0, 4")}
-GROUPS = ("load", "gauss_zyx", "gauss_z", "gauss_yx", "gauss_y", "gauss_x", "sample", "hessian_stats", "vesselness", "vesselness_resolve",
+GROUPS = ("load",) + GAUSS_ZYX + ("gauss_z", "gauss_yx", "gauss_y", "gauss_x", "sample", "hessian_stats", "vesselness", "vesselness_resolve",
           "finish", "mask_volume", "label", "halo")
 SLAB_PLANES = 128              # owned planes per GPU of the Z-slab run: BASELINE config 4 / 8
 SLAB_YX = (2048, 2048)
+
+
+def pmc_profile_file():
+    """The committed PMC profile the `traffic` / `counter_*` fields are read from (NOT measured in this run), repo-relative."""
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_hbm_bytes_1024cube.json")))
+    return os.path.relpath(files[-1], REPO) if files else None
+
+
+def sq_bound_of(kernel_group):
+    """What the committed SQ-counter pass says bounds the dominant kernel (profiles/r*_pmc_sq_*.json: {"kernel_group": ..., "bound":
+    "hbm" | "issue", ...}); the roofline object keeps the contract's vocabulary in `bound` and carries this verdict beside it."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_sq_*.json")), reverse=True):
+        try:
+            rec = json.load(open(f))
+        except ValueError:
+            continue
+        if rec.get("kernel_group") == kernel_group:
+            return {"limited_by": rec.get("bound"), "source": os.path.relpath(f, REPO), "evidence": rec.get("evidence")}
+    return None
 
 
 def pmc_traffic(group, shape):
@@ -88,6 +112,54 @@ def pmc_bytes_per_step(shape):
     if not files:
         return None
     return sum((2.0 * r["fetch_size_kb_per_launch"] + r["write_size_kb_per_launch"]) * 1024.0 * r.get("launches", 0) for r in json.load(open(files[-1])))
+
+
+class Control:
+    """The control plane of an N > 1 run -- a barrier, the maximum over the ranks, a value from rank 0 -- over the PRODUCT's own file
+    rendezvous (nellie_amd/rendezvous.py, the one `shard="env"` launches use): the bench needs torch for nothing (round 5; the
+    driver may still start the ranks with torch.distributed.run, only RANK / WORLD_SIZE / MASTER_PORT of its environment are read).
+    Barriers that bracket a timed region poll every 0.2 ms; every rank stops ITS clock after its own device sync, the maximum over
+    the ranks is taken afterwards -- what the barrier-bracketed region of the contract measures, without the polling interval in it."""
+
+    def __init__(self, rank, world, tag, timeout_s=600.0):
+        import tempfile
+        from nellie_amd.rendezvous import FileRendezvous
+        d = os.environ.get("NELLIE_RENDEZVOUS_DIR") or os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir(), "nellie_bench_rdv")
+        self.rank, self.world = rank, world
+        self.rdv = FileRendezvous(rank, world, d, tag=str(tag), timeout_s=timeout_s, poll_s=0.0002)
+
+    def barrier(self, name="b"):
+        self.rdv.barrier(name)
+
+    def allgather(self, name, obj):
+        return [json.loads(b.decode()) for b in self.rdv.allgather(name, json.dumps(obj).encode())]
+
+    def max(self, name, value):
+        return max(float(v) for v in self.allgather(name, float(value)))
+
+    def min_ints(self, name, values):
+        rows = self.allgather(name, [int(v) for v in values])
+        return [min(col) for col in zip(*rows)]
+
+    def from_rank0(self, name, make):
+        """rank 0's bytes (e.g. a communicator id), hex-encoded in transit"""
+        rows = self.allgather(name, make().hex() if self.rank == 0 else "")
+        return bytes.fromhex(rows[0])
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` started by hand: become the launcher (one process per GPU with RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT set, as torch.distributed.run would).  Returns the worst exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    return max(abs(p.wait()) for p in procs)
 
 
 def parse_args():
@@ -132,6 +204,9 @@ def cpu_baseline(shape, seed):
     n = float(np.prod(shape))
     return {
         "value": round(n / (t2 - t0) / 1e6, 4), "unit": "Mvoxel/s", "cores": 1, "kind": "port",
+        # the reference ITSELF (numpy / scipy path, 8 vCPU of the build container) on this sample's shape; the
+        # oracle is ~3x that because its eigen-solve is closed-form where the reference calls LAPACK per voxel
+        "reference_anchor_mvoxel_s": 0.391,
         "sample": f"oracle Filter+Label on a synthetic {shape[0]}x{shape[1]}x{shape[2]} float32 volume "
                   f"(BASELINE config 2 when 256x512x512; same generator, seed {seed}); Filter {n / (t1 - t0) / 1e6:.3f} Mvoxel/s, "
                   f"Label {n / (t2 - t1) / 1e6:.2f} Mvoxel/s, {float(np.mean(fr > 0)) * 100:.2f}% voxels survive, "
@@ -332,6 +407,9 @@ def roofline_of(groups, shape, steps, ms_per_step):
     out = {
         "bound": "hbm", "kernel": dom, "achieved": round(dom_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(dom_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
+        # where `traffic` and every counter_* figure below come from: a committed rocprofv3 --pmc pass of this command, not this run
+        "traffic_source": pmc_profile_file() if traffic is not None else None,
+        "limited_by_counters": sq_bound_of(dom),
         "achieved_by_counters": None if traffic is None else round(traffic / (groups[dom]["ms_avg"] * 1e-3) / 1e9, 1),
         "frac_of_measured_copy_peak": round(dom_gbs / HBM_COPY_GBS, 4),
         "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": round(groups[dom]["ms_avg"], 4),
@@ -378,19 +456,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world == 1 and args.gpus > 1:
         # started by hand as `python bench.py --gpus N`: become the launcher the contract describes (one rank per GPU)
-        import socket
-        import subprocess
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0))
-            port = sk.getsockname()[1]
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-        sys.exit(subprocess.call(cmd))
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     n_gpus = world if world > 1 else args.gpus
     dist = None
     if world > 1:
-        import torch.distributed as dist   # rendezvous + barrier + max-over-ranks only (control plane)
-        dist.init_process_group(backend="gloo", init_method="env://")
+        dist = Control(rank, world, tag="bench_" + os.environ.get("MASTER_PORT", "29500"))
 
     from nellie_amd import hipnative
     from nellie_amd import pipeline as pl
@@ -423,7 +493,7 @@ def main():
     def barrier():
         pipe.ctx.sync()
         if dist is not None:
-            dist.barrier()
+            dist.barrier("step")
 
     pipe.ctx.prof_enable(True)      # the event pairs of the per-group timers exist (and have been used) before the timed region
     for _ in range(args.warmup):
@@ -439,14 +509,12 @@ def main():
     n_labels = 0
     for _ in range(args.steps):
         n_labels = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    pipe.ctx.prof_enable(False)
+    pipe.ctx.sync()
+    elapsed = time.perf_counter() - t0             # this rank's clock stops after ITS device sync ...
     if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        dist.barrier("step")
+        elapsed = dist.max("elapsed", elapsed)     # ... and the figure is the maximum over the ranks (see Control)
+    pipe.ctx.prof_enable(False)
 
     groups = {}
     for name in GROUPS:
@@ -517,7 +585,7 @@ def main():
     # rank 0 prints the line either way.
     zslab = None
     if not args.no_zslab:
-        dist.barrier()                                     # rank 0 comes here late (CPU baseline): start the children together
+        dist.barrier("children")                           # rank 0 comes here late (CPU baseline): start the children together
         zslab = run_zslab_child(args, rank)
     if rank == 0:
         out["replicas"] = {"value": out["value"], "unit": "Mvoxel/s", "ms_per_step": out["ms_per_step"],
@@ -642,7 +710,6 @@ def zslab_run(dist, rank, world, local_rank, args):
     """ONE volume over `world` GPUs (nellie_amd/sharded.py).  First the timed run at 128 owned planes of 2048 x 2048 per GPU (a
     fresh process: see (2) below), then a small volume against a single-GPU run of the same volume (bit-for-bit equality of both
     outputs on every rank), then -- rank 0 -- the timed workload as `world` slab contexts on one GPU."""
-    import torch
     from nellie_amd import hipnative
     from nellie_amd import pipeline as pl
     from nellie_amd.sharded import RcclComm, ShardedFramePipeline, slab_range
@@ -650,9 +717,7 @@ def zslab_run(dist, rank, world, local_rank, args):
     p = pl.FilterParams(dim_res=ISO_01)
     min_area = pl.min_area_pixels_of(ISO_01)
     def fresh_uid():                    # an RCCL unique id opens exactly one communicator
-        box = [hipnative.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        return box[0]
+        return dist.from_rank0("uid", hipnative.comm_unique_id)
 
     res = {"world": world, "transport": "RCCL: ncclSend/ncclRecv (ghost planes, bit planes), ncclAllReduce (scalars, histograms), "
                                         "ncclAllGather (threshold samples, slab run tables); the per-step ghost-plane exchanges on a second communicator and stream"}
@@ -689,7 +754,7 @@ def zslab_run(dist, rank, world, local_rank, args):
         gc.collect(); gc.freeze()      # the interpreter's cyclic collector out of the timed region (as timeit does): see DESIGN.md section 5
     pipe.ctx.prof_reset()
     pipe.ctx.sync()
-    dist.barrier()
+    dist.barrier("zstep")
     t0 = time.perf_counter()
     each = []
     for _ in range(args.steps):
@@ -697,12 +762,10 @@ def zslab_run(dist, rank, world, local_rank, args):
         n_labels = step()
         each.append(round((time.perf_counter() - t1) * 1e3, 2))
     pipe.ctx.sync()
-    dist.barrier()
     elapsed = time.perf_counter() - t0
+    dist.barrier("zstep")
+    elapsed = dist.max("zelapsed", elapsed)
     pipe.ctx.prof_enable(False)
-    t = torch.tensor([elapsed], dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
     groups = {}
     for name in GROUPS:
         ms, k = pipe.ctx.prof_get(name)
@@ -764,8 +827,7 @@ def zslab_run(dist, rank, world, local_rank, args):
     n_ref = single.label(single.frangi_threshold(), min_area)
     ok_lab = bool(np.array_equal(single.download_labels()[o0:o1], lab)) and n_ref == n_small
     single.close()
-    flags = torch.tensor([int(ok_fr), int(ok_lab)], dtype=torch.int64)
-    dist.all_reduce(flags, op=dist.ReduceOp.MIN)
+    flags = dist.min_ints("equal", [int(ok_fr), int(ok_lab)])
     res["equality_check"] = {"volume": list(gshape), "labels": int(n_small), "frangi_equal": bool(flags[0]), "labels_equal": bool(flags[1])}
     res["frangi_equal"], res["labels_equal"] = bool(flags[0]), bool(flags[1])
 
@@ -786,9 +848,7 @@ def zslab_child_main(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = 0 if args.share_device else int(os.environ.get("LOCAL_RANK", "0"))
-    import datetime
-    import torch.distributed as dist
-    dist.init_process_group(backend="gloo", init_method="env://", timeout=datetime.timedelta(seconds=180))
+    dist = Control(rank, world, tag="zslab_" + os.environ.get("MASTER_PORT", "29500"), timeout_s=180.0)
     fake = os.environ.get("NELLIE_ZSLAB_FAKE", "")      # tests of the isolation: "crash" (the last rank aborts), "hang"
     if fake == "crash" and rank == world - 1:
         os.abort()

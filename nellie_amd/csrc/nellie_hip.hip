@@ -538,7 +538,9 @@ extern "C" int nl_gauss_step(nl_ctx *c, const double *wz, int rz, const double *
         if ((z0 - rz < 0 && c->gz0 > 0) || (z1 - 1 + rz >= c->nzl && c->gz0 + c->nzl < c->gnz))
             return nl_fail(err, errlen, NL_EINVAL, "Z pass of radius %d on planes [%lld,%lld) reaches outside the local slab", rz, (i64)z0, (i64)z1);
         const int dst = (src + 1) % 3;
-        ProfScope ps(c, "gauss_zyx");
+        char scope[32];
+        snprintf(scope, sizeof scope, "gauss_zyx<%d,%d>", rz, ry);        // one timer per kernel instantiation, as a profiler lists them
+        ProfScope ps(c, scope);
         (void)gl_zyx(c, rz, ry, srcp, c->f[dst], v, z0, z1, gauss_ws_of(gw), gauss_ws_of(gy));
         NL_CHECK_LAUNCH();
         src = dst; srcp = c->f[dst];

@@ -13,7 +13,7 @@ pipe = pl.FramePipeline(shape)
 pipe.load_input(make_volume(shape, 2345))
 p = pl.FilterParams(dim_res=ISO_01)
 ma = pl.min_area_pixels_of(ISO_01)
-GROUPS = ("gauss_zyx", "gauss_z", "gauss_yx", "sample", "vesselness", "vesselness_resolve", "mask_volume", "label")
+GROUPS = ("gauss_zyx<4,4>", "gauss_zyx<3,3>", "gauss_zyx<5,5>", "gauss_zyx<1,4>", "gauss_zyx<1,3>", "gauss_zyx<2,5>", "gauss_z", "gauss_yx", "sample", "vesselness", "vesselness_resolve", "mask_volume", "label")
 
 
 def step():

@@ -27,7 +27,7 @@ def child(shape, reps):
     pipe.ctx.prof_enable(False)
     out = {"ms_per_step": round(dt, 3), "labels": int(n), "npos": int(pipe.trace.n_positive),
            "mask_counts": [int(sc.mask_count) for sc in pipe.trace.scales], "one_pass": [bool(sc.one_pass) for sc in pipe.trace.scales]}
-    for g in ("gauss_zyx", "gauss_z", "gauss_yx", "sample", "hessian_stats", "vesselness", "vesselness_resolve", "mask_volume", "label"):
+    for g in ("gauss_zyx<4,4>", "gauss_zyx<3,3>", "gauss_zyx<5,5>", "gauss_zyx<1,4>", "gauss_zyx<1,3>", "gauss_zyx<2,5>", "gauss_z", "gauss_yx", "sample", "hessian_stats", "vesselness", "vesselness_resolve", "mask_volume", "label"):
         ms, k = pipe.ctx.prof_get(g)
         if k:
             out[g] = round(ms / reps, 3)

@@ -30,7 +30,7 @@ pipe.ctx.sync(); dt = (time.perf_counter() - t0) / n
 pipe.ctx.prof_reset(); pipe.ctx.prof_enable(True)
 step(); pipe.ctx.sync(); pipe.ctx.prof_enable(False)
 groups = {}
-for g in ("gauss_zyx", "gauss_z", "gauss_yx", "sample", "hessian_stats", "vesselness", "vesselness_resolve", "finish", "log2d", "mask_volume", "label", "load"):
+for g in ("gauss_zyx<4,4>", "gauss_zyx<3,3>", "gauss_zyx<5,5>", "gauss_zyx<1,4>", "gauss_zyx<1,3>", "gauss_zyx<2,5>", "gauss_z", "gauss_yx", "sample", "hessian_stats", "vesselness", "vesselness_resolve", "finish", "log2d", "mask_volume", "label", "load"):
     try:
         ms, k = pipe.ctx.prof_get(g)
         if k:

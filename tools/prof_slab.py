@@ -80,7 +80,7 @@ if prof is not None:
     pstats.Stats(prof).sort_stats("tottime").print_stats(25)
 ctx.prof_enable(False)
 groups = {}
-for g in ("gauss_zyx", "gauss_z", "gauss_yx", "sample", "hessian_stats", "vesselness", "vesselness_resolve", "mask_volume", "label", "halo"):
+for g in ("gauss_zyx<4,4>", "gauss_zyx<3,3>", "gauss_zyx<5,5>", "gauss_zyx<1,4>", "gauss_zyx<1,3>", "gauss_zyx<2,5>", "gauss_z", "gauss_yx", "sample", "hessian_stats", "vesselness", "vesselness_resolve", "mask_volume", "label", "halo"):
     ms, k = ctx.prof_get(g)
     if k:
         groups[g] = round(ms / reps, 3)
