@@ -35,4 +35,6 @@ bool gl_y_then_x(nl_ctx *c, bool acc, int r, const float *src, float *tmp, float
 // the whole cascade step in one kernel (gauss_zyx.inc, nellie_gzyx.hip): Z radius rz with weights gz, Y and X radius r with the SAME
 // weights gyx (sigma_vec = (s / z_ratio, s, s), filtering.py:816-825); false: no instantiation for these radii / this shape
 bool gl_zyx_ok(const nl_ctx *c, int rz, int r, const float *dst);
-bool gl_zyx(nl_ctx *c, int rz, int r, const float *src, float *dst, const VolGeom &v, i64 z0, i64 z1, const GaussWS &gz, const GaussWS &gyx);
+// zero_out (may be NULL): a volume filled with zeros on planes [z0, z1) in passing (the running scale maximum of a frame's first step)
+bool gl_zyx(nl_ctx *c, int rz, int r, const float *src, float *dst, const VolGeom &v, i64 z0, i64 z1, const GaussWS &gz, const GaussWS &gyx,
+            float *zero_out);

@@ -444,6 +444,7 @@ extern "C" int nl_filter_load(nl_ctx *c, const void *host, int dtype, int64_t z0
     c->ahead_pending = 0;
     c->fsq_cache_valid = 0;
     NL_HIP(zero_small((char *)c->d_small + (52 << 10), 4, c->stream));
+    c->vmax_zero_lo = c->vmax_zero_hi = 0;
     const i64 plane = c->ny * c->nx;
     int rc = upload_convert(c, host, dtype, c->f[0] + z0 * plane, (z1 - z0) * plane, err, errlen);
     if (rc) return rc;
@@ -481,6 +482,7 @@ extern "C" int nl_filter_begin(nl_ctx *c, char *err, size_t errlen) {
     c->ahead_pending = 0;
     c->fsq_cache_valid = 0;
     NL_HIP(zero_small((char *)c->d_small + (52 << 10), 4, c->stream));
+    c->vmax_zero_lo = c->vmax_zero_hi = 0;
     if (c->input_dtype == NL_F32 && !getenv("NELLIE_COPY_INPUT")) {
         // float32 frames are used where they lie: the cascade never writes its source (ping-pong volumes), so the
         // first Gaussian pass reads the resident input directly (the reference's gauss = frame view, filtering.py:811)
@@ -541,7 +543,12 @@ extern "C" int nl_gauss_step(nl_ctx *c, const double *wz, int rz, const double *
         char scope[32];
         snprintf(scope, sizeof scope, "gauss_zyx<%d,%d>", rz, ry);        // one timer per kernel instantiation, as a profiler lists them
         ProfScope ps(c, scope);
-        (void)gl_zyx(c, rz, ry, srcp, c->f[dst], v, z0, z1, gauss_ws_of(gw), gauss_ws_of(gy));
+        // the frame's first step also zeroes the running scale maximum on its planes (see gauss_zyx.inc: zero_out)
+        static int zero_in_passing = -1;
+        if (zero_in_passing < 0) { const char *e = getenv("NELLIE_ZERO_IN_GAUSS"); zero_in_passing = (e && !atoi(e)) ? 0 : 1; }
+        const bool zero = zero_in_passing && c->mask_slots_used == 0 && c->vmax_zero_hi == 0 && c->stream != c->side;
+        (void)gl_zyx(c, rz, ry, srcp, c->f[dst], v, z0, z1, gauss_ws_of(gw), gauss_ws_of(gy), zero ? c->f[c->i_vmax] : nullptr);
+        if (zero) { c->vmax_zero_lo = z0; c->vmax_zero_hi = z1; }
         NL_CHECK_LAUNCH();
         src = dst; srcp = c->f[dst];
         fused_yx = true;
@@ -1169,6 +1176,8 @@ static float mask_threshold_on_fsq(float max_abs, int use_thr, float thr) {
 }
 
 #define NL_NAN_FLAG_OFF (52 << 10)      // byte offset in d_small of the "NaN Hessian solved" word (VessP::nan_flag), zeroed per frame
+// the planes [z0, z1) of the vesselness volume are all zero already: the frame's first cascade step did it in passing (gauss_zyx.inc)
+static inline bool vmax_is_zero(const nl_ctx *c, i64 z0, i64 z1) { return c->vmax_zero_hi > 0 && c->vmax_zero_lo <= z0 && z1 <= c->vmax_zero_hi; }
 static VessP make_vessp(nl_ctx *c, float gamma_sq, float alpha_sq, float beta_sq, int use_thr, float thr) {
     VessP vp{};
     vp.gamma_sq = gamma_sq; vp.alpha_sq = alpha_sq; vp.beta_sq = beta_sq; vp.use_thr = use_thr; vp.thr = thr;
@@ -1320,8 +1329,9 @@ static int resolve_enqueue(nl_ctx *c, VessP vp, unsigned long long *d_cnt, const
         vp.have_prev = k_scale > 0;
         unsigned long long *cm = (unsigned long long *)c->m[0] + (i64)(k_scale & 1) * slot_words;
         const unsigned long long *pm = (unsigned long long *)c->m[0] + (i64)((k_scale + 1) & 1) * slot_words;
-        if (vp.first)
+        if (vp.first && !vmax_is_zero(c, z0, z1))
             NL_HIP(hipMemsetAsync(c->f[c->i_vmax] + z0 * plane, 0, (size_t)(z1 - z0) * plane * 4, st));
+        c->vmax_zero_hi = 0;
         vesselness_queue_kernel<true><<<resolve_grid((c->spec_nregions + 3) / 4), 256, 0, st>>>(
             (const float4 *)c->d_vq, c->d_vq_count, c->spec_nregions, c->f[c->i_vmax], z0 * plane, vp, cm, pm, wpr, (int)c->ny, (int)c->nx, z0, d_cnt,
             dev_params);
@@ -1563,7 +1573,8 @@ extern "C" int nl_vesselness_step(nl_ctx *c, float gamma_sq, float alpha_sq, flo
         vp.have_prev = k_scale > 0;
         unsigned long long *cm = (unsigned long long *)c->m[0] + (i64)(k_scale & 1) * slot_words;
         const unsigned long long *pm = (unsigned long long *)c->m[0] + (i64)((k_scale + 1) & 1) * slot_words;
-        if (vp.first) NL_HIP(hipMemsetAsync(c->f[c->i_vmax], 0, (size_t)c->n * 4, c->stream));
+        if (vp.first && !vmax_is_zero(c, 0, c->nzl)) NL_HIP(hipMemsetAsync(c->f[c->i_vmax], 0, (size_t)c->n * 4, c->stream));
+        c->vmax_zero_hi = 0;
         vesselness2d_kernel<<<grid2d_rows((i64)wpr * 64, c->ny), 256, 0, c->stream>>>(gauss_cur(c), c->f[c->i_vmax], cm, pm, wpr, geom(c), hessp(c), vp, d_cnt);
         NL_CHECK_LAUNCH();
     } else {
@@ -1580,8 +1591,9 @@ extern "C" int nl_vesselness_step(nl_ctx *c, float gamma_sq, float alpha_sq, flo
         const i64 plane = c->ny * c->nx;
         const i64 planes_per_launch = (i64)c->vq_chunks * HM_ZCHUNK;
         const VQueue vq{(float4 *)c->d_vq, c->d_vq_count};
-        if (vp.first)      // vesselness = zeros (filtering.py:807); only voxels alive in every mask are ever read again
+        if (vp.first && !vmax_is_zero(c, z0, z1))      // vesselness = zeros (filtering.py:807); only voxels alive in every mask are ever read again
             NL_HIP(hipMemsetAsync(c->f[c->i_vmax] + z0 * plane, 0, (size_t)(z1 - z0) * plane * 4, c->stream));
+        c->vmax_zero_hi = 0;
         const int rs = hv_rs(c);
         const int ty = rs ? 2 * rs : hm_ty();
         const int nty = (int)((c->ny + ty - 1) / ty);
@@ -1700,8 +1712,9 @@ extern "C" int nl_filter_finish(nl_ctx *c, int64_t z0, int64_t z1, int64_t *n_po
     unsigned long long *d_cnt = (unsigned long long *)c->d_small;
     NL_HIP(zero_small(d_cnt, 8, c->stream));
     const i64 plane = c->ny * c->nx;
-    if (c->mask_slots_used == 0)       // every scale was skipped: vesselness was never written
+    if (c->mask_slots_used == 0 && !vmax_is_zero(c, z0, z1))       // every scale was skipped: vesselness was never written
         NL_HIP(hipMemsetAsync(c->f[c->i_vmax] + z0 * plane, 0, (size_t)(z1 - z0) * plane * 4, c->stream));
+    c->vmax_zero_hi = 0;
     {
         ProfScope ps(c, "finish");
         const int wpr = (int)((c->nx + 63) / 64);

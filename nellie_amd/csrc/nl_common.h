@@ -104,6 +104,8 @@ struct nl_ctx {
     double chk_spacing[3] = {0, 0, 0};
     float frob_max_abs = 1.0f, frob_max_finite = 0.0f;
     int frangi_ready = 0;
+    i64 vmax_zero_lo = 0, vmax_zero_hi = 0;   // planes of the vesselness volume a cascade step of this frame has zeroed in passing and nothing
+                               // has written since (gauss_zyx.inc: zero_out); the first evaluated scale then skips its own fill
     int mask_slots_used = 0;   // per-scale h_mask bit planes written since the frame began
     hipEvent_t ev_chain = nullptr; int chain_copy_pending = 0;
     i64 gp_total = -1; float *gp_stage = nullptr;   // nl_sample_gather_positive_begin .. _end

@@ -323,7 +323,7 @@ static void bench_lib(const float *in, float *out, const float *ref, const VolGe
     const int ntx = (int)((v.nx + 63) / 64), nty = (int)((v.ny + TY - 1) / TY), nzc = (int)((v.nzl + zchunk - 1) / zchunk);
     const unsigned nb = (unsigned)ntx * nty * nzc;
     CK(hipMemset(out, 0xff, (size_t)v.nzl * v.ny * v.nx * 4));
-    auto f = [&]() { gauss_zyx_kernel<R, R><<<nb, GZ_NT>>>(in, out, v, 0, (int)v.nzl, zchunk, gz, gyx, ntx, nty); };
+    auto f = [&]() { gauss_zyx_kernel<R, R><<<nb, GZ_NT>>>(in, out, v, 0, (int)v.nzl, zchunk, gz, gyx, ntx, nty, nullptr); };
     const float best = tm.run(f, 5);
     CK(hipGetLastError());
     CK(hipMemset(d_cnt, 0, 8));
