@@ -344,11 +344,16 @@ def io_figures(pl, hipnative, shape, p, min_area, vol):
     # into the same dense page-locked arrays, zero-filling them: every byte of both outputs is written)
     blob = hipnative.PinnedArray((2 * int(n) + 4096,), np.uint8)
     threads = max(1, min(16, (os.cpu_count() or 2) // 2))
+    import threading
     for rep in range(2):
         pin_fr.array[...] = 1.0
         pin_lab.array[...] = -1
         pipe.ctx.sync()
         t0 = time.perf_counter()
+        # the zero fill of both dense outputs (8 B/voxel of host memory traffic) runs on host threads WHILE the frame travels and the
+        # GPU works (round 5); the unpack then only scatters the non-zero items.  Everything inside the timed region.
+        zero = threading.Thread(target=lambda: (hipnative.host_zero(pin_fr.array, threads), hipnative.host_zero(pin_lab.array, threads)))
+        zero.start()
         pipe.load_input(pin_in.array)
         pipe.filter(None, p)
         pipe.label(pipe.frangi_threshold(), min_area)
@@ -356,13 +361,16 @@ def io_figures(pl, hipnative, shape, p, min_area, vol):
         if nb:
             pipe.ctx.outputs_fetch_packed_async(blob, nb)
             pipe.ctx.outputs_wait()
-            hipnative.outputs_unpack(blob, nb, pin_fr.array, pin_lab.array, zero_fill=True, threads=threads)
+            zero.join()
+            hipnative.outputs_unpack(blob, nb, pin_fr.array, pin_lab.array, zero_fill=False, threads=threads)
+        zero.join()
         dtp = time.perf_counter() - t0
     if nb:
         out["pinned_host_to_host_packed_mvoxel_s"] = round(n / dtp / 1e6, 1)
         out["pinned_host_to_host_packed_ms"] = round(dtp * 1e3, 1)
         out["packed_bytes_over_pcie_per_voxel"] = round(4.0 + nb / n, 3)
         out["packed_unpack_threads"] = threads
+        out["packed_zero_fill"] = "on host threads, concurrent with the upload and the GPU step (inside the timed region)"
     blob.free()
     pipe.close()
     for a in (pin_in, pin_fr, pin_lab):

@@ -512,6 +512,11 @@ int nl_outputs_pack(nl_ctx *ctx, int with_labels, int64_t *nbytes, char *err, si
 int nl_outputs_fetch_packed_async(nl_ctx *ctx, void *host_pinned, int64_t nbytes, char *err, size_t errlen);
 int nl_outputs_unpack(const void *blob, int64_t nbytes, float *frangi, int32_t *labels, int64_t dst_elems, int zero_fill,
                       int threads, char *err, size_t errlen);
+/* Host code: zero `bytes` bytes at `dst` with `threads` host threads.  For callers that unpack into arrays of their own (not
+   freshly created sparse files): the fill of both dense outputs -- 8 B/voxel of host memory traffic, most of what an unpack
+   with zero_fill = 1 takes -- can run on host threads WHILE the GPU still works on the frame, and the unpack (zero_fill = 0)
+   then only scatters the non-zero items. */
+int nl_host_zero(void *dst, int64_t bytes, int threads, char *err, size_t errlen);
 
 /* ------------------------------------------------------------------ test hooks -------- */
 /* Known-answer hook for the fused device routine (filtering.py:581-585 + 744-766): for n explicit

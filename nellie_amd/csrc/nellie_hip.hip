@@ -283,6 +283,7 @@ extern "C" int nl_ctx_destroy(nl_ctx *c) {
     if (c->d_fsq_cache) hipFree(c->d_fsq_cache);
     if (c->d_vq) hipFree(c->d_vq);
     if (c->mk_scratch) hipFree(c->mk_scratch);
+    if (c->mk_act) hipFree(c->mk_act);
     if (c->d_vq_count) hipFree(c->d_vq_count);
     if (c->d_rows) hipFree(c->d_rows);
     if (c->d_ag) hipFree(c->d_ag);

@@ -1203,6 +1203,21 @@ extern "C" int nl_outputs_unpack(const void *blob_, int64_t nbytes, float *frang
 }
 
 
+extern "C" int nl_host_zero(void *dst, int64_t bytes, int threads, char *err, size_t errlen) {
+    if (!dst || bytes < 0) return nl_fail(err, errlen, NL_EINVAL, "bad zero-fill request");
+    const int nt = threads < 1 ? 1 : (threads > 64 ? 64 : threads);
+    const size_t chunk = (((size_t)bytes + nt - 1) / nt + 4095) & ~(size_t)4095;
+    std::vector<std::thread> pool;
+    for (int t = 0; t < nt; ++t) {
+        const size_t a = (size_t)t * chunk;
+        if (a >= (size_t)bytes) break;
+        const size_t b = a + chunk < (size_t)bytes ? a + chunk : (size_t)bytes;
+        pool.emplace_back([=]() { memset((char *)dst + a, 0, b - a); });
+    }
+    for (auto &th : pool) th.join();
+    return NL_OK;
+}
+
 // used by nl_mask_volume* in nellie_hip.hip (the kernel lives in this unit: label_runs.inc)
 void nl_launch_threshold_pack(unsigned int grid, hipStream_t st, const float *f, const unsigned long long *support, unsigned long long *bits,
                               int has_thr, float thr, int nx, i64 nrows, int wpr, const float *thr_dev) {

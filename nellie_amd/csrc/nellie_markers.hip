@@ -30,6 +30,7 @@ extern "C" int nl_markers_begin(nl_ctx *c, const int *labels_host, const void *i
     mk_pack_labels_kernel<<<grid1d(nrows * wpr * 64, 256, (i64)1 << 20), 256, 0, c->stream>>>(lab, (unsigned long long *)c->m[1], (int)c->nx, nrows, wpr);
     NL_CHECK_LAUNCH();
     // intensities as float32 (score_img[...] = intensity_im[...], mocap_marking.py:595-596)
+    c->mk_int = nullptr;
     if (intensity_host) {
         NL_HIP(hipStreamSynchronize(c->stream));
         const int keep_vmax = c->i_vmax;
@@ -47,7 +48,7 @@ extern "C" int nl_markers_begin(nl_ctx *c, const int *labels_host, const void *i
             case NL_I16: convert_kernel<int16_t><<<g, 256, 0, c->stream>>>((const int16_t *)c->d_input, mk_intensity(c), c->n); break;
             case NL_U32: convert_kernel<uint32_t><<<g, 256, 0, c->stream>>>((const uint32_t *)c->d_input, mk_intensity(c), c->n); break;
             case NL_I32: convert_kernel<int32_t><<<g, 256, 0, c->stream>>>((const int32_t *)c->d_input, mk_intensity(c), c->n); break;
-            case NL_F32: convert_kernel<float><<<g, 256, 0, c->stream>>>((const float *)c->d_input, mk_intensity(c), c->n); break;
+            case NL_F32: c->mk_int = (const float *)c->d_input; break;        // read where it lies (nothing writes the intensities)
             case NL_F64: convert_kernel<double><<<g, 256, 0, c->stream>>>((const double *)c->d_input, mk_intensity(c), c->n); break;
             case NL_U64: convert_kernel<uint64_t><<<g, 256, 0, c->stream>>>((const uint64_t *)c->d_input, mk_intensity(c), c->n); break;
             case NL_I64: convert_kernel<int64_t><<<g, 256, 0, c->stream>>>((const int64_t *)c->d_input, mk_intensity(c), c->n); break;
@@ -55,7 +56,7 @@ extern "C" int nl_markers_begin(nl_ctx *c, const int *labels_host, const void *i
         NL_CHECK_LAUNCH();
     }
     c->i_labels = -1; c->frangi_ready = 0; c->gauss_ext = nullptr; c->fsq_cache_valid = 0;
-    c->mk_state = 1; c->mk_first_scale = 1; c->mk_use = nullptr;
+    c->mk_state = 1; c->mk_first_scale = 1; c->mk_use = nullptr; c->mk_act_valid = 0;
     return NL_OK;
 }
 
@@ -131,8 +132,66 @@ extern "C" int nl_markers_log_step(nl_ctx *c, const double *wz2, const double *w
     const dim3 g2((unsigned)((c->nx + GYX_COLS - 1) / GYX_COLS), (unsigned)((c->ny + v.chunk - 1) / v.chunk), (unsigned)c->nzl);
     float *dist = c->f[0], *tz = c->f[1], *lap = c->f[2];
     const float *use = c->mk_use ? c->mk_use : dist;            // the image the LoG runs on
+    // Sparse LoG (round 5; markers.inc): the in-plane passes run on the 16 x 64 tiles that hold a voxel within one voxel of the mask
+    // (one workgroup per listed tile, log_yx_sparse_kernel), the Z march on the 64 x 4 x 64 tiles those stage.  NELLIE_MK_SPARSE=0:
+    // dense.  NELLIE_MK_POISON=1 (tests): both scratch volumes are filled with NaNs first -- a value read from a skipped tile would show.
+    const char *e_sp = getenv("NELLIE_MK_SPARSE");
+    const bool sparse = !(e_sp && !atoi(e_sp)) && !generic && !flat && gyx_tiled() && rz <= GM_MAX_R && rz <= c->gnz && ryx <= c->nx;
+    VolGeom vz = v;
+    const unsigned char *act_z = nullptr, *need_z = nullptr;
+    const int *tile_list = nullptr;
+    if (sparse) {
+        vz.chunk = 64;
+        const int ntx = (int)((c->nx + LS_TX - 1) / LS_TX), nty = (int)((c->ny + LS_TY - 1) / LS_TY);
+        const int nx64 = (int)((c->nx + 63) / 64), ny4 = (int)((c->ny + 3) / 4), nzc = (int)((c->nzl + vz.chunk - 1) / vz.chunk);
+        const size_t n_t = (size_t)c->nzl * nty * ntx, n_z = (size_t)nzc * ny4 * nx64;
+        const size_t n_zp = (size_t)c->nzl * ny4 * nx64;
+        const size_t need = n_t * 4 + n_t + n_z + n_zp + 64;
+        if (need > c->mk_act_cap) {
+            if (c->mk_act) { NL_HIP(hipStreamSynchronize(c->stream)); NL_HIP(hipFree(c->mk_act)); c->mk_act = nullptr; }
+            NL_HIP(hipMalloc((void **)&c->mk_act, need));
+            c->mk_act_cap = need; c->mk_act_valid = 0;
+        }
+        unsigned int *d_count = (unsigned int *)c->mk_act;             // [count | list | tile bytes | Z-march map]
+        int *list = (int *)(c->mk_act + 64);
+        unsigned char *tile_act = c->mk_act + 64 + n_t * 4, *zmap = tile_act + n_t, *zplane = zmap + n_z;
+        if (!c->mk_scratch) NL_HIP(hipMalloc((void **)&c->mk_scratch, (size_t)c->n * 4));       // the second Z-filtered volume (both Z terms in one walk)
+        const int wpr = (int)((c->nx + 63) / 64);
+        if (!c->mk_act_valid) {                         // the mask is the same for every sigma of a frame: one list, one wait
+            NL_HIP(hipMemsetAsync(tile_act, 0, n_t, c->stream));
+            NL_HIP(zero_small(d_count, 4, c->stream));
+            mk_tile_mark_kernel<<<grid1d(c->nzl * c->ny * wpr, 256, 1 << 14), 256, 0, c->stream>>>((const unsigned long long *)c->m[1], tile_act, v, wpr, ntx, nty);
+            mk_tile_list_kernel<<<grid1d((i64)n_t, 256, 1 << 12), 256, 0, c->stream>>>(tile_act, (i64)n_t, list, d_count);
+            NL_CHECK_LAUNCH();
+            NL_HIP(hipMemcpyAsync(c->h_small, d_count, 4, hipMemcpyDeviceToHost, c->stream));
+            NL_HIP(hipStreamSynchronize(c->stream));
+            c->mk_ntiles = (int)*(unsigned int *)c->h_small;
+            c->mk_act_valid = 1;
+        }
+        NL_HIP(hipMemsetAsync(zmap, 0, n_z + n_zp, c->stream));
+        if (c->mk_ntiles > 0)
+            mk_z_active_kernel<<<grid1d(c->mk_ntiles, 256, 1 << 12), 256, 0, c->stream>>>(list, d_count, zmap, zplane, v, ntx, nty, ryx, vz.chunk, nx64, ny4);
+        NL_CHECK_LAUNCH();
+        act_z = zmap; need_z = zplane; tile_list = list;
+        if (getenv("NELLIE_MK_DEBUG")) {              // occupancy of the maps (diagnostics: waits for the stream)
+            std::vector<unsigned char> h(n_z + n_zp);
+            NL_HIP(hipMemcpyAsync(h.data(), zmap, n_z + n_zp, hipMemcpyDeviceToHost, c->stream));
+            NL_HIP(hipStreamSynchronize(c->stream));
+            size_t a = 0, b = 0;
+            for (size_t k = 0; k < n_z; ++k) a += h[k];
+            for (size_t k = 0; k < n_zp; ++k) b += h[n_z + k];
+            fprintf(stderr, "[markers] r=%d: %d of %zu in-plane tiles listed (%.1f %%), Z-march workgroups %.1f %%, (plane, column tile) pairs %.1f %%\n", ryx,
+                    c->mk_ntiles, n_t, 100.0 * c->mk_ntiles / n_t, 100.0 * a / n_z, 100.0 * b / n_zp);
+        }
+        const char *e_po = getenv("NELLIE_MK_POISON");
+        if (e_po && atoi(e_po)) {
+            NL_HIP(hipMemsetAsync(tz, 0xff, (size_t)c->n * 4, c->stream));
+            NL_HIP(hipMemsetAsync(lap, 0xff, (size_t)c->n * 4, c->stream));
+            NL_HIP(hipMemsetAsync(c->mk_scratch, 0xff, (size_t)c->n * 4, c->stream));
+        }
+    }
     auto zpass = [&](const GaussW &gz) {
-        if (!gl_fast(0, c, use, tz, v, z0, z1, gz)) gl_axis(0, false, c, grid, use, tz, v, z0, z1, gz);
+        if (!gl_fast(0, c, use, tz, sparse ? vz : v, z0, z1, gz, act_z)) gl_axis(0, false, c, grid, use, tz, v, z0, z1, gz);
     };
     // large radii: the fused Y+X kernel turns compute-bound (one output per thread reads 2R+1 LDS values); a marching Y
     // pass plus the stand-alone X kernel (four outputs per thread) through one more scratch volume is faster there
@@ -140,16 +199,21 @@ extern "C" int nl_markers_log_step(nl_ctx *c, const double *wz2, const double *w
     if (split_from < 0) { const char *e = getenv("NELLIE_MK_SPLIT_R"); split_from = e ? atoi(e) : (gyx_tiled() ? 99 : 8); }
     float *tmp2 = mk_intensity(c) + c->n;
     const bool can_split = !c->mk_use && vq_alloc_entries(c->nzl, c->ny, c->nx) * 32 >= c->n * 8;     // mk_use lives in tmp2's place
-    const float *yx_src = flat ? use : tz;
+    const float *yx_src = flat ? use : tz;                     // (captured by reference: the sparse path switches it between its two walks)
     auto yx = [&](const GaussW &gy, const GaussW &gx, bool acc) {
         const GaussWS wy = gauss_ws_of(gy), wx = gauss_ws_of(gx);
         if (can_split && ryx >= split_from) { (void)gl_y_then_x(c, acc, ryx, yx_src, tmp2, lap, v, z0, z1, wy, wx); return; }
+        if (sparse) { (void)gl_log_yx_sparse(c, false, acc, ryx, yx_src, lap, v, tile_list, c->mk_ntiles, wy, wx, wy, wx); return; }
         (void)gl_yx(c, gyx_tiled(), acc, ryx, yx_src, lap, v, z0, z1, wy, wx, g2);
     };
     // the two in-plane terms in one walk over their common input
     static int dual = -1;
     if (dual < 0) { const char *e = getenv("NELLIE_MK_DUAL"); dual = (e && !atoi(e)) ? 0 : 1; }
     auto yx_dual = [&](bool acc) {
+        if (sparse) {
+            (void)gl_log_yx_sparse(c, true, acc, ryx, yx_src, lap, v, tile_list, c->mk_ntiles, gauss_ws_of(gy2), gauss_ws_of(gx0), gauss_ws_of(gy0), gauss_ws_of(gx2));
+            return;
+        }
         (void)gl_yx_dual(c, acc, ryx, yx_src, lap, v, z0, z1, gauss_ws_of(gy2), gauss_ws_of(gx0), gauss_ws_of(gy0), gauss_ws_of(gx2), g2);
     };
     const bool use_dual = dual && gyx_tiled();
@@ -166,6 +230,12 @@ extern "C" int nl_markers_log_step(nl_ctx *c, const double *wz2, const double *w
         } else if (flat) {
             if (use_dual) yx_dual(false);
             else { yx(gy2, gx0, false); yx(gy0, gx2, true); }
+        } else if (sparse && use_dual) {
+            // both Z terms in one walk over the image (tz = d2/dz2 term's input, mk_scratch = the plain-Gaussian one), then the listed tiles
+            (void)gl_z_dual(c, rz, use, tz, c->mk_scratch, vz, z0, z1, gauss_ws_of(gz2), gauss_ws_of(gz0), act_z, need_z);
+            yx(gy0, gx0, false);
+            yx_src = c->mk_scratch;
+            yx_dual(true);
         } else {
             zpass(gz2); yx(gy0, gx0, false);
             zpass(gz0);
@@ -196,7 +266,7 @@ extern "C" int nl_markers_finish(nl_ctx *c, int peak_min_distance, int64_t *n_ma
     NL_HIP(zero_small(d_cnt, 8, c->stream));
     {
         ProfScope ps(c, "markers_nms");
-        mk_nms_kernel<<<grid1d(nw, 256, 256 * 32), 256, 0, c->stream>>>((const unsigned long long *)c->m[0], mk_intensity(c), peak_min_distance,
+        mk_nms_kernel<<<grid1d(nw, 256, 256 * 32), 256, 0, c->stream>>>((const unsigned long long *)c->m[0], c->mk_int ? c->mk_int : mk_intensity(c), peak_min_distance,
                                                                              (unsigned long long *)c->m[0] + nw, geom(c), wpr, d_cnt);
         NL_CHECK_LAUNCH();
     }

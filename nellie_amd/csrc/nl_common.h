@@ -50,12 +50,16 @@ struct nl_ctx {
     float *d_vq = nullptr;     // global queue of voxels to eigen-solve (32-byte entries, one region per wave)
     unsigned int *d_vq_count = nullptr;   // entries written per region
     int nw_state = 0;             // Network: 1 after nl_skel_pixel_class (classes + branch bits resident)
+    const float *mk_int = nullptr;   // Markers: the float32 intensities when they are read in place (a resident float32 input), else they live in d_vq
     float *mk_use = nullptr;      // Markers: LoG source when use_im = 'frangi' (inside d_vq), else the distance image
     float *mk_scratch = nullptr;  // Markers: volume between the Y and the X pass of the any-radius LoG path, allocated on first use
     std::atomic<unsigned long long> epoch{0};      // C-ABI calls made on this context (see NL_KEEP_SUPPORT)
     unsigned long long support_epoch = ~0ull - 8;   // epoch at which d_support described the Frangi frame
     const unsigned long long *d_support = nullptr;
     int last_label_sparse = 0;
+    unsigned char *mk_act = nullptr; size_t mk_act_cap = 0;   // Markers, sparse LoG (markers.inc): [tile list (int32) | tile bytes | Z-march map]
+    int mk_act_valid = 0;         // the tile list describes the current mask ...
+    int mk_ntiles = 0;            // ... and holds this many active 16 x 64 tiles
     int mk_state = 0;             // Markers: 0 idle, 1 begun, 2 distance done, 3 finished
     int mk_first_scale = 1;
     int two_d = 0;                // the frame is a (Y, X) image (im_info.no_z): 2-D Hessian, eigenvalues, Frangi, opening

@@ -64,6 +64,7 @@ _PROTOS = {
     "nl_outputs_pack": [_p, _int, _p],
     "nl_outputs_fetch_packed_async": [_p, _p, _i64],
     "nl_outputs_unpack": [_p, _i64, _p, _p, _i64, _int, _int],
+    "nl_host_zero": [_p, _i64, _int],
     "nl_hessian_stats": [_p, C.POINTER(_f64), C.POINTER(_f32), C.POINTER(_f32), C.POINTER(_int)],
     "nl_set_frob_norm": [_p, _f32, _f32],
     "nl_vesselness_step": [_p, _f32, _f32, _f32, _int, _f32, _i64, _i64, C.POINTER(_i64)],
@@ -299,6 +300,13 @@ def outputs_unpack(blob, nbytes, frangi, labels=None, zero_fill=True, threads=8)
     src = blob._p if hasattr(blob, "_p") else _ptr(blob)
     load().call("nl_outputs_unpack", src, int(nbytes), _ptr(frangi), None if labels is None else _ptr(labels),
                 int(frangi.size), 1 if zero_fill else 0, int(threads))
+
+
+def host_zero(array, threads=8):
+    """Zero a C-contiguous host array with `threads` host threads (nl_host_zero; the call releases the GIL, so it can run on a
+    Python thread beside the GPU calls of the frame whose outputs the array will receive)."""
+    assert array.flags.c_contiguous and array.flags.writeable
+    load().call("nl_host_zero", _ptr(array), int(array.nbytes), int(threads))
 
 
 def comm_unique_id(loopback: bool = False) -> bytes:

@@ -364,10 +364,14 @@ def test_stage_api_2d(hip):
 
 
 @pytest.mark.parametrize("name", MARKERS_CASES)
-def test_markers_golden_bitexact(name, hip):
+@pytest.mark.parametrize("mode", ["sparse", "sparse+poison", "dense"])
+def test_markers_golden_bitexact(name, mode, hip, monkeypatch):
     """Markers stage against the reference's own outputs: marker, distance and border images bit for bit -- 3-D and
-    2-D images, use_im='distance' and use_im='frangi'."""
+    2-D images, use_im='distance' and use_im='frangi'.  The LoG only computes the tiles somebody reads (default); with the scratch
+    volumes poisoned by NaNs first a value taken from a skipped tile would show; NELLIE_MK_SPARSE=0 is the dense form."""
     from nellie_amd import pipeline as pl
+    monkeypatch.setenv("NELLIE_MK_SPARSE", "0" if mode == "dense" else "1")
+    monkeypatch.setenv("NELLIE_MK_POISON", "1" if mode == "sparse+poison" else "0")
     g = load_golden(name)
     dr = g["dim_res_dict"]
     kw = {k: (int(v) if k in ("peak_min_distance", "num_sigma") else v) for k, v in g["kwargs"].items()}
@@ -392,6 +396,37 @@ def test_markers_golden_bitexact(name, hip):
                 assert np.array_equal(m2, g["marker"]) and np.array_equal(d2, g["distance"]) and np.array_equal(b2, g["border"])
     finally:
         pipe.close()
+
+
+def test_markers_sparse_log_equals_dense_on_scattered_objects(hip, monkeypatch):
+    """The tile list and the Z-march map of the sparse LoG on a volume with skipped tiles in every pass (160 x 300 x 520: 19 x 9 in-plane
+    tiles, 3 Z chunks): objects in corners, on faces, across tile and chunk seams -- dense, sparse and sparse over NaN-poisoned
+    scratch give the same three products."""
+    from nellie_amd import pipeline as pl
+    from nellie_amd.synthetic import ISO_01
+    rng = np.random.default_rng(5)
+    shape = (160, 300, 520)
+    lab = np.zeros(shape, np.int32)
+    zz, yy, xx = np.ogrid[:shape[0], :shape[1], :shape[2]]
+    centres = [(0, 0, 0), (159, 299, 519), (80, 31, 255), (80, 32, 256), (63, 150, 300), (64, 150, 40), (10, 290, 500), (150, 5, 258)]
+    centres += [tuple(int(rng.integers(0, s)) for s in shape) for _ in range(10)]
+    for k, (cz, cy, cx) in enumerate(centres):
+        r = 3 + (k % 5)
+        lab[(zz - cz) ** 2 + (yy - cy) ** 2 + (xx - cx) ** 2 <= r * r] = k + 1
+    vol = rng.normal(100, 5, shape).astype(np.float32)
+    outs = []
+    for sparse, poison in (("0", "0"), ("1", "0"), ("1", "1")):
+        monkeypatch.setenv("NELLIE_MK_SPARSE", sparse)
+        monkeypatch.setenv("NELLIE_MK_POISON", poison)
+        pipe = pl.FramePipeline(shape)
+        n = pipe.markers(ISO_01, labels=lab, intensity=vol)
+        outs.append((n,) + tuple(a.copy() for a in pipe.download_markers()))
+        pipe.close()
+    assert outs[0][0] > 0
+    for o in outs[1:]:
+        assert o[0] == outs[0][0]
+        for a, b in zip(o[1:], outs[0][1:]):
+            assert np.array_equal(a, b)
 
 
 @pytest.mark.parametrize("shape,dr", [((20, 60, 70), {"X": 0.065, "Y": 0.065, "Z": 0.25, "T": 1.0}),      # LoG radii up to 21 in-plane

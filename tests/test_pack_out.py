@@ -157,6 +157,12 @@ def test_device_pack_equals_dense_download(hip, shape):
     out_f, out_l = np.full(shape, 2.0, np.float32), np.full(shape, -1, np.int32)
     hipnative.outputs_unpack(land, nbytes, out_f, out_l, zero_fill=True, threads=4)
     assert np.array_equal(out_f, fr) and np.array_equal(out_l, lab) and lab.max() == n
+    # the other order of the same work (bench.py's host-to-host figure): the fill by nl_host_zero beforehand, a scatter-only unpack
+    out_f[...] = 2.0; out_l[...] = -1
+    hipnative.host_zero(out_f, threads=3); hipnative.host_zero(out_l, threads=5)
+    assert not out_f.any() and not out_l.any()
+    hipnative.outputs_unpack(land, nbytes, out_f, out_l, zero_fill=False, threads=4)
+    assert np.array_equal(out_f, fr) and np.array_equal(out_l, lab)
     land.free()
     pipe.close()
 
