@@ -19,8 +19,10 @@ static int zyx_chunk(const nl_ctx *c, int rz, int r, i64 nplanes) {
     const i64 plane_bytes = c->ny * c->nx * 4;
     const int ty = r <= 2 ? GzyxCfg<2>::TY : (r <= 4 ? GzyxCfg<4>::TY : GzyxCfg<5>::TY);      // rows of a tile
     const i64 tiles = ((c->nx + 63) / 64) * ((c->ny + ty - 1) / ty);
+    static int min_wgs = 0;                      // NELLIE_ZYX_MIN_WGS: A/B of the rule (workgroups a launch should have)
+    if (!min_wgs) { const char *e = getenv("NELLIE_ZYX_MIN_WGS"); min_wgs = (e && atoi(e) > 0) ? atoi(e) : 512; }
     int zchunk = 128;
-    while (zchunk > 16 && tiles * ((nplanes + zchunk - 1) / zchunk) < 512) zchunk >>= 1;
+    while (zchunk > 8 && tiles * ((nplanes + zchunk - 1) / zchunk) < min_wgs) zchunk >>= 1;
     while (zchunk > 8 && (i64)(zchunk + 2 * rz) * plane_bytes >= ((i64)1 << 32)) zchunk >>= 1;
     return (i64)(zchunk + 2 * rz) * plane_bytes < ((i64)1 << 32) ? zchunk : 0;
 }

@@ -530,10 +530,14 @@ extern "C" int nl_gauss_step(nl_ctx *c, const double *wz, int rz, const double *
     int rc;
     const bool can_yx = wy && wx && ry == rx && ry >= 1 && ry <= GM_MAX_R && ry <= c->ny && !getenv("NELLIE_NO_FUSED_YX");
     bool fused_yx = false;
-    // the whole step in one kernel (gauss_zyx.inc) when the radii have an instantiation and Y and X share their weights, which is
-    // what Filter asks for (sigma_vec = (s / z_ratio, s, s)); NELLIE_GAUSS_FUSED=0: the Z march and the Y+X pass as two kernels
-    static int fused_zyx = -1;
-    if (fused_zyx < 0) { const char *e = getenv("NELLIE_GAUSS_FUSED"); fused_zyx = (e && !atoi(e)) ? 0 : 1; }
+    // The whole step in one kernel (gauss_zyx.inc) when the radii have an instantiation and Y and X share their weights, which is
+    // what Filter asks for (sigma_vec = (s / z_ratio, s, s)) -- on volumes that do not fit the caches: the fused kernel trades HBM
+    // traffic for redundant float64 work, and a 128 x 512 x 512 frame (134 MB a volume) streams from the 256 MB Infinity Cache anyway
+    // (gauss ms per frame, two kernels / fused: 128 x 512 x 512 0.62 / 0.77; 256 x 512 x 512 1.32 / 1.24; 512^3 2.24 / 2.16; 256 x 1024^2
+    // 4.44 / 4.00; 1024^3 17.7 / 15.3).
+    // NELLIE_GAUSS_FUSED=0 / 1: never / whenever the radii allow (tests run the fused kernel on small volumes that way).
+    const char *e_fz = getenv("NELLIE_GAUSS_FUSED");
+    const bool fused_zyx = e_fz ? atoi(e_fz) != 0 : c->n >= ((i64)1 << 26);
     if (fused_zyx && wz && can_yx && gyx_tiled() && gl_zyx_ok(c, rz, ry, c->f[(src + 1) % 3]) &&
         memcmp(wy, wx, (size_t)(2 * ry + 1) * sizeof(double)) == 0) {
         GaussW gy;

@@ -231,8 +231,13 @@ def test_two_pass_vesselness_in_several_launches(hip):
 
 
 @pytest.mark.parametrize("name", [n for n in FILTER_CASES if n.startswith(("iso", "aniso", "odd", "u16"))])
-def test_gaussian_scale_space_bitexact(name, pipes):
+@pytest.mark.parametrize("fused", ["auto", "fused", "two_kernels"])
+def test_gaussian_scale_space_bitexact(name, fused, pipes, monkeypatch):
+    """The Gaussian of every scale, CRC for CRC, through each form of the cascade step: the fused Z+Y+X kernel (the default on volumes
+    of 2^26 voxels and more; forced here), the Z march + the fused Y+X pass, and whatever the size rule picks."""
     from nellie_amd import pipeline as pl
+    if fused != "auto":
+        monkeypatch.setenv("NELLIE_GAUSS_FUSED", "1" if fused == "fused" else "0")
     g = load_golden(name)
     vol = g["input"]
     pipe = pipes(vol.shape)
@@ -243,6 +248,34 @@ def test_gaussian_scale_space_bitexact(name, pipes):
         pipe.ctx.gauss_step(*[pl.gaussian_weights(d) for d in delta])
         gauss = pipe.ctx.gauss_store()
         assert np.uint32(zlib.crc32(gauss.tobytes())) == g["gauss_crc"][s], f"scale {s}"
+
+
+@pytest.mark.parametrize("shape,dr", [((37, 70, 131), {"X": 0.1, "Y": 0.1, "Z": 0.1, "T": 1.0}),       # rows of 131: scalar stores, partial tiles both ways
+                                      ((21, 48, 64), {"X": 0.1, "Y": 0.1, "Z": 0.3, "T": 1.0}),         # Z radii 1, 1, 1, 1, 2 beside in-plane 4, 3, 4, 4, 5
+                                      ((150, 49, 66), {"X": 0.1, "Y": 0.1, "Z": 0.2, "T": 1.0}),        # two Z chunks, Z radii 2-3
+                                      ((9, 200, 300), {"X": 0.1, "Y": 0.1, "Z": 0.1, "T": 1.0})])       # fewer planes than 2 R + 1 of the last scale
+def test_fused_cascade_step_equals_two_kernels(hip, shape, dr, monkeypatch):
+    """The fused Z+Y+X kernel against the Z march + Y+X pass on shapes the goldens do not have: every scale's Gaussian volume and the
+    frame, bit for bit, from float32 and uint16 input."""
+    from nellie_amd import pipeline as pl
+    from nellie_amd.synthetic import make_volume
+    for dtype in (np.float32, np.uint16):
+        vol = make_volume(shape, 17, dtype=dtype)
+        outs = []
+        for fused in ("0", "1"):
+            monkeypatch.setenv("NELLIE_GAUSS_FUSED", fused)
+            pipe = pl.FramePipeline(shape)
+            pipe.ctx.filter_load(vol)
+            crcs = []
+            sig = pl.default_sigmas(dr)
+            for delta in pl.cascade_deltas(sig, pl.z_ratio_of(dr)):
+                pipe.ctx.gauss_step(*[pl.gaussian_weights(d) for d in delta])
+                crcs.append(zlib.crc32(pipe.ctx.gauss_store().tobytes()))
+            pipe.filter(vol, pl.FilterParams(dim_res=dr))
+            outs.append((crcs, pipe.download_frangi()))
+            pipe.close()
+        assert outs[0][0] == outs[1][0], f"{shape} {dtype}: Gaussian volumes differ"
+        assert np.array_equal(outs[0][1], outs[1][1])
 
 
 @pytest.mark.parametrize("name", [n for n in FILTER_CASES] + LABEL_ONLY_CASES)

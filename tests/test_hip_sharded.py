@@ -95,6 +95,32 @@ def test_zslab_filter_equals_single_gpu(hip, gshape, aniso, world, halo_mode):
     assert ref_n >= 1
 
 
+@pytest.mark.parametrize("gshape,aniso,world,halo_mode", [((96, 64, 80), False, 2, "steps"), ((100, 48, 70), False, 3, "steps+raw"),
+                                                         ((60, 64, 64), True, 4, "fat"), ((75, 50, 133), True, 3, "steps")])
+def test_zslab_filter_with_the_fused_cascade_kernel(hip, gshape, aniso, world, halo_mode, monkeypatch):
+    """The fused Z+Y+X cascade kernel (gauss_zyx.inc; by default only on volumes of 2^26 voxels and more) on Z slabs: ghost planes, plane
+    ranges that start inside the slab, reflection at true faces only (gz0 / gnz), partial tiles, rows of a length that is no
+    multiple of four -- slabs with the fused kernel forced == one context with the two-kernel form, bit for bit."""
+    raw_ghosts = halo_mode.endswith("+raw")
+    halo_mode = halo_mode.split("+")[0]
+    from nellie_amd import pipeline as pl
+    from nellie_amd.synthetic import ANISO_03, ISO_01, make_volume
+    dr = ANISO_03 if aniso else ISO_01
+    vol = make_volume(gshape, 93)
+    monkeypatch.setenv("NELLIE_GAUSS_FUSED", "0")
+    single = pl.FramePipeline(gshape)
+    p = pl.FilterParams(dim_res=dr)
+    single.filter(vol, p)
+    ref = single.download_frangi()
+    ref_thr = single.frangi_threshold()
+    single.close()
+    monkeypatch.setenv("NELLIE_GAUSS_FUSED", "1")
+    parts = _run_sharded(gshape, dr, 93, world, halo_mode, raw_ghosts)
+    got = np.concatenate([p_[0] for p_ in parts])
+    assert np.array_equal(got, ref), f"{int((got != ref).sum())} voxels differ"
+    assert all(p_[1] == ref_thr for p_ in parts) and (ref > 0).any()
+
+
 def _single_reference(gshape, dr, seed):
     from nellie_amd import pipeline as pl
     from nellie_amd.synthetic import make_volume
