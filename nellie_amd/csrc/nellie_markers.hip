@@ -94,8 +94,7 @@ extern "C" int nl_markers_distance(nl_ctx *c, float clamp, int64_t *n_mask, char
     mk_edt_axis_kernel<1, 0><<<gw_, 256, 0, c->stream>>>(mask, (const int *)c->f[1], (int *)c->f[2], nullptr, clamp, v, wpr, W);
     mk_edt_axis_kernel<0, 1><<<gw_, 256, 0, c->stream>>>(mask, (const int *)c->f[2], nullptr, c->f[0], clamp, v, wpr, W);
     NL_CHECK_LAUNCH();
-    // best response = 0, no peaks yet (mocap_marking.py:483-484)
-    NL_HIP(hipMemsetAsync(c->f[3], 0, (size_t)c->n * 4, c->stream));
+    // best response = 0, no peaks yet (mocap_marking.py:483-484): the first scale's peak kernel defines `best` where it is read
     NL_HIP(hipMemsetAsync(c->m[0], 0, (size_t)nw * 8 * 2, c->stream));
     NL_HIP(hipMemcpyAsync(c->h_small, d_cnt, 8, hipMemcpyDeviceToHost, c->stream));
     NL_HIP(hipStreamSynchronize(c->stream));
@@ -249,8 +248,9 @@ extern "C" int nl_markers_log_step(nl_ctx *c, const double *wz2, const double *w
         const int wpr = (int)((c->nx + 63) / 64);
         const i64 nw = c->nzl * c->ny * wpr;
         mk_peak_kernel<<<grid1d(nw, 256, (i64)1 << 20), 256, 0, c->stream>>>(lap, s2, (const unsigned long long *)c->m[1], dist, c->f[3],
-                                                                                 (unsigned long long *)c->m[0], v, wpr);
+                                                                                 (unsigned long long *)c->m[0], v, wpr, c->mk_first_scale);
         NL_CHECK_LAUNCH();
+        c->mk_first_scale = 0;
     }
     return NL_OK;
 }
