@@ -21,8 +21,7 @@ static int fill_gw(GaussW &gw, const double *w, int r, char *err, size_t errlen)
 static inline GaussWS gauss_ws_of(const GaussW &g) { GaussWS w; for (int k = 0; k <= GM_MAX_R; ++k) w.w[k] = k <= g.r ? g.w[k] : 0.0; return w; }
 
 // marching Z / Y pass or the LDS X pass of radius gw.r <= GM_MAX_R (axis 0, 1, 2)
-// act (Z pass only; may be NULL): one byte per workgroup of the 64-column x 4-row x v.chunk-plane grid, 0 = skip the tile
-bool gl_fast(int axis, nl_ctx *c, const float *src, float *dst, const VolGeom &v, i64 z0, i64 z1, const GaussW &gw, const unsigned char *act = nullptr);
+bool gl_fast(int axis, nl_ctx *c, const float *src, float *dst, const VolGeom &v, i64 z0, i64 z1, const GaussW &gw);
 // one thread per voxel, any radius, scipy's multiple reflection; acc: dst += result
 void gl_axis(int axis, bool acc, nl_ctx *c, dim3 grid, const float *src, float *dst, const VolGeom &v, i64 z0, i64 z1, const GaussW &gw);
 // fused Y+X pass (tiled: the register-blocked X pass; else one row at a time), radius r on both axes; g2 = (x tiles, y chunks, planes)
@@ -39,11 +38,11 @@ bool gl_y_then_x(nl_ctx *c, bool acc, int r, const float *src, float *tmp, float
 #define LS_TX 64
 bool gl_log_yx_sparse(nl_ctx *c, bool dual, bool acc, int r, const float *src, float *dst, const VolGeom &v, const int *list, int ntiles,
                       const GaussWS &wya, const GaussWS &wxa, const GaussWS &wyb, const GaussWS &wxb);
-// Z march for both Z terms of a LoG scale in one walk (gauss_march_dual_kernel): dst_a = Z(wa)(src), dst_b = Z(wb)(src) on the tiles /
-// planes the maps name (chunk_act: one byte per 64 x 4 x v.chunk workgroup; plane_need: one byte per (local plane, 64 x 4 column tile),
-// local plane 0 = plane 0 of the volume; either may be NULL = everything)
+// Z march for both Z terms of a LoG scale in one walk (gauss_march_dual_kernel): dst_a = Z(wa)(src), dst_b = Z(wb)(src) on the planes the map
+// names -- need_bits: one 64-bit word per workgroup of the 64-column x 4-row x v.chunk-plane grid (v.chunk <= 64), bit k = plane k of the
+// chunk; NULL = everything
 bool gl_z_dual(nl_ctx *c, int r, const float *src, float *dst_a, float *dst_b, const VolGeom &v, i64 z0, i64 z1, const GaussWS &wa, const GaussWS &wb,
-               const unsigned char *chunk_act, const unsigned char *plane_need);
+               const unsigned long long *need_bits);
 // the whole cascade step in one kernel (gauss_zyx.inc, nellie_gzyx.hip): Z radius rz with weights gz, Y and X radius r with the SAME
 // weights gyx (sigma_vec = (s / z_ratio, s, s), filtering.py:816-825); false: no instantiation for these radii / this shape
 bool gl_zyx_ok(const nl_ctx *c, int rz, int r, const float *dst);

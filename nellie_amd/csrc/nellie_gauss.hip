@@ -9,18 +9,18 @@ static bool gm_z2() {
     return on != 0;
 }
 template <int AXIS, int R>
-static void launch_gauss_march(nl_ctx *c, const float *src, float *dst, const VolGeom &v, i64 z0, i64 z1, const GaussW &gw, const unsigned char *act) {
+static void launch_gauss_march(nl_ctx *c, const float *src, float *dst, const VolGeom &v, i64 z0, i64 z1, const GaussW &gw) {
     GaussWS ws;
     for (int k = 0; k <= GM_MAX_R; ++k) ws.w[k] = k <= R ? gw.w[k] : 0.0;
     dim3 grid;
     if (AXIS == 0) grid = dim3((unsigned)((c->nx + 63) / 64), (unsigned)((c->ny + 3) / 4), (unsigned)((z1 - z0 + v.chunk - 1) / v.chunk));
     else grid = dim3((unsigned)((c->nx + 63) / 64), (unsigned)((z1 - z0 + 3) / 4), (unsigned)((c->ny + v.chunk - 1) / v.chunk));
-    if (AXIS == 0 && R <= 6 && (c->nx & 1) == 0 && ((size_t)src & 7) == 0 && ((size_t)dst & 7) == 0 && gm_z2() && !act) {
+    if (AXIS == 0 && R <= 6 && (c->nx & 1) == 0 && ((size_t)src & 7) == 0 && ((size_t)dst & 7) == 0 && gm_z2()) {
         grid.x = (unsigned)((c->nx / 2 + 63) / 64);              // two columns per thread (float2 accesses): see gauss_march_z2_kernel
         gauss_march_z2_kernel<(R <= 6 ? R : 1)><<<grid, 256, 0, c->stream>>>(src, dst, v, z0, z1, ws);
         return;
     }
-    gauss_march_kernel<AXIS, R><<<grid, 256, 0, c->stream>>>(src, dst, v, z0, z1, ws, act);      // act: the tile map of this very grid
+    gauss_march_kernel<AXIS, R><<<grid, 256, 0, c->stream>>>(src, dst, v, z0, z1, ws);
 }
 template <int R>
 static void launch_gauss_x(nl_ctx *c, const float *src, float *dst, const VolGeom &v, i64 z0, i64 z1, const GaussW &gw) {
@@ -31,11 +31,11 @@ static void launch_gauss_x(nl_ctx *c, const float *src, float *dst, const VolGeo
 }
 // returns false when the radius has no specialised kernel
 template <int AXIS>
-static bool launch_gauss_fast(nl_ctx *c, const float *src, float *dst, const VolGeom &v, i64 z0, i64 z1, const GaussW &gw, const unsigned char *act = nullptr) {
+static bool launch_gauss_fast(nl_ctx *c, const float *src, float *dst, const VolGeom &v, i64 z0, i64 z1, const GaussW &gw) {
 #define NL_GCASE(RR)                                                                         \
     case RR:                                                                                 \
         if (AXIS == 2) launch_gauss_x<RR>(c, src, dst, v, z0, z1, gw);                       \
-        else launch_gauss_march<(AXIS == 2 ? 0 : AXIS), RR>(c, src, dst, v, z0, z1, gw, act); \
+        else launch_gauss_march<(AXIS == 2 ? 0 : AXIS), RR>(c, src, dst, v, z0, z1, gw);     \
         return true;
     // the marching kernels reflect at most once: the radius must not exceed the line length
     const i64 n_line = AXIS == 0 ? c->gnz : (AXIS == 1 ? c->ny : c->nx);
@@ -48,8 +48,8 @@ static bool launch_gauss_fast(nl_ctx *c, const float *src, float *dst, const Vol
 #undef NL_GCASE
 }
 
-bool gl_fast(int axis, nl_ctx *c, const float *src, float *dst, const VolGeom &v, i64 z0, i64 z1, const GaussW &gw, const unsigned char *act) {
-    if (axis == 0) return launch_gauss_fast<0>(c, src, dst, v, z0, z1, gw, act);
+bool gl_fast(int axis, nl_ctx *c, const float *src, float *dst, const VolGeom &v, i64 z0, i64 z1, const GaussW &gw) {
+    if (axis == 0) return launch_gauss_fast<0>(c, src, dst, v, z0, z1, gw);
     if (axis == 1) return launch_gauss_fast<1>(c, src, dst, v, z0, z1, gw);
     return launch_gauss_fast<2>(c, src, dst, v, z0, z1, gw);
 }
@@ -117,10 +117,10 @@ bool gl_log_yx_sparse(nl_ctx *c, bool dual, bool acc, int r, const float *src, f
     const int ntx = (int)((c->nx + LS_TX - 1) / LS_TX), nty = (int)((c->ny + LS_TY - 1) / LS_TY);
     switch (r) {
 #define NL_LS(RR) case RR:                                                                                                          \
-        if (dual) { if (acc) log_yx_sparse_kernel<RR, true, true><<<ntiles, 256, 0, c->stream>>>(src, dst, v, list, ntx, nty, wya, wxa, wyb, wxb); \
-                    else log_yx_sparse_kernel<RR, true, false><<<ntiles, 256, 0, c->stream>>>(src, dst, v, list, ntx, nty, wya, wxa, wyb, wxb); }  \
-        else { if (acc) log_yx_sparse_kernel<RR, false, true><<<ntiles, 256, 0, c->stream>>>(src, dst, v, list, ntx, nty, wya, wxa, wyb, wxb);    \
-               else log_yx_sparse_kernel<RR, false, false><<<ntiles, 256, 0, c->stream>>>(src, dst, v, list, ntx, nty, wya, wxa, wyb, wxb); }      \
+        if (dual) { if (acc) log_yx_sparse_kernel<RR, true, true><<<ntiles, LS_NT, 0, c->stream>>>(src, dst, v, list, ntx, nty, wya, wxa, wyb, wxb); \
+                    else log_yx_sparse_kernel<RR, true, false><<<ntiles, LS_NT, 0, c->stream>>>(src, dst, v, list, ntx, nty, wya, wxa, wyb, wxb); }  \
+        else { if (acc) log_yx_sparse_kernel<RR, false, true><<<ntiles, LS_NT, 0, c->stream>>>(src, dst, v, list, ntx, nty, wya, wxa, wyb, wxb);    \
+               else log_yx_sparse_kernel<RR, false, false><<<ntiles, LS_NT, 0, c->stream>>>(src, dst, v, list, ntx, nty, wya, wxa, wyb, wxb); }      \
         return true;
         NL_R12(NL_LS)
 #undef NL_LS
@@ -129,11 +129,11 @@ bool gl_log_yx_sparse(nl_ctx *c, bool dual, bool acc, int r, const float *src, f
 }
 
 bool gl_z_dual(nl_ctx *c, int r, const float *src, float *dst_a, float *dst_b, const VolGeom &v, i64 z0, i64 z1, const GaussWS &wa, const GaussWS &wb,
-               const unsigned char *chunk_act, const unsigned char *plane_need) {
-    if (r < 1 || r > GM_MAX_R || r > c->gnz) return false;
+               const unsigned long long *need_bits) {
+    if (r < 1 || r > GM_MAX_R || r > c->gnz || (need_bits && v.chunk > 64)) return false;
     const dim3 grid((unsigned)((c->nx + 63) / 64), (unsigned)((c->ny + 3) / 4), (unsigned)((z1 - z0 + v.chunk - 1) / v.chunk));
     switch (r) {
-#define NL_ZD(RR) case RR: gauss_march_dual_kernel<RR><<<grid, 256, 0, c->stream>>>(src, dst_a, dst_b, v, z0, z1, wa, wb, chunk_act, plane_need); return true;
+#define NL_ZD(RR) case RR: gauss_march_dual_kernel<RR><<<grid, 256, 0, c->stream>>>(src, dst_a, dst_b, v, z0, z1, wa, wb, need_bits); return true;
         NL_R12(NL_ZD)
 #undef NL_ZD
     }

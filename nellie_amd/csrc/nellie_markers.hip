@@ -137,15 +137,15 @@ extern "C" int nl_markers_log_step(nl_ctx *c, const double *wz2, const double *w
     const char *e_sp = getenv("NELLIE_MK_SPARSE");
     const bool sparse = !(e_sp && !atoi(e_sp)) && !generic && !flat && gyx_tiled() && rz <= GM_MAX_R && rz <= c->gnz && ryx <= c->nx;
     VolGeom vz = v;
-    const unsigned char *act_z = nullptr, *need_z = nullptr;
+    const unsigned long long *need_z = nullptr;
     const int *tile_list = nullptr;
     if (sparse) {
         vz.chunk = 64;
         const int ntx = (int)((c->nx + LS_TX - 1) / LS_TX), nty = (int)((c->ny + LS_TY - 1) / LS_TY);
         const int nx64 = (int)((c->nx + 63) / 64), ny4 = (int)((c->ny + 3) / 4), nzc = (int)((c->nzl + vz.chunk - 1) / vz.chunk);
         const size_t n_t = (size_t)c->nzl * nty * ntx, n_z = (size_t)nzc * ny4 * nx64;
-        const size_t n_zp = (size_t)c->nzl * ny4 * nx64;
-        const size_t need = n_t * 4 + n_t + n_z + n_zp + 64;
+        const size_t list_bytes = ((n_t * 4 + 7) & ~(size_t)7);
+        const size_t need = 64 + list_bytes + n_z * 8 + n_t;
         if (need > c->mk_act_cap) {
             if (c->mk_act) { NL_HIP(hipStreamSynchronize(c->stream)); NL_HIP(hipFree(c->mk_act)); c->mk_act = nullptr; }
             NL_HIP(hipMalloc((void **)&c->mk_act, need));
@@ -153,7 +153,8 @@ extern "C" int nl_markers_log_step(nl_ctx *c, const double *wz2, const double *w
         }
         unsigned int *d_count = (unsigned int *)c->mk_act;             // [count | list | tile bytes | Z-march map]
         int *list = (int *)(c->mk_act + 64);
-        unsigned char *tile_act = c->mk_act + 64 + n_t * 4, *zmap = tile_act + n_t, *zplane = zmap + n_z;
+        unsigned long long *zbits = (unsigned long long *)(c->mk_act + 64 + list_bytes);    // [count | list | Z-march plane bits | tile bytes]
+        unsigned char *tile_act = (unsigned char *)(zbits + n_z);
         if (!c->mk_scratch) NL_HIP(hipMalloc((void **)&c->mk_scratch, (size_t)c->n * 4));       // the second Z-filtered volume (both Z terms in one walk)
         const int wpr = (int)((c->nx + 63) / 64);
         if (!c->mk_act_valid) {                         // the mask is the same for every sigma of a frame: one list, one wait
@@ -167,20 +168,19 @@ extern "C" int nl_markers_log_step(nl_ctx *c, const double *wz2, const double *w
             c->mk_ntiles = (int)*(unsigned int *)c->h_small;
             c->mk_act_valid = 1;
         }
-        NL_HIP(hipMemsetAsync(zmap, 0, n_z + n_zp, c->stream));
+        NL_HIP(hipMemsetAsync(zbits, 0, n_z * 8, c->stream));
         if (c->mk_ntiles > 0)
-            mk_z_active_kernel<<<grid1d(c->mk_ntiles, 256, 1 << 12), 256, 0, c->stream>>>(list, d_count, zmap, zplane, v, ntx, nty, ryx, vz.chunk, nx64, ny4);
+            mk_z_active_kernel<<<grid1d(c->mk_ntiles, 256, 1 << 12), 256, 0, c->stream>>>(list, d_count, zbits, v, ntx, nty, ryx, vz.chunk, nx64, ny4);
         NL_CHECK_LAUNCH();
-        act_z = zmap; need_z = zplane; tile_list = list;
+        need_z = zbits; tile_list = list;
         if (getenv("NELLIE_MK_DEBUG")) {              // occupancy of the maps (diagnostics: waits for the stream)
-            std::vector<unsigned char> h(n_z + n_zp);
-            NL_HIP(hipMemcpyAsync(h.data(), zmap, n_z + n_zp, hipMemcpyDeviceToHost, c->stream));
+            std::vector<unsigned long long> h(n_z);
+            NL_HIP(hipMemcpyAsync(h.data(), zbits, n_z * 8, hipMemcpyDeviceToHost, c->stream));
             NL_HIP(hipStreamSynchronize(c->stream));
             size_t a = 0, b = 0;
-            for (size_t k = 0; k < n_z; ++k) a += h[k];
-            for (size_t k = 0; k < n_zp; ++k) b += h[n_z + k];
+            for (size_t k = 0; k < n_z; ++k) { a += h[k] != 0; b += (size_t)__builtin_popcountll(h[k]); }
             fprintf(stderr, "[markers] r=%d: %d of %zu in-plane tiles listed (%.1f %%), Z-march workgroups %.1f %%, (plane, column tile) pairs %.1f %%\n", ryx,
-                    c->mk_ntiles, n_t, 100.0 * c->mk_ntiles / n_t, 100.0 * a / n_z, 100.0 * b / n_zp);
+                    c->mk_ntiles, n_t, 100.0 * c->mk_ntiles / n_t, 100.0 * a / n_z, 100.0 * b / ((double)c->nzl * ny4 * nx64));
         }
         const char *e_po = getenv("NELLIE_MK_POISON");
         if (e_po && atoi(e_po)) {
@@ -190,7 +190,7 @@ extern "C" int nl_markers_log_step(nl_ctx *c, const double *wz2, const double *w
         }
     }
     auto zpass = [&](const GaussW &gz) {
-        if (!gl_fast(0, c, use, tz, sparse ? vz : v, z0, z1, gz, act_z)) gl_axis(0, false, c, grid, use, tz, v, z0, z1, gz);
+        if (!gl_fast(0, c, use, tz, v, z0, z1, gz)) gl_axis(0, false, c, grid, use, tz, v, z0, z1, gz);
     };
     // large radii: the fused Y+X kernel turns compute-bound (one output per thread reads 2R+1 LDS values); a marching Y
     // pass plus the stand-alone X kernel (four outputs per thread) through one more scratch volume is faster there
@@ -231,7 +231,7 @@ extern "C" int nl_markers_log_step(nl_ctx *c, const double *wz2, const double *w
             else { yx(gy2, gx0, false); yx(gy0, gx2, true); }
         } else if (sparse && use_dual) {
             // both Z terms in one walk over the image (tz = d2/dz2 term's input, mk_scratch = the plain-Gaussian one), then the listed tiles
-            (void)gl_z_dual(c, rz, use, tz, c->mk_scratch, vz, z0, z1, gauss_ws_of(gz2), gauss_ws_of(gz0), act_z, need_z);
+            (void)gl_z_dual(c, rz, use, tz, c->mk_scratch, vz, z0, z1, gauss_ws_of(gz2), gauss_ws_of(gz0), need_z);
             yx(gy0, gx0, false);
             yx_src = c->mk_scratch;
             yx_dual(true);
