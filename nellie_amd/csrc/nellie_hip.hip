@@ -2011,6 +2011,7 @@ int store_planes(nl_ctx *c, const void *dev_base, void *host, size_t elem, int64
 
 extern "C" int nl_filter_store(nl_ctx *c, float *host, int64_t z0, int64_t z1, char *err, size_t errlen) {
     NL_ENTER(c);
+    NL_KEEP_LABBITS(c);
     NL_KEEP_SUPPORT(c);
     return store_planes(c, c->f[c->i_vmax], host, 4, z0, z1, err, errlen);
 }

@@ -375,6 +375,7 @@ extern "C" int nl_label_run(nl_ctx *c, int has_thr, float thr, int64_t min_area,
     int rc = label_core(c, g, min_area, fill_holes, n_labels, &overflow, err, errlen);
     if (rc) return rc;
     if (overflow) return label_run_voxels(c, has_thr, thr, min_area, fill_holes, n_labels, err, errlen);
+    c->labbits_epoch = c->epoch.load();           // m[1] = the mask the labels were painted from (labels > 0, bit for bit)
     return NL_OK;
 }
 
@@ -858,6 +859,7 @@ extern "C" int nl_host_slab_join(int world, const int32_t *blobs, int64_t block_
 
 extern "C" int nl_label_store(nl_ctx *c, int32_t *host, int64_t z0, int64_t z1, char *err, size_t errlen) {
     NL_ENTER(c);
+    NL_KEEP_LABBITS(c);
     if (c->i_labels < 0) return nl_fail(err, errlen, NL_ESTATE, "nl_label_store before nl_label_run");
     return store_planes(c, c->f[c->i_labels], host, 4, z0, z1, err, errlen);
 }
@@ -996,6 +998,7 @@ extern "C" int nl_input_select(nl_ctx *c, int slot, char *err, size_t errlen) {
 // D2D of the frame's outputs into staging volumes (compute stream), so the next frame may overwrite the originals
 extern "C" int nl_outputs_stage(nl_ctx *c, int with_labels, char *err, size_t errlen) {
     NL_ENTER(c);
+    NL_KEEP_LABBITS(c);
     int rc = stream_init(c, err, errlen);
     if (rc) return rc;
     if (!c->d_stage_fr) NL_HIP(hipMalloc((void **)&c->d_stage_fr, (size_t)c->n * 4));
@@ -1040,6 +1043,7 @@ static inline size_t pk_pad(size_t b) { return (b + 15) & ~(size_t)15; }
 // of the voxels non-zero, or X-neighbours with different labels): use nl_outputs_stage / nl_outputs_fetch_async then.
 extern "C" int nl_outputs_pack(nl_ctx *c, int with_labels, int64_t *nbytes, char *err, size_t errlen) {
     NL_ENTER(c);
+    NL_KEEP_LABBITS(c);
     NL_JOIN_SIDE(c);
     if (!nbytes) return nl_fail(err, errlen, NL_EINVAL, "nbytes is NULL");
     if (with_labels && c->i_labels < 0) return nl_fail(err, errlen, NL_ESTATE, "nl_outputs_pack(with_labels) before nl_label_run");

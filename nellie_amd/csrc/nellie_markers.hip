@@ -27,8 +27,12 @@ extern "C" int nl_markers_begin(nl_ctx *c, const int *labels_host, const void *i
         if (c->i_labels < 0) return nl_fail(err, errlen, NL_ESTATE, "nl_markers_begin(labels = NULL) before nl_label_run");
         lab = (const int *)c->f[c->i_labels];
     }
-    mk_pack_labels_kernel<<<grid1d(nrows * wpr * 64, 256, (i64)1 << 20), 256, 0, c->stream>>>(lab, (unsigned long long *)c->m[1], (int)c->nx, nrows, wpr);
-    NL_CHECK_LAUNCH();
+    // device-resident labels straight from nl_label_run: m[1] still holds the mask they were painted from -- the bits wanted here
+    const bool have_bits = !labels_host && c->labbits_epoch + 1 == c->epoch.load() && !getenv("NELLIE_MK_REPACK");
+    if (!have_bits) {
+        mk_pack_labels_kernel<<<grid1d(nrows * wpr * 64, 256, (i64)1 << 20), 256, 0, c->stream>>>(lab, (unsigned long long *)c->m[1], (int)c->nx, nrows, wpr);
+        NL_CHECK_LAUNCH();
+    }
     // intensities as float32 (score_img[...] = intensity_im[...], mocap_marking.py:595-596)
     c->mk_int = nullptr;
     if (intensity_host) {

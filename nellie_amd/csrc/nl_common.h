@@ -56,6 +56,8 @@ struct nl_ctx {
     std::atomic<unsigned long long> epoch{0};      // C-ABI calls made on this context (see NL_KEEP_SUPPORT)
     unsigned long long support_epoch = ~0ull - 8;   // epoch at which d_support described the Frangi frame
     const unsigned long long *d_support = nullptr;
+    unsigned long long labbits_epoch = ~0ull - 8;   // epoch at which m[1] held the bits `labels > 0` of the label volume (nl_label_run's last
+                                                    // mask: what it painted from); Markers then skips re-deriving them from 4 B/voxel of labels
     int last_label_sparse = 0;
     unsigned char *mk_act = nullptr; size_t mk_act_cap = 0;   // Markers, sparse LoG (markers.inc): [tile list (int32) | tile bytes | Z-march map]
     int mk_act_valid = 0;         // the tile list describes the current mask ...

@@ -101,6 +101,9 @@ static size_t dtype_size(int dt) {
 // use it to skip the 98 % of the frame that is zero -- but only if nothing else ran in between.  Every entry point
 // bumps `epoch`; the few that read the frame without touching it or the mask planes carry the validity forward.
 #define NL_KEEP_SUPPORT(c) if ((c)->support_epoch + 1 == (c)->epoch.load()) (c)->support_epoch = (c)->epoch.load();
+// the same for the label bits nl_label_run leaves in m[1] (read by nl_markers_begin): carried over entry points that write neither the
+// label volume nor the bit planes
+#define NL_KEEP_LABBITS(c) if ((c)->labbits_epoch + 1 == (c)->epoch.load()) (c)->labbits_epoch = (c)->epoch.load();
 
 // Orders the main stream after whatever is still running on the side stream (the resolve kernel of the previous
 // scale).  Called by every entry point that touches the vesselness volume, the mask planes or the queue.
