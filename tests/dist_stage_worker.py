@@ -1,6 +1,8 @@
-"""One rank of the world_size-2 gloo test of the STAGE API on CPU: `Filter(im_info, shard=...).run()` and
-`Label(im_info, shard=...).run()` with the oracle-backed context and the gloo communicator -- every rank writes its own
-planes of the shared output files (nellie_amd/engine.py: RankSlab)."""
+"""One rank of the world_size-2 gloo test of the STAGE API: `Filter(im_info, shard=...).run()` and `Label(im_info, shard=...).run()`
+with the gloo communicator (host-staged exchanges, tests/comms.py) -- every rank writes its own planes of the shared output files
+(nellie_amd/engine.py: RankSlab).  On CPU the contexts are oracle-backed doubles; with `--hip` as the last argument they are the
+real HIP contexts, both ranks on device 0 (tests/test_hip_sharded.py: the multi-process path with the real library on a one-GPU box;
+RCCL itself refuses two ranks on one device, so the communicator stays gloo there)."""
 import os
 import sys
 
@@ -11,20 +13,24 @@ sys.path.insert(0, HERE)
 
 def main():
     import torch.distributed as dist
+    hip = sys.argv[-1] == "--hip"
+    if hip:
+        sys.argv.pop()
     src, out_dir = sys.argv[1], sys.argv[2]
     dist.init_process_group("gloo", init_method="env://")
     rank, world = dist.get_rank(), dist.get_world_size()
     from comms import GlooComm
     from fake_ctx import OracleCtx
     from nellie_amd.utils import adaptive_run
-    adaptive_run.gpu_available = lambda: True           # no GPU here: the contexts below are oracle-backed
+    if not hip:
+        adaptive_run.gpu_available = lambda: True       # no GPU here: the contexts below are oracle-backed
     from nellie_amd.engine import ShardSpec
     from nellie_amd.im_info.verifier import ImInfo
     from nellie_amd.segmentation.filtering import Filter
     from nellie_amd.segmentation.labelling import Label
     im_info = ImInfo(src, output_dir=out_dir)            # the canonical copy was made by the parent: reused, not rewritten
     spec = ShardSpec(rank=rank, world=world, comm_factory=lambda ctx: GlooComm(dist, rank, world),
-                     ctx_factory=lambda shp, dev, g0, gn, ow: OracleCtx(shp, dev, g0, gn, ow))
+                     ctx_factory=None if hip else (lambda shp, dev, g0, gn, ow: OracleCtx(shp, dev, g0, gn, ow)))
     Filter(im_info, shard=spec).run()
     Label(im_info, shard=spec).run()
     dist.barrier()

@@ -121,6 +121,47 @@ def test_zslab_filter_with_the_fused_cascade_kernel(hip, gshape, aniso, world, h
     assert all(p_[1] == ref_thr for p_ in parts) and (ref > 0).any()
 
 
+def test_stage_api_two_processes_share_one_gpu(hip, tmp_path):
+    """The multi-process path with the REAL library on a one-GPU box: two processes (torch.distributed.run, gloo), each with its own HIP
+    context on device 0, run `Filter(im_info, shard=...).run()` and `Label(im_info, shard=...).run()` on their Z slabs of both
+    frames -- rank 0 creates the files, both write their planes (nellie_amd/engine.py: RankSlab; the exchanges are host-staged over
+    gloo, tests/comms.py: RCCL refuses two ranks on one device).  The files equal what ONE context writes, byte for byte; the second
+    Label run masks with the original image (labelling.py:513-520)."""
+    import os
+    import subprocess
+    import sys
+    pytest.importorskip("torch")
+    from fakes import ArrayImInfo
+    from nellie_amd.im_info import ome_tiff
+    from nellie_amd.im_info.verifier import ImInfo
+    from nellie_amd.segmentation.filtering import Filter
+    from nellie_amd.segmentation.labelling import Label
+    from nellie_amd.synthetic import ISO_01, make_volume
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    vols = np.stack([make_volume((72, 50, 66), 170 + t) for t in range(2)])
+    src = str(tmp_path / "stack.ome.tif")
+    ome_tiff.create(src, vols.shape, np.float32, ISO_01, "raw", data=vols)
+    out_dir = str(tmp_path / "out")
+    im_info = ImInfo(src, output_dir=out_dir)
+    port = 29700 + (os.getpid() % 90)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(repo, "tests", "dist_stage_worker.py"), src, out_dir, "101.5", "--hip"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    fr = np.asarray(im_info.get_memmap(im_info.pipeline_paths["im_preprocessed"], read_mode="r"))
+    lab = np.load(os.path.join(out_dir, "labels_plain.npy"))
+    lab_thr = np.asarray(im_info.get_memmap(im_info.pipeline_paths["im_instance_label"], read_mode="r"))
+    one = ArrayImInfo(vols, ISO_01)
+    Filter(one).run()
+    Label(one).run()
+    assert np.array_equal(fr, np.asarray(one.store["frangi"])), f"{int((fr != np.asarray(one.store['frangi'])).sum())} voxels differ"
+    assert np.array_equal(lab, np.asarray(one.store["labels"])) and lab.max() >= 1
+    Label(one, threshold=101.5).run()
+    assert np.array_equal(lab_thr, np.asarray(one.store["labels"])) and not np.array_equal(lab_thr, lab)
+    assert np.array_equal(np.asarray(im_info.get_memmap(im_info.im_path, read_mode="r")), vols), "input file was modified"
+
+
 def _single_reference(gshape, dr, seed):
     from nellie_amd import pipeline as pl
     from nellie_amd.synthetic import make_volume
