@@ -522,7 +522,6 @@ extern "C" int nl_gauss_step(nl_ctx *c, const double *wz, int rz, const double *
     const VolGeom v = geom(c);
     // three ping-pong volumes f[0..2]: the source of a pass is dead once the pass has run,
     // so "the next one" is always a legal destination
-    const dim3 blk(256, 1, 1);
     const dim3 grid((unsigned)((c->nx + 255) / 256), (unsigned)c->ny, (unsigned)(z1 - z0));
     int src = c->i_gauss;
     const float *srcp = gauss_cur(c);       // the source of the next pass (the borrowed input before the first one)
@@ -1656,7 +1655,6 @@ extern "C" int nl_log2d_step(nl_ctx *c, const double *wy2, const double *wy0, co
     if ((rc = fill_gw(gy2, wy2, r, err, errlen)) || (rc = fill_gw(gy0, wy0, r, err, errlen)) ||
         (rc = fill_gw(gx2, wx2, r, err, errlen)) || (rc = fill_gw(gx0, wx0, r, err, errlen))) return rc;
     const VolGeom v = geom(c);
-    const dim3 blk(256, 1, 1);
     const dim3 grid((unsigned)((c->nx + 255) / 256), (unsigned)c->ny, 1);
     ProfScope ps(c, "log2d");
     const float *src = gauss_cur(c);

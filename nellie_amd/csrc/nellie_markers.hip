@@ -130,7 +130,6 @@ extern "C" int nl_markers_log_step(nl_ctx *c, const double *wz2, const double *w
         (rc = fill_gw(gy0, wy0, ryx, err, errlen)) || (rc = fill_gw(gx2, wx2, ryx, err, errlen)) || (rc = fill_gw(gx0, wx0, ryx, err, errlen))) return rc;
     const VolGeom v = geom(c);
     const i64 z0 = 0, z1 = c->nzl;
-    const dim3 blk(256, 1, 1);
     const dim3 grid((unsigned)((c->nx + 255) / 256), (unsigned)c->ny, (unsigned)c->nzl);
     const dim3 g2((unsigned)((c->nx + GYX_COLS - 1) / GYX_COLS), (unsigned)((c->ny + v.chunk - 1) / v.chunk), (unsigned)c->nzl);
     float *dist = c->f[0], *tz = c->f[1], *lap = c->f[2];
