@@ -41,7 +41,8 @@ class StreamedSegmenter:
         self.packed_frames = 0
         self._zero_fill = True
         self.io = ThreadPoolExecutor(max_workers=3)
-        self.copy_threads = max(1, min(8, (os.cpu_count() or 2) // 2))
+        # host threads of the copies / the packed-output expansion (NELLIE_STREAM_COPY_THREADS: A/B)
+        self.copy_threads = int(os.environ.get("NELLIE_STREAM_COPY_THREADS", "0")) or max(1, min(8, (os.cpu_count() or 2) // 2))
         self.copiers = ThreadPoolExecutor(max_workers=self.copy_threads)
         self.stats = []
         self.timing = {"wait_upload": 0.0, "compute": 0.0, "wait_download": 0.0, "frames": 0}   # main-thread seconds
