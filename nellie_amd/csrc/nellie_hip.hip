@@ -158,6 +158,13 @@ static HessDv<1> hessdv_fast(const nl_ctx *c) { return hessdv_fast(hessp(c)); } 
 static HessDv<0> hessdv_exact(const nl_ctx *c) { return hessdv_exact(hessp(c)); }
 // the pair walk (its own translation unit, hv_launch.h): division variant as proven for this context's divisors
 static int hv_fastv(const nl_ctx *c) { return c->fast_div2 ? 2 : (c->fast_div ? 1 : 0); }
+// pair-rows per lane of the pair walk (NELLIE_HV_NP=2: four voxels per lane at 2 waves / SIMD -- the round-5 experiment, hessian_pair.inc;
+// only instantiated for the 16-row tile with the two-instruction division)
+static int hv_np(const nl_ctx *c) {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("NELLIE_HV_NP"); v = (e && atoi(e) == 2) ? 2 : 1; }
+    return (v == 2 && hv_rs(c) == 8 && hv_fastv(c) == 2) ? 2 : 1;
+}
 // Exhaustive proof that the 3-instruction division is exact for the six divisors in use.
 static int check_fast_div(nl_ctx *c, char *err, size_t errlen) {
     const float ds[6] = {c->hz, c->hy, c->hx, c->hz2, c->hy2, c->hx2};
@@ -1133,7 +1140,7 @@ extern "C" int nl_hessian_stats(nl_ctx *c, const double spacing[3], float *max_a
             (int)((c->ny + TYV - 1) / TYV), res, nullptr)
         if (hv_rs(c)) {
             const int rsv = hv_rs(c), ntyv = (int)((c->ny + 2 * rsv - 1) / (2 * rsv));
-            NL_HIP(nl_hv_launch(HvLaunch{0, rsv, hv_fastv(c), (unsigned)(ntx * ntyv * nzc), c->stream, gauss_cur(c), nullptr, nullptr, 0, geom(c),
+            NL_HIP(nl_hv_launch(HvLaunch{0, rsv, hv_np(c), hv_fastv(c), (unsigned)(ntx * ntyv * nzc), c->stream, gauss_cur(c), nullptr, nullptr, 0, geom(c),
                                          hessp(c), vp, VQueue{}, (int)c->own_lo, (int)c->own_hi, ntx, ntyv, res, nullptr, nullptr}));
         }
         else if (hm_ty() == 8) { if (c->fast_div) NL_LAUNCH_STATS(8, true, hessdv_fast(c)); else NL_LAUNCH_STATS(8, false, hessdv_exact(c)); }
@@ -1242,20 +1249,20 @@ static int spec_enqueue(nl_ctx *c, const double spacing[3], float fsq_lo, float 
         const int nzc = (int)((z1 - z0 + zch - 1) / zch);
         const unsigned nblocks = (unsigned)(ntx * nty * nzc);
         vp.qcap = HM_SPEC_CAP * (zch / HM_ZCHUNK);
-        if (rs) vp.qcap *= 2;                           // a wave owns two row segments
+        if (rs) vp.qcap *= 2 * hv_np(c);                 // a wave owns two (four) row segments
         hipStream_t hs = c->stream;
 #define NL_DEV_LOHI dev_lohi
 #define NL_LAUNCH_SPEC(TYV, FASTV, HR)                                                                                    \
         hessian_g_kernel<2, TYV, FASTV><<<nblocks, HGCfg<TYV>::NT, HGCfg<TYV>::lds_bytes(), c->stream>>>(                 \
             gauss_cur(c), cm, pm, wpr, geom(c), HR, vp, vq, (int)z0, (int)z1, ntx, nty, res, d_cnt)
-        if (rs) NL_HIP(nl_hv_launch(HvLaunch{2, rs, hv_fastv(c), nblocks, hs, gauss_cur(c), cm, pm, wpr, geom(c), hessp(c), vp, vq, (int)z0, (int)z1,
+        if (rs) NL_HIP(nl_hv_launch(HvLaunch{2, rs, hv_np(c), hv_fastv(c), nblocks, hs, gauss_cur(c), cm, pm, wpr, geom(c), hessp(c), vp, vq, (int)z0, (int)z1,
                                              ntx, nty, res, d_cnt, NL_DEV_LOHI}));
         else if (ty == 8) { if (c->fast_div) NL_LAUNCH_SPEC(8, true, hessdv_fast(c)); else NL_LAUNCH_SPEC(8, false, hessdv_exact(c)); }
         else { if (c->fast_div) NL_LAUNCH_SPEC(16, true, hessdv_fast(c)); else NL_LAUNCH_SPEC(16, false, hessdv_exact(c)); }
 #undef NL_LAUNCH_SPEC
 #undef NL_DEV_LOHI
         NL_CHECK_LAUNCH();
-        c->spec_nregions = nblocks * (unsigned)(rs ? rs : ty);
+        c->spec_nregions = nblocks * (unsigned)(rs ? rs / hv_np(c) : ty);
         c->spec_qcap = vp.qcap;
     }
     // fused: max |H|, max frob_sq (bit patterns of non-negative floats), the inf and overflow flags -- all "max"; the count stays local
@@ -1601,7 +1608,7 @@ extern "C" int nl_vesselness_step(nl_ctx *c, float gamma_sq, float alpha_sq, flo
         const int rs = hv_rs(c);
         const int ty = rs ? 2 * rs : hm_ty();
         const int nty = (int)((c->ny + ty - 1) / ty);
-        if (rs) vp.qcap = 2 * HM_REGION;
+        if (rs) vp.qcap = 2 * hv_np(c) * HM_REGION;
 #define NL_LAUNCH_VESS(TYV, FASTV, HR)                                                                                    \
         hessian_g_kernel<1, TYV, FASTV><<<nblocks, HGCfg<TYV>::NT, HGCfg<TYV>::lds_bytes(), c->stream>>>(                 \
             gauss_cur(c), cm, pm, wpr, geom(c), HR, vp, vq, (int)za, (int)zb, ntx, nty, nullptr, d_cnt)
@@ -1609,12 +1616,12 @@ extern "C" int nl_vesselness_step(nl_ctx *c, float gamma_sq, float alpha_sq, flo
             const i64 zb = za + planes_per_launch < z1 ? za + planes_per_launch : z1;
             const int nzc = (int)((zb - za + HM_ZCHUNK - 1) / HM_ZCHUNK);
             const unsigned nblocks = (unsigned)(ntx * nty * nzc);
-            if (rs) NL_HIP(nl_hv_launch(HvLaunch{1, rs, hv_fastv(c), nblocks, c->stream, gauss_cur(c), cm, pm, wpr, geom(c), hessp(c), vp, vq, (int)za, (int)zb,
+            if (rs) NL_HIP(nl_hv_launch(HvLaunch{1, rs, hv_np(c), hv_fastv(c), nblocks, c->stream, gauss_cur(c), cm, pm, wpr, geom(c), hessp(c), vp, vq, (int)za, (int)zb,
                                                  ntx, nty, nullptr, d_cnt, nullptr}));
             else if (ty == 8) { if (c->fast_div) NL_LAUNCH_VESS(8, true, hessdv_fast(c)); else NL_LAUNCH_VESS(8, false, hessdv_exact(c)); }
             else { if (c->fast_div) NL_LAUNCH_VESS(16, true, hessdv_fast(c)); else NL_LAUNCH_VESS(16, false, hessdv_exact(c)); }
             NL_CHECK_LAUNCH();
-            const unsigned nregions = nblocks * (unsigned)(rs ? rs : ty);
+            const unsigned nregions = nblocks * (unsigned)(rs ? rs / hv_np(c) : ty);
             vesselness_queue_kernel<false><<<resolve_grid((nregions + 3) / 4), 256, 0, c->stream>>>(vq.ent, vq.count, nregions, c->f[c->i_vmax], za * plane, vp,
                                                                                       nullptr, nullptr, wpr, (int)c->ny, (int)c->nx, za, nullptr, nullptr);
             NL_CHECK_LAUNCH();

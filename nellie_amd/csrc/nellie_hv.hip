@@ -15,11 +15,16 @@ template <typename K> static void allow_lds(K kernel, int bytes) {
     if (bytes > (64 << 10)) (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
+template <int MODE, int RS, int FAST, int NP>
+static void launch_np(const HvLaunch &a, const HessDv<FAST> &hr) {
+    allow_lds(hessian_v_kernel<MODE, RS, FAST, NP>, HVCfg<RS, NP>::lds_bytes());
+    hessian_v_kernel<MODE, RS, FAST, NP><<<a.nblocks, HVCfg<RS, NP>::NT, HVCfg<RS, NP>::lds_bytes(), a.stream>>>(
+        a.g, a.cmask, a.pmask, a.wpr, a.geom, hr, a.vp, a.vq, a.z0, a.z1, a.ntx, a.nty, a.res, a.d_cnt, a.dev_lohi);
+}
 template <int MODE, int RS, int FAST>
 static void launch_one(const HvLaunch &a, const HessDv<FAST> &hr) {
-    allow_lds(hessian_v_kernel<MODE, RS, FAST>, HVCfg<RS>::lds_bytes());
-    hessian_v_kernel<MODE, RS, FAST><<<a.nblocks, HVCfg<RS>::NT, HVCfg<RS>::lds_bytes(), a.stream>>>(
-        a.g, a.cmask, a.pmask, a.wpr, a.geom, hr, a.vp, a.vq, a.z0, a.z1, a.ntx, a.nty, a.res, a.d_cnt, a.dev_lohi);
+    if constexpr (RS == 8 && FAST == 2) { if (a.np == 2) { launch_np<MODE, RS, FAST, 2>(a, hr); return; } }
+    launch_np<MODE, RS, FAST, 1>(a, hr);
 }
 template <int MODE, int RS>
 static void launch_div(const HvLaunch &a) {
@@ -34,6 +39,7 @@ static void launch_rs(const HvLaunch &a) {
 
 hipError_t nl_hv_launch(const HvLaunch &a) {
     if (a.rs != 8 && a.rs != 16) return hipErrorInvalidValue;
+    if (a.np != 1 && !(a.np == 2 && a.rs == 8 && a.fastv == 2)) return hipErrorInvalidValue;
     switch (a.mode) {
         case 0: launch_rs<0>(a); break;
         case 1: launch_rs<1>(a); break;

@@ -555,13 +555,28 @@ class FramePipeline:
         # No cascade step runs ahead here: that device (sharded.py) fills the GPU while the host waits for a scale's collectives,
         # and the chain has no such waits -- beside the walk the step only competes with it (measured on a 128 x 2048 x 2048 slab:
         # 34.1 ms/step with a step running ahead, 29.9 without; the synchronous path: 31.6 / 30.4).
-        for k in range(len(sigmas)):
+        # ... except on frames that stream from the caches (below 2^26 voxels: a config-5 frame).  There a scale's threshold kernels --
+        # one wave or a 10^6-point lattice each, ten of them per scale -- leave the GPU idle for 0.12 ms of every 0.5 ms, and the next
+        # cascade step, enqueued on the side stream, fills those holes (round 5: 2.70 -> see profiles/r05_c5_chain_ahead.txt).
+        run_ahead = self._chain_ahead(int(np.prod(self.shape)))
+        ahead = False
+
+        def cascade_step(k, on_side):
             delta = deltas[k]
-            if any(s > 0 for s in delta):
-                ws = [gaussian_weights(d) for d in delta]
-                z0, z1 = self._gauss_range(0 if ws[0] is None else (len(ws[0]) - 1) // 2)
-                ctx.gauss_step(*ws, z0=z0, z1=z1)
+            if not any(s > 0 for s in delta):
+                return False
+            ws = [gaussian_weights(d) for d in delta]
+            z0, z1 = self._gauss_range(0 if ws[0] is None else (len(ws[0]) - 1) // 2)
+            ctx.gauss_step(*ws, z0=z0, z1=z1, **({"ahead": True} if on_side else {}))
+            return True
+
+        for k in range(len(sigmas)):
+            if ahead:
+                ctx.gauss_commit()
+            else:
+                cascade_step(k, False)
             self._after_cascade_step(k)
+            ahead = run_ahead and k + 1 < len(sigmas) and cascade_step(k + 1, True)
             vz0, vz1 = self._vess_range()
             ctx.chain_scale(spacing, strides, float(p.alpha_sq), float(p.beta_sq), float(p.frob_thresh_division), self.one_pass_margin,
                             self._one_pass_test_scale, z0=vz0, z1=vz1)
@@ -600,6 +615,14 @@ class FramePipeline:
 
     def _all_ranks_agree(self, ok: bool) -> bool:
         return ok
+
+    # NELLIE_CHAIN_AHEAD: unset = frames below 2^26 voxels on a single context; 0 / 1: never / always
+    _chain_ahead_env = os.environ.get("NELLIE_CHAIN_AHEAD")
+
+    def _chain_ahead(self, n_voxels: int) -> bool:
+        if self._chain_ahead_env is not None:
+            return self._chain_ahead_env == "1"
+        return n_voxels < (1 << 26)
 
     def _finish_frame(self, finish: bool, p: FilterParams, mask: bool):
         """The product `vesselness * masks` (filtering.py:926) once every scale is in."""

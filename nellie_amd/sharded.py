@@ -335,6 +335,9 @@ class ShardedFramePipeline(FramePipeline):
         if self.halo_mode == "steps" and self.world > 1 and k + 1 < len(self._rz) and self._rz[k + 1] > 0:
             self.comm.exchange_halo(self.ctx, FIELD_GAUSS, self._rz[k + 1], 4, True)
 
+    def _chain_ahead(self, n_voxels):
+        return False             # a slab's next cascade step needs ghost planes that are still travelling (_after_cascade_step)
+
     def _vess_range(self):
         lo, hi = self.own
         return max(lo - 2, 0), min(hi + 2, self.lshape[0])

@@ -1095,6 +1095,33 @@ def test_device_chain_equals_the_synchronous_path(hip, shape, seed, aniso):
     assert np.array_equal(fr_c, fr_s) and (fr_c > 0).any()
 
 
+@pytest.mark.parametrize("fused", ["0", "1"])
+def test_device_chain_with_the_next_cascade_step_running_ahead(hip, fused, monkeypatch):
+    """Round 5: on frames below 2^26 voxels the chain enqueues the cascade step of scale s+1 on the side stream beside the
+    threshold kernels and the walk of scale s (pipeline._chain_ahead).  Forced on and off, with the two-kernel and the fused
+    cascade step (which may not zero the scale maximum in passing from the side stream): same trace, same frame, same labels."""
+    from nellie_amd import pipeline as pl
+    from nellie_amd.synthetic import ISO_01, make_volume
+    monkeypatch.setenv("NELLIE_GAUSS_FUSED", fused)
+    vol = make_volume((72, 136, 200), 31)
+    p = pl.FilterParams(dim_res=ISO_01)
+    got = []
+    for ahead in ("1", "0"):
+        pipe = pl.FramePipeline(vol.shape)
+        pipe._chain_ahead_env = ahead
+        for _ in range(2):                       # the second frame starts from the state the first one left
+            pipe.filter(vol, p)
+        tr = [(s.sigma, s.gamma, s.max_abs, s.frob_thr, s.mask_count, s.skipped) for s in pipe.trace.scales]
+        fr = pipe.download_frangi()
+        n = pipe.label(pipe.frangi_threshold(), pl.min_area_pixels_of(ISO_01))
+        got.append((fr, tr, pipe.trace.n_positive, n, pipe.download_labels(), pipe.chain_fallbacks))
+        pipe.close()
+    (fa, ta, pa, na, la, fba), (fb, tb, pb, nb, lb, fbb) = got
+    assert fba == 0 and fbb == 0
+    assert ta == tb and pa == pb and na == nb
+    assert np.array_equal(fa, fb) and (fa > 0).any() and np.array_equal(la, lb)
+
+
 def test_device_chain_falls_back_on_a_bracket_miss(hip):
     """A prediction pushed off by 50 % misses the bracket: the chain flags it (NL_CF_MISS = 128), the frame is redone the
     synchronous way (which goes two-pass) and the result is the one-pass result."""

@@ -7,3 +7,7 @@
 #include "../../nellie_amd/csrc/hessian_pair.inc"
 template __global__ void hessian_v_kernel<2, 8, 2>(const float *, unsigned long long *, const unsigned long long *, int, VolGeom, HessDv<2>, VessP,
                                                       VQueue, int, int, int, int, unsigned int *, unsigned long long *, const float *);
+#ifdef HV_ONLY_NP2
+template __global__ void hessian_v_kernel<2, 8, 2, 2>(const float *, unsigned long long *, const unsigned long long *, int, VolGeom, HessDv<2>, VessP,
+                                                         VQueue, int, int, int, int, unsigned int *, unsigned long long *, const float *);
+#endif
