@@ -23,8 +23,13 @@ struct RcclApi {
 static RcclApi &rccl_real() {
     static RcclApi api;
     if (!api.handle) {
-        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
-        for (const char *n : names) { api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (api.handle) break; }
+        // The installed ROCm's copy BY PATH first: a bare "librccl.so.1" is answered with whatever object of that SONAME the process
+        // already holds -- e.g. the RCCL a PyTorch wheel bundles (built against another HIP runtime: ncclCommInitRank then fails with
+        // "unhandled cuda error"; found when a test imported torch into the pytest process, round 5).
+        std::string rp;
+        if (const char *e = getenv("ROCM_PATH")) rp = std::string(e) + "/lib/librccl.so.1";
+        const char *names[] = {rp.c_str(), "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so", "librccl.so.1", "librccl.so"};
+        for (const char *n : names) { if (!*n) continue; api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (api.handle) break; }
         if (api.handle) {
 #define NL_SYM(F) api.F = (decltype(api.F))dlsym(api.handle, "nccl" #F)
             NL_SYM(GetUniqueId); NL_SYM(CommInitRank); NL_SYM(CommDestroy); NL_SYM(GetErrorString); NL_SYM(GroupStart);
@@ -161,9 +166,8 @@ static int hv_fastv(const nl_ctx *c) { return c->fast_div2 ? 2 : (c->fast_div ? 
 // pair-rows per lane of the pair walk (NELLIE_HV_NP=2: four voxels per lane at 2 waves / SIMD -- the round-5 experiment, hessian_pair.inc;
 // only instantiated for the 16-row tile with the two-instruction division)
 static int hv_np(const nl_ctx *c) {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("NELLIE_HV_NP"); v = (e && atoi(e) == 2) ? 2 : 1; }
-    return (v == 2 && hv_rs(c) == 8 && hv_fastv(c) == 2) ? 2 : 1;
+    const char *e = getenv("NELLIE_HV_NP");            // read per call: tests switch it inside one process
+    return (e && atoi(e) == 2 && hv_rs(c) == 8 && hv_fastv(c) == 2) ? 2 : 1;
 }
 // Exhaustive proof that the 3-instruction division is exact for the six divisors in use.
 static int check_fast_div(nl_ctx *c, char *err, size_t errlen) {
@@ -517,6 +521,16 @@ extern "C" int nl_filter_begin(nl_ctx *c, char *err, size_t errlen) {
 }
 
 
+// Y and X passes in one kernel (gauss_yx_tile_kernel): equal radii up to GM_MAX_R that fit the Y axis
+static bool gauss_can_yx(const nl_ctx *c, const double *wy, int ry, const double *wx, int rx) {
+    return wy && wx && ry == rx && ry >= 1 && ry <= GM_MAX_R && ry <= c->ny && !getenv("NELLIE_NO_FUSED_YX");
+}
+// Ping-pong volumes a cascade step writes one after the other: 1 (fused Z+Y+X), 2 (Z, then Y+X) or 3 (one per axis: radii beyond
+// GM_MAX_R, unequal in-plane radii).  The third destination of a three-pass step is the step's own SOURCE volume.
+static int gauss_step_volumes(const nl_ctx *c, const double *wz, const double *wy, int ry, const double *wx, int rx) {
+    return (wz ? 1 : 0) + (gauss_can_yx(c, wy, ry, wx, rx) ? 1 : (wy ? 1 : 0) + (wx ? 1 : 0));
+}
+
 extern "C" int nl_gauss_step(nl_ctx *c, const double *wz, int rz, const double *wy, int ry, const double *wx, int rx,
                              int64_t z0, int64_t z1, char *err, size_t errlen) {
     NL_ENTER(c);
@@ -534,7 +548,7 @@ extern "C" int nl_gauss_step(nl_ctx *c, const double *wz, int rz, const double *
     const float *srcp = gauss_cur(c);       // the source of the next pass (the borrowed input before the first one)
     GaussW gw;
     int rc;
-    const bool can_yx = wy && wx && ry == rx && ry >= 1 && ry <= GM_MAX_R && ry <= c->ny && !getenv("NELLIE_NO_FUSED_YX");
+    const bool can_yx = gauss_can_yx(c, wy, ry, wx, rx);
     bool fused_yx = false;
     // The whole step in one kernel (gauss_zyx.inc) when the radii have an instantiation and Y and X share their weights, which is
     // what Filter asks for (sigma_vec = (s / z_ratio, s, s)) -- on volumes that do not fit the caches: the fused kernel trades HBM
@@ -620,6 +634,11 @@ extern "C" int nl_gauss_step_ahead(nl_ctx *c, const double *wz, int rz, const do
                                    int64_t z0, int64_t z1, char *err, size_t errlen) {
     NL_ENTER(c);
     if (c->ahead_pending) return nl_fail(err, errlen, NL_ESTATE, "a step enqueued ahead is already pending");
+    // A step of three passes would write its third pass into the volume it started from -- the Gaussian the current scale is
+    // still reading (found by the fuzzer's explicit sigma lists, round 5: radii beyond GM_MAX_R).  Callers ask
+    // nl_ctx_info("gauss_yx_max_r") and run such steps in order.
+    if (gauss_step_volumes(c, wz, wy, ry, wx, rx) > 2)
+        return nl_fail(err, errlen, NL_ESTATE, "a cascade step of three passes (radii %d / %d / %d) cannot run ahead: it needs the current Gaussian's volume", rz, ry, rx);
     NL_HIP(hipEventRecord(c->ev_main, c->stream));
     hipStream_t ahead_stream = c->side;
     NL_HIP(hipStreamWaitEvent(ahead_stream, c->ev_main, 0));
@@ -2055,6 +2074,7 @@ extern "C" int nl_comm_unique_id(char *id128, char *err, size_t errlen) {
     if (!id128) return nl_fail(err, errlen, NL_EINVAL, "id buffer is NULL");
     ncclUniqueId id;
     {
+        (void)hipGetLastError();        // (see comm_acquire)
         ncclResult_t r_ = rccl().GetUniqueId(&id);
         if (r_ != ncclSuccess) return nl_fail(err, errlen, NL_ECOMM, "ncclGetUniqueId: %s", rccl().GetErrorString(r_));
     }
@@ -2109,6 +2129,7 @@ static int comm_acquire(nl_ctx *c, int world, int rank, const char *id128, int r
         ncclComm_t pooled = comm_pool_take(c->device, world, rank, role);
         if (pooled) { *out = pooled; return NL_OK; }
     }
+    (void)hipGetLastError();        // RCCL checks the thread's last HIP error during init: it must not inherit one that was handled long ago
     NL_NCCL(rccl().CommInitRank(out, world, id, rank));
     return NL_OK;
 }
@@ -2444,6 +2465,7 @@ extern "C" int nl_ctx_info(nl_ctx *c, const char *key, double *value) {
     else if (!strcmp(key, "last_spec_overflow")) *value = c->last_spec_overflow;
     else if (!strcmp(key, "last_label_sparse")) *value = c->last_label_sparse;
     else if (!strcmp(key, "device_bytes")) *value = (double)nl_ctx_bytes(c->nzl, c->ny, c->nx);
+    else if (!strcmp(key, "gauss_yx_max_r")) *value = getenv("NELLIE_NO_FUSED_YX") ? 0 : GM_MAX_R;   // largest in-plane radius whose Y and X passes share a kernel
     else if (!strcmp(key, "nan_hessian")) {
         // Filter.run(mask=False) only: 1 if a Hessian with a NaN entry reached the eigen-solver since the frame began (waits for the stream)
         if (hipSetDevice(c->device) != hipSuccess) return NL_EHIP;

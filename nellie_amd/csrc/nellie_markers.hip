@@ -250,8 +250,14 @@ extern "C" int nl_markers_log_step(nl_ctx *c, const double *wz2, const double *w
         ProfScope ps(c, "markers_peaks");
         const int wpr = (int)((c->nx + 63) / 64);
         const i64 nw = c->nzl * c->ny * wpr;
-        mk_peak_kernel<<<grid1d(nw, 256, (i64)1 << 20), 256, 0, c->stream>>>(lap, s2, (const unsigned long long *)c->m[1], dist, c->f[3],
-                                                                                 (unsigned long long *)c->m[0], v, wpr, c->mk_first_scale);
+        // groups of four rows share their neighbour rows (NELLIE_MK_PEAK4=0: one word at a time, the round-3 kernel)
+        const char *e4 = getenv("NELLIE_MK_PEAK4");
+        if (e4 && !atoi(e4))
+            mk_peak_kernel<<<grid1d(nw, 256, (i64)1 << 20), 256, 0, c->stream>>>(lap, s2, (const unsigned long long *)c->m[1], dist, c->f[3],
+                                                                                     (unsigned long long *)c->m[0], v, wpr, c->mk_first_scale);
+        else
+            mk_peak4_kernel<<<grid1d(c->nzl * ((c->ny + 3) / 4) * wpr, 256, (i64)1 << 20), 256, 0, c->stream>>>(
+                lap, s2, (const unsigned long long *)c->m[1], dist, c->f[3], (unsigned long long *)c->m[0], v, wpr, c->mk_first_scale);
         NL_CHECK_LAUNCH();
         c->mk_first_scale = 0;
     }

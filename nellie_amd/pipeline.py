@@ -253,6 +253,21 @@ class FramePipeline:
         self._pair_hist = hasattr(self.ctx, "sample_range_hist2") and os.environ.get("NELLIE_PAIR_HIST", "1") != "0"
         self.check_device_edges = os.environ.get("NELLIE_CHECK_EDGES", "0") == "1"
         self._one_pass_test_scale = 1.0      # tests: shifts the prediction to force a miss
+        try:
+            self._yx_max_r = int(self.ctx.info("gauss_yx_max_r"))
+        except (KeyError, AttributeError):
+            self._yx_max_r = 0
+
+    def _step_fits_ahead(self, ws) -> bool:
+        """nl_gauss_step_ahead takes steps that write at most two of the three ping-pong volumes (a Z pass and a fused Y+X pass):
+        the third pass of a one-kernel-per-axis step lands in the volume the current scale still reads."""
+        wz, wy, wx = ws
+        n = 0 if wz is None else 1
+        if wy is not None and wx is not None and len(wy) == len(wx) and 1 <= (len(wy) - 1) // 2 <= min(self._yx_max_r, self.shape[1]):
+            n += 1
+        else:
+            n += (wy is not None) + (wx is not None)
+        return n <= 2
 
     def close(self):
         self.ctx.close()
@@ -440,6 +455,8 @@ class FramePipeline:
             if not any(s > 0 for s in delta):
                 return False
             ws = [gaussian_weights(d) for d in delta]
+            if run_ahead and not self._step_fits_ahead(ws):
+                return False
             z0, z1 = self._gauss_range(0 if ws[0] is None else (len(ws[0]) - 1) // 2)
             ctx.gauss_step(*ws, z0=z0, z1=z1, **({"ahead": True} if run_ahead else {}))
             return True
@@ -566,6 +583,8 @@ class FramePipeline:
             if not any(s > 0 for s in delta):
                 return False
             ws = [gaussian_weights(d) for d in delta]
+            if on_side and not self._step_fits_ahead(ws):
+                return False                 # (it runs in order at the top of the next trip)
             z0, z1 = self._gauss_range(0 if ws[0] is None else (len(ws[0]) - 1) // 2)
             ctx.gauss_step(*ws, z0=z0, z1=z1, **({"ahead": True} if on_side else {}))
             return True

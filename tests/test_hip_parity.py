@@ -1095,6 +1095,23 @@ def test_device_chain_equals_the_synchronous_path(hip, shape, seed, aniso):
     assert np.array_equal(fr_c, fr_s) and (fr_c > 0).any()
 
 
+@pytest.mark.parametrize("shape,seed,aniso", [((40, 96, 96), 21, False), ((33, 70, 130), 22, True), ((70, 150, 200), 25, False)])
+def test_walk_with_four_voxels_per_lane_is_bit_identical(hip, shape, seed, aniso, monkeypatch):
+    """NELLIE_HV_NP=2 (round 5, profiles/r05_walk_variants_1024cube.txt block 4): the pair walk with two pair-rows per lane -- measured
+    26 % slower and therefore off, but the same bits: trace, frame (chain and synchronous path, which also runs the two-pass modes)."""
+    from nellie_amd.synthetic import ANISO_03, ISO_01, make_volume
+    vol = make_volume(shape, seed)
+    dr = ANISO_03 if aniso else ISO_01
+    ref = _run_both_ways(vol, dr)
+    monkeypatch.setenv("NELLIE_HV_NP", "2")
+    got = _run_both_ways(vol, dr)
+    for (fr_a, tr_a, np_a, pt_a, _, _), (fr_b, tr_b, np_b, pt_b, _, _) in zip(ref, got):
+        assert tr_a == tr_b and np_a == np_b and pt_a == pt_b
+        assert np.array_equal(fr_a, fr_b) and (fr_a > 0).any()
+    two = _run_both_ways(vol, dr, one_pass=False)[1]          # statistics walk + known-threshold walk (MODE 0 / MODE 1) of the same kernel
+    assert two[1] == ref[1][1] and np.array_equal(two[0], ref[1][0])
+
+
 @pytest.mark.parametrize("fused", ["0", "1"])
 def test_device_chain_with_the_next_cascade_step_running_ahead(hip, fused, monkeypatch):
     """Round 5: on frames below 2^26 voxels the chain enqueues the cascade step of scale s+1 on the side stream beside the

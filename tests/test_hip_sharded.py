@@ -15,6 +15,16 @@ from comms import ThreadComm, ThreadGroup
 pytestmark = pytest.mark.gpu
 
 
+
+def _need_torch():
+    """Skips without torch -- WITHOUT importing it here: the workers run in their own processes, and a torch imported into the pytest
+    process brings its bundled librccl / HIP runtime along, which the library's own dlopen("librccl.so.1") then gets handed
+    (ncclCommInitRank: "unhandled cuda error", 150 tests later -- round 5)."""
+    import importlib.util
+    if importlib.util.find_spec("torch") is None:
+        pytest.skip("torch (torch.distributed.run + gloo for the worker processes) is not installed")
+
+
 def _comm_factory(transport, world, group):
     """rank -> comm_factory(ctx).  "host": planes and scalars travel through numpy arrays (nl_planes_get / _put); "loopback":
     the production RcclComm over the library's loopback transport -- the nccl* call sites, their plane offsets and counts,
@@ -130,7 +140,7 @@ def test_stage_api_two_processes_share_one_gpu(hip, tmp_path):
     import os
     import subprocess
     import sys
-    pytest.importorskip("torch")
+    _need_torch()
     from fakes import ArrayImInfo
     from nellie_amd.im_info import ome_tiff
     from nellie_amd.im_info.verifier import ImInfo

@@ -9,6 +9,9 @@ from nellie_amd import pipeline as pl
 from nellie_amd.streaming import StreamedSegmenter
 from nellie_amd.synthetic import ISO_01, make_volume
 
+# lanes are Python threads: a lane coming back from a C call waits for the GIL up to one switch interval (5 ms by default -- longer than a frame)
+if os.environ.get("NELLIE_SWITCH_INTERVAL"):
+    sys.setswitchinterval(float(os.environ["NELLIE_SWITCH_INTERVAL"]))
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 lanes_list = [int(a) for a in sys.argv[2:]] or [1, 2, 3]
 fs = (128, 512, 512)
