@@ -21,7 +21,9 @@ static int zyx_chunk(const nl_ctx *c, int rz, int r, i64 nplanes) {
     const i64 tiles = ((c->nx + 63) / 64) * ((c->ny + ty - 1) / ty);
     static int min_wgs = 0;                      // NELLIE_ZYX_MIN_WGS: A/B of the rule (workgroups a launch should have)
     if (!min_wgs) { const char *e = getenv("NELLIE_ZYX_MIN_WGS"); min_wgs = (e && atoi(e) > 0) ? atoi(e) : 512; }
-    int zchunk = 128;
+    // planes a workgroup marches: 128 (R = 4 at 1024^3: 64 / 128 / 256 planes 2.91 / 2.73 / 2.92 ms), 256 for the 32-row tiles of R = 5, whose 2R-plane warm-up
+    // weighs more (3.82 -> 3.71 ms; profiles/r05_ubench_gauss_zyx_lds64.txt)
+    int zchunk = r >= 5 ? 256 : 128;
     while (zchunk > 8 && tiles * ((nplanes + zchunk - 1) / zchunk) < min_wgs) zchunk >>= 1;
     while (zchunk > 8 && (i64)(zchunk + 2 * rz) * plane_bytes >= ((i64)1 << 32)) zchunk >>= 1;
     return (i64)(zchunk + 2 * rz) * plane_bytes < ((i64)1 << 32) ? zchunk : 0;

@@ -132,7 +132,17 @@ def case_2d(rng, idx):
             raise last
         # Label on the oracle's masked image: bit-exact
         ref_fr = orc.mask_volume_2d(ref_run) if float(np.sum(ref_run)) > 0 else ref_run
-        ref_lab, ref_thr = orc.label_frame_2d(ref_fr, dr, return_thr=True)
+        try:
+            ref_lab, ref_thr = orc.label_frame_2d(ref_fr, dr, return_thr=True)
+        except ValueError as exc:                    # one non-empty bin in the log-domain histogram of Label's threshold (labelling.py:385-455): numpy raises,
+            pipe.upload_frangi(ref_fr)               # and so must the product (seed 33, cases 2950 and 6174: the first two such 2-D frames any seed drew)
+            try:
+                pipe.frangi_threshold()
+            except ValueError as exc2:
+                assert str(exc2)[:30] == str(exc)[:30], f"messages differ: {exc2} / {exc}"
+                info.update(ok=True, result=level + ", Label: both raise")
+                return info
+            raise AssertionError(f"the oracle's Label threshold raised ({exc}), the device's did not")
         pipe.upload_frangi(ref_fr)
         thr = pipe.frangi_threshold()
         assert (thr is None and ref_thr is None) or float(thr) == float(ref_thr), f"label threshold {thr} vs {ref_thr}"
