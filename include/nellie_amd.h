@@ -120,7 +120,10 @@ int nl_gauss_step(nl_ctx *ctx,
    scale s, so it can overlap the Hessian walk of scale s.  The result becomes NL_FIELD_GAUSS at nl_gauss_commit
    (call it before anything of scale s+1).  In between, only the per-scale calls of Filter are allowed (sampling by
    min/max + histogram, nl_hessian_stats, nl_vesselness_*); nl_sample_gather, nl_mask_volume* and Label use the free
-   Gaussian volumes as scratch. */
+   Gaussian volumes as scratch.
+   Only steps that write at most TWO of the three ping-pong volumes can run ahead (a Z pass + a fused Y+X pass: equal
+   in-plane radii up to nl_ctx_info("gauss_yx_max_r")); a step of one pass per axis would write its third pass into the
+   volume the current scale reads and is refused with NL_ESTATE -- run it with nl_gauss_step, in order. */
 int nl_gauss_step_ahead(nl_ctx *ctx, const double *wz, int rz, const double *wy, int ry, const double *wx, int rx,
                         int64_t z0, int64_t z1, char *err, size_t errlen);
 int nl_gauss_commit(nl_ctx *ctx, char *err, size_t errlen);
@@ -526,7 +529,8 @@ int nl_debug_eig_frangi(nl_ctx *ctx, const float *h6, int64_t n, int impl, float
                         float gamma_sq, float *out4, char *err, size_t errlen);
 
 /* Introspection: "fast_div" (2 / 1 when the 2- / 3-instruction constant division was proven exact for the
-   current spacings, 0: the float64 form), "hessian_tile_rows", "device_bytes". */
+   current spacings, 0: the float64 form), "hessian_tile_rows", "device_bytes", "gauss_yx_max_r" (largest in-plane
+   radius whose Y and X passes share a kernel: see nl_gauss_step_ahead). */
 int nl_ctx_info(nl_ctx *ctx, const char *key, double *value);
 
 /* ------------------------------------------------------------------ timing ------------ */

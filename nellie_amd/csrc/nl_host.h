@@ -37,11 +37,11 @@ CommApi &rccl();
 #include "convert.inc"
 #include "gauss_launch.h"
 
-// 2-D images: 256 columns per workgroup in x, rows by a stride loop in the kernel (~4096 workgroups: the statistics kernels end
-// in one set of atomics per workgroup)
+// 2-D images: 256 columns per workgroup in x, rows by a stride loop in the kernel (~1024 workgroups = four per CU: the kernels end
+// in one atomic per workgroup on one word, ~10 ns each -- with 4096 workgroups they were 40 of vesselness2d_kernel's 60 us at 2048^2)
 static inline dim3 grid2d_rows(i64 nx, i64 ny) {
     const i64 gx = (nx + 255) / 256;
-    i64 gy = (4096 + gx - 1) / gx;
+    i64 gy = (1024 + gx - 1) / gx;
     if (gy > ny) gy = ny;
     if (gy < 1) gy = 1;
     return dim3((unsigned)gx, (unsigned)gy, 1);

@@ -1139,6 +1139,41 @@ def test_device_chain_with_the_next_cascade_step_running_ahead(hip, fused, monke
     assert np.array_equal(fa, fb) and (fa > 0).any() and np.array_equal(la, lb)
 
 
+def test_cascade_steps_of_three_passes_never_run_ahead(hip):
+    """A cascade step whose in-plane radius has no fused Y+X kernel (> 12) makes three passes, and the third lands in the volume the step
+    started from -- the Gaussian the current scale still reads when the step runs ahead (found by the fuzz slice's explicit sigma lists,
+    round 5).  The library refuses such a step ahead, the pipeline runs it in order: sigma lists with radius-13 / radius-21 steps give the
+    frame the chain gives without running ahead, and the one the synchronous path gives."""
+    from nellie_amd import hipnative
+    from nellie_amd import pipeline as pl
+    from nellie_amd.synthetic import ISO_01, make_volume
+    vol = make_volume((48, 96, 120), 33)
+    pipe = pl.FramePipeline(vol.shape)
+    assert pipe._yx_max_r == 12
+    w1, w4, w13 = pl.gaussian_weights(0.4), pl.gaussian_weights(1.3), pl.gaussian_weights(4.3)
+    assert (len(w4) - 1) // 2 == 4 and (len(w13) - 1) // 2 == 13
+    assert pipe._step_fits_ahead([w1, w4, w4]) and pipe._step_fits_ahead([None, w4, w4]) and pipe._step_fits_ahead([w1, w13, None])
+    assert not pipe._step_fits_ahead([w1, w13, w13]) and not pipe._step_fits_ahead([w1, w4, w13])
+    pipe.ctx.filter_load(vol)
+    pipe.ctx.gauss_step(w1, w4, w4, z0=0, z1=vol.shape[0])
+    with pytest.raises(hipnative.NellieHipError, match="cannot run ahead"):
+        pipe.ctx.gauss_step(w1, w13, w13, z0=0, z1=vol.shape[0], ahead=True)
+    pipe.close()
+    for sig in ([0.936, 1.629, 1.638, 4.673], [2.238, 7.372]):
+        p = pl.FilterParams(dim_res=ISO_01, sigmas=sig)
+        got = []
+        for ahead, chain in (("1", True), ("0", True), ("0", False)):
+            pipe = pl.FramePipeline(vol.shape)
+            pipe._chain_ahead_env = ahead
+            pipe._device_chain = chain
+            pipe.filter(vol, p)
+            got.append((pipe.download_frangi(), [(s.gamma, s.max_abs, s.frob_thr, s.mask_count) for s in pipe.trace.scales]))
+            pipe.close()
+        for fr, tr in got[1:]:
+            assert tr == got[0][1] and np.array_equal(fr, got[0][0])
+        assert (got[0][0] > 0).any()
+
+
 def test_device_chain_falls_back_on_a_bracket_miss(hip):
     """A prediction pushed off by 50 % misses the bracket: the chain flags it (NL_CF_MISS = 128), the frame is redone the
     synchronous way (which goes two-pass) and the result is the one-pass result."""
