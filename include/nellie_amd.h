@@ -512,6 +512,10 @@ int nl_outputs_wait(nl_ctx *ctx, char *err, size_t errlen);
    sections / row offsets do not fit its size, is refused before anything is written; zero_fill = 0 if the arrays are known
    to hold zeros (a freshly created file), rows without content are then not touched at all. */
 int nl_outputs_pack(nl_ctx *ctx, int with_labels, int64_t *nbytes, char *err, size_t errlen);
+/* on != 0: every nl_label_run of this context ends by enqueueing nl_outputs_pack(ctx, 1, ...) of its frame UNDER ITS OWN WAIT (the
+   item counts stay on the device: no host round trip between counting and emitting); the nl_outputs_pack(ctx, 1, ...) that follows
+   returns at once.  A streamed stack (labelling.py:701-734 has a blocking .get() per frame instead) loses two host waits per frame. */
+int nl_outputs_pack_with_label(nl_ctx *ctx, int on, char *err, size_t errlen);
 int nl_outputs_fetch_packed_async(nl_ctx *ctx, void *host_pinned, int64_t nbytes, char *err, size_t errlen);
 int nl_outputs_unpack(const void *blob, int64_t nbytes, float *frangi, int32_t *labels, int64_t dst_elems, int zero_fill,
                       int threads, char *err, size_t errlen);

@@ -169,6 +169,7 @@ struct LabelGeo {
     int zf_lo = 0, zf_hi = -2;    // planes of this run set that are true Z faces of the volume (-1: none; set by label_geo_faces)
     i64 gz0 = 0, gnz = 0;         // placement of plane 0 of the run set in the global volume (boundary rules)
     bool rank_independent_bands = false;   // Z slab: the row bands of the in-LDS union level are a function of ny alone (build_components)
+    bool whole_frame_paint = false;        // nl_label_run on a whole local volume: paint_out holds the frame's labels (the pack may follow, number_and_paint)
 };
 static void label_geo_whole(LabelGeo &g) { g.zf_lo = 0; g.zf_hi = (int)g.nz - 1; g.gz0 = 0; g.gnz = g.nz; }
 
@@ -253,6 +254,7 @@ static int build_components(nl_ctx *c, const LabelGeo &g, const unsigned long lo
     return NL_OK;
 }
 
+static int pack_enqueue_fwd(nl_ctx *c, int with_labels, const float *frangi, const int *labels, char *err, size_t errlen);
 // ids 1..K in raster order of each component's first voxel (scipy.ndimage.label numbering), painted as int32
 static int number_and_paint(nl_ctx *c, const LabelGeo &g, const RunSet &rs, int *aux, int64_t *n_labels, char *err, size_t errlen,
                             bool *overflow = nullptr) {
@@ -275,9 +277,17 @@ static int number_and_paint(nl_ctx *c, const LabelGeo &g, const RunSet &rs, int 
     rl_paint_kernel<<<grid1d((g.paint_row1 - g.paint_row0) * 64, 256, (i64)1 << 22), 256, 0, c->stream>>>(
         g.bitsA, rs.row_off, rs.parent, aux, g.paint_out, g.paint_row0, g.paint_row1, g.wpr, (int)g.nx);
     NL_CHECK_LAUNCH();
+    // a streamed stack packs every frame right behind its labels: enqueue that now, under this wait (nl_outputs_pack_with_label)
+    bool packed = false;
+    if (c->pack_with_label && g.whole_frame_paint && c->own_lo == 0 && c->own_hi == c->nzl && c->frangi_ready) {
+        const int rcp = pack_enqueue_fwd(c, 1, c->f[c->i_vmax], g.paint_out, err, errlen);
+        if (rcp) return rcp;
+        packed = true;
+    }
     NL_HIP(hipStreamSynchronize(c->stream));
     if (any) total = *(unsigned long long *)c->h_small;
     if (overflow) *overflow = any && !rs.host_count && *(unsigned int *)((char *)c->h_small + 8) != 0;
+    c->pack_pending = (packed && !(overflow && *overflow)) ? 1 : 0;
     if (n_labels) *n_labels = (int64_t)total;
     return NL_OK;
 }
@@ -364,6 +374,8 @@ extern "C" int nl_label_run(nl_ctx *c, int has_thr, float thr, int64_t min_area,
     g.paint_row0 = 0; g.paint_row1 = g.nrows; g.paint_out = (int *)c->f[label_out_index(c)];
     g.link_scratch = g.paint_out;                 // the whole label volume (4N bytes) is idle until the paint
     label_geo_whole(g);
+    g.whole_frame_paint = true;
+    c->pack_pending = 0;
     ProfScope ps(c, "label");
     const unsigned long long *support = (c->support_epoch + 1 == c->epoch.load() && c->d_support && has_thr && thr >= 0.0f) ? c->d_support : nullptr;
     c->last_label_sparse = support ? 1 : 0;
@@ -1041,13 +1053,25 @@ static inline size_t pk_pad(size_t b) { return (b + 15) & ~(size_t)15; }
 // Frangi frame (+ labels) of the current frame -> packed blob in a staging buffer of the context (compute stream; the next
 // frame may then overwrite the volumes).  *nbytes = size of the blob, 0 when the frame does not pack (more than a quarter
 // of the voxels non-zero, or X-neighbours with different labels): use nl_outputs_stage / nl_outputs_fetch_async then.
-extern "C" int nl_outputs_pack(nl_ctx *c, int with_labels, int64_t *nbytes, char *err, size_t errlen) {
-    NL_ENTER(c);
-    NL_KEEP_LABBITS(c);
-    NL_JOIN_SIDE(c);
-    if (!nbytes) return nl_fail(err, errlen, NL_EINVAL, "nbytes is NULL");
-    if (with_labels && c->i_labels < 0) return nl_fail(err, errlen, NL_ESTATE, "nl_outputs_pack(with_labels) before nl_label_run");
-    if (c->own_lo != 0 || c->own_hi != c->nzl) return nl_fail(err, errlen, NL_EINVAL, "packed outputs are for whole local volumes (no ghost planes)");
+// header, closing entries of the offset tables, and what the emit kernels need -- from the device's own counts (one thread)
+__global__ void pk_header_kernel(PkHeader h, char *blob, const unsigned int *flag, PkDev *dev, unsigned long long cap, long long rows) {
+    const unsigned long long nv = dev->n_values, nr = h.with_labels ? dev->n_runs : 0ull;
+    const unsigned long long off_lr = (unsigned long long)h.off_fv + ((nv * 4ull + 15ull) & ~15ull);
+    const unsigned long long total = off_lr + ((nr * 4ull + 15ull) & ~15ull);
+    const bool ok = *flag == 0u && total <= cap && nv <= 0xffffffffull && nr <= 0xffffffffull;
+    dev->n_runs = nr; dev->off_lr = off_lr; dev->total = ok ? total : 0ull;
+    if (!ok) return;
+    h.n_values = (long long)nv; h.n_runs = (long long)nr; h.off_lr = (long long)off_lr; h.total = (long long)total;
+    *reinterpret_cast<PkHeader *>(blob) = h;
+    reinterpret_cast<unsigned int *>(blob + h.off_fo)[rows] = (unsigned int)nv;
+    if (h.with_labels) reinterpret_cast<unsigned int *>(blob + h.off_lo)[rows] = (unsigned int)nr;
+}
+
+#define NL_PK_DEV_OFF (56 << 10)           // byte offset of the PkDev record in d_small / of its landing place in h_small
+// Everything of nl_outputs_pack up to (not including) the wait: counts, bit planes, row offsets, header, items, and the D2H of the
+// PkDev record.  Round 5: no host round trip between counting and emitting, so that nl_label_run can enqueue the pack of the frame
+// under its OWN wait (nl_outputs_pack_with_label) -- a streamed config-5 frame loses two of its six host waits.
+static int pack_enqueue(nl_ctx *c, int with_labels, const float *frangi, const int *labels, char *err, size_t errlen) {
     int rc = stream_init(c, err, errlen);
     if (rc) return rc;
     const i64 rows = c->nzl * c->ny;
@@ -1059,55 +1083,74 @@ extern "C" int nl_outputs_pack(nl_ctx *c, int with_labels, int64_t *nbytes, char
     h.off_lo = h.off_fo + off_b; h.off_fv = h.off_lo + (with_labels ? off_b : 0);
     const size_t cap = (size_t)h.off_fv + pk_pad((size_t)c->n) + 64;              // room for n / 4 items in total
     if (cap > c->pack_cap) {
-        if (c->d_pack) hipFree(c->d_pack);
+        if (c->d_pack) { NL_HIP(hipStreamSynchronize(c->stream)); hipFree(c->d_pack); }
         c->d_pack = nullptr; c->pack_cap = 0;
         NL_HIP(hipMalloc(&c->d_pack, cap));
         c->pack_cap = cap;
     }
     char *blob = (char *)c->d_pack;
     NL_HIP(hipStreamWaitEvent(c->stream, c->ev_fetched, 0));     // the previous frame's blob has left the staging buffer
-    unsigned int *cnt = c->d_rows;                                // per-row counts (Label's row tables are free between frames)
+    unsigned int *cnt = c->d_rows;                                // per-row counts (Label's row tables are free once the labels are painted)
     unsigned int *flag = (unsigned int *)c->d_small + 40;
     unsigned long long *d_total = (unsigned long long *)c->d_small + 16;
-    unsigned long long *h_tot = (unsigned long long *)c->h_small;
+    PkDev *dev = (PkDev *)((char *)c->d_small + NL_PK_DEV_OFF);
     NL_HIP(zero_small(flag, 4, c->stream));
     const unsigned grid = grid1d(rows * 64, 256, (i64)1 << 22);
     ProfScope ps(c, "pack");
     // counts, bit planes, row offsets
-    pk_count_kernel<0><<<grid, 256, 0, c->stream>>>((const unsigned int *)c->f[c->i_vmax], (unsigned long long *)(blob + h.off_fb), cnt, rows, nx, wpr, flag);
+    pk_count_kernel<0><<<grid, 256, 0, c->stream>>>((const unsigned int *)frangi, (unsigned long long *)(blob + h.off_fb), cnt, rows, nx, wpr, flag);
     NL_CHECK_LAUNCH();
     if ((rc = scan_excl_u32(c, cnt, (unsigned int *)(blob + h.off_fo), rows, err, errlen))) return rc;
-    NL_HIP(hipMemcpyAsync(&h_tot[0], d_total, 8, hipMemcpyDeviceToHost, c->stream));
+    NL_HIP(hipMemcpyAsync(&dev->n_values, d_total, 8, hipMemcpyDeviceToDevice, c->stream));
     if (with_labels) {
-        pk_count_kernel<1><<<grid, 256, 0, c->stream>>>((const unsigned int *)c->f[c->i_labels], (unsigned long long *)(blob + h.off_lb), cnt, rows, nx, wpr, flag);
+        pk_count_kernel<1><<<grid, 256, 0, c->stream>>>((const unsigned int *)labels, (unsigned long long *)(blob + h.off_lb), cnt, rows, nx, wpr, flag);
         NL_CHECK_LAUNCH();
         if ((rc = scan_excl_u32(c, cnt, (unsigned int *)(blob + h.off_lo), rows, err, errlen))) return rc;
-        NL_HIP(hipMemcpyAsync(&h_tot[1], d_total, 8, hipMemcpyDeviceToHost, c->stream));
+        NL_HIP(hipMemcpyAsync(&dev->n_runs, d_total, 8, hipMemcpyDeviceToDevice, c->stream));
     }
-    NL_HIP(hipMemcpyAsync(&h_tot[2], flag, 4, hipMemcpyDeviceToHost, c->stream));
-    NL_HIP(hipStreamSynchronize(c->stream));
-    h.n_values = (long long)h_tot[0]; h.n_runs = with_labels ? (long long)h_tot[1] : 0;
-    const bool bad = (*(unsigned int *)&h_tot[2]) != 0u;
-    h.off_lr = h.off_fv + pk_pad((size_t)h.n_values * 4);
-    h.total = h.off_lr + pk_pad((size_t)h.n_runs * 4);
-    if (bad || (size_t)h.total > c->pack_cap || h.n_values > 0xffffffffll || h.n_runs > 0xffffffffll) { *nbytes = 0; return NL_OK; }
-    // header, the closing entries of the offset tables, then the items
-    unsigned int *h_u = (unsigned int *)(h_tot + 4);
-    h_u[0] = (unsigned int)h.n_values; h_u[1] = (unsigned int)h.n_runs;
-    PkHeader *h_hdr = (PkHeader *)(h_tot + 8);
-    *h_hdr = h;
-    NL_HIP(hipMemcpyAsync(blob, h_hdr, sizeof(PkHeader), hipMemcpyHostToDevice, c->stream));
-    NL_HIP(hipMemcpyAsync(blob + h.off_fo + (size_t)rows * 4, &h_u[0], 4, hipMemcpyHostToDevice, c->stream));
-    if (with_labels) NL_HIP(hipMemcpyAsync(blob + h.off_lo + (size_t)rows * 4, &h_u[1], 4, hipMemcpyHostToDevice, c->stream));
-    if (h.n_values) pk_emit_kernel<0><<<grid, 256, 0, c->stream>>>((const unsigned int *)c->f[c->i_vmax], (const unsigned long long *)(blob + h.off_fb),
-                                                                 (const unsigned int *)(blob + h.off_fo), (unsigned int *)(blob + h.off_fv), rows, nx, wpr);
-    if (h.n_runs) pk_emit_kernel<1><<<grid, 256, 0, c->stream>>>((const unsigned int *)c->f[c->i_labels], (const unsigned long long *)(blob + h.off_lb),
-                                                               (const unsigned int *)(blob + h.off_lo), (unsigned int *)(blob + h.off_lr), rows, nx, wpr);
+    pk_header_kernel<<<1, 1, 0, c->stream>>>(h, blob, flag, dev, (unsigned long long)c->pack_cap, (long long)rows);
+    NL_CHECK_LAUNCH();
+    // the items (the kernels return at once when the frame does not pack)
+    pk_emit_kernel<0><<<grid, 256, 0, c->stream>>>((const unsigned int *)frangi, (const unsigned long long *)(blob + h.off_fb),
+                                                   (const unsigned int *)(blob + h.off_fo), blob, (long long)h.off_fv, dev, rows, nx, wpr);
+    if (with_labels) pk_emit_kernel<1><<<grid, 256, 0, c->stream>>>((const unsigned int *)labels, (const unsigned long long *)(blob + h.off_lb),
+                                                                    (const unsigned int *)(blob + h.off_lo), blob, (long long)h.off_fv, dev, rows, nx, wpr);
     NL_CHECK_LAUNCH();
     NL_HIP(hipEventRecord(c->ev_staged, c->stream));
-    // the pinned scratch the header travelled through is reused by the next entry point: let the copies finish
-    NL_HIP(hipStreamSynchronize(c->stream));
-    *nbytes = h.total;
+    NL_HIP(hipMemcpyAsync((char *)c->h_small + NL_PK_DEV_OFF, dev, sizeof(PkDev), hipMemcpyDeviceToHost, c->stream));
+    return NL_OK;
+}
+
+static int pack_enqueue_fwd(nl_ctx *c, int with_labels, const float *frangi, const int *labels, char *err, size_t errlen) {
+    return pack_enqueue(c, with_labels, frangi, labels, err, errlen);
+}
+
+extern "C" int nl_outputs_pack(nl_ctx *c, int with_labels, int64_t *nbytes, char *err, size_t errlen) {
+    NL_ENTER(c);
+    NL_KEEP_LABBITS(c);
+    NL_JOIN_SIDE(c);
+    if (!nbytes) return nl_fail(err, errlen, NL_EINVAL, "nbytes is NULL");
+    if (with_labels && c->i_labels < 0) return nl_fail(err, errlen, NL_ESTATE, "nl_outputs_pack(with_labels) before nl_label_run");
+    if (c->own_lo != 0 || c->own_hi != c->nzl) return nl_fail(err, errlen, NL_EINVAL, "packed outputs are for whole local volumes (no ghost planes)");
+    // nl_label_run of THIS frame already enqueued the pack and waited for it (nl_outputs_pack_with_label)
+    const bool done = c->pack_pending && with_labels;
+    c->pack_pending = 0;
+    if (!done) {
+        int rc = pack_enqueue(c, with_labels, c->f[c->i_vmax], with_labels ? (const int *)c->f[c->i_labels] : nullptr, err, errlen);
+        if (rc) return rc;
+        NL_HIP(hipStreamSynchronize(c->stream));
+    }
+    const PkDev *h = (const PkDev *)((const char *)c->h_small + NL_PK_DEV_OFF);
+    *nbytes = (int64_t)h->total;
+    return NL_OK;
+}
+
+// on != 0: nl_label_run ends by enqueueing nl_outputs_pack(with_labels = 1) of the frame under its own wait; the next
+// nl_outputs_pack(ctx, 1, ...) then returns at once.  For streamed stacks (nellie_amd/streaming.py).
+extern "C" int nl_outputs_pack_with_label(nl_ctx *c, int on, char *err, size_t errlen) {
+    NL_ENTER(c);
+    c->pack_with_label = on ? 1 : 0;
+    c->pack_pending = 0;
     return NL_OK;
 }
 

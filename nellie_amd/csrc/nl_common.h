@@ -43,6 +43,8 @@ struct nl_ctx {
     hipEvent_t ev_staged = nullptr, ev_fetched = nullptr;
     float *d_stage_fr = nullptr;
     void *d_pack = nullptr; size_t pack_cap = 0;       // packed outputs (pack_out.inc): header | bit planes | row offsets | items
+    int pack_with_label = 0;                           // nl_outputs_pack_with_label: nl_label_run enqueues the frame's pack under its own wait
+    int pack_pending = 0;                              // ... and has done so for the labels now on the device (nl_outputs_pack returns at once)
     int *d_stage_lab = nullptr;
     void *d_small = nullptr;   // scratch for reductions / histograms / weights (64 KiB)
     void *h_small = nullptr;   // pinned mirror

@@ -62,6 +62,7 @@ _PROTOS = {
     "nl_positive_samples_world": [_p, _int, _int, _i64, _i64, _i64, _i64, _p, _i64, _p],
     "nl_host_slab_join": [_int, _p, _i64, _i64, C.POINTER(_i64), C.POINTER(_i64), _p, _p, _p, _p],
     "nl_outputs_pack": [_p, _int, _p],
+    "nl_outputs_pack_with_label": [_p, _int],
     "nl_outputs_fetch_packed_async": [_p, _p, _i64],
     "nl_outputs_unpack": [_p, _i64, _p, _p, _i64, _int, _int],
     "nl_host_zero": [_p, _i64, _int],
@@ -816,6 +817,10 @@ class Context:
         n = _i64(0)
         self._call("nl_outputs_pack", 1 if with_labels else 0, C.byref(n))
         return int(n.value)
+
+    def outputs_pack_with_label(self, on=True):
+        """label_run() then enqueues the frame's outputs_pack(True) under its own wait; the outputs_pack(True) that follows returns at once."""
+        self._call("nl_outputs_pack_with_label", 1 if on else 0)
 
     def outputs_fetch_packed_async(self, pinned, nbytes):
         self._call("nl_outputs_fetch_packed_async", pinned._p if hasattr(pinned, "_p") else _ptr(pinned), int(nbytes))

@@ -39,6 +39,9 @@ class StreamedSegmenter:
         self.packed = os.environ.get("NELLIE_STREAM_PACKED", "1") == "1"
         self.blob_buf = [hipnative.PinnedArray((2 * int(np.prod(self.shape)) + 4096,), np.uint8) for _ in range(2)] if self.packed else []
         self.packed_frames = 0
+        # the pack of a frame rides under Label's own wait (two host waits per frame less; NELLIE_STREAM_PACK_WITH_LABEL=0: as before)
+        if self.packed and os.environ.get("NELLIE_STREAM_PACK_WITH_LABEL", "1") == "1" and hasattr(self.pipe.ctx, "outputs_pack_with_label"):
+            self.pipe.ctx.outputs_pack_with_label(True)
         self._zero_fill = True
         self.io = ThreadPoolExecutor(max_workers=3)
         # host threads of the copies / the packed-output expansion (NELLIE_STREAM_COPY_THREADS: A/B)

@@ -168,6 +168,49 @@ def test_device_pack_equals_dense_download(hip, shape):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(40, 96, 130), (64, 128, 136)])
+def test_pack_enqueued_under_labels_wait_equals_the_separate_call(hip, shape):
+    """nl_outputs_pack_with_label (round 5): nl_label_run enqueues the frame's pack before its own wait and the outputs_pack that follows only
+    reads the size.  Same blob, byte for byte, as the separate call on the same frame -- over three frames of one context (the second blob
+    may only overwrite the staging buffer once the first has been fetched) and with an outputs_pack(False) in between (Frangi only: redone)."""
+    from nellie_amd import hipnative
+    from nellie_amd import pipeline as pl
+    from nellie_amd.synthetic import ISO_01, make_volume
+    p = pl.FilterParams(dim_res=ISO_01)
+    ma = pl.min_area_pixels_of(ISO_01)
+
+    def blobs(with_label):
+        pipe = pl.FramePipeline(shape)
+        pipe.ctx.outputs_pack_with_label(with_label)
+        out = []
+        for seed in (11, 12, 13):
+            pipe.filter(make_volume(shape, seed), p)
+            n = pipe.label(pipe.frangi_threshold(), ma)
+            if seed == 12:
+                nf = pipe.ctx.outputs_pack(False)                # a Frangi-only blob in between: the pending pack is dropped, this one is computed
+                assert 0 < nf
+            nbytes = pipe.ctx.outputs_pack(True)
+            assert nbytes > 0
+            land = hipnative.PinnedArray((nbytes,), np.uint8)
+            pipe.ctx.outputs_fetch_packed_async(land, nbytes)
+            pipe.ctx.outputs_wait()
+            fr, lab = pipe.download_frangi(), pipe.download_labels()
+            of, ol = np.full(shape, 2.0, np.float32), np.full(shape, -1, np.int32)
+            hipnative.outputs_unpack(land, nbytes, of, ol, zero_fill=True, threads=2)
+            assert np.array_equal(of, fr) and np.array_equal(ol, lab) and lab.max() == n
+            hdr = land.array[:128].view(np.int64).copy()
+            sect = [bytes(land.array[int(hdr[k]):int(hdr[k]) + sz]) for k, sz in ((12, int(hdr[5]) * 4), (13, int(hdr[6]) * 4))]
+            out.append((nbytes, hdr, sect))
+            land.free()
+        pipe.close()
+        return out
+
+    a, b = blobs(True), blobs(False)
+    for (na, ha, sa), (nb, hb, sb) in zip(a, b):
+        assert na == nb and np.array_equal(ha, hb) and sa == sb
+
+
+@pytest.mark.gpu
 def test_dense_frame_does_not_pack(hip):
     """More than a quarter of the voxels non-zero: nbytes == 0, the caller takes the dense download."""
     from nellie_amd import pipeline as pl
