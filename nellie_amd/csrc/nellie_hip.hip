@@ -1341,9 +1341,9 @@ static bool resolve_on_side() {
     if (overlap < 0) { const char *e = getenv("NELLIE_RESOLVE_OVERLAP"); overlap = (e && atoi(e)) ? 1 : 0; }
     return overlap != 0;
 }
-static int resolve_enqueue(nl_ctx *c, VessP vp, unsigned long long *d_cnt, const float *dev_params, char *err, size_t errlen) {
+static int resolve_enqueue(nl_ctx *c, VessP vp, unsigned long long *d_cnt, const float *dev_params, char *err, size_t errlen, bool force_side = false) {
     const i64 plane = c->ny * c->nx, z0 = c->spec_z0, z1 = c->spec_z1;
-    const bool side = resolve_on_side();
+    const bool side = force_side || resolve_on_side();
     hipStream_t st = side ? c->side : c->stream;
     if (side) {
         NL_HIP(hipEventRecord(c->ev_main, c->stream));
@@ -1373,6 +1373,28 @@ static int resolve_enqueue(nl_ctx *c, VessP vp, unsigned long long *d_cnt, const
     }
     c->spec_valid = 0;
     return NL_OK;
+}
+
+// Device chain (round 5, second session): the resolve kernel of scale s needs nothing the cascade step of scale s+1 touches, and the ten
+// threshold kernels of scale s+1 (one wave or a 10^6-point lattice each: ~0.15 ms of a nearly idle GPU) need nothing the resolve kernel
+// writes.  So nl_chain_scale(s) only NOTES the resolve launch; nl_chain_scale(s+1) -- called after the host has enqueued cascade step
+// s+1 -- starts it on the side stream behind that step, and the threshold kernels run beside it on the main stream; the walk of scale
+// s+1 joins (spec_enqueue: NL_JOIN_SIDE).  Beside the cascade step itself the resolve kernel only costs (both are bound by the float64
+// pipe: NELLIE_RESOLVE_OVERLAP, profiles/r05_walk_variants_1024cube.txt).  Single context, volumes of 2^26 voxels and more (below, the
+// side stream carries the cascade step that runs ahead); NELLIE_RESOLVE_DEFER=0: off.
+static bool resolve_defer_ok(const nl_ctx *c) {
+    const char *e = getenv("NELLIE_RESOLVE_DEFER");               // read per call: tests switch it (2: whatever the size, for the small volumes of the suite)
+    const int on = e ? atoi(e) : 1;
+    if (on == 2) return !c->comm && !resolve_on_side();
+    return on && !c->comm && !c->ahead_pending && !resolve_on_side() && c->n >= ((i64)1 << 26);
+}
+static int resolve_deferred_launch(nl_ctx *c, bool on_side, char *err, size_t errlen) {
+    if (!c->def_resolve) return NL_OK;
+    c->def_resolve = 0;
+    VessP vp;
+    static_assert(sizeof(VessP) <= sizeof(((nl_ctx *)nullptr)->def_vp), "nl_ctx::def_vp holds a VessP");
+    memcpy(&vp, c->def_vp, sizeof(VessP));
+    return resolve_enqueue(c, vp, c->def_cnt, c->def_params, err, errlen, on_side);
 }
 
 extern "C" int nl_vesselness_resolve(nl_ctx *c, float gamma_sq, float alpha_sq, float beta_sq, int use_thr, float thr,
@@ -1477,6 +1499,7 @@ extern "C" int nl_chain_begin(nl_ctx *c, int n_scales, char *err, size_t errlen)
     chain_init2_kernel<<<1, 64, 0, c->stream>>>((ChainScale *)c->d_chain, n_scales);
     NL_CHECK_LAUNCH();
     c->chain_n = n_scales; c->chain_k = 0; c->chain_copy_pending = 0;
+    c->def_resolve = 0;
     return NL_OK;
 }
 
@@ -1488,6 +1511,8 @@ extern "C" int nl_chain_scale(nl_ctx *c, const double spacing[3], int64_t sz, in
     if (!(division != 0.0)) return nl_fail(err, errlen, NL_EINVAL, "the chain needs a non-zero threshold division");
     int rc;
     if ((rc = set_spacing(c, spacing, err, errlen))) return rc;
+    // the resolve kernel of the previous scale, held back until now: beside this scale's threshold kernels, behind its cascade step
+    if ((rc = resolve_deferred_launch(c, true, err, errlen))) return rc;
     ChainScale *cs = (ChainScale *)c->d_chain + c->chain_k;
     c->chain_par[c->chain_k][0] = division; c->chain_par[c->chain_k][1] = margin; c->chain_par[c->chain_k][2] = test_scale;
     ++c->chain_k;
@@ -1523,6 +1548,11 @@ extern "C" int nl_chain_scale(nl_ctx *c, const double spacing[3], int64_t sz, in
     vp.alpha_sq = (float)alpha_sq; vp.beta_sq = (float)beta_sq; vp.use_thr = 1;
     vp.cnt_lo = (int)c->own_lo; vp.cnt_hi = (int)c->own_hi;
     vp.first = c->mask_slots_used == 0 ? 1 : 0;
+    if (resolve_defer_ok(c)) {
+        memcpy(c->def_vp, &vp, sizeof(VessP));
+        c->def_cnt = &cs->cnt_resolve; c->def_params = (const float *)cs; c->def_resolve = 1;
+        return NL_OK;
+    }
     return resolve_enqueue(c, vp, &cs->cnt_resolve, (const float *)cs, err, errlen);
 }
 
@@ -1532,6 +1562,7 @@ extern "C" int nl_chain_scale(nl_ctx *c, const double spacing[3], int64_t sz, in
 extern "C" int nl_chain_flush(nl_ctx *c, char *err, size_t errlen) {
     NL_ENTER(c);
     if (!c->d_chain || c->chain_k < 1) return nl_fail(err, errlen, NL_ESTATE, "nl_chain_flush without scales");
+    { int rcd = resolve_deferred_launch(c, false, err, errlen); if (rcd) return rcd; }       // the last scale's: nothing left to run beside
     NL_JOIN_SIDE(c);
     NL_HIP(hipMemcpyAsync(c->h_chain, c->d_chain, sizeof(ChainScale) * (size_t)c->chain_k, hipMemcpyDeviceToHost, c->stream));
     NL_HIP(hipEventRecord(c->ev_chain, c->stream));
@@ -1545,6 +1576,7 @@ extern "C" int nl_chain_finish(nl_ctx *c, int *flags, double *gamma, double *max
     NL_ENTER(c);
     if (!c->d_chain || c->chain_k < 1) return nl_fail(err, errlen, NL_ESTATE, "nl_chain_finish without scales");
     const int n = c->chain_k;
+    if (!c->chain_copy_pending) { int rcd = resolve_deferred_launch(c, false, err, errlen); if (rcd) return rcd; }
     if (c->chain_copy_pending) {
         NL_HIP(hipEventSynchronize(c->ev_chain));
         c->chain_copy_pending = 0;

@@ -86,6 +86,12 @@ struct nl_ctx {
     hipEvent_t ev_ahead = nullptr;       // a cascade step enqueued ahead on `side` (nl_gauss_step_ahead)
     int ahead_pending = 0, ahead_gauss = 0;
     int side_pending = 0;                // work on `side` the main stream has not been ordered after yet
+    // device chain, round 5: the resolve kernel of scale s is held back until the cascade step of scale s+1 has been enqueued and then runs
+    // on `side` beside that scale's threshold kernels (nl_chain_scale); def_* = what resolve_enqueue needs then
+    int def_resolve = 0;
+    alignas(8) unsigned char def_vp[160] = {};       // a VessP (hessian.inc), copied in and out
+    unsigned long long *def_cnt = nullptr;
+    const float *def_params = nullptr;
     int last_spec_overflow = 0;          // the last one-pass walk overflowed a queue region (diagnostics)
     float last_fsq_min = 0;    // the exact mask threshold of the last scale (diagnostics)
     void *d_blk = nullptr;     // per-block partials for scans

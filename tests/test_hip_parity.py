@@ -1139,6 +1139,30 @@ def test_device_chain_with_the_next_cascade_step_running_ahead(hip, fused, monke
     assert np.array_equal(fa, fb) and (fa > 0).any() and np.array_equal(la, lb)
 
 
+@pytest.mark.parametrize("ahead", ["0", "1"])
+@pytest.mark.parametrize("shape,seed,aniso", [((40, 96, 96), 21, False), ((33, 70, 130), 22, True), ((96, 160, 200), 24, False)])
+def test_device_chain_with_the_resolve_kernel_held_back(hip, shape, seed, aniso, ahead, monkeypatch):
+    """Round 5: on volumes of 2^26 voxels and more the chain starts the resolve kernel of scale s only behind the cascade step of scale
+    s+1, on the side stream, beside that scale's threshold kernels (nl_chain_scale).  Forced here on small volumes (NELLIE_RESOLVE_DEFER=2),
+    with and without the cascade step running ahead on the same side stream: the chain stands, same trace and frame as the synchronous path,
+    frame after frame on one context."""
+    from nellie_amd import pipeline as pl
+    from nellie_amd.synthetic import ANISO_03, ISO_01, make_volume
+    dr = ANISO_03 if aniso else ISO_01
+    vol = make_volume(shape, seed)
+    ref = _run_both_ways(vol, dr)[1]
+    monkeypatch.setenv("NELLIE_RESOLVE_DEFER", "2")
+    pipe = pl.FramePipeline(shape)
+    pipe._chain_ahead_env = ahead
+    for rep in range(3):
+        pipe.filter(vol, pl.FilterParams(dim_res=dr))
+        tr = [(s.sigma, s.gamma, s.max_abs, s.frob_thr, s.mask_count, s.skipped) for s in pipe.trace.scales]
+        assert pipe.chain_fallbacks == 0 and pipe.last_chain_flags == [0] * len(tr)
+        assert tr == ref[1] and pipe.trace.n_positive == ref[2] and pipe.trace.percentile_thr == ref[3]
+        assert np.array_equal(pipe.download_frangi(), ref[0])
+    pipe.close()
+
+
 def test_cascade_steps_of_three_passes_never_run_ahead(hip):
     """A cascade step whose in-plane radius has no fused Y+X kernel (> 12) makes three passes, and the third lands in the volume the step
     started from -- the Gaussian the current scale still reads when the step runs ahead (found by the fuzz slice's explicit sigma lists,

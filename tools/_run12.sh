@@ -1,0 +1,8 @@
+cd $GRAFT_REPO_ROOT
+python -m pytest tests/test_hip_parity.py tests/test_hip_full_size.py -m gpu -q -x -k "held_back or chain or 1024 or full or crops" 2>&1 | tail -15 | grep -v "RCCL\|HIP version\|ROCm version\|Hostname\|Librccl" 
+for rep in 1 2 3; do
+for cfg in "NELLIE_RESOLVE_DEFER=0" "A=1"; do
+  env $cfg python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-io 2>/dev/null | tail -1 | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('[$cfg]', d['value'], d['ms_per_step'], {k:v['ms_per_step'] for k,v in d['roofline']['groups'].items()})" >> gpurun_out/s12_ab_resolve_defer.txt
+done; done
+cat gpurun_out/s12_ab_resolve_defer.txt
