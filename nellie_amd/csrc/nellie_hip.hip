@@ -1384,13 +1384,14 @@ static int resolve_enqueue(nl_ctx *c, VessP vp, unsigned long long *d_cnt, const
 // side stream carries the cascade step that runs ahead); NELLIE_RESOLVE_DEFER=0: off.
 static bool resolve_defer_ok(const nl_ctx *c) {
     const char *e = getenv("NELLIE_RESOLVE_DEFER");               // read per call: tests switch it (2: whatever the size, for the small volumes of the suite)
-    const int on = e ? atoi(e) : 1;
-    if (on == 2) return !c->comm && !resolve_on_side();
+    const int on = e ? atoi(e) : 1;                                // 4: as 1 and the scale's exact round on the side stream too (A/B); 5: as 2 with that
+    if (on == 2 || on == 5) return !c->comm && !resolve_on_side();
     return on && !c->comm && !c->ahead_pending && !resolve_on_side() && c->n >= ((i64)1 << 26);
 }
 static int resolve_deferred_launch(nl_ctx *c, bool on_side, char *err, size_t errlen) {
     if (!c->def_resolve) return NL_OK;
     c->def_resolve = 0;
+    NL_JOIN_SIDE(c);          // the exact round of that scale ran on the side stream: whatever the main stream does next comes after it
     VessP vp;
     static_assert(sizeof(VessP) <= sizeof(((nl_ctx *)nullptr)->def_vp), "nl_ctx::def_vp holds a VessP");
     memcpy(&vp, c->def_vp, sizeof(VessP));
@@ -1526,7 +1527,19 @@ extern "C" int nl_chain_scale(nl_ctx *c, const double spacing[3], int64_t sz, in
     chain_thr1_kernel<<<2, 64, 0, c->stream>>>(cs, division, margin, test_scale);
     NL_CHECK_LAUNCH();
     if ((rc = spec_enqueue(c, spacing, 0.0f, 0.0f, z0, z1, cs->stats, &cs->cnt_walk, &cs->fsq_lo, err, errlen))) return rc;
-    chain_post_kernel<<<1, 64, 0, c->stream>>>(cs);
+    // With the resolve kernel held back (below) the exact round -- four small kernels, ~50 us of a nearly idle GPU at 1024^3 -- moves to the
+    // side stream too, behind the walk: the cascade step of the next scale, which the host enqueues on the main stream next, then starts
+    // right behind the walk instead of behind them.  The next nl_chain_scale joins the side stream before it touches the frob_sq cache.
+    const bool defer = resolve_defer_ok(c) && c->fsq_cache_valid;     // (the cache is this scale's: use_fsq_cache below launches nothing)
+    hipStream_t st = c->stream;
+    bool exact_on_side = false;
+    if (defer) { const char *e = getenv("NELLIE_RESOLVE_DEFER"); exact_on_side = e && (atoi(e) == 4 || atoi(e) == 5); }     // 4 / 5: see resolve_defer_ok
+    if (exact_on_side) {
+        NL_HIP(hipEventRecord(c->ev_main, c->stream));
+        NL_HIP(hipStreamWaitEvent(c->side, c->ev_main, 0));
+        st = c->side;
+    }
+    chain_post_kernel<<<1, 64, 0, st>>>(cs);
     NL_CHECK_LAUNCH();
     {   // the exact round: edges from the normalised range, histogram of the cached frob_sq under the device's normalisation
         Lattice L; FieldSrc fs;
@@ -1535,20 +1548,24 @@ extern "C" int nl_chain_scale(nl_ctx *c, const double spacing[3], int64_t sz, in
         if ((rc = use_fsq_cache(c, fs, L, err, errlen))) return rc;
         fs.norm_dev = cs->norm;
         const i64 total = L.cz * L.cy * L.cx;
-        ProfScope ps(c, "sample");
-        sample_edges_kernel<<<1, 64, 0, c->stream>>>(cs->h_exact.res, NL_CHAIN_BINS, cs->h_exact.edges, cs->h_exact.res + 4);
+        ProfScope ps(c, "sample", st);
+        sample_edges_kernel<<<1, 64, 0, st>>>(cs->h_exact.res, NL_CHAIN_BINS, cs->h_exact.edges, cs->h_exact.res + 4);
         const size_t sh = (size_t)(NL_CHAIN_BINS + 2) * 4 + (size_t)NL_CHAIN_BINS * 4;
-        if (total > 0) sample_hist_kernel<<<grid1d(total, 256, sample_grid_cap()), 256, sh, c->stream>>>(fs, geom(c), L, cs->h_exact.edges, NL_CHAIN_BINS, cs->h_exact.counts, cs->h_exact.res + 4);
+        if (total > 0) sample_hist_kernel<<<grid1d(total, 256, sample_grid_cap()), 256, sh, st>>>(fs, geom(c), L, cs->h_exact.edges, NL_CHAIN_BINS, cs->h_exact.counts, cs->h_exact.res + 4);
         NL_CHECK_LAUNCH();
         if (fused(c) && (rc = reduce_u64_sum(c, cs->h_exact.counts, NL_CHAIN_BINS, err, errlen))) return rc;
     }
-    chain_thr2_kernel<<<1, 64, 0, c->stream>>>(cs, division);
+    chain_thr2_kernel<<<1, 64, 0, st>>>(cs, division);
     NL_CHECK_LAUNCH();
+    if (exact_on_side) {
+        NL_HIP(hipEventRecord(c->ev_side, c->side));
+        c->side_pending = 1;
+    }
     VessP vp{};
     vp.alpha_sq = (float)alpha_sq; vp.beta_sq = (float)beta_sq; vp.use_thr = 1;
     vp.cnt_lo = (int)c->own_lo; vp.cnt_hi = (int)c->own_hi;
     vp.first = c->mask_slots_used == 0 ? 1 : 0;
-    if (resolve_defer_ok(c)) {
+    if (defer) {
         memcpy(c->def_vp, &vp, sizeof(VessP));
         c->def_cnt = &cs->cnt_resolve; c->def_params = (const float *)cs; c->def_resolve = 1;
         return NL_OK;

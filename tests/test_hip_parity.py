@@ -1139,9 +1139,10 @@ def test_device_chain_with_the_next_cascade_step_running_ahead(hip, fused, monke
     assert np.array_equal(fa, fb) and (fa > 0).any() and np.array_equal(la, lb)
 
 
+@pytest.mark.parametrize("mode", ["2", "5"])
 @pytest.mark.parametrize("ahead", ["0", "1"])
 @pytest.mark.parametrize("shape,seed,aniso", [((40, 96, 96), 21, False), ((33, 70, 130), 22, True), ((96, 160, 200), 24, False)])
-def test_device_chain_with_the_resolve_kernel_held_back(hip, shape, seed, aniso, ahead, monkeypatch):
+def test_device_chain_with_the_resolve_kernel_held_back(hip, shape, seed, aniso, ahead, mode, monkeypatch):
     """Round 5: on volumes of 2^26 voxels and more the chain starts the resolve kernel of scale s only behind the cascade step of scale
     s+1, on the side stream, beside that scale's threshold kernels (nl_chain_scale).  Forced here on small volumes (NELLIE_RESOLVE_DEFER=2),
     with and without the cascade step running ahead on the same side stream: the chain stands, same trace and frame as the synchronous path,
@@ -1151,7 +1152,7 @@ def test_device_chain_with_the_resolve_kernel_held_back(hip, shape, seed, aniso,
     dr = ANISO_03 if aniso else ISO_01
     vol = make_volume(shape, seed)
     ref = _run_both_ways(vol, dr)[1]
-    monkeypatch.setenv("NELLIE_RESOLVE_DEFER", "2")
+    monkeypatch.setenv("NELLIE_RESOLVE_DEFER", mode)          # 5: the scale's exact round (post / histogram / threshold kernels) on the side stream too
     pipe = pl.FramePipeline(shape)
     pipe._chain_ahead_env = ahead
     for rep in range(3):
