@@ -5,6 +5,9 @@
 // rounding point: the kernels' results are bit for bit the same either way (the whole GPU suite runs on this build).
 // nellie_hip.hip fills an HvLaunch and calls nl_hv_launch; everything else about the walk (queue, records, streams) stays there.
 #pragma once
+#ifndef NL_HV_VARIANTS
+#define NL_HV_VARIANTS 0       // 1: the rejected forms of the walk are built too (nellie_hv.hip)
+#endif
 
 struct HvLaunch {
     int mode;                 // 0 statistics, 1 known threshold, 2 one pass with a bracket (hessian.inc)

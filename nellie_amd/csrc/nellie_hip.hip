@@ -153,7 +153,7 @@ static int hm_ty() {
 // one-voxel kernel of hessian.inc
 static int hv_rs_env() {
     static int v = -1;
-    if (v < 0) { const char *e = getenv("NELLIE_HV_RS"); v = e ? atoi(e) : 8; if (v != 0 && v != 8 && v != 16) v = 8; }
+    if (v < 0) { const char *e = getenv("NELLIE_HV_RS"); v = e ? atoi(e) : 8; if (v != 0 && v != 8 && !(NL_HV_VARIANTS && v == 16)) v = 8; }
     return v;
 }
 // the pair kernel addresses the planes of a Z chunk through one buffer resource (32-bit byte offsets)
@@ -166,8 +166,13 @@ static int hv_fastv(const nl_ctx *c) { return c->fast_div2 ? 2 : (c->fast_div ? 
 // pair-rows per lane of the pair walk (NELLIE_HV_NP=2: four voxels per lane at 2 waves / SIMD -- the round-5 experiment, hessian_pair.inc;
 // only instantiated for the 16-row tile with the two-instruction division)
 static int hv_np(const nl_ctx *c) {
+#if NL_HV_VARIANTS
     const char *e = getenv("NELLIE_HV_NP");            // read per call: tests switch it inside one process
     return (e && atoi(e) == 2 && hv_rs(c) == 8 && hv_fastv(c) == 2) ? 2 : 1;
+#else
+    (void)c;
+    return 1;
+#endif
 }
 // Exhaustive proof that the 3-instruction division is exact for the six divisors in use.
 static int check_fast_div(nl_ctx *c, char *err, size_t errlen) {
@@ -453,6 +458,9 @@ extern "C" int nl_filter_load(nl_ctx *c, const void *host, int dtype, int64_t z0
     if (!host || z0 < 0 || z1 > c->nzl || z0 >= z1) return nl_fail(err, errlen, NL_EINVAL, "bad plane range [%lld,%lld)", (i64)z0, (i64)z1);
     c->i_gauss = 0; c->i_vmax = 3; c->i_labels = -1; c->frangi_ready = 0;
     c->gauss_ext = nullptr;
+    // a frame abandoned between nl_gauss_step_ahead and nl_gauss_commit (an exception in the host's scale loop) leaves a cascade step on the
+    // side stream that still writes the ping-pong volumes: this frame's first kernels come after it
+    if (c->ahead_pending) NL_HIP(hipStreamWaitEvent(c->stream, c->ev_ahead, 0));
     c->ahead_pending = 0;
     c->fsq_cache_valid = 0;
     NL_HIP(zero_small((char *)c->d_small + (52 << 10), 4, c->stream));
@@ -491,6 +499,9 @@ extern "C" int nl_filter_begin(nl_ctx *c, char *err, size_t errlen) {
     c->i_gauss = 0; c->i_vmax = 3; c->i_labels = -1; c->frangi_ready = 0;
     c->mask_slots_used = 0;
     c->gauss_ext = nullptr;
+    // a frame abandoned between nl_gauss_step_ahead and nl_gauss_commit (an exception in the host's scale loop) leaves a cascade step on the
+    // side stream that still writes the ping-pong volumes: this frame's first kernels come after it
+    if (c->ahead_pending) NL_HIP(hipStreamWaitEvent(c->stream, c->ev_ahead, 0));
     c->ahead_pending = 0;
     c->fsq_cache_valid = 0;
     NL_HIP(zero_small((char *)c->d_small + (52 << 10), 4, c->stream));
@@ -1384,8 +1395,8 @@ static int resolve_enqueue(nl_ctx *c, VessP vp, unsigned long long *d_cnt, const
 // side stream carries the cascade step that runs ahead); NELLIE_RESOLVE_DEFER=0: off.
 static bool resolve_defer_ok(const nl_ctx *c) {
     const char *e = getenv("NELLIE_RESOLVE_DEFER");               // read per call: tests switch it (2: whatever the size, for the small volumes of the suite)
-    const int on = e ? atoi(e) : 1;                                // 4: as 1 and the scale's exact round on the side stream too (A/B); 5: as 2 with that
-    if (on == 2 || on == 5) return !c->comm && !resolve_on_side();
+    const int on = e ? atoi(e) : 1;
+    if (on == 2) return !c->comm && !resolve_on_side();
     return on && !c->comm && !c->ahead_pending && !resolve_on_side() && c->n >= ((i64)1 << 26);
 }
 static int resolve_deferred_launch(nl_ctx *c, bool on_side, char *err, size_t errlen) {
@@ -1527,18 +1538,9 @@ extern "C" int nl_chain_scale(nl_ctx *c, const double spacing[3], int64_t sz, in
     chain_thr1_kernel<<<2, 64, 0, c->stream>>>(cs, division, margin, test_scale);
     NL_CHECK_LAUNCH();
     if ((rc = spec_enqueue(c, spacing, 0.0f, 0.0f, z0, z1, cs->stats, &cs->cnt_walk, &cs->fsq_lo, err, errlen))) return rc;
-    // With the resolve kernel held back (below) the exact round -- four small kernels, ~50 us of a nearly idle GPU at 1024^3 -- moves to the
-    // side stream too, behind the walk: the cascade step of the next scale, which the host enqueues on the main stream next, then starts
-    // right behind the walk instead of behind them.  The next nl_chain_scale joins the side stream before it touches the frob_sq cache.
+    // (With the resolve kernel held back, the exact round of the scale on the side stream as well was measured: no gain, docs/HISTORY.md.)
     const bool defer = resolve_defer_ok(c) && c->fsq_cache_valid;     // (the cache is this scale's: use_fsq_cache below launches nothing)
     hipStream_t st = c->stream;
-    bool exact_on_side = false;
-    if (defer) { const char *e = getenv("NELLIE_RESOLVE_DEFER"); exact_on_side = e && (atoi(e) == 4 || atoi(e) == 5); }     // 4 / 5: see resolve_defer_ok
-    if (exact_on_side) {
-        NL_HIP(hipEventRecord(c->ev_main, c->stream));
-        NL_HIP(hipStreamWaitEvent(c->side, c->ev_main, 0));
-        st = c->side;
-    }
     chain_post_kernel<<<1, 64, 0, st>>>(cs);
     NL_CHECK_LAUNCH();
     {   // the exact round: edges from the normalised range, histogram of the cached frob_sq under the device's normalisation
@@ -1557,10 +1559,6 @@ extern "C" int nl_chain_scale(nl_ctx *c, const double spacing[3], int64_t sz, in
     }
     chain_thr2_kernel<<<1, 64, 0, st>>>(cs, division);
     NL_CHECK_LAUNCH();
-    if (exact_on_side) {
-        NL_HIP(hipEventRecord(c->ev_side, c->side));
-        c->side_pending = 1;
-    }
     VessP vp{};
     vp.alpha_sq = (float)alpha_sq; vp.beta_sq = (float)beta_sq; vp.use_thr = 1;
     vp.cnt_lo = (int)c->own_lo; vp.cnt_hi = (int)c->own_hi;
@@ -2509,6 +2507,7 @@ extern "C" int nl_ctx_info(nl_ctx *c, const char *key, double *value) {
     if (!c || !key || !value) return NL_EINVAL;
     if (!strcmp(key, "fast_div")) *value = c->fast_div2 ? 2 : c->fast_div;      // 2: two-instruction division proven, 1: three, 0: float64
     else if (!strcmp(key, "hessian_tile_rows")) *value = hv_rs(c) ? 2 * hv_rs(c) : hm_ty();
+    else if (!strcmp(key, "hv_variants")) *value = NL_HV_VARIANTS;               // 1: a build with the rejected forms of the walk (nellie_hv.hip)
     else if (!strcmp(key, "vesselness_one_pass")) *value = c->spec_ok;
     else if (!strcmp(key, "chain_available")) *value = (!c->two_d && c->spec_ok && hv_rs(c)) ? 1 : 0;   // nl_chain_begin's own precondition
     else if (!strcmp(key, "last_fsq_min")) *value = c->last_fsq_min;

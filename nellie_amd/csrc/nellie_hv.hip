@@ -21,25 +21,36 @@ static void launch_np(const HvLaunch &a, const HessDv<FAST> &hr) {
     hessian_v_kernel<MODE, RS, FAST, NP><<<a.nblocks, HVCfg<RS, NP>::NT, HVCfg<RS, NP>::lds_bytes(), a.stream>>>(
         a.g, a.cmask, a.pmask, a.wpr, a.geom, hr, a.vp, a.vq, a.z0, a.z1, a.ntx, a.nty, a.res, a.d_cnt, a.dev_lohi);
 }
+// The shipping library holds SIX instantiations: modes 0-2 x {the two-instruction division, the float64 division}, 16-row tiles, two voxels
+// per lane.  What measurement rejected is built on request only (tools/build_variant.sh hv_all "-DNL_HV_VARIANTS=1"): 32-row tiles
+// (NELLIE_HV_RS=16), four voxels per lane (NELLIE_HV_NP=2: 26 % slower, docs/HISTORY.md round 5) and the three-instruction division
+// (NELLIE_EXACT_DIV=3; a divisor the two-instruction form is not proven for takes the float64 form here).
 template <int MODE, int RS, int FAST>
 static void launch_one(const HvLaunch &a, const HessDv<FAST> &hr) {
+#if NL_HV_VARIANTS
     if constexpr (RS == 8 && FAST == 2) { if (a.np == 2) { launch_np<MODE, RS, FAST, 2>(a, hr); return; } }
+#endif
     launch_np<MODE, RS, FAST, 1>(a, hr);
 }
 template <int MODE, int RS>
 static void launch_div(const HvLaunch &a) {
     if (a.fastv == 2) launch_one<MODE, RS, 2>(a, hessdv_two(a.hp));
+#if NL_HV_VARIANTS
     else if (a.fastv == 1) launch_one<MODE, RS, 1>(a, hessdv_fast(a.hp));
+#endif
     else launch_one<MODE, RS, 0>(a, hessdv_exact(a.hp));
 }
 template <int MODE>
 static void launch_rs(const HvLaunch &a) {
-    if (a.rs == 16) launch_div<MODE, 16>(a); else launch_div<MODE, 8>(a);
+#if NL_HV_VARIANTS
+    if (a.rs == 16) { launch_div<MODE, 16>(a); return; }
+#endif
+    launch_div<MODE, 8>(a);
 }
 
 hipError_t nl_hv_launch(const HvLaunch &a) {
-    if (a.rs != 8 && a.rs != 16) return hipErrorInvalidValue;
-    if (a.np != 1 && !(a.np == 2 && a.rs == 8 && a.fastv == 2)) return hipErrorInvalidValue;
+    if (a.rs != 8 && !(NL_HV_VARIANTS && a.rs == 16)) return hipErrorInvalidValue;
+    if (a.np != 1 && !(NL_HV_VARIANTS && a.np == 2 && a.rs == 8 && a.fastv == 2)) return hipErrorInvalidValue;
     switch (a.mode) {
         case 0: launch_rs<0>(a); break;
         case 1: launch_rs<1>(a); break;

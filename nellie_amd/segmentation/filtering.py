@@ -95,7 +95,7 @@ class Filter:
     def _resolve_backend(self, device):
         """filtering.py:117-159 with HIP in the role of CuPy."""
         device = (device or "auto").lower()
-        if device not in ("auto", "cpu", "gpu", "cuda"):
+        if device not in ("auto", "cpu", "gpu", "cuda", "hip"):          # "hip": what INTEGRATION.md's dispatch forwards; same engine as "gpu"
             raise ValueError(f"Unsupported device '{device}'. Use 'auto', 'cpu', or 'gpu'.")
         if device == "cpu":
             raise RuntimeError(

@@ -85,7 +85,7 @@ class Label:
     def _resolve_backend(self, device):
         """labelling.py:115-154 with HIP in the role of CuPy."""
         device = (device or "auto").lower()
-        if device not in ("auto", "cpu", "gpu", "cuda"):
+        if device not in ("auto", "cpu", "gpu", "cuda", "hip"):          # "hip": what INTEGRATION.md's dispatch forwards; same engine as "gpu"
             raise ValueError(f"Unsupported device '{device}'. Use 'auto', 'cpu', or 'gpu'.")
         if device == "cpu":
             raise RuntimeError(

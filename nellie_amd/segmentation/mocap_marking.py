@@ -54,7 +54,7 @@ class Markers:
         self.debug = None
         self.viewer = viewer
         dev = str(device or "auto").lower()
-        if dev not in ("auto", "cpu", "gpu", "cuda"):
+        if dev not in ("auto", "cpu", "gpu", "cuda", "hip"):
             raise ValueError(f"Unsupported device '{device}'. Use 'auto', 'cpu', or 'gpu'.")
         if dev == "cpu" or (dev == "auto" and not prefer_gpu):
             raise RuntimeError("nellie_amd provides the MI355X HIP backend only: device='cpu' is not available "

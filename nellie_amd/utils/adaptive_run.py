@@ -16,7 +16,7 @@ _MEMORY_HEADROOM = 0.7
 def normalize_device(device):
     """adaptive_run.py:14-20."""
     device = (device or "auto").lower()
-    if device == "cuda":
+    if device in ("cuda", "hip"):         # "hip": the name INTEGRATION.md's dispatch uses for this backend
         device = "gpu"
     if device not in ("auto", "cpu", "gpu"):
         raise ValueError(f"Unsupported device '{device}'. Use 'auto', 'cpu', or 'gpu'.")

@@ -1099,7 +1099,15 @@ def test_device_chain_equals_the_synchronous_path(hip, shape, seed, aniso):
 def test_walk_with_four_voxels_per_lane_is_bit_identical(hip, shape, seed, aniso, monkeypatch):
     """NELLIE_HV_NP=2 (round 5, profiles/r05_walk_variants_1024cube.txt block 4): the pair walk with two pair-rows per lane -- measured
     26 % slower and therefore off, but the same bits: trace, frame (chain and synchronous path, which also runs the two-pass modes)."""
+    from nellie_amd import pipeline as pl
     from nellie_amd.synthetic import ANISO_03, ISO_01, make_volume
+    probe = pl.FramePipeline((8, 16, 64))
+    try:
+        built = probe.ctx.info("hv_variants")
+    finally:
+        probe.close()
+    if not built:
+        pytest.skip("the shipping library no longer carries the rejected walk variants (tools/build_variant.sh hv_all -DNL_HV_VARIANTS=1)")
     vol = make_volume(shape, seed)
     dr = ANISO_03 if aniso else ISO_01
     ref = _run_both_ways(vol, dr)
@@ -1139,7 +1147,7 @@ def test_device_chain_with_the_next_cascade_step_running_ahead(hip, fused, monke
     assert np.array_equal(fa, fb) and (fa > 0).any() and np.array_equal(la, lb)
 
 
-@pytest.mark.parametrize("mode", ["2", "5"])
+@pytest.mark.parametrize("mode", ["2"])
 @pytest.mark.parametrize("ahead", ["0", "1"])
 @pytest.mark.parametrize("shape,seed,aniso", [((40, 96, 96), 21, False), ((33, 70, 130), 22, True), ((96, 160, 200), 24, False)])
 def test_device_chain_with_the_resolve_kernel_held_back(hip, shape, seed, aniso, ahead, mode, monkeypatch):
@@ -1152,7 +1160,7 @@ def test_device_chain_with_the_resolve_kernel_held_back(hip, shape, seed, aniso,
     dr = ANISO_03 if aniso else ISO_01
     vol = make_volume(shape, seed)
     ref = _run_both_ways(vol, dr)[1]
-    monkeypatch.setenv("NELLIE_RESOLVE_DEFER", mode)          # 5: the scale's exact round (post / histogram / threshold kernels) on the side stream too
+    monkeypatch.setenv("NELLIE_RESOLVE_DEFER", mode)
     pipe = pl.FramePipeline(shape)
     pipe._chain_ahead_env = ahead
     for rep in range(3):
