@@ -27,7 +27,7 @@
  *  - Entry points call hipSetDevice themselves and are synchronous on return unless noted
  *    (nl_* _async variants enqueue on the context stream; nl_sync waits).  One context must
  *    not be used from two threads at once; different contexts may be.  The one exception are
- *    the copy-thread calls of the frame streamer -- nl_input_load_async, nl_outputs_fetch_async,
+ *    the copy-thread calls of the frame streamer -- nl_input_load_async, nl_input_wait, nl_outputs_fetch_async,
  *    nl_outputs_wait -- which touch only the copy streams, the input slots and the staging
  *    volumes and may run beside the compute thread's calls on the same context.
  */
@@ -496,6 +496,12 @@ int nl_host_register(void *ptr, int64_t bytes, char *err, size_t errlen);   /* p
 int nl_host_unregister(void *ptr);
 int nl_input_load_async(nl_ctx *ctx, int slot, const void *host_pinned, int dtype, char *err, size_t errlen);
 int nl_input_select(nl_ctx *ctx, int slot, char *err, size_t errlen);
+/* Blocks until the upload nl_input_load_async started into that slot has arrived.  The streamer with several lanes (contexts of one
+   GPU working on different frames of a stack, nellie_amd/streaming.py) feeds them from ONE upload thread that keeps exactly one
+   host -> HBM copy in flight: two concurrent copies share the link badly (measured: 2.49 ms alone, 3.57 ms each as a pair for a
+   134 MB frame, profiles/r06_stream_lanes_trace.txt), and the upload is what bounds a float32 stack (filtering.py:917-924 is the
+   blocking load this replaces). */
+int nl_input_wait(nl_ctx *ctx, int slot, char *err, size_t errlen);
 int nl_outputs_stage(nl_ctx *ctx, int with_labels, char *err, size_t errlen);
 int nl_outputs_fetch_async(nl_ctx *ctx, float *frangi_pinned, int32_t *labels_pinned, char *err, size_t errlen);
 int nl_outputs_wait(nl_ctx *ctx, char *err, size_t errlen);

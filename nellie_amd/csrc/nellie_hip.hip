@@ -2515,6 +2515,19 @@ extern "C" int nl_ctx_info(nl_ctx *c, const char *key, double *value) {
     else if (!strcmp(key, "last_label_sparse")) *value = c->last_label_sparse;
     else if (!strcmp(key, "device_bytes")) *value = (double)nl_ctx_bytes(c->nzl, c->ny, c->nx);
     else if (!strcmp(key, "gauss_yx_max_r")) *value = getenv("NELLIE_NO_FUSED_YX") ? 0 : GM_MAX_R;   // largest in-plane radius whose Y and X passes share a kernel
+    else if (!strcmp(key, "queue_entries")) {
+        // entries the last one-pass walk (nl_vesselness_spec / a chain scale) left in the eigen queue: the sum of the per-wave region counts
+        // (waits for the stream; bench.py's fused-design byte model prices the walk's stores and the resolve kernel's reads with it)
+        if (hipSetDevice(c->device) != hipSuccess) return NL_EHIP;
+        if (c->side_pending && hipStreamSynchronize(c->side) != hipSuccess) return NL_EHIP;
+        const unsigned nreg = c->spec_nregions;
+        std::vector<unsigned int> h(nreg);
+        if (nreg && (hipMemcpyAsync(h.data(), c->d_vq_count, (size_t)nreg * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+                     hipStreamSynchronize(c->stream) != hipSuccess)) return NL_EHIP;
+        double t = 0.0;
+        for (unsigned k = 0; k < nreg; ++k) t += (double)h[k];
+        *value = t;
+    }
     else if (!strcmp(key, "nan_hessian")) {
         // Filter.run(mask=False) only: 1 if a Hessian with a NaN entry reached the eigen-solver since the frame began (waits for the stream)
         if (hipSetDevice(c->device) != hipSuccess) return NL_EHIP;

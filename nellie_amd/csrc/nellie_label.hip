@@ -995,6 +995,14 @@ extern "C" int nl_input_load_async(nl_ctx *c, int slot, const void *host_pinned,
     return NL_OK;
 }
 
+// host wait for that slot's upload (copy-thread call: touches the slot's event only)
+extern "C" int nl_input_wait(nl_ctx *c, int slot, char *err, size_t errlen) {
+    NL_ENTER_IO(c);
+    if (slot < 0 || slot > 1 || !c->copy_in || !c->d_in_slot[slot]) return nl_fail(err, errlen, NL_ESTATE, "input slot %d was never loaded", slot);
+    NL_HIP(hipEventSynchronize(c->ev_in[slot]));
+    return NL_OK;
+}
+
 // make the compute stream wait for that slot and use it as the resident input of the next nl_filter_begin
 extern "C" int nl_input_select(nl_ctx *c, int slot, char *err, size_t errlen) {
     NL_ENTER(c);

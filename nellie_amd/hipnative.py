@@ -135,6 +135,7 @@ _PROTOS = {
     "nl_host_register": [_p, _i64],
     "nl_input_load_async": [_p, _int, _p, _int],
     "nl_input_select": [_p, _int],
+    "nl_input_wait": [_p, _int],
     "nl_outputs_stage": [_p, _int],
     "nl_outputs_fetch_async": [_p, _p, _p],
     "nl_outputs_wait": [_p],
@@ -798,6 +799,10 @@ class Context:
 
     def input_select(self, slot):
         self._call("nl_input_select", int(slot))
+
+    def input_wait(self, slot):
+        """Block until the upload into that slot has arrived (copy-thread call)."""
+        self._call("nl_input_wait", int(slot))
 
     def outputs_stage(self, with_labels=True):
         self._call("nl_outputs_stage", 1 if with_labels else 0)

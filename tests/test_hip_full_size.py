@@ -242,29 +242,76 @@ def test_c2_parity_at_its_own_size(hip, aniso):
 
 
 def test_c5_streamed_equals_per_frame_at_its_frame_size(hip):
-    """BASELINE config 5 at its own frame size (128 x 512 x 512, seeds 4567 + t), 8 frames: the double-buffered streamer
+    """BASELINE config 5 at its own frame size (128 x 512 x 512, seeds 4567 + t), 7 frames: the double-buffered streamer
     (H2D of frame t+1 and D2H of frame t-1 on their own HIP streams while frame t computes) writes the arrays the
-    frame-by-frame path writes."""
+    frame-by-frame path writes -- with one lane, with two (the default at this frame size: two contexts of the GPU take the
+    frames alternately, one upload thread feeds both), and with three and four, where the stack length is no multiple of the lane count."""
     from nellie_amd import pipeline as pl
-    from nellie_amd.streaming import StreamedSegmenter
+    from nellie_amd.streaming import StreamedSegmenter, default_lanes
     from nellie_amd.synthetic import ISO_01, make_volume
-    T, fs = 8, (128, 512, 512)
+    T, fs = 7, (128, 512, 512)
     frames = np.stack([make_volume(fs, 4567 + t) for t in range(T)])
     p = pl.FilterParams(dim_res=ISO_01)
     ma = pl.min_area_pixels_of(ISO_01)
     fr, lab = np.empty(frames.shape, np.float32), np.empty(frames.shape, np.int32)
     pipe = pl.FramePipeline(fs)
+    counts = []
     for t in range(T):
-        pipe.filter(frames[t], p)
+        npos = pipe.filter(frames[t], p)
+        counts.append((npos, pipe.label(pipe.frangi_threshold(), ma)))
+        pipe.download_frangi(out=fr[t]); pipe.download_labels(out=lab[t])
+    pipe.close()
+    assert default_lanes(fs) == 2 and default_lanes((1024, 1024, 1024)) == 1
+    for lanes in (None, 1, 3, 4):
+        fr2, lab2 = np.full_like(fr, -1.0), np.full_like(lab, -1)
+        seg = StreamedSegmenter(fs, frames.dtype, p, lanes=lanes)
+        assert seg.n_lanes == (lanes or 2)
+        stats = seg.run(frames, fr2, lab2, flush=False)
+        if lanes == 3:                      # a second stack through the same streamer: nothing of the first one lingers
+            fr2[:] = -1.0; lab2[:] = -1
+            stats = seg.run(frames, fr2, lab2, flush=False)
+        seg.close()
+        assert np.array_equal(fr, fr2) and np.array_equal(lab, lab2), f"lanes={lanes}"
+        assert [tuple(int(v) for v in s_) for s_ in stats] == [tuple(int(v) for v in c) for c in counts]
+    assert all(int(lab[t].max()) >= 1 for t in range(T)) and (fr >= 0).all()
+
+
+def test_streamer_lanes_on_a_memory_mapped_stack_and_a_failing_frame(hip, tmp_path):
+    """Two lanes fed from a file-backed stack (no page-locking in place: the upload thread stages through pinned buffers, the host copy
+    of frame t + 1 beside the H2D of frame t), uint16 frames; and a stack whose third frame makes the engine raise (a +Inf voxel:
+    numpy's histogram refuses the range, filtering.py:365-380 via gpu_functions.py) ends the run with that exception instead of a hang."""
+    from nellie_amd import pipeline as pl
+    from nellie_amd.streaming import StreamedSegmenter
+    from nellie_amd.synthetic import ISO_01, make_volume
+    T, fs = 5, (40, 96, 136)
+    p = pl.FilterParams(dim_res=ISO_01)
+    ma = pl.min_area_pixels_of(ISO_01)
+    stack = np.lib.format.open_memmap(str(tmp_path / "stack.npy"), mode="w+", dtype=np.uint16, shape=(T,) + fs)
+    for t in range(T):
+        stack[t] = np.clip(make_volume(fs, 900 + t), 0, 65535).astype(np.uint16)
+    stack.flush()
+    stack = np.load(str(tmp_path / "stack.npy"), mmap_mode="r")
+    fr, lab = np.empty(stack.shape, np.float32), np.empty(stack.shape, np.int32)
+    pipe = pl.FramePipeline(fs)
+    for t in range(T):
+        pipe.filter(np.asarray(stack[t]), p)
         pipe.label(pipe.frangi_threshold(), ma)
         pipe.download_frangi(out=fr[t]); pipe.download_labels(out=lab[t])
     pipe.close()
-    fr2, lab2 = np.empty_like(fr), np.empty_like(lab)
-    seg = StreamedSegmenter(fs, frames.dtype, p)
-    seg.run(frames, fr2, lab2, flush=False)
-    seg.close()
-    assert np.array_equal(fr, fr2) and np.array_equal(lab, lab2)
-    assert all(int(lab[t].max()) >= 1 for t in range(T)) and (fr >= 0).all()
+    fr2, lab2 = np.zeros_like(fr), np.zeros_like(lab)
+    seg = StreamedSegmenter(fs, stack.dtype, p, lanes=2)
+    seg.run(stack, fr2, lab2, flush=False, outputs_zeroed=True)
+    assert np.array_equal(fr, fr2) and np.array_equal(lab, lab2) and int(lab.max()) >= 1
+    bad = np.stack([make_volume(fs, 900 + t) for t in range(T)])
+    bad[2, 5, 5, 5] = np.inf
+    seg2 = StreamedSegmenter(fs, bad.dtype, p, lanes=2)
+    with pytest.raises(ValueError):
+        seg2.run(bad, np.empty(bad.shape, np.float32), np.empty(bad.shape, np.int32), flush=False)
+    fr3, lab3 = np.empty(bad.shape, np.float32), np.empty(bad.shape, np.int32)          # ... and the streamer is usable afterwards
+    good = np.stack([make_volume(fs, 900 + t) for t in range(T)])
+    seg2.run(good, fr3, lab3, flush=False)
+    seg.close(); seg2.close()
+    assert (lab3.reshape(T, -1).max(axis=1) >= 1).all()
 
 
 def test_c4_volume_partition_invariance(hip):

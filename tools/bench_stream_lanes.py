@@ -21,7 +21,7 @@ ref = None
 out = {"stack": [T] + list(fs)}
 for L in lanes_list:
     fr, lab = np.empty(frames.shape, np.float32), np.empty(frames.shape, np.int32)
-    segs = [StreamedSegmenter(fs, frames.dtype, p) for _ in range(L)]
+    segs = [StreamedSegmenter(fs, frames.dtype, p, lanes=1) for _ in range(L)]     # (round 6: the streamer has lanes of its own -- tools/diag_stream_lanes.py)
 
     def run_all():
         errs = []

@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$1; T=${2:-16}
-for cfg in "1 1 1" "2 1 1"; do
+for cfg in "1 0 f32" "2 0 f32" "3 0 f32"; do
 rm -rf /tmp/kt && NELLIE_DIAG_ONLY="$cfg" rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d /tmp/kt -- python $R/tools/diag_stream_lanes.py $T > /tmp/kt.log 2>&1
 tail -2 /tmp/kt.log
 K=$(find /tmp/kt -name '*kernel_trace.csv' | head -1); M=$(find /tmp/kt -name '*memory_copy_trace.csv' | head -1)
@@ -39,6 +39,11 @@ for r in ms:
     agg[key][0] += 1; agg[key][1] += e - s
 for k, (c, d, _) in sorted(agg.items()):
     print(f"  {k}: {c} copies, total {d/1e6:.2f} ms, avg {d/c/1e3:.1f} us")
+big = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp'])) for r in ms if t0 <= int(r['Start_Timestamp']) <= t1 and r.get('Direction', '').endswith('HOST_TO_DEVICE') and int(r['End_Timestamp']) - int(r['Start_Timestamp']) > 200000)
+if len(big) > 1:
+    gaps = [(b[0] - a[1]) / 1e6 for a, b in zip(big, big[1:])]
+    print("  uploads: durations ms", [round((e - s_) / 1e6, 2) for s_, e in big])
+    print("  uploads: gap to the next one ms", [round(g, 2) for g in gaps])
 PY
 done > $R/gpurun_out/$OUT 2>&1
 cat $R/gpurun_out/$OUT
