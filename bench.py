@@ -79,7 +79,7 @@ PMC_KERNEL_OF_GROUP = {"vesselness": ("hessian_v_kernel<2", "hessian_g_kernel<2"
                        "sample": ("sample_", "chain_")}
 PMC_SUMMED_GROUPS = ("mask_volume", "label", "sample")
 GROUPS = ("load",) + GAUSS_ZYX + ("gauss_z", "gauss_yx", "gauss_y", "gauss_x", "sample", "hessian_stats", "vesselness", "vesselness_resolve",
-          "finish", "mask_volume", "label", "halo")
+          "finish", "mask_volume", "label", "halo", "halo_wait")
 SLAB_PLANES = 128              # owned planes per GPU of the Z-slab run: BASELINE config 4 / 8
 SLAB_YX = (2048, 2048)
 
@@ -791,26 +791,7 @@ def main():
         dist.barrier("children")                           # rank 0 comes here late (CPU baseline): start the children together
         zslab = run_zslab_child(args, rank)
     if rank == 0:
-        out["replicas"] = {"value": out["value"], "unit": "Mvoxel/s", "ms_per_step": out["ms_per_step"],
-                           "workload": f"3-D+T stack of {n_gpus} frames of {shape[0]}x{shape[1]}x{shape[2]}, one frame per GPU, no data-path collective"}
-        if zslab is not None:
-            out["zslab"] = zslab
-            if "error" not in zslab and zslab.get("value"):
-                out["value"] = zslab["value"]
-                out["ms_per_step"] = zslab["ms_per_step"]
-                out["config"]["workload"] = zslab["workload"]
-                out["config"]["voxels"] = zslab["voxels"]
-                out["config"]["per_gpu_shape"] = zslab["per_gpu_owned_shape"]
-                out["config"]["parallelism"] = f"zslab{n_gpus}"
-                for k in ("survival_fraction", "labels", "mask_fraction_per_scale", "one_pass_scales"):
-                    out["config"][k] = zslab.get(k)
-            else:
-                # the decomposition this line is about did not run: no number is reported for it (the frame-replica figure
-                # stays under `replicas`, it is a different workload)
-                out["value"] = None
-                out["ms_per_step"] = None
-                out["zslab_failed"] = True
-                out["config"]["parallelism"] = f"zslab{n_gpus} (failed: see zslab.error; `replicas` = {n_gpus} independent frames, no collective)"
+        merge_zslab_into_line(out, zslab, n_gpus)
         print(json.dumps(out), flush=True)
     sys.stdout.flush()
     os._exit(0)      # skip collective teardown: nothing after the JSON line may hang the job
@@ -966,6 +947,7 @@ def zslab_run(dist, rank, world, local_rank, args):
         each.append(round((time.perf_counter() - t1) * 1e3, 2))
     pipe.ctx.sync()
     elapsed = time.perf_counter() - t0
+    elapsed_own = elapsed
     dist.barrier("zstep")
     elapsed = dist.max("zelapsed", elapsed)
     pipe.ctx.prof_enable(False)
@@ -976,6 +958,12 @@ def zslab_run(dist, rank, world, local_rank, args):
             groups[name] = round(ms / args.steps, 3)
     crc = __import__("zlib").crc32(pipe.download_labels().tobytes())
     n_global = float(np.prod(gshape))
+    # every rank's own figures (rank 0 assembles them: zslab_rank_summary)
+    mine = {"rank": rank, "ms_per_step": round(elapsed_own / args.steps * 1e3, 3), "ms_of_each_step": each,
+            "halo_ms": groups.get("halo"), "halo_wait_ms": groups.get("halo_wait", 0.0),
+            "cascade_steps_per_step": len(p.resolved_sigmas()),
+            "kernel_groups_ms": {k: v for k, v in groups.items() if k not in ("halo", "halo_wait")}}
+    res.update(zslab_rank_summary(dist.allgather("zrows", mine)))
     tr = pipe.trace
     # The event pairs of two kernels that overlap (the cascade step running ahead beside the walk and the threshold kernels)
     # each count the overlap: the per-group table above does not add up on slabs.  Two more steps with nothing running ahead
@@ -1045,6 +1033,76 @@ def zslab_run(dist, rank, world, local_rank, args):
             res["same_workload_single_gpu_ms"] = one["ms_per_step"]
             res["speedup_vs_same_workload_on_one_gpu"] = round(one["ms_per_step"] / res["ms_per_step"], 3)
     return res
+
+
+def zslab_rank_summary(rows):
+    """What the N > 1 line says about the ranks (round 6: the first SCALE record must explain itself): per rank the step time on its own
+    clock, the time the ghost-plane exchanges took on their stream (`halo_ms`) and the time the main stream WAITED for them
+    (`halo_wait_ms`: the exposed part, also per cascade step), the slowest rank and the skew.  rows: one dict per rank, as every rank's
+    zslab_run builds it (tests/test_bench_multi.py feeds eight made-up ones)."""
+    rows = sorted(rows, key=lambda r: r["rank"])
+    ms = [float(r["ms_per_step"]) for r in rows]
+    waits = [float(r.get("halo_wait_ms") or 0.0) for r in rows]
+    steps = max(1, int(rows[0].get("cascade_steps_per_step") or 1))
+    slow = max(range(len(rows)), key=lambda k: ms[k])
+    return {
+        "per_rank": [{"rank": r["rank"], "ms_per_step": round(float(r["ms_per_step"]), 3), "halo_ms": r.get("halo_ms"),
+                      "halo_wait_ms": round(float(r.get("halo_wait_ms") or 0.0), 3),
+                      "kernel_sum_ms": round(sum(float(v) for v in (r.get("kernel_groups_ms") or {}).values()), 3)} for r in rows],
+        "slowest_rank": rows[slow]["rank"], "rank_skew_ms": round(max(ms) - min(ms), 3),
+        "exchange_exposed_ms_per_step_max_over_ranks": round(max(waits), 3),
+        "exchange_exposed_ms_per_cascade_step_max_over_ranks": round(max(waits) / steps, 4),
+    }
+
+
+def n1_reference():
+    """The N = 1 figures a multi-GPU line is read against, from the committed profiles of the same commands: the 1024^3 line (what
+    `replicas` re-measures in the same run) and ONE rank's share of the slab run at world 1 (a 128 x 2048 x 2048 slab alone on a GPU)."""
+    import glob
+    out = {}
+    for key, pat in (("one_rank_alone_128x2048x2048", "r*_zslab_world1_128x2048x2048.json"), ("frame_1024cube", "r*_bench_n1_1024cube.json")):
+        files = sorted(glob.glob(os.path.join(REPO, "profiles", pat)))
+        if not files:
+            continue
+        try:
+            rec = json.loads(open(files[-1]).read().strip().splitlines()[-1])
+            out[key] = {"ms_per_step": rec.get("ms_per_step"), "mvoxel_s": rec.get("value"), "source": os.path.relpath(files[-1], REPO)}
+        except (ValueError, IndexError, OSError):
+            pass
+    return out or None
+
+
+def merge_zslab_into_line(out, zslab, n_gpus):
+    """rank 0: the Z-slab child's result becomes the line's `value` (or its absence the line's failure); the frame-replica figure moves
+    to `replicas`.  Pure function of its arguments (tests/test_bench_multi.py::test_assembled_eight_gpu_line)."""
+    out["replicas"] = {"value": out["value"], "unit": "Mvoxel/s", "ms_per_step": out["ms_per_step"],
+                       "workload": f"3-D+T stack of {n_gpus} frames, one frame per GPU, no data-path collective"}
+    if zslab is None:
+        return out
+    out["zslab"] = zslab
+    if "error" not in zslab and zslab.get("value"):
+        out["value"] = zslab["value"]
+        out["ms_per_step"] = zslab["ms_per_step"]
+        out["config"]["workload"] = zslab["workload"]
+        out["config"]["voxels"] = zslab["voxels"]
+        out["config"]["per_gpu_shape"] = zslab["per_gpu_owned_shape"]
+        out["config"]["parallelism"] = f"zslab{n_gpus}"
+        for k in ("survival_fraction", "labels", "mask_fraction_per_scale", "one_pass_scales"):
+            out["config"][k] = zslab.get(k)
+        ref = n1_reference()
+        out["zslab"]["n1_reference"] = ref
+        one = (ref or {}).get("one_rank_alone_128x2048x2048", {}).get("ms_per_step")
+        if one and zslab.get("per_gpu_owned_shape") == [SLAB_PLANES, SLAB_YX[0], SLAB_YX[1]]:
+            # weak scaling read directly: a rank alone takes `one` ms for its slab; N ranks take ms_per_step for N slabs
+            out["zslab"]["step_over_one_rank_alone"] = round(zslab["ms_per_step"] / one, 3)
+    else:
+        # the decomposition this line is about did not run: no number is reported for it (the frame-replica figure
+        # stays under `replicas`, it is a different workload)
+        out["value"] = None
+        out["ms_per_step"] = None
+        out["zslab_failed"] = True
+        out["config"]["parallelism"] = f"zslab{n_gpus} (failed: see zslab.error; `replicas` = {n_gpus} independent frames, no collective)"
+    return out
 
 
 def zslab_child_main(args):

@@ -13,6 +13,7 @@ struct HvLaunch {
     int mode;                 // 0 statistics, 1 known threshold, 2 one pass with a bracket (hessian.inc)
     int rs;                   // rows per wave pair: 8 or 16 (HVCfg<RS>)
     int np;                   // pair-rows per lane: 1, or 2 with rs = 8 (four voxels per lane)
+                              // np = 0: the wave-autonomous walk (hessian_dpp.inc), rs = rows of a wave's strip (4), nblocks = WAVES (tiles)
     int fastv;                // division: 0 float64, 1 three instructions, 2 two instructions (proven exact per divisor first)
     unsigned int nblocks;
     hipStream_t stream;

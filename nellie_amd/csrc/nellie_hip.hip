@@ -174,6 +174,28 @@ static int hv_np(const nl_ctx *c) {
     return 1;
 #endif
 }
+// The wave-autonomous walk (round 6, hessian_dpp.inc): strips of 4 rows x 60 columns per wave, no LDS.  Statistics and one-pass modes; the
+// statistics and known-threshold modes (MODE 0 / 1: the two-pass fallback of a scale) stay with the pair kernel.  NELLIE_HV_DPP=1 selects it
+// for the one-pass walk (default: the pair kernel -- measured equal at 1024^3, profiles/r06_walk_dpp_production.txt).
+#define HD_SR 4
+#define HD_COLS 60
+static bool hv_dpp(const nl_ctx *c) {
+    const char *e = getenv("NELLIE_HV_DPP");            // read per call: tests switch it inside one process
+    return hv_rs(c) != 0 && e && atoi(e) == 1;
+}
+// Planes per wave: 128 where that leaves several rounds of waves (a chunk's prologue -- four planes loaded, the first derivatives of one --
+// is paid half as often), 32 on small frames (a 128 x 512 x 512 frame has 1152 strips: 64-plane chunks would fill three quarters of the
+// 3072 wave slots once), else 64.
+static int hd_zchunk(const nl_ctx *c, i64 nz, i64 strips) {
+    static int forced = -1;
+    if (forced < 0) { const char *e = getenv("NELLIE_HV_ZCHUNK"); forced = e ? atoi(e) : 0; }
+    auto fits = [&](int z) { return (i64)(z + 4) * c->ny * c->nx * 4 < ((i64)1 << 32); };
+    if (forced > 0 && (forced & 3) == 0 && fits(forced)) return forced;
+    if (fits(128) && strips * ((nz + 127) / 128) >= 8192) return 128;
+    if (fits(64) && strips * ((nz + 63) / 64) >= 4096) return 64;
+    return 32;
+}
+
 // Exhaustive proof that the 3-instruction division is exact for the six divisors in use.
 static int check_fast_div(nl_ctx *c, char *err, size_t errlen) {
     const float ds[6] = {c->hz, c->hy, c->hx, c->hz2, c->hy2, c->hx2};
@@ -548,6 +570,9 @@ extern "C" int nl_gauss_step(nl_ctx *c, const double *wz, int rz, const double *
     if (c->ahead_pending) return nl_fail(err, errlen, NL_ESTATE, "nl_gauss_step while a step enqueued ahead is uncommitted");
     if (z0 < 0 || z1 > c->nzl || z0 >= z1) return nl_fail(err, errlen, NL_EINVAL, "bad plane range [%lld,%lld)", (i64)z0, (i64)z1);
     if (c->halo_pending) {                       // ghost planes of the source volume still travelling (nl_halo_exchange_at, async)
+        // "halo_wait": the event pair brackets nothing but the wait, so its time is what the exchange of this cascade step EXPOSED on the
+        // main stream (0 when the planes arrived while the scale's walk ran) -- the figure bench.py's N > 1 line reports per rank
+        ProfScope ps(c, "halo_wait");
         NL_HIP(hipStreamWaitEvent(c->stream, c->ev_x_done, 0));
         c->halo_pending = 0;
     }
@@ -1168,7 +1193,8 @@ extern "C" int nl_hessian_stats(nl_ctx *c, const double spacing[3], float *max_a
                                           HGCfg<TYV>::lds_bytes(), c->stream>>>(                                          \
             gauss_cur(c), nullptr, nullptr, 0, geom(c), HR, vp, VQueue{}, (int)c->own_lo, (int)c->own_hi, ntx,        \
             (int)((c->ny + TYV - 1) / TYV), res, nullptr)
-        if (hv_rs(c)) {
+        if (false) {}
+        else if (hv_rs(c)) {
             const int rsv = hv_rs(c), ntyv = (int)((c->ny + 2 * rsv - 1) / (2 * rsv));
             NL_HIP(nl_hv_launch(HvLaunch{0, rsv, hv_np(c), hv_fastv(c), (unsigned)(ntx * ntyv * nzc), c->stream, gauss_cur(c), nullptr, nullptr, 0, geom(c),
                                          hessp(c), vp, VQueue{}, (int)c->own_lo, (int)c->own_hi, ntx, ntyv, res, nullptr, nullptr}));
@@ -1281,6 +1307,28 @@ static int spec_enqueue(nl_ctx *c, const double spacing[3], float fsq_lo, float 
         vp.qcap = HM_SPEC_CAP * (zch / HM_ZCHUNK);
         if (rs) vp.qcap *= 2 * hv_np(c);                 // a wave owns two (four) row segments
         hipStream_t hs = c->stream;
+        if (rs && hv_dpp(c)) {
+            // wave-autonomous walk: one region per strip and chunk; the queue's bytes are shared out evenly (0.47 entries per voxel of a strip
+            // where the pair kernel has 0.5: its strips overhang the volume by up to 59 columns)
+            const int ntxd = (int)((c->nx + HD_COLS - 1) / HD_COLS), ntyd = (int)((c->ny + HD_SR - 1) / HD_SR);
+            const int zd = hd_zchunk(c, z1 - z0, (i64)ntxd * ntyd);
+            const i64 nzd = (z1 - z0 + zd - 1) / zd;
+            const i64 nreg = (i64)ntxd * ntyd * nzd;
+            i64 cap = vq_alloc_entries(c->nzl, c->ny, c->nx) / nreg;
+            if (cap > (i64)HD_SR * 64 * zd) cap = (i64)HD_SR * 64 * zd;
+            if (cap > (1 << 24) - 1) cap = (1 << 24) - 1;
+            if (cap >= 64 && 2 * nreg <= vq_alloc_regions(c->nzl, c->ny, c->nx)) {     // (region counts + the strips' h_mask counts)
+                vp.zchunk = zd; vp.qcap = (int)cap;
+                // the strips OR their bits into the words (two strips share a word): the slot's planes start from zero
+                NL_HIP(hipMemsetAsync(cm + z0 * c->ny * wpr, 0, (size_t)(z1 - z0) * c->ny * wpr * 8, hs));
+                NL_HIP(nl_hv_launch(HvLaunch{2, HD_SR, 0, hv_fastv(c), (unsigned)nreg, hs, gauss_cur(c), cm, pm, wpr, geom(c), hessp(c), vp, vq, (int)z0, (int)z1,
+                                             ntxd, ntyd, res, d_cnt, dev_lohi}));
+                NL_CHECK_LAUNCH();
+                c->spec_nregions = (unsigned)nreg;
+                c->spec_qcap = vp.qcap;
+                goto launched;
+            }
+        }
 #define NL_DEV_LOHI dev_lohi
 #define NL_LAUNCH_SPEC(TYV, FASTV, HR)                                                                                    \
         hessian_g_kernel<2, TYV, FASTV><<<nblocks, HGCfg<TYV>::NT, HGCfg<TYV>::lds_bytes(), c->stream>>>(                 \
@@ -1294,6 +1342,7 @@ static int spec_enqueue(nl_ctx *c, const double spacing[3], float fsq_lo, float 
         NL_CHECK_LAUNCH();
         c->spec_nregions = nblocks * (unsigned)(rs ? rs / hv_np(c) : ty);
         c->spec_qcap = vp.qcap;
+launched: ;
     }
     // fused: max |H|, max frob_sq (bit patterns of non-negative floats), the inf and overflow flags -- all "max"; the count stays local
     if (fused(c)) { int rcr = reduce_u32_max(c, res, 4, err, errlen); if (rcr) return rcr; }

@@ -8,6 +8,7 @@
 #include "device_math.inc"
 #include "hessian.inc"
 #include "hessian_pair.inc"
+#include "hessian_dpp.inc"
 #include "hv_launch.h"
 
 // dynamic LDS beyond 64 KiB has to be allowed per kernel (the RS = 16 tile of the pair kernel takes 121 KiB)
@@ -48,7 +49,24 @@ static void launch_rs(const HvLaunch &a) {
     launch_div<MODE, 8>(a);
 }
 
+// the wave-autonomous walk (hessian_dpp.inc): a.nblocks counts waves, four to a workgroup
+template <int MODE, int FAST>
+static void launch_dpp(const HvLaunch &a, const HessDv<FAST> &hr) {
+    hessian_d_kernel<MODE, 4, FAST><<<(a.nblocks + 3u) / 4u, HD_NT, 0, a.stream>>>(
+        a.g, a.cmask, a.pmask, a.wpr, a.geom, hr, a.vp, a.vq, a.z0, a.z1, a.ntx, a.nty, a.res, a.d_cnt, a.dev_lohi);
+    if (MODE != 0 && a.d_cnt) hd_count_kernel<<<1, 1024, 0, a.stream>>>(a.vq.count + a.nblocks, a.nblocks, a.d_cnt);
+}
+template <int MODE>
+static void launch_dpp_div(const HvLaunch &a) {
+    if (a.fastv == 2) launch_dpp<MODE, 2>(a, hessdv_two(a.hp)); else launch_dpp<MODE, 0>(a, hessdv_exact(a.hp));
+}
+
 hipError_t nl_hv_launch(const HvLaunch &a) {
+    if (a.np == 0) {          // (the one-pass mode only: statistics and known-threshold walks are the rare two-pass fallback and stay with the pair kernel)
+        if (a.rs != 4 || a.mode != 2) return hipErrorInvalidValue;
+        launch_dpp_div<2>(a);
+        return hipGetLastError();
+    }
     if (a.rs != 8 && !(NL_HV_VARIANTS && a.rs == 16)) return hipErrorInvalidValue;
     if (a.np != 1 && !(NL_HV_VARIANTS && a.np == 2 && a.rs == 8 && a.fastv == 2)) return hipErrorInvalidValue;
     switch (a.mode) {

@@ -53,20 +53,78 @@ class ShardSpec:
                          rendezvous_dir=rendezvous_dir, tag=os.environ.get("MASTER_PORT", ""))
 
 
-def slabs_needed(shape_zyx, halo: int, n_devices: int = 1) -> int:
-    """Smallest slab count (a multiple of the device count) whose slabs, ghost planes included, fit a context."""
+def context_bytes(local_shape) -> Optional[int]:
+    """HBM a context of this local shape takes: nl_ctx_bytes (35 B/voxel: four float32 volumes, the mask bit planes, the eigen queue --
+    DESIGN.md section 3) plus the resident input (4 B/voxel at most).  None where the library cannot be asked."""
+    try:
+        from nellie_amd import hipnative
+        nz, ny, nx = (int(s) for s in local_shape)
+        return int(hipnative.load().cdll.nl_ctx_bytes(nz, ny, nx)) + 4 * nz * ny * nx
+    except Exception:  # noqa: BLE001
+        return None
+
+
+def _free_bytes(device):
+    from nellie_amd.utils import adaptive_run
+    return adaptive_run.get_gpu_free_bytes(int(device))
+
+
+HBM_HEADROOM = 0.95                         # of the free bytes a plan may claim (adaptive_run.frame_fits_on_device uses the same figure)
+
+
+def memory_plan(shape_zyx, halo: int, w: int, devices, free_of=None, bytes_of=None):
+    """Where the w slabs of a frame go (contiguous blocks of slabs per device, as LocalSlabs places them) and whether they fit:
+    -> (fits, {device: bytes needed}, {device: bytes free}).  A device whose free memory cannot be asked counts as fitting."""
+    free_of = free_of or _free_bytes
+    bytes_of = bytes_of or context_bytes
+    nz, ny, nx = (int(s) for s in shape_zyx)
+    devs = [int(d) for d in (devices or [0])]
+    owned = -(-nz // w)
+    need = {}
+    for r in range(w):
+        lo, hi = r * owned, min(nz, (r + 1) * owned)
+        if hi <= lo:
+            continue
+        local = (hi - lo) + ((halo if r > 0 else 0) + (halo if hi < nz else 0) if w > 1 else 0)
+        b = bytes_of((local, ny, nx))
+        if b is None:
+            return True, {}, {}
+        d = devs[r * len(devs) // w]
+        need[d] = need.get(d, 0) + b
+    free = {d: free_of(d) for d in need}
+    fits = all(free[d] is None or need[d] <= free[d] * HBM_HEADROOM for d in need)
+    return fits, need, free
+
+
+def slabs_needed(shape_zyx, halo: int, n_devices: int = 1, devices=None, free_of=None, bytes_of=None) -> int:
+    """Smallest slab count (a multiple of the device count) whose slabs, ghost planes included, fit a context's index range AND the
+    free HBM of the devices they land on (round 6; the reference's ladder asks the same question with a 6 x frame heuristic,
+    nellie/utils/adaptive_run.py:88-113).  The slabs of a frame are all resident at once (they exchange ghost planes every cascade step),
+    so more slabs only help where there are more devices: when the smallest layout the index range allows does not fit the memory,
+    this raises MemoryError with the figures -- the message carries "out of memory", which adaptive_run.is_oom_error and the
+    reference's callers parse."""
     nz, ny, nx = (int(s) for s in shape_zyx)
     plane = ny * nx
-    w = max(1, int(n_devices))
+    nd = max(1, int(n_devices))
+    devs = [int(d) for d in devices] if devices else list(range(nd))
+    w = nd
     while True:
         owned = -(-nz // w)
         local = owned + (2 * halo if w > 1 else 0)
         if local * plane <= MAX_CONTEXT_VOXELS:
-            return w
+            break
         if owned <= halo:
             raise MemoryError(f"a {nz} x {ny} x {nx} frame cannot be cut into Z slabs that fit a context "
                               f"({plane} voxels per plane, {halo} ghost planes per side)")
-        w += max(1, int(n_devices))
+        w += nd
+    fits, need, free = memory_plan((nz, ny, nx), halo, w, devs, free_of, bytes_of)
+    if not fits:
+        gb = lambda b: "?" if b is None else f"{b / 2**30:.1f}"            # noqa: E731
+        detail = ", ".join(f"GPU {d}: needs {gb(need[d])} GiB, {gb(free.get(d))} GiB free" for d in sorted(need))
+        raise MemoryError(f"out of memory: a {nz} x {ny} x {nx} frame as {w} Z slab(s) on device(s) {sorted(set(devs))} does not fit the free HBM "
+                          f"({detail}; a plan may claim {HBM_HEADROOM:.0%} of the free bytes). Name more GPUs (devices=[...]) or run one rank "
+                          f"per GPU (shard='env'): the slabs of a frame are resident together, so more slabs on the same GPUs need more memory, not less")
+    return w
 
 
 class SingleContext:
@@ -296,8 +354,10 @@ class RankSlab(_SlabBase):
         self.pipe.close()
 
 
-def plan_engine(shape_zyx, params: FilterParams, devices=None, shard: Optional[ShardSpec] = None, halo_mode=None, label_only=False):
-    """("single" | "local-slabs" | "rank-slab", slab count) make_engine would build -- without building it."""
+def plan_engine(shape_zyx, params: FilterParams, devices=None, shard: Optional[ShardSpec] = None, halo_mode=None, label_only=False,
+                free_of=None, bytes_of=None):
+    """("single" | "local-slabs" | "rank-slab", slab count) make_engine would build -- without building it.  The plan looks at the index
+    range of a context AND at the free HBM of the devices (free_of / bytes_of: test doubles for the two questions)."""
     shape = tuple(int(s) for s in shape_zyx)
     if len(shape) == 2:
         return "single", 1
@@ -306,7 +366,7 @@ def plan_engine(shape_zyx, params: FilterParams, devices=None, shard: Optional[S
     from nellie_amd.sharded import halo_depth, halo_depth_steps
     mode = halo_mode or os.environ.get("NELLIE_HALO", "steps")
     need = 1 if label_only else (halo_depth_steps(params) if mode == "steps" else halo_depth(params))
-    w = slabs_needed(shape, need, len(devices) if devices else 1)
+    w = slabs_needed(shape, need, len(devices) if devices else 1, devices=devices, free_of=free_of, bytes_of=bytes_of)
     forced = int(os.environ.get("NELLIE_FORCE_SLABS", "0"))
     if forced > 1:
         w = max(w, forced)
@@ -331,6 +391,14 @@ def make_engine(shape_zyx, params: FilterParams, device_index=0, devices=None, s
         return RankSlab(shape, params, shard, halo_mode=halo_mode, halo=halo)
     devs = [int(d) for d in devices] if devices else [int(device_index)]
     _, w = plan_engine(shape, params, devs, None, halo_mode, label_only)
-    if w == 1:
-        return SingleContext(shape, device=devs[0])
-    return LocalSlabs(shape, params, devices=devs, n_slabs=w, halo_mode=halo_mode, halo=halo)
+    try:
+        if w == 1:
+            return SingleContext(shape, device=devs[0])
+        return LocalSlabs(shape, params, devices=devs, n_slabs=w, halo_mode=halo_mode, halo=halo)
+    except Exception as exc:  # noqa: BLE001
+        # the plan asked for the free HBM a moment ago; another process can still take it before the contexts exist: the library's
+        # "[out of memory]" then becomes the MemoryError the reference's ladder (filtering.py:1053-1076) and its callers expect
+        from nellie_amd.utils import adaptive_run
+        if adaptive_run.is_oom_error(exc) and not isinstance(exc, MemoryError):
+            raise MemoryError(f"out of memory while building the engine of a {shape} frame on device(s) {devs}: {exc}") from exc
+        raise

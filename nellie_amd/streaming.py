@@ -34,11 +34,14 @@ from nellie_amd.pipeline import FilterParams, FramePipeline, min_area_pixels_of
 LANES_BELOW_VOXELS = 1 << 27
 
 
-def default_lanes(frame_shape) -> int:
+def default_lanes(frame_shape, device: int = 0) -> int:
     env = os.environ.get("NELLIE_STREAM_LANES")
     if env:
         return max(1, int(env))
-    return 2 if int(np.prod(frame_shape)) < LANES_BELOW_VOXELS else 1
+    if int(np.prod(frame_shape)) >= LANES_BELOW_VOXELS:
+        return 1
+    from nellie_amd.utils import adaptive_run
+    return 2 if adaptive_run.frame_fits_on_device(frame_shape, device, contexts=2) else 1       # a second lane is a second context's HBM
 
 
 class _Lane:
@@ -73,7 +76,7 @@ class StreamedSegmenter:
             dtype = np.dtype(np.float32)
         self.in_dtype = dtype
         self.packed = os.environ.get("NELLIE_STREAM_PACKED", "1") == "1"
-        self.n_lanes = int(lanes) if lanes else default_lanes(self.shape)
+        self.n_lanes = int(lanes) if lanes else default_lanes(self.shape, device)
         self.lanes = [_Lane(self.shape, dtype, device, self.packed) for _ in range(self.n_lanes)]
         self.pipe = self.lanes[0].pipe                      # (the single-lane names of round 5: tools and tests read them)
         self.in_buf, self.fr_buf, self.lab_buf, self.blob_buf = (self.lanes[0].in_buf, self.lanes[0].fr_buf, self.lanes[0].lab_buf,

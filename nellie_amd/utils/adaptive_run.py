@@ -50,13 +50,15 @@ def estimate_frame_bytes(im_info):
     return int(math.prod(frame_shape) * itemsize)
 
 
-def frame_fits_on_device(shape_zyx, device: int = 0) -> bool:
-    """The engine needs nl_ctx_bytes(shape) (35 B/voxel: four float32 volumes, three byte volumes and the eigen queue) of HBM; the reference's 6x-frame heuristic
-    (adaptive_run.py:88-100) is replaced by the exact figure."""
-    lib = hipnative.load()
-    need = lib.cdll.nl_ctx_bytes(*[int(s) for s in shape_zyx])
+def frame_fits_on_device(shape_zyx, device: int = 0, contexts: int = 1) -> bool:
+    """The engine needs nl_ctx_bytes(shape) (35 B/voxel: four float32 volumes, three byte volumes and the eigen queue) of HBM
+    per context, plus the resident input; the reference's 6x-frame heuristic (adaptive_run.py:88-100) is replaced by the exact figure.
+    contexts: how many contexts of that shape are wanted at once (the frame streamer's lanes).  The engine plan asks the same question per
+    device for slab layouts (nellie_amd/engine.py: memory_plan)."""
+    from nellie_amd import engine
+    need = engine.context_bytes(shape_zyx)
     free = get_gpu_free_bytes(device)
-    return free is None or need <= free * 0.95
+    return need is None or free is None or need * max(1, int(contexts)) <= free * engine.HBM_HEADROOM
 
 
 def is_oom_error(exc: Exception) -> bool:

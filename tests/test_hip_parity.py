@@ -1095,6 +1095,27 @@ def test_device_chain_equals_the_synchronous_path(hip, shape, seed, aniso):
     assert np.array_equal(fr_c, fr_s) and (fr_c > 0).any()
 
 
+@pytest.mark.parametrize("shape,seed,aniso", [((40, 96, 96), 21, False), ((33, 70, 130), 22, True), ((70, 150, 200), 25, False), ((9, 61, 121), 26, False),
+                                              ((130, 64, 61), 27, True), ((24, 7, 300), 28, False)])
+def test_wave_autonomous_walk_is_bit_identical(hip, shape, seed, aniso, monkeypatch):
+    """NELLIE_HV_DPP=1 (round 6, csrc/hessian_dpp.inc; profiles/r06_walk_dpp_*.txt): the one-pass walk without LDS and without the barrier --
+    strips of 4 rows x 60 columns per wave, Y neighbours in registers, X neighbours through DPP, mask words shared by two strips OR-ed in with
+    atomics.  Measured equal to the pair walk at 1024^3 (the mask / queue logic bounds both), hence opt-in -- but the same bits: trace, frame,
+    chain and synchronous path, on shapes whose strips stick out of the volume in X and Y, one strip wide or high, with planes that are no
+    multiple of a group of four, and with a cumulative mask from the earlier scales."""
+    from nellie_amd.synthetic import ANISO_03, ISO_01, make_volume
+    vol = make_volume(shape, seed)
+    dr = ANISO_03 if aniso else ISO_01
+    monkeypatch.setenv("NELLIE_HV_DPP", "0")
+    ref = _run_both_ways(vol, dr)
+    monkeypatch.setenv("NELLIE_HV_DPP", "1")
+    got = _run_both_ways(vol, dr)
+    for (fr_a, tr_a, np_a, pt_a, _, _), (fr_b, tr_b, np_b, pt_b, fb_b, _) in zip(ref, got):
+        assert tr_a == tr_b and np_a == np_b and pt_a == pt_b
+        assert np.array_equal(fr_a, fr_b)
+    assert (ref[0][0] > 0).any() or shape[1] < 16
+
+
 @pytest.mark.parametrize("shape,seed,aniso", [((40, 96, 96), 21, False), ((33, 70, 130), 22, True), ((70, 150, 200), 25, False)])
 def test_walk_with_four_voxels_per_lane_is_bit_identical(hip, shape, seed, aniso, monkeypatch):
     """NELLIE_HV_NP=2 (round 5, profiles/r05_walk_variants_1024cube.txt block 4): the pair walk with two pair-rows per lane -- measured
