@@ -104,7 +104,7 @@ def create(path, shape_tzyx, dtype, dim_res=None, description="", data=None):
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
     # written under a temporary name and moved into place: a reader (another rank of a multi-process run, a viewer) sees the old
     # complete file or the new complete file, never a truncated one, and a map of the old file keeps its pages
-    final_path, path = path, f"{path}.tmp{os.getpid()}_{uuid.uuid4().hex[:8]}"
+    final_path, path = path, f"{path}.tmp{os.getpid()}_{_host_tag()}_{uuid.uuid4().hex[:8]}"
     _sweep_stale_tmp(final_path)
     try:
         _write_file(path, t, z, y, x, dt, nplanes, plane_bytes, data_offset, data_bytes, xml, software, data)
@@ -118,25 +118,36 @@ def create(path, shape_tzyx, dtype, dim_res=None, description="", data=None):
     return data_offset
 
 
+def _host_tag() -> str:
+    """This host (and PID namespace, as far as a name can tell) in a form that fits a file name: a process id in a temporary's name
+    only means something to the host that wrote it."""
+    import hashlib
+    import socket
+    return hashlib.sha1(socket.gethostname().encode("utf-8", "replace")).hexdigest()[:8]
+
+
 def _sweep_stale_tmp(final_path, max_age_s=3600.0):
-    """A process killed inside create() leaves `<path>.tmp<pid>_<hex>` behind (possibly a full-size sparse file next to the
-    outputs): the next create() of the same path removes such siblings once their writer is gone (pid not alive) or they are an
-    hour old."""
+    """A process killed inside create() leaves `<path>.tmp<pid>_<host>_<hex>` behind (possibly a full-size sparse file next to the
+    outputs): the next create() of the same path removes such siblings once their writer is gone -- pid not alive, asked only when
+    the temporary was written on THIS host (on a shared file system another node's live writer has a pid that means
+    nothing here) -- or once they are an hour old, whoever wrote them (also the round-5 names without a host tag)."""
     import glob
     import re
     import time
+    here = _host_tag()
     for p in glob.glob(glob.escape(final_path) + ".tmp*"):
-        m = re.fullmatch(r"\.tmp(\d+)_[0-9a-f]{8}", p[len(final_path):])
+        m = re.fullmatch(r"\.tmp(\d+)_(?:([0-9a-f]{8})_)?[0-9a-f]{8}", p[len(final_path):])
         if not m:
             continue
         try:
             alive = True
-            try:
-                os.kill(int(m.group(1)), 0)
-            except ProcessLookupError:
-                alive = False
-            except PermissionError:
-                pass
+            if m.group(2) == here:
+                try:
+                    os.kill(int(m.group(1)), 0)
+                except ProcessLookupError:
+                    alive = False
+                except PermissionError:
+                    pass
             if not alive or time.time() - os.path.getmtime(p) > max_age_s:
                 os.remove(p)
         except OSError:

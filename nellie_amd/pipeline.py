@@ -635,12 +635,14 @@ class FramePipeline:
     def _all_ranks_agree(self, ok: bool) -> bool:
         return ok
 
-    # NELLIE_CHAIN_AHEAD: unset = frames below 2^26 voxels on a single context; 0 / 1: never / always
-    _chain_ahead_env = os.environ.get("NELLIE_CHAIN_AHEAD")
+    # NELLIE_CHAIN_AHEAD: unset = frames below 2^26 voxels on a single context; 0 / 1: never / always.  Read per frame (a test or
+    # a tool that sets it after the import is heard); an instance attribute `_chain_ahead_env` overrides the environment.
+    _chain_ahead_env = None
 
     def _chain_ahead(self, n_voxels: int) -> bool:
-        if self._chain_ahead_env is not None:
-            return self._chain_ahead_env == "1"
+        env = self._chain_ahead_env if self._chain_ahead_env is not None else os.environ.get("NELLIE_CHAIN_AHEAD")
+        if env is not None:
+            return env == "1"
         return n_voxels < (1 << 26)
 
     def _finish_frame(self, finish: bool, p: FilterParams, mask: bool):

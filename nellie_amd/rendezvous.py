@@ -136,12 +136,16 @@ class FileRendezvous:
             time.sleep(self.poll_s)
 
     def wait(self, name: str, timeout_s: float = None) -> bytes:
+        """The payload of `name`'s next generation.  One publisher per name (rank 0 in every use of this package).  The generation counter
+        moves only when the wait has SUCCEEDED: a TimeoutError followed by a retry polls the same generation again."""
         if name in self._unwaited:         # the publisher reading its own marker: the same use
+            data = self._wait_path(self._path_g(name, self._gen[name]), timeout_s)
             self._unwaited.discard(name)
-            gen = self._gen[name]
-        else:
-            gen = self._next(name)
-        return self._wait_path(self._path_g(name, gen), timeout_s)
+            return data
+        gen = self._gen.get(name, 0) + 1
+        data = self._wait_path(self._path_g(name, gen), timeout_s)
+        self._gen[name] = gen
+        return data
 
     def remove(self, name: str):
         """Removes the marker of `name`'s current generation (the publisher's job, after a barrier)."""
@@ -170,6 +174,7 @@ class FileRendezvous:
         until every rank has written its `b` file, i.e. has finished looking at the `a` files.  The files carry the generation of
         this use of `name`, so the next barrier of the same name starts from files nobody has written yet."""
         gen = self._next("barrier:" + name)
+        self._unwaited.clear()             # a marker published before a barrier has been seen by whoever waits for it: never "own, unread" afterwards
         f = lambda ab, r: os.path.join(self.dir, f".nellie_{self.nonce}_{name}.g{gen}_{ab}_{r}")
         _atomic_write(f("a", self.rank), b"1")
         for r in range(self.world):

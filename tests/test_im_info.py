@@ -50,13 +50,19 @@ def test_create_removes_the_temporaries_of_writers_that_died(tmp_path):
     path = str(tmp_path / "o.ome.tif")
     dead = subprocess.Popen([sys.executable, "-c", "pass"])
     dead.wait()
-    stale = f"{path}.tmp{dead.pid}_0123abcd"
-    mine = f"{path}.tmp{os.getpid()}_89abcdef"                 # a writer that is alive (this process) and recent: kept
+    here = ome_tiff._host_tag()
+    stale = f"{path}.tmp{dead.pid}_{here}_0123abcd"
+    mine = f"{path}.tmp{os.getpid()}_{here}_89abcdef"          # a writer that is alive (this process) and recent: kept
     other = f"{path}.tmpnotes"
-    for p in (stale, mine, other):
+    # the same dead pid in a temporary ANOTHER host wrote (shared file system) says nothing here -- kept while it is recent,
+    # removed once it is an hour old; the names of round 5 (no host tag) are treated the same way
+    elsewhere, elsewhere_old, legacy = f"{path}.tmp{dead.pid}_deadbeef_0123abcd", f"{path}.tmp{dead.pid}_deadbeef_76543210", f"{path}.tmp{dead.pid}_0123abcd"
+    for p in (stale, mine, other, elsewhere, elsewhere_old, legacy):
         open(p, "wb").write(b"x")
+    os.utime(elsewhere_old, (1.0e9, 1.0e9))
     ome_tiff.create(path, (1, 2, 4, 4), np.uint8, {"X": 1.0, "Y": 1.0, "Z": 1.0, "T": 1.0}, "d")
     assert not os.path.exists(stale) and os.path.exists(mine) and os.path.exists(other) and os.path.exists(path)
+    assert os.path.exists(elsewhere) and os.path.exists(legacy) and not os.path.exists(elsewhere_old)
 
 
 def test_iminfo_layout_matches_nellie_convention(tmp_path):

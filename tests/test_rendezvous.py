@@ -6,6 +6,8 @@ import os
 import sys
 import time
 
+import pytest
+
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
@@ -155,3 +157,24 @@ def test_ranks_build_the_im_info_in_order(tmp_path):
     assert all(o[1] != "error" for o in out), out
     assert len({o[1] for o in out}) == 1 and len({o[3] for o in out}) == 1, out      # same path, same inode: written once
     assert all(o[2] == int(vols.sum()) for o in out)
+
+
+def test_a_wait_that_timed_out_can_be_retried(tmp_path):
+    """wait() moves a name's generation only when it SUCCEEDED -- a TimeoutError followed by a retry polls the generation it
+    timed out on, not the next one."""
+    import threading
+    from nellie_amd.rendezvous import FileRendezvous
+    rdvs = [None, None]
+
+    def make(r):
+        rdvs[r] = FileRendezvous(r, 2, str(tmp_path), tag="retry", timeout_s=20.0, poll_s=0.001)
+    ts = [threading.Thread(target=make, args=(r,)) for r in range(2)]
+    for t in ts: t.start()
+    for t in ts: t.join()
+    with pytest.raises(TimeoutError):
+        rdvs[1].wait("late", timeout_s=0.05)
+    rdvs[0].publish("late", b"now")
+    assert rdvs[1].wait("late", timeout_s=5.0) == b"now"
+    rdvs[0].remove("late")
+    rdvs[0].publish("late", b"again")                      # the second use of the name: the next generation on both sides
+    assert rdvs[1].wait("late", timeout_s=5.0) == b"again"
