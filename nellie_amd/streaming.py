@@ -29,8 +29,10 @@ import numpy as np
 from nellie_amd import hipnative
 from nellie_amd.pipeline import FilterParams, FramePipeline, min_area_pixels_of
 
-# frames below this many voxels get two lanes by default (a 256 x 512 x 512 frame still gains 17 %; at 2^27 voxels and more a
-# frame fills the GPU by itself and a second context would only cost HBM)
+# Lanes by default (profiles/r06_stream_lanes.txt: 64 frames of 128 x 512 x 512, three alternating repetitions on one box --
+# float32 3.2-4.3 / 3.5-3.8 / 2.67-2.71 / 2.8-3.1 ms per frame with 1 / 2 / 3 / 4 lanes, uint16 4.1-4.2 / 2.7 / 2.3-2.6 / 2.6-2.8):
+# three below 2^26 voxels, two below 2^27 (a resident 256 x 512 x 512 frame gains 17 % from the second), one from there on -- a frame
+# of that size fills the GPU by itself and another context would only cost HBM.
 LANES_BELOW_VOXELS = 1 << 27
 
 
@@ -38,10 +40,12 @@ def default_lanes(frame_shape, device: int = 0) -> int:
     env = os.environ.get("NELLIE_STREAM_LANES")
     if env:
         return max(1, int(env))
-    if int(np.prod(frame_shape)) >= LANES_BELOW_VOXELS:
-        return 1
+    n = int(np.prod(frame_shape))
+    want = 3 if n < (1 << 26) else (2 if n < LANES_BELOW_VOXELS else 1)
     from nellie_amd.utils import adaptive_run
-    return 2 if adaptive_run.frame_fits_on_device(frame_shape, device, contexts=2) else 1       # a second lane is a second context's HBM
+    while want > 1 and not adaptive_run.frame_fits_on_device(frame_shape, device, contexts=want):      # a lane is a context's HBM
+        want -= 1
+    return want
 
 
 class _Lane:

@@ -244,8 +244,8 @@ def test_c2_parity_at_its_own_size(hip, aniso):
 def test_c5_streamed_equals_per_frame_at_its_frame_size(hip):
     """BASELINE config 5 at its own frame size (128 x 512 x 512, seeds 4567 + t), 7 frames: the double-buffered streamer
     (H2D of frame t+1 and D2H of frame t-1 on their own HIP streams while frame t computes) writes the arrays the
-    frame-by-frame path writes -- with one lane, with two (the default at this frame size: two contexts of the GPU take the
-    frames alternately, one upload thread feeds both), and with three and four, where the stack length is no multiple of the lane count."""
+    frame-by-frame path writes -- with one lane, with three (the default at this frame size: three contexts of the GPU take the
+    frames in turn, one upload thread feeds them), with two and with four, where the stack length is no multiple of the lane count."""
     from nellie_amd import pipeline as pl
     from nellie_amd.streaming import StreamedSegmenter, default_lanes
     from nellie_amd.synthetic import ISO_01, make_volume
@@ -261,13 +261,13 @@ def test_c5_streamed_equals_per_frame_at_its_frame_size(hip):
         counts.append((npos, pipe.label(pipe.frangi_threshold(), ma)))
         pipe.download_frangi(out=fr[t]); pipe.download_labels(out=lab[t])
     pipe.close()
-    assert default_lanes(fs) == 2 and default_lanes((1024, 1024, 1024)) == 1
-    for lanes in (None, 1, 3, 4):
+    assert default_lanes(fs) == 3 and default_lanes((256, 512, 512)) == 2 and default_lanes((1024, 1024, 1024)) == 1
+    for lanes in (None, 1, 2, 4):
         fr2, lab2 = np.full_like(fr, -1.0), np.full_like(lab, -1)
         seg = StreamedSegmenter(fs, frames.dtype, p, lanes=lanes)
-        assert seg.n_lanes == (lanes or 2)
+        assert seg.n_lanes == (lanes or 3)
         stats = seg.run(frames, fr2, lab2, flush=False)
-        if lanes == 3:                      # a second stack through the same streamer: nothing of the first one lingers
+        if lanes is None:                   # a second stack through the same streamer: nothing of the first one lingers
             fr2[:] = -1.0; lab2[:] = -1
             stats = seg.run(frames, fr2, lab2, flush=False)
         seg.close()
