@@ -990,6 +990,8 @@ extern "C" int nl_input_load_async(nl_ctx *c, int slot, const void *host_pinned,
     if (c->d_in_slot[slot] && c->in_bytes[slot] < (size_t)c->n * es) { hipFree(c->d_in_slot[slot]); c->d_in_slot[slot] = nullptr; }
     if (!c->d_in_slot[slot]) { NL_HIP(hipMalloc(&c->d_in_slot[slot], (size_t)c->n * es)); c->in_bytes[slot] = (size_t)c->n * es; }
     c->in_dtype[slot] = dtype;
+    // (a kernel that PULLS the frame from page-locked host memory instead of the SDMA copy was tried in round 6: 8 workgroups already slow the
+    // other contexts' kernels more than the copy engine does -- profiles/r06_h2d_pull.txt)
     NL_HIP(hipMemcpyAsync(c->d_in_slot[slot], host_pinned, (size_t)c->n * es, hipMemcpyHostToDevice, c->copy_in));
     NL_HIP(hipEventRecord(c->ev_in[slot], c->copy_in));
     return NL_OK;
