@@ -1550,7 +1550,7 @@ static int chain_verify(const ChainScale &s, double division, double margin, dou
 extern "C" int nl_chain_begin(nl_ctx *c, int n_scales, char *err, size_t errlen) {
     NL_ENTER(c);
     if (n_scales < 1 || n_scales > NL_CHAIN_MAX_SCALES) return nl_fail(err, errlen, NL_EINVAL, "a chain holds 1..%d scales", NL_CHAIN_MAX_SCALES);
-    if (c->two_d || !c->spec_ok || !hv_rs(c)) return nl_fail(err, errlen, NL_ESTATE, "the device-resident chain needs the 3-D one-pass walk");
+    if (!c->two_d && (!c->spec_ok || !hv_rs(c))) return nl_fail(err, errlen, NL_ESTATE, "the device-resident chain needs the 3-D one-pass walk");
     if (!c->d_chain) {
         NL_HIP(hipMalloc(&c->d_chain, sizeof(ChainScale) * NL_CHAIN_MAX_SCALES));
         NL_HIP(hipHostMalloc(&c->h_chain, sizeof(ChainScale) * NL_CHAIN_MAX_SCALES, hipHostMallocDefault));
@@ -1578,6 +1578,59 @@ extern "C" int nl_chain_scale(nl_ctx *c, const double spacing[3], int64_t sz, in
     c->chain_par[c->chain_k][0] = division; c->chain_par[c->chain_k][1] = margin; c->chain_par[c->chain_k][2] = test_scale;
     ++c->chain_k;
     c->frob_max_abs = 1.0f; c->frob_max_finite = 0.0f;                    // the bracket round: max_abs := 1 (pipeline.py _fsq_bracket)
+    if (c->two_d) {
+        // Round 6: images (im_info.no_z; filtering.py:675-690, 732-741) through the same records -- two passes, no walk and no queue: the
+        // raw round only measures the sample range the exact round's edges are derived from (its "bracket" decides nothing: the caller passes
+        // a margin of 1), the statistics kernel stands where the walk stands, and the vesselness kernel reads gamma_sq / fsq_min / m_inf
+        // from the record as the resolve kernel does.  ~20 host round trips of a 2048^2 frame gone.
+        if (!chain_unfused_sampling()) {
+            if ((rc = range_hist_pair_enqueue(c, sz, sy, sx, NL_CHAIN_BINS, (char *)&cs->h_gauss, (char *)&cs->h_raw, nullptr, nullptr, err, errlen))) return rc;
+        } else {
+            if ((rc = range_hist_enqueue_at(c, NL_FIELD_GAUSS, sz, sy, sx, NL_CHAIN_BINS, (char *)&cs->h_gauss, nullptr, err, errlen))) return rc;
+            if ((rc = range_hist_enqueue_at(c, NL_FIELD_FROB, sz, sy, sx, NL_CHAIN_BINS, (char *)&cs->h_raw, nullptr, err, errlen))) return rc;
+        }
+        chain_thr1_kernel<<<2, 64, 0, c->stream>>>(cs, division, margin, test_scale);
+        {
+            ProfScope ps(c, "hessian_stats");
+            hessian2d_stats_kernel<<<grid2d_rows(c->nx, c->ny), 256, 0, c->stream>>>(gauss_cur(c), geom(c), hessp(c), cs->stats);
+        }
+        chain_post_kernel<<<1, 64, 0, c->stream>>>(cs);
+        NL_CHECK_LAUNCH();
+        {
+            Lattice L; FieldSrc fs;
+            if ((rc = make_lattice(c, sz, sy, sx, L, err, errlen))) return rc;
+            if ((rc = make_field(c, NL_FIELD_FROB, fs, err, errlen))) return rc;
+            if ((rc = use_fsq_cache(c, fs, L, err, errlen))) return rc;
+            fs.norm_dev = cs->norm;
+            const i64 total = L.cz * L.cy * L.cx;
+            ProfScope ps(c, "sample");
+            sample_edges_kernel<<<1, 64, 0, c->stream>>>(cs->h_exact.res, NL_CHAIN_BINS, cs->h_exact.edges, cs->h_exact.res + 4);
+            const size_t sh = (size_t)(NL_CHAIN_BINS + 2) * 4 + (size_t)NL_CHAIN_BINS * 4;
+            if (total > 0) sample_hist_kernel<<<grid1d(total, 256, sample_grid_cap()), 256, sh, c->stream>>>(fs, geom(c), L, cs->h_exact.edges, NL_CHAIN_BINS, cs->h_exact.counts, cs->h_exact.res + 4);
+            NL_CHECK_LAUNCH();
+        }
+        chain_thr2_kernel<<<1, 64, 0, c->stream>>>(cs, division);
+        NL_CHECK_LAUNCH();
+        VessP vp{};
+        vp.alpha_sq = (float)alpha_sq; vp.beta_sq = (float)beta_sq; vp.use_thr = 1;
+        vp.cnt_lo = (int)c->own_lo; vp.cnt_hi = (int)c->own_hi;
+        vp.first = c->mask_slots_used == 0 ? 1 : 0;
+        vp.nan_flag = (unsigned int *)((char *)c->d_small + NL_NAN_FLAG_OFF);
+        ProfScope ps(c, "vesselness");
+        const int wpr = (int)((c->nx + 63) / 64);
+        const i64 slot_words = c->nzl * c->ny * wpr;
+        const int k_scale = c->mask_slots_used++;
+        vp.have_prev = k_scale > 0;
+        unsigned long long *cm = (unsigned long long *)c->m[0] + (i64)(k_scale & 1) * slot_words;
+        const unsigned long long *pm = (unsigned long long *)c->m[0] + (i64)((k_scale + 1) & 1) * slot_words;
+        if (vp.first && !vmax_is_zero(c, 0, c->nzl)) NL_HIP(hipMemsetAsync(c->f[c->i_vmax], 0, (size_t)c->n * 4, c->stream));
+        c->vmax_zero_hi = 0;
+        c->spec_valid = 0;
+        vesselness2d_kernel<<<grid2d_rows((i64)wpr * 64, c->ny), 256, 0, c->stream>>>(gauss_cur(c), c->f[c->i_vmax], cm, pm, wpr, geom(c), hessp(c), vp,
+                                                                                        &cs->cnt_resolve, (const float *)cs);
+        NL_CHECK_LAUNCH();
+        return NL_OK;
+    }
     if (!chain_unfused_sampling()) {
         if ((rc = range_hist_pair_enqueue(c, sz, sy, sx, NL_CHAIN_BINS, (char *)&cs->h_gauss, (char *)&cs->h_raw, nullptr, nullptr, err, errlen))) return rc;
     } else {
@@ -2558,7 +2611,7 @@ extern "C" int nl_ctx_info(nl_ctx *c, const char *key, double *value) {
     else if (!strcmp(key, "hessian_tile_rows")) *value = hv_rs(c) ? 2 * hv_rs(c) : hm_ty();
     else if (!strcmp(key, "hv_variants")) *value = NL_HV_VARIANTS;               // 1: a build with the rejected forms of the walk (nellie_hv.hip)
     else if (!strcmp(key, "vesselness_one_pass")) *value = c->spec_ok;
-    else if (!strcmp(key, "chain_available")) *value = (!c->two_d && c->spec_ok && hv_rs(c)) ? 1 : 0;   // nl_chain_begin's own precondition
+    else if (!strcmp(key, "chain_available")) *value = (c->two_d || (c->spec_ok && hv_rs(c))) ? 1 : 0;   // nl_chain_begin's own precondition
     else if (!strcmp(key, "last_fsq_min")) *value = c->last_fsq_min;
     else if (!strcmp(key, "last_spec_overflow")) *value = c->last_spec_overflow;
     else if (!strcmp(key, "last_label_sparse")) *value = c->last_label_sparse;

@@ -550,7 +550,7 @@ class FramePipeline:
     chain_fallbacks = 0
 
     def _chain_usable(self, p: FilterParams, mask: bool) -> bool:
-        return bool(self._device_chain and self.one_pass and mask and not self.two_d and p.frob_thresh is None and p.frob_thresh_division
+        return bool(self._device_chain and (self.one_pass or self.two_d) and mask and p.frob_thresh is None and p.frob_thresh_division
                     and hasattr(self.ctx, "chain_begin") and getattr(self.ctx, "chain_available", lambda: True)()
                     and self._chain_reductions_on_device())
 
@@ -568,6 +568,8 @@ class FramePipeline:
             return False
         strides = self._strides(max_samples)
         deltas = list(cascade_deltas(sigmas, zr))
+        if self.two_d:
+            deltas = [(0.0, d[1], d[2]) for d in deltas]          # sigma_vec = (s, s): no Z axis (filtering.py:281-282)
         ctx.chain_begin(len(sigmas))
         # No cascade step runs ahead here: that device (sharded.py) fills the GPU while the host waits for a scale's collectives,
         # and the chain has no such waits -- beside the walk the step only competes with it (measured on a 128 x 2048 x 2048 slab:
@@ -575,8 +577,10 @@ class FramePipeline:
         # ... except on frames that stream from the caches (below 2^26 voxels: a config-5 frame).  There a scale's threshold kernels --
         # one wave or a 10^6-point lattice each, ten of them per scale -- leave the GPU idle for 0.12 ms of every 0.5 ms, and the next
         # cascade step, enqueued on the side stream, fills those holes (round 5: 2.70 -> see profiles/r05_c5_chain_ahead.txt).
-        run_ahead = self._chain_ahead(int(np.prod(self.shape)))
+        run_ahead = self._chain_ahead(int(np.prod(self.shape))) and not self.two_d
         ahead = False
+        # images: two passes per scale, the raw round's "bracket" decides nothing (margin 1: nl_chain_scale)
+        margin = 1.0 if self.two_d else self.one_pass_margin
 
         def cascade_step(k, on_side):
             delta = deltas[k]
@@ -597,7 +601,7 @@ class FramePipeline:
             self._after_cascade_step(k)
             ahead = run_ahead and k + 1 < len(sigmas) and cascade_step(k + 1, True)
             vz0, vz1 = self._vess_range()
-            ctx.chain_scale(spacing, strides, float(p.alpha_sq), float(p.beta_sq), float(p.frob_thresh_division), self.one_pass_margin,
+            ctx.chain_scale(spacing, strides, float(p.alpha_sq), float(p.beta_sq), float(p.frob_thresh_division), margin,
                             self._one_pass_test_scale, z0=vz0, z1=vz1)
         # filter()'s percentile threshold reads lattice samples of the result: their compaction is enqueued BEFORE the wait, so it
         # runs while the host waits for the chain's records and repeats its decisions (one round trip less per frame)
@@ -629,7 +633,7 @@ class FramePipeline:
                     assert np.array_equal(edges, histogram_edges(rng[0], rng[1], 256)), "device-built histogram edges differ from numpy's"
         for k, sigma in enumerate(sigmas):
             self.trace.scales.append(ScaleTrace(float(sigma), float(gamma[k]), float(max_abs[k]), float(thr[k]),
-                                                self._reduce_mask_count(int(counts[k])), False, True))
+                                                self._reduce_mask_count(int(counts[k])), False, not self.two_d))
         return True
 
     def _all_ranks_agree(self, ok: bool) -> bool:

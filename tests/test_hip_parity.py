@@ -1095,6 +1095,31 @@ def test_device_chain_equals_the_synchronous_path(hip, shape, seed, aniso):
     assert np.array_equal(fr_c, fr_s) and (fr_c > 0).any()
 
 
+@pytest.mark.parametrize("shape,seed", [((96, 80), 41), ((257, 513), 42), ((64, 1000), 43), ((700, 33), 44)])
+def test_device_chain_on_images(hip, shape, seed):
+    """Round 6: 2-D images (im_info.no_z; filtering.py:675-690, 732-741) go through the device-resident threshold chain too -- two passes per
+    scale, no walk: the statistics kernel and the vesselness kernel read / write the scale's record.  Same trace, same frame as the synchronous
+    path, and the chain stood (no flag), frame after frame on one context."""
+    from nellie_amd import pipeline as pl
+    from nellie_amd.synthetic import make_image_2d
+    img = make_image_2d(shape, seed)
+    dr = {"X": 0.1, "Y": 0.1, "Z": None, "T": 1.0}
+    out = []
+    for chain in (True, False):
+        pipe = pl.FramePipeline(img.shape)
+        assert pipe.two_d
+        pipe._device_chain = chain
+        assert pipe._chain_usable(pl.FilterParams(dim_res=dr), True) == chain
+        for _ in range(2):
+            n = pipe.filter(img, pl.FilterParams(dim_res=dr))
+        tr = [(s.sigma, s.gamma, s.max_abs, s.frob_thr, s.mask_count, s.skipped) for s in pipe.trace.scales]
+        out.append((pipe.download_frangi(), tr, n, pipe.chain_fallbacks, getattr(pipe, "last_chain_flags", None)))
+        pipe.close()
+    (fa, ta, na, fba, flags), (fb, tb, nb, _, _) = out
+    assert fba == 0 and flags == [0] * len(ta), f"the chain fell back: {flags}"
+    assert ta == tb and na == nb and np.array_equal(fa, fb) and (fa > 0).any()
+
+
 @pytest.mark.parametrize("shape,seed,aniso", [((40, 96, 96), 21, False), ((33, 70, 130), 22, True), ((70, 150, 200), 25, False), ((9, 61, 121), 26, False),
                                               ((130, 64, 61), 27, True), ((24, 7, 300), 28, False)])
 def test_wave_autonomous_walk_is_bit_identical(hip, shape, seed, aniso, monkeypatch):

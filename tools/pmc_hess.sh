@@ -2,7 +2,7 @@
 # SQ counters of the Hessian walk (several --pmc passes, counters only): tools/pmc_hess.sh [Z Y X] -> gpurun_out/r3/pmc_hess.txt
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
-mkdir -p $R/gpurun_out/r5; OUT=$R/gpurun_out/r5/pmc_sq_${TAG:-x}.txt; : > $OUT
+mkdir -p $R/gpurun_out/${RND:-r6}; OUT=$R/gpurun_out/${RND:-r6}/pmc_sq_${TAG:-x}.txt; : > $OUT
 i=0
 for C in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU" "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC" "SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU SQ_LDS_BANK_CONFLICT" "SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_BRANCH SQ_INSTS_SENDMSG"; do
   i=$((i+1))
